@@ -1,0 +1,121 @@
+"""Host shims for ``kaolin._C.metrics`` (bindings.cpp:103-108)."""
+import torch
+
+from .. import _lib
+from .._checks import (Arg, check_same_gpu, check_all_same_gpu, check_all_contiguous, check_same_type,
+                       check_size, check_same_size, torch_check)
+
+
+def sided_distance_forward_cuda(p1, p2):
+    """reference: kaolin/csrc/metrics/sided_distance.cpp:65-89 -> [dist, idx]"""
+    fn = 'sided_distance_forward_cuda'
+    p1_arg, p2_arg = Arg(p1, 'p1', 1), Arg(p2, 'p2', 2)
+    check_same_gpu(fn, p1_arg, p2_arg)
+    check_all_contiguous(fn, [p1_arg, p2_arg])
+    check_same_type(fn, p1_arg, p2_arg)
+    batch_size, num_p1, num_p2 = p1.size(0), p1.size(1), p2.size(1)
+    check_size(fn, p1_arg, [batch_size, num_p1, 3])
+    check_size(fn, p2_arg, [batch_size, num_p2, 3])
+    sfx = _lib.dtype_suffix(p1.dtype, fn, ('f32', 'f64', 'f16'))
+    lib = _lib.load()
+    with torch.cuda.device(p1.device):
+        dist = torch.zeros((batch_size, num_p1), dtype=p1.dtype, device=p1.device)
+        idx = torch.zeros((batch_size, num_p1), dtype=torch.long, device=p1.device)
+        ws = _lib.workspace(
+            lib.kamd_sided_distance_forward_workspace(batch_size, num_p1, num_p2, p1.element_size()), p1.device)
+        st = getattr(lib, f'kamd_sided_distance_forward_{sfx}')(
+            _lib.stream_ptr(p1.device), batch_size, num_p1, num_p2,
+            _lib.ptr(p1), _lib.ptr(p2), _lib.ptr(dist), _lib.ptr(idx), _lib.ptr(ws))
+    _lib.check(st, fn)
+    return [dist, idx]
+
+
+def sided_distance_backward_cuda(grad_output, p1, p2, idx):
+    """reference: kaolin/csrc/metrics/sided_distance.cpp:91-122 -> [grad_p1, grad_p2]"""
+    fn = 'sided_distance_backward_cuda'
+    g_arg, p1_arg, p2_arg, idx_arg = (Arg(grad_output, 'grad_output', 1), Arg(p1, 'p1', 2),
+                                      Arg(p2, 'p2', 3), Arg(idx, 'idx', 4))
+    check_all_same_gpu(fn, [g_arg, p1_arg, p2_arg, idx_arg])
+    check_all_contiguous(fn, [g_arg, p1_arg, p2_arg, idx_arg])
+    batch_size, num_p1, num_p2 = p1.size(0), p1.size(1), p2.size(1)
+    check_size(fn, idx_arg, [batch_size, num_p1])
+    check_size(fn, p1_arg, [batch_size, num_p1, 3])
+    check_size(fn, p2_arg, [batch_size, num_p2, 3])
+    check_same_size(fn, idx_arg, g_arg)
+    sfx = _lib.dtype_suffix(p1.dtype, fn, ('f32', 'f64', 'f16'))
+    lib = _lib.load()
+    with torch.cuda.device(p1.device):
+        g1 = torch.zeros_like(p1)
+        g2 = torch.zeros_like(p2)
+        st = getattr(lib, f'kamd_sided_distance_backward_{sfx}')(
+            _lib.stream_ptr(p1.device), batch_size, num_p1, num_p2,
+            _lib.ptr(grad_output), _lib.ptr(p1), _lib.ptr(p2), _lib.ptr(idx), _lib.ptr(g1), _lib.ptr(g2))
+    _lib.check(st, fn)
+    return [g1, g2]
+
+
+def _check_cuda_contig(pairs):
+    # CHECK_CUDA / CHECK_CONTIGUOUS (kaolin/csrc/check.h:22-24), in the reference's order
+    for name, t in pairs:
+        torch_check(t.is_cuda, f'{name} must be a CUDA tensor')
+    for name, t in pairs:
+        torch_check(t.is_contiguous(), f'{name} must be contiguous')
+
+
+def _check_sizes(name, t, sizes, spelled):
+    # CHECK_SIZES (check.h:37-39)
+    torch_check(list(t.shape) == list(sizes), f'{name} must of size {{{spelled}}}')
+
+
+def unbatched_triangle_distance_forward_cuda(points, face_vertices, dist, face_idx, dist_type):
+    """reference: kaolin/csrc/metrics/unbatched_triangle_distance.cpp:43-72 -> None (outputs are
+    caller-allocated: metrics/trianglemesh.py:130-134)"""
+    fn = 'unbatched_triangle_distance_forward_cuda'
+    _check_cuda_contig([('points', points), ('face_vertices', face_vertices), ('dist', dist),
+                        ('face_idx', face_idx), ('dist_type', dist_type)])
+    num_points, num_faces = points.size(0), face_vertices.size(0)
+    _check_sizes('points', points, [num_points, 3], 'num_points, 3')
+    _check_sizes('face_vertices', face_vertices, [num_faces, 3, 3], 'num_faces, 3, 3')
+    _check_sizes('dist', dist, [num_points], 'num_points')
+    _check_sizes('face_idx', face_idx, [num_points], 'num_points')
+    _check_sizes('dist_type', dist_type, [num_points], 'num_points')
+    sfx = _lib.dtype_suffix(points.dtype, fn)
+    torch_check(face_vertices.dtype == points.dtype and dist.dtype == points.dtype,
+                'expected scalar type of points, face_vertices and dist to match')
+    torch_check(face_idx.dtype == torch.long, 'expected scalar type Long but found ' + str(face_idx.dtype))
+    torch_check(dist_type.dtype == torch.int32, 'expected scalar type Int but found ' + str(dist_type.dtype))
+    lib = _lib.load()
+    with torch.cuda.device(points.device):
+        ws = _lib.workspace(
+            lib.kamd_triangle_distance_forward_workspace(num_points, num_faces, points.element_size()),
+            points.device)
+        st = getattr(lib, f'kamd_triangle_distance_forward_{sfx}')(
+            _lib.stream_ptr(points.device), num_points, num_faces, _lib.ptr(points), _lib.ptr(face_vertices),
+            _lib.ptr(dist), _lib.ptr(face_idx), _lib.ptr(dist_type), _lib.ptr(ws))
+    _lib.check(st, fn)
+
+
+def unbatched_triangle_distance_backward_cuda(grad_dist, points, face_vertices, face_idx, dist_type,
+                                              grad_points, grad_face_vertices):
+    """reference: kaolin/csrc/metrics/unbatched_triangle_distance.cpp:74-114 -> None; accumulates into the
+    caller-zeroed grad_points / grad_face_vertices (metrics/trianglemesh.py:144-148)"""
+    fn = 'unbatched_triangle_distance_backward_cuda'
+    _check_cuda_contig([('grad_dist', grad_dist), ('points', points), ('face_vertices', face_vertices),
+                        ('face_idx', face_idx), ('dist_type', dist_type), ('grad_points', grad_points),
+                        ('grad_face_vertices', grad_face_vertices)])
+    num_points, num_faces = points.size(0), face_vertices.size(0)
+    _check_sizes('grad_dist', grad_dist, [num_points], 'num_points')
+    _check_sizes('points', points, [num_points, 3], 'num_points, 3')
+    _check_sizes('face_vertices', face_vertices, [num_faces, 3, 3], 'num_faces, 3, 3')
+    _check_sizes('face_idx', face_idx, [num_points], 'num_points')
+    _check_sizes('dist_type', dist_type, [num_points], 'num_points')
+    _check_sizes('grad_points', grad_points, [num_points, 3], 'num_points, 3')
+    _check_sizes('grad_face_vertices', grad_face_vertices, [num_faces, 3, 3], 'num_faces, 3, 3')
+    sfx = _lib.dtype_suffix(points.dtype, fn)
+    lib = _lib.load()
+    with torch.cuda.device(points.device):
+        st = getattr(lib, f'kamd_triangle_distance_backward_{sfx}')(
+            _lib.stream_ptr(points.device), num_points, num_faces, _lib.ptr(grad_dist), _lib.ptr(points),
+            _lib.ptr(face_vertices), _lib.ptr(face_idx), _lib.ptr(dist_type), _lib.ptr(grad_points),
+            _lib.ptr(grad_face_vertices))
+    _lib.check(st, fn)

@@ -1,0 +1,105 @@
+"""ctypes binding of libkaolin_amd.so (the C ABI declared in include/kaolin_amd.h).
+
+This is the binding a maintainer of the reference would add in place of
+``kaolin/csrc/bindings.cpp:103-115``.  There is NO fallback:
+if the shared library is missing or a symbol cannot be resolved the operator
+fails loudly -- the product never routes through a CPU path.
+"""
+import ctypes
+import os
+import threading
+
+import torch  # noqa: F401  (must be imported first: we share torch's libamdhip64.so.7)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libkaolin_amd.so')
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+_f = ctypes.c_float
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes).  Lists every symbol include/kaolin_amd.h declares;
+# tests/test_abi.py cross-checks this table against the header and the built library.
+SIGNATURES = {
+    'kamd_version': (ctypes.c_char_p, []),
+    'kamd_sided_distance_forward_workspace': (_sz, [_i, _i, _i, _i]),
+    'kamd_rasterize_forward_workspace': (_sz, [_i, _i, _i, _i64]),
+    'kamd_dibr_soft_mask_forward_workspace': (_sz, [_i, _i, _i, _i]),
+    'kamd_triangle_distance_forward_workspace': (_sz, [_i, _i, _i]),
+}
+for _t in ('f32', 'f64', 'f16'):
+    SIGNATURES[f'kamd_sided_distance_forward_{_t}'] = (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp])
+    SIGNATURES[f'kamd_sided_distance_backward_{_t}'] = (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp])
+for _t in ('f32', 'f64'):
+    SIGNATURES[f'kamd_packed_rasterize_forward_{_t}'] = (
+        _i, [_vp, _i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp])
+    SIGNATURES[f'kamd_rasterize_backward_{_t}'] = (
+        _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp])
+    SIGNATURES[f'kamd_dibr_soft_mask_forward_{_t}'] = (
+        _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp])
+    SIGNATURES[f'kamd_dibr_soft_mask_backward_{_t}'] = (
+        _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp])
+    SIGNATURES[f'kamd_triangle_distance_forward_{_t}'] = (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp])
+    SIGNATURES[f'kamd_triangle_distance_backward_{_t}'] = (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+    SIGNATURES[f'kamd_trianglemeshes_to_voxelgrids_{_t}'] = (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp])
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load():
+    """Returns the loaded library (loading it on first use). Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    f'kaolin_amd: {LIB_PATH} is missing -- build it with '
+                    '`python -c "import __graft_entry__ as g; g.build()"` or `make -C kaolin_amd/csrc`. '
+                    'There is no CPU fallback for the HIP operators.')
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def check(status, what):
+    """Maps a non-zero hipError_t returned by the C ABI to RuntimeError (the reference
+    surfaces kernel errors through AT_CUDA_CHECK(cudaGetLastError()))."""
+    if status != 0:
+        raise RuntimeError(f'HIP error {status} in {what}')
+
+
+_PRETTY = {torch.float16: 'Half', torch.float32: 'Float', torch.float64: 'Double', torch.int64: 'Long',
+           torch.int32: 'Int', torch.int16: 'Short', torch.uint8: 'Byte', torch.bfloat16: 'BFloat16',
+           torch.bool: 'Bool', torch.int8: 'Char'}
+
+
+def dtype_suffix(dtype, what, allowed=('f32', 'f64')):
+    s = {torch.float32: 'f32', torch.float64: 'f64', torch.float16: 'f16'}.get(dtype)
+    if s is None or s not in allowed:
+        # reference: AT_ERROR(name, " not implemented for '", toString(TYPE), "'")
+        raise RuntimeError(f'"{what}" not implemented for \'{_PRETTY.get(dtype, dtype)}\'')
+    return s
+
+
+def stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def workspace(nbytes, device):
+    """Scratch for one call, owned by torch's caching allocator (stream-ordered reuse)."""
+    if nbytes <= 0:
+        return None
+    return torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=device)

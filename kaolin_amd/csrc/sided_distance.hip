@@ -1,0 +1,357 @@
+// sided_distance forward / backward for MI355X (gfx950).
+//
+// Replaces kaolin/csrc/metrics/sided_distance_cuda.cu:52-242 (K5, K6) behind the
+// C ABI in include/kaolin_amd.h.  Semantics kept from the reference:
+//   dist[b,i] = min_j d(p1[b,i], p2[b,j]),  d = dx*dx + dy*dy + dz*dz with
+//   dx = p2.x - p1.x (sided_distance_cuda.cu:83-86), idx = LOWEST j attaining
+//   the minimum (strict '<' inside a tile :88,100, strict '>' across tiles :193),
+//   a NaN distance to target 0 sticks (the `k == 0 ||` seed, :88), M == 0 leaves
+//   the at::zeros outputs untouched (sided_distance.cpp:80-81).
+// Arithmetic contract (pinned identically in oracle/kaolin_oracle.c so device and
+// oracle agree bit-for-bit): fp32/fp64 evaluate d = fma(dz,dz, fma(dy,dy, dx*dx))
+// -- the contraction nvcc's default -fmad=true applies to the reference source;
+// fp16 follows c10::Half (float op, round to half after every operation).
+//
+// MI355X design (this is a VALU-bound all-pairs search, 8300 FLOP/B, see
+// DESIGN.md): instead of the reference's fixed 32x16 grid with one query per
+// thread and a global read-modify-write per 512-tile, the fp32 fast path
+//   * keeps Q=4 queries per lane in registers so one broadcast ds_read_b128 of a
+//     target feeds 4 distance evaluations (LDS pipe ~30% busy instead of >100%),
+//   * splits the target set across blockIdx.y so >= 6 workgroups/CU are resident
+//     for any N (100k queries alone are only 390 waves for 1024 SIMDs),
+//   * tracks only the running MIN in the hot loop (v_min3_f32: 0.5 VALU/pair)
+//     and the 16-target chunk in which it last improved (3 VALU per 16 pairs);
+//     the exact lowest index is recovered afterwards by re-evaluating that one
+//     chunk with the identical arithmetic (kernel sd_final_f32).
+// That is 6.7 VALU/pair instead of 9 for the compare+2xselect formulation.
+#include "common.h"
+#include "../../include/kaolin_amd.h"
+
+namespace {
+
+// ---- per-dtype arithmetic ---------------------------------------------------
+template <typename T> struct SdArith;
+template <> struct SdArith<float> {
+  using acc_t = float;
+  static __device__ __forceinline__ float load(const float* p) { return *p; }
+  static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ float dist(float tx, float ty, float tz, float qx, float qy, float qz) {
+    float dx = tx - qx, dy = ty - qy, dz = tz - qz;
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+  }
+  // 2 * (a - b) * g
+  static __device__ __forceinline__ float grad(float a, float b, float g) { return 2.f * (a - b) * g; }
+};
+template <> struct SdArith<double> {
+  using acc_t = double;
+  static __device__ __forceinline__ double load(const double* p) { return *p; }
+  static __device__ __forceinline__ void store(double* p, double v) { *p = v; }
+  static __device__ __forceinline__ double dist(double tx, double ty, double tz, double qx, double qy, double qz) {
+    double dx = tx - qx, dy = ty - qy, dz = tz - qz;
+    return __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+  }
+  static __device__ __forceinline__ double grad(double a, double b, double g) { return 2. * (a - b) * g; }
+};
+template <> struct SdArith<__half> {
+  using acc_t = float;  // half values carried in float, rounded after every op
+  static __device__ __forceinline__ float load(const __half* p) { return __half2float(*p); }
+  static __device__ __forceinline__ void store(__half* p, float v) { *p = __float2half(v); }
+  static __device__ __forceinline__ float dist(float tx, float ty, float tz, float qx, float qy, float qz) {
+    float dx = kamd_hround(tx - qx), dy = kamd_hround(ty - qy), dz = kamd_hround(tz - qz);
+    float xx = kamd_hround(dx * dx), yy = kamd_hround(dy * dy), zz = kamd_hround(dz * dz);
+    return kamd_hround(kamd_hround(xx + yy) + zz);
+  }
+  static __device__ __forceinline__ float grad(float a, float b, float g) {
+    // 2 * (a - b) * g with c10::Half rounding: int*Half -> Half, Half*Half -> Half
+    return kamd_hround(kamd_hround(2.f * kamd_hround(a - b)) * g);
+  }
+};
+
+// ---- generic forward: one query per lane, exact reference semantics ---------
+constexpr int SDG_THREADS = 256;
+constexpr int SDG_TILE = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(SDG_THREADS) void sd_forward_generic(
+    int N, int M, const T* __restrict__ p1, const T* __restrict__ p2,
+    T* __restrict__ dist, int64_t* __restrict__ idx) {
+  using A = SdArith<T>;
+  using acc_t = typename A::acc_t;
+  __shared__ acc_t tile[SDG_TILE * 3];
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * SDG_THREADS + threadIdx.x;
+  const T* P1 = p1 + (size_t)b * N * 3;
+  const T* P2 = p2 + (size_t)b * M * 3;
+  const bool active = i < N;
+  acc_t qx = 0, qy = 0, qz = 0;
+  if (active) {
+    qx = A::load(P1 + (size_t)i * 3 + 0);
+    qy = A::load(P1 + (size_t)i * 3 + 1);
+    qz = A::load(P1 + (size_t)i * 3 + 2);
+  }
+  acc_t best = 0;
+  int best_i = 0;
+  for (int t0 = 0; t0 < M; t0 += SDG_TILE) {
+    const int cnt = min(SDG_TILE, M - t0);
+    __syncthreads();
+    for (int k = threadIdx.x; k < cnt * 3; k += SDG_THREADS) tile[k] = A::load(P2 + (size_t)t0 * 3 + k);
+    __syncthreads();
+    if (active) {
+      for (int k = 0; k < cnt; ++k) {
+        acc_t d = A::dist(tile[k * 3 + 0], tile[k * 3 + 1], tile[k * 3 + 2], qx, qy, qz);
+        if ((t0 + k) == 0 || d < best) {
+          best = d;
+          best_i = t0 + k;
+        }
+      }
+    }
+  }
+  if (active && M > 0) {
+    A::store(dist + (size_t)b * N + i, best);
+    idx[(size_t)b * N + i] = best_i;
+  }
+}
+
+// ---- fp32 fast path -----------------------------------------------------------
+constexpr int SD_THREADS = 256;
+constexpr int SD_Q = 4;        // queries per lane
+constexpr int SD_TILE = 512;   // targets per LDS tile (xyz packed -> 6 KiB)
+constexpr int SD_CHUNK = 16;   // targets per index chunk
+
+__device__ __forceinline__ float sd_min3(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+__global__ __launch_bounds__(SD_THREADS) void sd_main_f32(
+    int B, int N, int M, int Ms, const float* __restrict__ p1, const float* __restrict__ p2,
+    float* __restrict__ part_d, int* __restrict__ part_c) {
+  // Targets sit in LDS exactly as in HBM (xyz xyz ...): 4 targets = 3 float4, so a
+  // 16-target chunk costs 12 broadcast ds_read_b128 (4 LDS cycles each) instead of
+  // 16 ds_read_b96 (8 cycles each).
+  __shared__ __attribute__((aligned(16))) float tile[SD_TILE * 3];
+  const int b = blockIdx.z, s = blockIdx.y;
+  const float* P1 = p1 + (size_t)b * N * 3;
+  const float* P2 = p2 + (size_t)b * M * 3;
+  const int q0 = blockIdx.x * (SD_THREADS * SD_Q) + threadIdx.x;
+
+  float qx[SD_Q], qy[SD_Q], qz[SD_Q], best[SD_Q];
+  int bc[SD_Q];
+#pragma unroll
+  for (int q = 0; q < SD_Q; ++q) {
+    const int j = q0 + q * SD_THREADS;
+    const int jj = j < N ? j : N - 1;
+    qx[q] = P1[(size_t)jj * 3 + 0];
+    qy[q] = P1[(size_t)jj * 3 + 1];
+    qz[q] = P1[(size_t)jj * 3 + 2];
+    best[q] = INFINITY;
+    bc[q] = 0;
+  }
+
+  const int m0 = s * Ms;
+  const int m1 = min(M, m0 + Ms);
+  for (int t0 = m0; t0 < m1; t0 += SD_TILE) {
+    const int cnt = min(SD_TILE, m1 - t0);
+    __syncthreads();
+    {
+      const float* src = P2 + (size_t)t0 * 3;
+#pragma unroll
+      for (int k = threadIdx.x; k < SD_TILE * 3; k += SD_THREADS)
+        tile[k] = k < cnt * 3 ? src[k] : INFINITY;  // padding never wins: d = inf or NaN
+    }
+    __syncthreads();
+    const int nchunks = (cnt + SD_CHUNK - 1) / SD_CHUNK;
+    const int cid0 = t0 / SD_CHUNK;
+    const float4* tile4 = reinterpret_cast<const float4*>(tile);
+    for (int c = 0; c < nchunks; ++c) {
+      float old[SD_Q];
+#pragma unroll
+      for (int q = 0; q < SD_Q; ++q) old[q] = best[q];
+#pragma unroll
+      for (int g = 0; g < SD_CHUNK / 4; ++g) {
+        const float4 a = tile4[(c * (SD_CHUNK / 4) + g) * 3 + 0];
+        const float4 bb = tile4[(c * (SD_CHUNK / 4) + g) * 3 + 1];
+        const float4 cc = tile4[(c * (SD_CHUNK / 4) + g) * 3 + 2];
+#pragma unroll
+        for (int q = 0; q < SD_Q; ++q) {
+          const float d0 = SdArith<float>::dist(a.x, a.y, a.z, qx[q], qy[q], qz[q]);
+          const float d1 = SdArith<float>::dist(a.w, bb.x, bb.y, qx[q], qy[q], qz[q]);
+          const float d2 = SdArith<float>::dist(bb.z, bb.w, cc.x, qx[q], qy[q], qz[q]);
+          const float d3 = SdArith<float>::dist(cc.y, cc.z, cc.w, qx[q], qy[q], qz[q]);
+          best[q] = sd_min3(sd_min3(best[q], d0, d1), d2, d3);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < SD_Q; ++q) bc[q] = best[q] < old[q] ? (cid0 + c) : bc[q];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < SD_Q; ++q) {
+    const int j = q0 + q * SD_THREADS;
+    if (j < N) {
+      const size_t o = ((size_t)s * B + b) * N + j;
+      part_d[o] = best[q];
+      part_c[o] = bc[q];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sd_final_f32(
+    int B, int N, int M, int S, const float* __restrict__ p1, const float* __restrict__ p2,
+    const float* __restrict__ part_d, const int* __restrict__ part_c,
+    float* __restrict__ dist, int64_t* __restrict__ idx) {
+  const size_t total = (size_t)B * N;
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int b = (int)(gid / N);
+  float best = part_d[gid];
+  int c = part_c[gid];
+  for (int s = 1; s < S; ++s) {
+    const float d = part_d[(size_t)s * total + gid];
+    if (d < best) {  // strict: the lower split (lower indices) keeps ties
+      best = d;
+      c = part_c[(size_t)s * total + gid];
+    }
+  }
+  const float qx = p1[gid * 3 + 0], qy = p1[gid * 3 + 1], qz = p1[gid * 3 + 2];
+  const float* T = p2 + (size_t)b * M * 3;
+  const float d0 = SdArith<float>::dist(T[0], T[1], T[2], qx, qy, qz);
+  int found;
+  if (d0 != d0) {  // the reference's `k == 0 ||` seed: a NaN distance to target 0 sticks
+    best = d0;
+    found = 0;
+  } else {
+    const int k0 = c * SD_CHUNK;
+    const int k1 = min(M, k0 + SD_CHUNK);
+    found = k0;
+    for (int k = k0; k < k1; ++k) {
+      const float d = SdArith<float>::dist(T[(size_t)k * 3], T[(size_t)k * 3 + 1], T[(size_t)k * 3 + 2], qx, qy, qz);
+      if (d == best) {
+        found = k;
+        break;
+      }
+    }
+  }
+  dist[gid] = best;
+  idx[gid] = found;
+}
+
+// split plan shared by the workspace query and the launcher
+struct SdPlan {
+  bool fast;
+  int nx, S, Ms;
+};
+inline SdPlan sd_plan(int B, int N, int M) {
+  SdPlan p;
+  p.fast = (long long)N * M >= (1ll << 22) && N >= 1024 && M >= 2 * SD_TILE;
+  p.nx = kamd_cdiv(N, SD_THREADS * SD_Q);
+  const int ntiles = kamd_cdiv(M, SD_TILE);
+  long long want = (long long)KAMD_NUM_CU * 6;  // ~6 resident workgroups per CU
+  int S = (int)((want + (long long)p.nx * B - 1) / ((long long)p.nx * B));
+  if (S < 1) S = 1;
+  if (S > ntiles) S = ntiles;
+  int tiles_per = kamd_cdiv(ntiles, S);
+  p.Ms = tiles_per * SD_TILE;
+  p.S = kamd_cdiv(M, p.Ms);
+  return p;
+}
+
+template <typename T>
+int sd_forward_generic_launch(hipStream_t st, int B, int N, int M, const T* p1, const T* p2, T* dist, int64_t* idx) {
+  if (B <= 0 || N <= 0 || M <= 0) return 0;  // M == 0: outputs keep the caller's zeros
+  dim3 grid(kamd_cdiv(N, SDG_THREADS), B);
+  hipLaunchKernelGGL(sd_forward_generic<T>, grid, dim3(SDG_THREADS), 0, st, N, M, p1, p2, dist, idx);
+  KAMD_RETURN_LAST_ERROR();
+}
+
+// ---- backward (K6) ------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void sd_backward(
+    int N, int M, const T* __restrict__ grad, const T* __restrict__ p1, const T* __restrict__ p2,
+    const int64_t* __restrict__ idx, T* __restrict__ g1, T* __restrict__ g2) {
+  using A = SdArith<T>;
+  using acc_t = typename A::acc_t;
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const size_t main_id = (size_t)b * N + i;
+  const acc_t x1 = A::load(p1 + main_id * 3), y1 = A::load(p1 + main_id * 3 + 1), z1 = A::load(p1 + main_id * 3 + 2);
+  const size_t t = ((size_t)idx[main_id] + (size_t)b * M) * 3;
+  const acc_t x2 = A::load(p2 + t), y2 = A::load(p2 + t + 1), z2 = A::load(p2 + t + 2);
+  const acc_t g = A::load(grad + main_id);
+  A::store(g1 + main_id * 3 + 0, A::grad(x1, x2, g));
+  A::store(g1 + main_id * 3 + 1, A::grad(y1, y2, g));
+  A::store(g1 + main_id * 3 + 2, A::grad(z1, z2, g));
+  T rx, ry, rz;
+  A::store(&rx, A::grad(x2, x1, g));
+  A::store(&ry, A::grad(y2, y1, g));
+  A::store(&rz, A::grad(z2, z1, g));
+  kamd_atomic_add(g2 + t + 0, rx);
+  kamd_atomic_add(g2 + t + 1, ry);
+  kamd_atomic_add(g2 + t + 2, rz);
+}
+
+template <typename T>
+int sd_backward_launch(hipStream_t st, int B, int N, int M, const T* grad, const T* p1, const T* p2,
+                       const int64_t* idx, T* g1, T* g2) {
+  if (B <= 0 || N <= 0 || M <= 0) return 0;
+  dim3 grid(kamd_cdiv(N, 256), B);
+  hipLaunchKernelGGL(sd_backward<T>, grid, dim3(256), 0, st, N, M, grad, p1, p2, idx, g1, g2);
+  KAMD_RETURN_LAST_ERROR();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t kamd_sided_distance_forward_workspace(int B, int N, int M, int elem_size) {
+  if (elem_size != 4 || B <= 0 || N <= 0 || M <= 0) return 0;
+  SdPlan p = sd_plan(B, N, M);
+  if (!p.fast) return 0;
+  return (size_t)p.S * B * N * (sizeof(float) + sizeof(int));
+}
+
+int kamd_sided_distance_forward_f32(void* stream, int B, int N, int M, const float* p1, const float* p2,
+                                    float* dist, int64_t* idx, void* workspace) {
+  hipStream_t st = (hipStream_t)stream;
+  if (B <= 0 || N <= 0 || M <= 0) return 0;
+  SdPlan p = sd_plan(B, N, M);
+  if (!p.fast || workspace == nullptr) return sd_forward_generic_launch<float>(st, B, N, M, p1, p2, dist, idx);
+  float* part_d = (float*)workspace;
+  int* part_c = (int*)(part_d + (size_t)p.S * B * N);
+  hipLaunchKernelGGL(sd_main_f32, dim3(p.nx, p.S, B), dim3(SD_THREADS), 0, st, B, N, M, p.Ms, p1, p2, part_d, part_c);
+  KAMD_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(sd_final_f32, dim3(kamd_cdiv((long long)B * N, 256)), dim3(256), 0, st, B, N, M, p.S, p1, p2,
+                     part_d, part_c, dist, idx);
+  KAMD_RETURN_LAST_ERROR();
+}
+
+int kamd_sided_distance_forward_f64(void* stream, int B, int N, int M, const double* p1, const double* p2,
+                                    double* dist, int64_t* idx, void* workspace) {
+  (void)workspace;
+  return sd_forward_generic_launch<double>((hipStream_t)stream, B, N, M, p1, p2, dist, idx);
+}
+
+int kamd_sided_distance_forward_f16(void* stream, int B, int N, int M, const uint16_t* p1, const uint16_t* p2,
+                                    uint16_t* dist, int64_t* idx, void* workspace) {
+  (void)workspace;
+  return sd_forward_generic_launch<__half>((hipStream_t)stream, B, N, M, (const __half*)p1, (const __half*)p2,
+                                           (__half*)dist, idx);
+}
+
+int kamd_sided_distance_backward_f32(void* stream, int B, int N, int M, const float* grad, const float* p1,
+                                     const float* p2, const int64_t* idx, float* g1, float* g2) {
+  return sd_backward_launch<float>((hipStream_t)stream, B, N, M, grad, p1, p2, idx, g1, g2);
+}
+int kamd_sided_distance_backward_f64(void* stream, int B, int N, int M, const double* grad, const double* p1,
+                                     const double* p2, const int64_t* idx, double* g1, double* g2) {
+  return sd_backward_launch<double>((hipStream_t)stream, B, N, M, grad, p1, p2, idx, g1, g2);
+}
+int kamd_sided_distance_backward_f16(void* stream, int B, int N, int M, const uint16_t* grad, const uint16_t* p1,
+                                     const uint16_t* p2, const int64_t* idx, uint16_t* g1, uint16_t* g2) {
+  return sd_backward_launch<__half>((hipStream_t)stream, B, N, M, (const __half*)grad, (const __half*)p1,
+                                    (const __half*)p2, idx, (__half*)g1, (__half*)g2);
+}
+
+}  // extern "C"
