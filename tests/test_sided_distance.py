@@ -1,0 +1,236 @@
+"""sided_distance / chamfer_distance / f_score.
+
+CPU part (-m "not gpu"): pins oracle/kaolin_oracle.c against the reference's known answers
+(tests/python/kaolin/metrics/test_pointcloud.py:104-112,270-345) and against golden vectors made
+from the reference's own _sided_distance (tests/golden/make_golden.py).
+GPU part (-m gpu): the HIP path through the C ABI vs the oracle (bit-exact dist and idx), the
+reference's KATs, error strings, fp64 gradcheck, ties, edge sizes, full-size properties.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import GOLDEN_DIR
+
+DTYPES = [torch.half, torch.float, torch.double]
+TOL = {torch.half: (1e-3, 1e-3), torch.float: (1e-5, 1e-4), torch.double: (1e-6, 1e-5)}  # (atol, rtol) of the ref tests
+
+P1 = [[[8.8977, 4.1709, 1.2839], [8.5640, 7.7767, 9.4214]],
+      [[0.5431, 6.4495, 11.4914], [3.2126, 8.0865, 3.1018]]]
+P2 = [[[6.9340, 6.1152, 3.4435], [0.1032, 9.8181, 11.3350]],
+      [[11.4006, 2.2154, 7.9589], [4.2586, 1.4133, 7.2606]]]
+KAT_DIST = [[12.3003, 41.1528], [57.0679, 62.9213]]
+KAT_IDX = [[0, 0], [1, 1]]
+
+
+def golden():
+    return np.load(os.path.join(GOLDEN_DIR, 'sided_distance.npz'))
+
+
+# ------------------------------------------------------------------ CPU: oracle pins
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_oracle_kat(dtype):
+    d, i = oracle.sided_distance_forward(torch.tensor(P1, dtype=dtype), torch.tensor(P2, dtype=dtype))
+    atol, rtol = TOL[dtype]
+    assert torch.allclose(d, torch.tensor(KAT_DIST, dtype=dtype), atol=atol, rtol=rtol)
+    assert torch.equal(i, torch.tensor(KAT_IDX))
+
+
+@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
+@pytest.mark.parametrize('dn,dtype', [('f32', torch.float), ('f64', torch.double)])
+def test_oracle_vs_reference_golden(tag, dn, dtype):
+    g = golden()
+    p1, p2 = torch.from_numpy(g[f'{tag}_p1']).to(dtype), torch.from_numpy(g[f'{tag}_p2']).to(dtype)
+    d, i = oracle.sided_distance_forward(p1, p2)
+    atol, rtol = TOL[dtype]
+    assert torch.allclose(d, torch.from_numpy(g[f'{tag}_{dn}_dist']), atol=atol, rtol=rtol)
+    assert torch.equal(i, torch.from_numpy(g[f'{tag}_{dn}_idx']))
+
+
+def test_oracle_omp_equals_serial():
+    torch.manual_seed(3)
+    p1, p2 = torch.rand(2, 700, 3), torch.rand(2, 1300, 3)
+    a = oracle.sided_distance_forward(p1, p2)
+    b = oracle.sided_distance_forward(p1, p2, omp=True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_oracle_backward_matches_autograd_of_definition():
+    torch.manual_seed(0)
+    p1 = torch.randn(2, 20, 3, dtype=torch.double, requires_grad=True)
+    p2 = torch.randn(2, 15, 3, dtype=torch.double, requires_grad=True)
+    d = ((p1[:, :, None] - p2[:, None]) ** 2).sum(-1).min(-1)
+    g = torch.rand(2, 20, dtype=torch.double)
+    (d.values * g).sum().backward()
+    g1, g2 = oracle.sided_distance_backward(g, p1, p2, d.indices)
+    assert torch.allclose(g1, p1.grad) and torch.allclose(g2, p2.grad)
+
+
+def test_oracle_ties_lowest_index_and_empty():
+    p2 = torch.rand(1, 700, 3).repeat(1, 3, 1)
+    p1 = p2[:, :100].clone()
+    d, i = oracle.sided_distance_forward(p1, p2)
+    assert torch.equal(i, torch.arange(100)[None]) and float(d.abs().max()) == 0.
+    d, i = oracle.sided_distance_forward(torch.rand(2, 5, 3), torch.zeros(2, 0, 3))
+    assert float(d.abs().max()) == 0. and int(i.abs().max()) == 0
+
+
+# ------------------------------------------------------------------ GPU: HIP path
+def _pc():
+    from kaolin_amd.metrics import pointcloud as pc
+    return pc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', DTYPES)
+class TestSidedDistanceGPU:
+    def test_kat(self, dtype):
+        pc = _pc()
+        p1, p2 = torch.tensor(P1, dtype=dtype, device='cuda'), torch.tensor(P2, dtype=dtype, device='cuda')
+        d, i = pc.sided_distance(p1, p2)
+        atol, rtol = TOL[dtype]
+        assert torch.allclose(d, torch.tensor(KAT_DIST, dtype=dtype, device='cuda'), atol=atol, rtol=rtol)
+        assert torch.equal(i, torch.tensor(KAT_IDX, device='cuda'))
+
+    @pytest.mark.parametrize('shape', [(2, 1000, 777), (1, 5000, 4099), (3, 1, 1), (1, 2048, 6000), (4, 513, 2)])
+    def test_bit_exact_vs_oracle(self, dtype, shape):
+        pc = _pc()
+        B, N, M = shape
+        torch.manual_seed(0)
+        p1, p2 = torch.rand(B, N, 3).to(dtype), torch.rand(B, M, 3).to(dtype)
+        d_ref, i_ref = oracle.sided_distance_forward(p1, p2)
+        d, i = pc.sided_distance(p1.cuda(), p2.cuda())
+        assert torch.equal(d.cpu(), d_ref)
+        assert torch.equal(i.cpu(), i_ref)
+
+    def test_chamfer_kats(self, dtype):
+        pc = _pc()
+        p1, p2 = torch.tensor(P1, dtype=dtype, device='cuda'), torch.tensor(P2, dtype=dtype, device='cuda')
+        atol, rtol = TOL[dtype]
+        exp = lambda v: torch.tensor(v, dtype=dtype, device='cuda')  # noqa: E731
+        assert torch.allclose(pc.chamfer_distance(p1, p2), exp([72.5838, 151.0809]), atol=atol, rtol=rtol)
+        assert torch.allclose(pc.chamfer_distance(p1, p2, w1=1.3, w2=0.8), exp([71.4303, 150.8620]), atol=atol, rtol=rtol)
+        assert torch.allclose(pc.chamfer_distance(p1, p2, squared=False), exp([11.1704, 17.1130]), atol=atol, rtol=rtol)
+
+    def test_f_score_kats(self, dtype):
+        pc = _pc()
+        gt = torch.tensor(P1, dtype=dtype, device='cuda')
+        pred = torch.tensor([[[8.8914, 4.1788, 1.2176], [8.5291, 7.5513, 9.5412]],
+                             [[0.4010, 6.4602, 11.5183], [3.2977, 8.0325, 3.1180]]], dtype=dtype, device='cuda')
+        atol, rtol = TOL[dtype]
+        assert torch.allclose(pc.f_score(gt, pred, radius=0.2), torch.tensor([0.5, 1], dtype=dtype, device='cuda'), atol=atol, rtol=rtol)
+        assert torch.allclose(pc.f_score(gt, pred, radius=0.12), torch.tensor([0.5, 0.5], dtype=dtype, device='cuda'), atol=atol, rtol=rtol)
+        pred3 = torch.tensor([[[8.8914, 4.1788, 1.2176], [8.5291, 7.5513, 9.5412], [3.7831, 6.0182, 4.1208]],
+                              [[0.4010, 6.4602, 11.5183], [3.2977, 8.0325, 3.1180], [2.4987, 5.8763, 3.1987]]],
+                             dtype=dtype, device='cuda')
+        assert torch.allclose(pc.f_score(gt, pred3, radius=0.2), torch.tensor([0.4, 0.8], dtype=dtype, device='cuda'), atol=atol, rtol=rtol)
+        assert torch.allclose(pc.f_score(gt, pred3, radius=0.12), torch.tensor([0.4, 0.4], dtype=dtype, device='cuda'), atol=atol, rtol=rtol)
+
+    def test_backward_vs_oracle(self, dtype):
+        pc = _pc()
+        torch.manual_seed(0)
+        p1 = (torch.randn(3, 300, 3) * 10).to(dtype)
+        p2 = (torch.randn(3, 200, 3) * 10).to(dtype)
+        a, b = p1.cuda().requires_grad_(), p2.cuda().requires_grad_()
+        d, i = pc.sided_distance(a, b)
+        g = torch.rand(3, 300).to(dtype)
+        (d * g.cuda()).sum().backward()
+        g1, g2 = oracle.sided_distance_backward(g.double(), p1.double(), p2.double(), i.cpu())
+        tol = {torch.half: 2e-2, torch.float: 1e-5, torch.double: 1e-12}[dtype]
+        s1, s2 = float(g1.abs().max()), float(g2.abs().max())
+        assert float((a.grad.cpu().double() - g1).abs().max()) <= tol * s1
+        assert float((b.grad.cpu().double() - g2).abs().max()) <= tol * s2 * (8 if dtype == torch.half else 1)
+
+
+@pytest.mark.gpu
+def test_golden_c1_gpu():
+    """BASELINE config C1 (2k x 2k, seed 0) against the reference's own _sided_distance output."""
+    pc = _pc()
+    g = golden()
+    p1, p2 = torch.from_numpy(g['c_p1']).cuda(), torch.from_numpy(g['c_p2']).cuda()
+    d, i = pc.sided_distance(p1, p2)
+    assert torch.allclose(d.cpu(), torch.from_numpy(g['c_f32_dist']), rtol=1e-5, atol=1e-7)
+    assert torch.equal(i.cpu(), torch.from_numpy(g['c_f32_idx']))
+
+
+@pytest.mark.gpu
+def test_gradcheck_double():
+    pc = _pc()
+    torch.manual_seed(0)
+    p1 = torch.randn(5, 20, 3, dtype=torch.double, device='cuda', requires_grad=True)
+    p2 = torch.randn(5, 15, 3, dtype=torch.double, device='cuda', requires_grad=True)
+    assert torch.autograd.gradcheck(lambda a, b: pc.sided_distance(a, b)[0], (p1, p2), eps=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_fast_path_ties_nan_and_sizes():
+    """fp32 fast path (N*M >= 4M): duplicates resolve to the lowest index; a NaN distance to target 0
+    sticks (sided_distance_cuda.cu:88 `k == 0 ||`); ragged N, M."""
+    pc = _pc()
+    torch.manual_seed(1)
+    p2 = torch.rand(1, 4096, 3).repeat(1, 4, 1)
+    p1 = torch.rand(1, 4099, 3)
+    d_ref, i_ref = oracle.sided_distance_forward(p1, p2)
+    d, i = pc.sided_distance(p1.cuda(), p2.cuda())
+    assert torch.equal(i.cpu(), i_ref) and torch.equal(d.cpu(), d_ref) and int(i.max()) < 4096
+    p2n = torch.rand(1, 5000, 3)
+    p2n[0, 0, 1] = float('nan')
+    p1n = torch.rand(1, 3000, 3)
+    d_ref, i_ref = oracle.sided_distance_forward(p1n, p2n)
+    d, i = pc.sided_distance(p1n.cuda(), p2n.cuda())
+    assert torch.equal(i.cpu(), i_ref) and bool(torch.isnan(d).all()) and bool(torch.isnan(d_ref).all())
+    for (B, N, M) in [(1, 20000, 30011), (2, 1025, 4097), (8, 1024, 1024)]:
+        a, b = torch.rand(B, N, 3), torch.rand(B, M, 3)
+        d_ref, i_ref = oracle.sided_distance_forward(a, b, omp=True)
+        d, i = pc.sided_distance(a.cuda(), b.cuda())
+        assert torch.equal(i.cpu(), i_ref) and torch.equal(d.cpu(), d_ref)
+
+
+@pytest.mark.gpu
+def test_empty_target_keeps_zeros():
+    pc = _pc()
+    d, i = pc.sided_distance(torch.rand(2, 5, 3, device='cuda'), torch.zeros(2, 0, 3, device='cuda'))
+    assert float(d.abs().max()) == 0. and int(i.abs().max()) == 0
+
+
+@pytest.mark.gpu
+def test_error_strings():
+    """ATen checkSize/checkSameGPU/checkSameType texts the reference's tests regex-match
+    (tests/python/kaolin/metrics/test_pointcloud.py:126-151)."""
+    pc = _pc()
+    with pytest.raises(RuntimeError, match=r"Expected tensor of size \[3, 3, 3\], but got tensor of size \[2, 3, 3\] "
+                                           r"for argument #2 'p2' \(while checking arguments for sided_distance_forward_cuda\)"):
+        pc.sided_distance(torch.randn(3, 4, 3, device='cuda'), torch.randn(2, 3, 3, device='cuda'))
+    with pytest.raises(RuntimeError, match=r"Expected tensor of size \[3, 4, 3\], but got tensor of size \[3, 4, 2\] "
+                                           r"for argument #1 'p1' \(while checking arguments for sided_distance_forward_cuda\)"):
+        pc.sided_distance(torch.randn(3, 4, 2, device='cuda'), torch.randn(3, 3, 3, device='cuda'))
+    with pytest.raises(RuntimeError, match=r"Tensor for argument #1 'p1' is on CPU, but expected it to be on GPU"):
+        pc.sided_distance(torch.randn(3, 4, 3), torch.randn(3, 3, 3, device='cuda'))
+    with pytest.raises(RuntimeError, match=r"to have the same type as tensor for argument #2 'p2'"):
+        pc.sided_distance(torch.randn(3, 4, 3, device='cuda'), torch.randn(3, 3, 3, device='cuda', dtype=torch.double))
+
+
+@pytest.mark.gpu
+def test_full_size_properties_100k():
+    """BASELINE config C3 shape (100k x 100k): size-independent properties instead of an oracle run:
+    (i) dist equals the distance to the reported index, recomputed in torch; (ii) no target is closer
+    on a random sample of targets; (iii) a point set against itself gives idx = arange, dist = 0;
+    (iv) permuting the queries permutes the answers."""
+    pc = _pc()
+    torch.manual_seed(0)
+    p1 = torch.rand(1, 100000, 3, device='cuda')
+    p2 = torch.rand(1, 100000, 3, device='cuda')
+    d, i = pc.sided_distance(p1, p2)
+    diff = p2[0, i[0]] - p1[0]
+    assert torch.allclose((diff ** 2).sum(-1), d[0], rtol=1e-5, atol=1e-9)
+    samp = p2[0, torch.randint(0, 100000, (2048,), device='cuda')]
+    dd = ((p1[0, :, None, :] - samp[None]) ** 2).sum(-1).min(-1).values
+    assert bool((d[0] <= dd * (1 + 1e-5)).all())
+    d0, i0 = pc.sided_distance(p1, p1)
+    assert torch.equal(i0[0], torch.arange(100000, device='cuda')) and float(d0.max()) == 0.
+    perm = torch.randperm(100000, device='cuda')
+    dp, ip = pc.sided_distance(p1[:, perm], p2)
+    assert torch.equal(dp, d[:, perm]) and torch.equal(ip, i[:, perm])
