@@ -1,0 +1,1 @@
+from . import testing  # noqa: F401

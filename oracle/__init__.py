@@ -18,10 +18,11 @@ _libs = {}
 
 def build(force=False):
     targets = ['libkaolin_oracle.so', 'libkaolin_oracle_omp.so']
-    src = os.path.join(_HERE, 'kaolin_oracle.c')
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(('.c', '.inc'))]
+    newest = max(os.path.getmtime(f) for f in srcs)
     stale = force or any(
         not os.path.exists(os.path.join(_HERE, t)) or
-        os.path.getmtime(os.path.join(_HERE, t)) < os.path.getmtime(src) for t in targets)
+        os.path.getmtime(os.path.join(_HERE, t)) < newest for t in targets)
     if stale:
         subprocess.run(['make', '-C', _HERE, '-B'] if force else ['make', '-C', _HERE], check=True,
                        stdout=subprocess.DEVNULL)
@@ -76,3 +77,123 @@ def sided_distance_backward(grad, p1, p2, idx):
     f = getattr(lib(False), f'oracle_sided_distance_backward_{_SFX[p1.dtype]}')
     f(ctypes.c_int(B), ctypes.c_int(N), ctypes.c_int(M), _p(grad), _p(p1), _p(p2), _p(idx), _p(g1), _p(g2))
     return g1, g2
+
+
+# ---- DIB-R: the four kernels (reference `_C.render.mesh.*` signatures) ---------------
+def _ci(v):
+    return ctypes.c_int(int(v))
+
+
+def _cf(v):
+    return ctypes.c_float(float(v))
+
+
+def packed_rasterize_forward(height, width, face_vertices_z, face_vertices_image, face_bboxes, face_features,
+                             first_idx_face_per_mesh, multiplier, eps, omp=False):
+    """rasterization.cpp:49-104: allocates sel_idx = -1, weights = 0, interp = 0, runs K1."""
+    z, img, bbox, feat = _cpu(face_vertices_z), _cpu(face_vertices_image), _cpu(face_bboxes), _cpu(face_features)
+    first = _cpu(first_idx_face_per_mesh, torch.long)
+    B, D = first.shape[0] - 1, feat.shape[-1]
+    interp = torch.zeros((B, height, width, D), dtype=z.dtype)
+    sel = torch.full((B, height, width), -1, dtype=torch.long)
+    wts = torch.zeros((B, height, width, 3), dtype=z.dtype)
+    f = getattr(lib(omp), f'oracle_packed_rasterize_forward_{_SFX[z.dtype]}')
+    f(_ci(B), _ci(height), _ci(width), _ci(D), _p(z), _p(img), _p(bbox), _p(feat), _p(first), _cf(multiplier), _cf(eps),
+      _p(interp), _p(sel), _p(wts))
+    return interp, sel, wts
+
+
+def rasterize_backward(grad, face_idx, weights, face_vertices_image, face_features, eps):
+    """rasterization.cpp:106-168 (interpolated_features is accepted by the reference but never read)."""
+    grad, face_idx, weights = _cpu(grad), _cpu(face_idx, torch.long), _cpu(weights)
+    img, feat = _cpu(face_vertices_image), _cpu(face_features)
+    B, H, W, D = grad.shape
+    F = img.shape[1]
+    g_img, g_feat = torch.zeros_like(img), torch.zeros_like(feat)
+    f = getattr(lib(False), f'oracle_rasterize_backward_{_SFX[grad.dtype]}')
+    f(_ci(B), _ci(H), _ci(W), _ci(F), _ci(D), _p(grad), _p(face_idx), _p(weights), _p(img), _p(feat), _cf(eps),
+      _p(g_img), _p(g_feat))
+    return g_img, g_feat
+
+
+def dibr_soft_mask_forward(face_vertices_image, face_large_bboxes, selected_face_idx, sigmainv, knum, multiplier,
+                           omp=False):
+    """dibr_soft_mask.cpp:48-108; face_vertices_image is already multiplied by `multiplier`."""
+    img, bbox, sel = _cpu(face_vertices_image), _cpu(face_large_bboxes), _cpu(selected_face_idx, torch.long)
+    B, F = img.shape[0], img.shape[1]
+    H, W = sel.shape[1], sel.shape[2]
+    soft = torch.zeros((B, H, W), dtype=img.dtype)
+    prob = torch.zeros((B, H, W, knum), dtype=img.dtype)
+    idx = torch.full((B, H, W, knum), -1, dtype=torch.long)
+    typ = torch.zeros((B, H, W, knum), dtype=torch.uint8)
+    f = getattr(lib(omp), f'oracle_dibr_soft_mask_forward_{_SFX[img.dtype]}')
+    f(_ci(B), _ci(H), _ci(W), _ci(F), _ci(knum), _p(img), _p(bbox), _p(sel), _cf(sigmainv), _cf(multiplier),
+      _p(soft), _p(prob), _p(idx), _p(typ))
+    return soft, prob, idx, typ
+
+
+def dibr_soft_mask_backward(grad_soft_mask, soft_mask, selected_face_idx, close_face_prob, close_face_idx,
+                            close_face_dist_type, face_vertices_image, sigmainv, multiplier):
+    """dibr_soft_mask.cpp:110-183; face_vertices_image already scaled."""
+    g, soft, sel = _cpu(grad_soft_mask), _cpu(soft_mask), _cpu(selected_face_idx, torch.long)
+    prob, idx, typ = _cpu(close_face_prob), _cpu(close_face_idx, torch.long), _cpu(close_face_dist_type, torch.uint8)
+    img = _cpu(face_vertices_image)
+    B, F = img.shape[0], img.shape[1]
+    H, W, K = sel.shape[1], sel.shape[2], prob.shape[-1]
+    g_img = torch.zeros_like(img)
+    f = getattr(lib(False), f'oracle_dibr_soft_mask_backward_{_SFX[img.dtype]}')
+    f(_ci(B), _ci(H), _ci(W), _ci(F), _ci(K), _p(g), _p(soft), _p(sel), _p(prob), _p(idx), _p(typ), _p(img),
+      _cf(sigmainv), _cf(multiplier), _p(g_img))
+    return g_img
+
+
+# ---- DIB-R: the Python layers above the kernels (CPU torch, restating the reference's glue) ----
+def rasterize(height, width, face_vertices_z, face_vertices_image, face_features, valid_faces=None,
+              multiplier=1000, eps=1e-8, omp=False):
+    """RasterizeCuda.forward (kaolin/render/mesh/rasterization.py:273-352): pack the valid faces
+    (:292-317), scale by multiplier (:320), per-face bbox (:325-327), K1, map the packed index back to
+    the mesh index and restore -1 (:340-346).  Returns (features, face_idx, weights)."""
+    z, img, feat = _cpu(face_vertices_z), _cpu(face_vertices_image), _cpu(face_features)
+    B, F = z.shape[0], z.shape[1]
+    if valid_faces is None:
+        valid = torch.ones((B, F), dtype=torch.bool)
+    else:
+        valid = _cpu(valid_faces).bool()
+    bi, fi = torch.where(valid)
+    first = torch.zeros(B + 1, dtype=torch.long)
+    first[1:] = torch.cumsum(valid.reshape(B, -1).sum(dim=1), dim=0)
+    pimg = img[bi, fi] * multiplier
+    bbox = torch.cat((pimg.min(dim=1)[0], pimg.max(dim=1)[0]), dim=1)
+    interp, sel, wts = packed_rasterize_forward(height, width, z[bi, fi], pimg, bbox, feat[bi, fi], first,
+                                                multiplier, eps, omp=omp)
+    if fi.numel() > 0:
+        face_idx = fi[(sel + first[:-1].reshape(-1, 1, 1)).clamp(min=0).reshape(-1)].reshape(sel.shape).contiguous()
+    else:
+        face_idx = torch.full_like(sel, -1)
+    face_idx[sel == -1] = -1
+    return interp, face_idx, wts
+
+
+def dibr_soft_mask(face_vertices_image, selected_face_idx, sigmainv=7000, boxlen=0.02, knum=30, multiplier=1000.,
+                   omp=False):
+    """DibrSoftMaskCuda.forward (kaolin/render/mesh/dibr.py:29-55). Returns (soft_mask, prob, idx, type,
+    scaled_vertices)."""
+    img = _cpu(face_vertices_image) * multiplier
+    pmin, pmax = img.min(dim=-2)[0], img.max(dim=-2)[0]
+    bbox = torch.cat([pmin - boxlen * multiplier, pmax + boxlen * multiplier], dim=-1)
+    soft, prob, idx, typ = dibr_soft_mask_forward(img, bbox, selected_face_idx, sigmainv, knum, multiplier, omp=omp)
+    return soft, prob, idx, typ, img
+
+
+def dibr_rasterization(height, width, face_vertices_z, face_vertices_image, face_features, face_normals_z,
+                       sigmainv=7000, boxlen=0.02, knum=30, multiplier=None, eps=None, omp=False):
+    """dibr_rasterization (kaolin/render/mesh/dibr.py:119-209): rasterize with valid = normals_z >= 0,
+    then the soft mask over ALL faces."""
+    mult = 1000 if multiplier is None else multiplier
+    e = 1e-8 if eps is None else eps
+    feats, face_idx, wts = rasterize(height, width, face_vertices_z, face_vertices_image, face_features,
+                                     _cpu(face_normals_z) >= 0., mult, e, omp=omp)
+    soft, prob, idx, typ, simg = dibr_soft_mask(face_vertices_image, face_idx, sigmainv, boxlen, knum,
+                                                1000. if multiplier is None else multiplier, omp=omp)
+    return {'features': feats, 'face_idx': face_idx, 'weights': wts, 'soft_mask': soft, 'close_face_prob': prob,
+            'close_face_idx': idx, 'close_face_dist_type': typ, 'scaled_vertices': simg}

@@ -213,3 +213,19 @@ ORACLE_API void oracle_sided_distance_forward_f16(int B, int N, int M, const uin
   }
 DEFINE_SIDED_BWD(oracle_sided_distance_backward_f32, float)
 DEFINE_SIDED_BWD(oracle_sided_distance_backward_f64, double)
+
+/* ---- DIB-R kernels K1-K4, instantiated for float and double ----------------- */
+#define T float
+#define FN(n) n##_f32
+#define EXPFN expf
+#include "dibr_oracle.inc"
+#undef T
+#undef FN
+#undef EXPFN
+#define T double
+#define FN(n) n##_f64
+#define EXPFN exp
+#include "dibr_oracle.inc"
+#undef T
+#undef FN
+#undef EXPFN

@@ -59,6 +59,126 @@ def sided_distance():
     save('sided_distance', **cases)
 
 
+
+
+# --------------------------------------------------------------------------- DIB-R
+def _model_obj_scene(dtype, batch_size=3, flip=False):
+    """Inputs of the reference's DIB-R tests (tests/python/kaolin/render/mesh/test_rasterization.py:38-119,
+    test_dibr.py:201-263): tests/samples/model.obj normalised to [0,1]^3, 3 cameras, fov pi/4, built with
+    the REFERENCE's own camera functions."""
+    import math
+    sys.path.insert(0, os.path.join(HERE, os.pardir, os.pardir))
+    from kaolin_amd.io import obj as myobj            # plain v / vt / f parser (the data is the reference's)
+    from kaolin_amd.ops.mesh import index_vertices_by_faces
+    cam = _refload.load_reference()['legacy_camera']
+    mesh = myobj.import_mesh(os.path.join(_refload.REF, 'tests/samples/model.obj'))
+    faces, face_uvs_idx = mesh.faces, mesh.face_uvs_idx
+    if flip:
+        faces, face_uvs_idx = torch.flip(faces, dims=(-1,)), torch.flip(face_uvs_idx, dims=(-1,))
+    camera_pos = torch.tensor([[0.5, 0.5, 3.], [2., 2., -2.], [3., 0.5, 0.5]], dtype=dtype)[:batch_size]
+    look_at = torch.full((batch_size, 3), 0.5, dtype=dtype)
+    camera_up = torch.tensor([[0., 1., 0.]], dtype=dtype).repeat(batch_size, 1)
+    proj = cam.generate_perspective_projection(fovyangle=math.pi / 4., dtype=dtype)
+    v = mesh.vertices.to(dtype).unsqueeze(0)
+    vmin, vmax = v.min(dim=1, keepdim=True)[0], v.max(dim=1, keepdim=True)[0]
+    v = (v - vmin) / (vmax - vmin)
+    rot, trans = cam.generate_rotate_translate_matrices(camera_pos, look_at, camera_up)
+    v_cam = cam.rotate_translate_points(v, rot, trans)
+    v_img = cam.perspective_camera(v_cam, proj)
+    fz = index_vertices_by_faces(v_cam[:, :, -1:], faces).squeeze(-1)
+    fimg = index_vertices_by_faces(v_img, faces)
+    fuv = index_vertices_by_faces(mesh.uvs.unsqueeze(0).to(dtype), face_uvs_idx).repeat(batch_size, 1, 1, 1)
+    zmin = fz.reshape(batch_size, -1).min(dim=1, keepdim=True)[0]
+    zmax = fz.reshape(batch_size, -1).max(dim=1, keepdim=True)[0]
+    valid = torch.all(fz < ((zmin + zmax) / 2.).unsqueeze(-1), dim=-1)
+    rr = torch.stack([v_cam[:, :, -1].min(dim=1)[0] - 1e-2, v_cam[:, :, -1].max(dim=1)[0] + 1e-2], dim=-1)
+    return fz, fimg, fuv, valid, rr
+
+
+@section
+def rasterize():
+    """reference oracle: _naive_deftet_sparse_render(knum=1) (kaolin/render/mesh/deftet.py:101-267) on the
+    fixtures of test_rasterization.py:137-158 (32x32, model.obj, 3 cameras, flip, valid_faces)."""
+    deftet = _refload.load_reference()['deftet']
+    H = W = 32
+    out = {}
+    for dn, dtype in (('f32', torch.float), ('f64', torch.double)):
+        for flip in (False, True):
+            fz, fimg, fuv, valid, rr = _model_obj_scene(dtype, 3, flip)
+            x = (2 * torch.arange(W, dtype=dtype) + 1 - W) / W
+            y = (H - 2 * torch.arange(H, dtype=dtype) - 1.) / H
+            pix = torch.stack([x.reshape(1, 1, -1).repeat(3, H, 1), y.reshape(1, -1, 1).repeat(3, 1, W)],
+                              dim=-1).reshape(3, -1, 2)
+            ranges = rr.unsqueeze(1).repeat(1, H * W, 1)
+            tag = f'{dn}_flip{int(flip)}'
+            out[tag + '_z'], out[tag + '_img'], out[tag + '_uv'], out[tag + '_valid'] = fz, fimg, fuv, valid
+            for wv in (False, True):
+                kw = {'valid_faces': valid} if wv else {}
+                feats, idx = deftet._naive_deftet_sparse_render(pix, ranges, fz, fimg, fuv, 1, **kw)
+                out[f'{tag}_valid{int(wv)}_face_idx'] = idx.reshape(3, H, W).to(torch.int32)
+                out[f'{tag}_valid{int(wv)}_feat'] = feats.reshape(3, H, W, 2)
+    save('rasterize', **out)
+
+
+@section
+def rasterize_backward():
+    """Autograd through the reference's torch oracle (_naive_deftet_sparse_render, knum=1) with a seeded
+    grad_out, as test_rasterization.py:190-233 does; float64 only (the reference compares at rtol 1e-3 /
+    atol 1e-2 (vertices), 1e-3 (features))."""
+    deftet = _refload.load_reference()['deftet']
+    H = W = 32
+    dtype = torch.double
+    out = {}
+    for flip in (False, True):
+        fz, fimg, fuv, valid, rr = _model_obj_scene(dtype, 3, flip)
+        x = (2 * torch.arange(W, dtype=dtype) + 1 - W) / W
+        y = (H - 2 * torch.arange(H, dtype=dtype) - 1.) / H
+        pix = torch.stack([x.reshape(1, 1, -1).repeat(3, H, 1), y.reshape(1, -1, 1).repeat(3, 1, W)],
+                          dim=-1).reshape(3, -1, 2)
+        ranges = rr.unsqueeze(1).repeat(1, H * W, 1)
+        a = fimg.clone().requires_grad_()
+        u = fuv.clone().requires_grad_()
+        feats, idx = deftet._naive_deftet_sparse_render(pix, ranges, fz, a, u, 1)
+        torch.manual_seed(7)
+        grad_out = torch.rand(3, H, W, 2, dtype=dtype)
+        feats.reshape(3, H, W, 2).backward(grad_out)
+        tag = f'flip{int(flip)}'
+        out[tag + '_grad_out'], out[tag + '_g_img'], out[tag + '_g_uv'] = grad_out, a.grad, u.grad
+    save('rasterize_backward', **out)
+
+
+def _dibr_gt(sub, stem, H, W, sigmainv, boxlen):
+    return torch.load(os.path.join(_refload.REF, 'tests/samples/dibr', sub, f'{stem}_{H}_{W}_{int(sigmainv)}_{boxlen}.pt'),
+                      map_location='cpu')
+
+
+@section
+def dibr_soft_mask():
+    """Golden tensors produced by the reference's CUDA kernels (Kaolin v0.10.0), shipped in
+    tests/samples/dibr/{simple,sphere}/*.pt and used by test_dibr.py:41-394; repacked losslessly
+    (float64 kept, idx -> int16 0-based, type -> uint8) together with the sphere inputs built by
+    the reference's camera code."""
+    H, W = 35, 31
+    out = {}
+    for sub, boxlens in (('simple', (0.02, 0.2)), ('sphere', (0.02, 0.01))):
+        for sigmainv in (7000, 70):
+            for boxlen in boxlens:
+                tag = f'{sub}_{sigmainv}_{boxlen}'
+                out[tag + '_soft_mask'] = _dibr_gt(sub, 'soft_mask', H, W, sigmainv, boxlen)
+                out[tag + '_idx'] = (_dibr_gt(sub, 'close_face_idx', H, W, sigmainv, boxlen).long() - 1).to(torch.int16)
+                out[tag + '_prob'] = _dibr_gt(sub, 'close_face_dist', H, W, sigmainv, boxlen)
+                out[tag + '_type'] = _dibr_gt(sub, 'close_face_dist_type', H, W, sigmainv, boxlen).to(torch.uint8)
+                out[tag + '_grad'] = _dibr_gt(sub, 'grad_face_vertices_image', H, W, sigmainv, boxlen)
+    for dn, dtype in (('f32', torch.float), ('f64', torch.double)):
+        for flip in (False, True):
+            fz, fimg, _, _, _ = _model_obj_scene(dtype, 3, flip)
+            out[f'sphere_in_{dn}_flip{int(flip)}_z'] = fz
+            out[f'sphere_in_{dn}_flip{int(flip)}_img'] = fimg
+    out['simple_new_face_idx'] = torch.load(os.path.join(_refload.REF, 'tests/samples/dibr/simple/new_face_idx_35_31.pt'),
+                                            map_location='cpu').to(torch.int16)
+    save('dibr_soft_mask', **out)
+
+
 if __name__ == '__main__':
     todo = sys.argv[1:] or list(SECTIONS)
     for s in todo:
