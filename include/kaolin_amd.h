@@ -80,7 +80,7 @@ int kamd_sided_distance_backward_f16(void* stream, int B, int N, int M,
 /* sel_idx (B,H,W) int64 relative to the mesh's first packed face (-1 none),  */
 /* weights (B,H,W,3).  `workspace`: kamd_rasterize_forward_workspace bytes.   */
 /* ------------------------------------------------------------------------- */
-size_t kamd_rasterize_forward_workspace(int B, int H, int W, int64_t total_faces);
+size_t kamd_rasterize_forward_workspace(int B, int H, int W, int64_t total_faces, int elem_size);
 int kamd_packed_rasterize_forward_f32(void* stream, int B, int H, int W, int D,
                                       int64_t total_faces,
                                       const float* z, const float* img, const float* bbox,
@@ -120,7 +120,7 @@ int kamd_rasterize_backward_f64(void* stream, int B, int H, int W, int F, int D,
 /* Outputs fully written: soft_mask (B,H,W), prob (B,H,W,K) (0 fill),         */
 /* idx (B,H,W,K) int64 (-1 fill), type (B,H,W,K) uint8 (0 fill).              */
 /* ------------------------------------------------------------------------- */
-size_t kamd_dibr_soft_mask_forward_workspace(int B, int H, int W, int F);
+size_t kamd_dibr_soft_mask_forward_workspace(int B, int H, int W, int F, int elem_size);
 int kamd_dibr_soft_mask_forward_f32(void* stream, int B, int H, int W, int F, int K,
                                     const float* img, const float* large_bbox,
                                     const int64_t* sel_idx, float sigmainv, float multiplier,

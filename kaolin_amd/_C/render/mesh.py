@@ -1,0 +1,152 @@
+"""Host shims for ``kaolin._C.render.mesh`` (bindings.cpp:109-115): same names, argument order,
+allocation rules and ATen check strings; the work is done by libkaolin_amd.so."""
+import torch
+
+from ... import _lib
+from ..._checks import Arg, check_all_same_gpu, check_all_contiguous, check_size
+
+
+def packed_rasterize_forward_cuda(height, width, face_vertices_z, face_vertices_image, face_bboxes,
+                                  face_features, first_idx_face_per_mesh, multiplier, eps):
+    """reference: kaolin/csrc/render/mesh/rasterization.cpp:49-104
+    -> [interpolated_features (B,H,W,D), selected_face_idx (B,H,W) int64, output_weights (B,H,W,3)]"""
+    fn = 'packed_rasterize_forward_cuda'
+    args = [Arg(face_vertices_z, 'face_vertices_z', 3), Arg(face_vertices_image, 'face_vertices_image', 4),
+            Arg(face_bboxes, 'face_bboxes', 5), Arg(face_features, 'face_features', 6),
+            Arg(first_idx_face_per_mesh, 'first_idx_face_per_mesh', 7)]
+    check_all_same_gpu(fn, args)
+    check_all_contiguous(fn, args)
+    num_faces = face_vertices_z.size(0)
+    batch_size = first_idx_face_per_mesh.size(0) - 1
+    feat_dim = face_features.size(2)
+    check_size(fn, args[0], [num_faces, 3])
+    check_size(fn, args[1], [num_faces, 3, 2])
+    check_size(fn, args[2], [num_faces, 4])
+    check_size(fn, args[3], [num_faces, 3, feat_dim])
+    check_size(fn, args[4], [batch_size + 1])
+    dtype, device = face_vertices_z.dtype, face_vertices_z.device
+    sfx = _lib.dtype_suffix(dtype, 'packed_rasterize_forward_cuda')
+    for a in args[1:4]:
+        if a.t.dtype != dtype:
+            raise RuntimeError(f'expected scalar type {_lib._PRETTY[dtype]} but found {_lib._PRETTY.get(a.t.dtype, a.t.dtype)}')
+    if first_idx_face_per_mesh.dtype != torch.long:
+        raise RuntimeError(f'expected scalar type Long but found {_lib._PRETTY.get(first_idx_face_per_mesh.dtype)}')
+    lib = _lib.load()
+    with torch.cuda.device(device):
+        # every element of the three outputs is written by the kernel (uncovered pixels: -1 / 0 / 0),
+        # which is what at::full(-1) / at::zeros give in the reference
+        sel = torch.empty((batch_size, height, width), dtype=torch.long, device=device)
+        wts = torch.empty((batch_size, height, width, 3), dtype=dtype, device=device)
+        interp = torch.empty((batch_size, height, width, feat_dim), dtype=dtype, device=device)
+        ws = _lib.workspace(lib.kamd_rasterize_forward_workspace(batch_size, height, width, num_faces,
+                                                                 face_vertices_z.element_size()), device)
+        st = getattr(lib, f'kamd_packed_rasterize_forward_{sfx}')(
+            _lib.stream_ptr(device), batch_size, height, width, feat_dim, num_faces,
+            _lib.ptr(face_vertices_z), _lib.ptr(face_vertices_image), _lib.ptr(face_bboxes), _lib.ptr(face_features),
+            _lib.ptr(first_idx_face_per_mesh), float(multiplier), float(eps),
+            _lib.ptr(interp), _lib.ptr(sel), _lib.ptr(wts), _lib.ptr(ws))
+    _lib.check(st, fn)
+    return [interp, sel, wts]
+
+
+def rasterize_backward_cuda(grad_interpolated_features, interpolated_features, selected_face_idx, output_weights,
+                            face_vertices_image, face_features, eps):
+    """reference: rasterization.cpp:106-168 -> [grad_face_vertices_image (B,F,3,2), grad_face_features (B,F,3,D)]"""
+    fn = 'rasterize_backward_cuda'
+    args = [Arg(grad_interpolated_features, 'grad_interpolated_features', 1),
+            Arg(interpolated_features, 'interpolated_features', 2),
+            Arg(selected_face_idx, 'selected_face_idx', 3), Arg(output_weights, 'output_weights', 4),
+            Arg(face_vertices_image, 'face_vertices_image', 5), Arg(face_features, 'face_features', 6)]
+    check_all_same_gpu(fn, args)
+    check_all_contiguous(fn, args)
+    batch_size, height, width, feat_dim = (grad_interpolated_features.size(0), grad_interpolated_features.size(1),
+                                           grad_interpolated_features.size(2), grad_interpolated_features.size(3))
+    num_faces = face_vertices_image.size(1)
+    check_size(fn, args[0], [batch_size, height, width, feat_dim])
+    check_size(fn, args[1], [batch_size, height, width, feat_dim])
+    check_size(fn, args[2], [batch_size, height, width])
+    check_size(fn, args[3], [batch_size, height, width, 3])
+    check_size(fn, args[4], [batch_size, num_faces, 3, 2])
+    check_size(fn, args[5], [batch_size, num_faces, 3, feat_dim])
+    dtype, device = grad_interpolated_features.dtype, grad_interpolated_features.device
+    sfx = _lib.dtype_suffix(dtype, 'rasterize_backward_cuda')
+    lib = _lib.load()
+    with torch.cuda.device(device):
+        g_img = torch.zeros_like(face_vertices_image)
+        g_feat = torch.zeros_like(face_features)
+        st = getattr(lib, f'kamd_rasterize_backward_{sfx}')(
+            _lib.stream_ptr(device), batch_size, height, width, num_faces, feat_dim,
+            _lib.ptr(grad_interpolated_features), _lib.ptr(selected_face_idx), _lib.ptr(output_weights),
+            _lib.ptr(face_vertices_image), _lib.ptr(face_features), float(eps), _lib.ptr(g_img), _lib.ptr(g_feat))
+    _lib.check(st, fn)
+    return [g_img, g_feat]
+
+
+def dibr_soft_mask_forward_cuda(face_vertices_image, face_large_bboxes, selected_face_idx, sigmainv, knum,
+                                multiplier):
+    """reference: kaolin/csrc/render/mesh/dibr_soft_mask.cpp:48-108
+    -> [soft_mask (B,H,W), close_face_prob (B,H,W,K), close_face_idx (B,H,W,K) int64,
+        close_face_dist_type (B,H,W,K) uint8]; face_vertices_image is already scaled by `multiplier`."""
+    fn = 'dibr_soft_mask_forward_cuda'
+    args = [Arg(face_vertices_image, 'face_vertices_image', 1), Arg(face_large_bboxes, 'face_bboxes', 2),
+            Arg(selected_face_idx, 'selected_face_idx', 3)]
+    check_all_same_gpu(fn, args)
+    check_all_contiguous(fn, args)
+    batch_size, num_faces = face_vertices_image.size(0), face_vertices_image.size(1)
+    height, width = selected_face_idx.size(1), selected_face_idx.size(2)
+    check_size(fn, args[0], [batch_size, num_faces, 3, 2])
+    check_size(fn, args[1], [batch_size, num_faces, 4])
+    check_size(fn, args[2], [batch_size, height, width])
+    dtype, device = face_vertices_image.dtype, face_vertices_image.device
+    sfx = _lib.dtype_suffix(dtype, 'dibr_soft_mask_forward_cuda')
+    knum = int(knum)
+    lib = _lib.load()
+    with torch.cuda.device(device):
+        # the library initialises the K-buffers itself (prob 0, idx -1, type 0) in one streaming pass
+        soft_mask = torch.empty((batch_size, height, width), dtype=dtype, device=device)
+        prob = torch.empty((batch_size, height, width, knum), dtype=dtype, device=device)
+        idx = torch.empty((batch_size, height, width, knum), dtype=torch.long, device=device)
+        typ = torch.empty((batch_size, height, width, knum), dtype=torch.uint8, device=device)
+        ws = _lib.workspace(lib.kamd_dibr_soft_mask_forward_workspace(batch_size, height, width, num_faces,
+                                                                      face_vertices_image.element_size()), device)
+        st = getattr(lib, f'kamd_dibr_soft_mask_forward_{sfx}')(
+            _lib.stream_ptr(device), batch_size, height, width, num_faces, knum,
+            _lib.ptr(face_vertices_image), _lib.ptr(face_large_bboxes), _lib.ptr(selected_face_idx),
+            float(sigmainv), float(multiplier), _lib.ptr(soft_mask), _lib.ptr(prob), _lib.ptr(idx), _lib.ptr(typ),
+            _lib.ptr(ws))
+    _lib.check(st, fn)
+    return [soft_mask, prob, idx, typ]
+
+
+def dibr_soft_mask_backward_cuda(grad_soft_mask, soft_mask, selected_face_idx, close_face_prob, close_face_idx,
+                                 close_face_dist_type, face_vertices_image, sigmainv, multiplier):
+    """reference: dibr_soft_mask.cpp:110-183 -> grad_face_vertices_image (B,F,3,2) (w.r.t. the UNSCALED input)"""
+    fn = 'dibr_soft_mask_backward_cuda'
+    args = [Arg(grad_soft_mask, 'grad_soft_mask', 1), Arg(soft_mask, 'soft_mask', 2),
+            Arg(selected_face_idx, 'selected_face_idx', 3), Arg(close_face_prob, 'close_face_prob', 4),
+            Arg(close_face_idx, 'close_face_idx', 5), Arg(close_face_dist_type, 'close_face_dist_type', 6),
+            Arg(face_vertices_image, 'face_vertices_image', 7)]
+    check_all_same_gpu(fn, args)
+    check_all_contiguous(fn, args)
+    batch_size, num_faces = face_vertices_image.size(0), face_vertices_image.size(1)
+    height, width = selected_face_idx.size(1), selected_face_idx.size(2)
+    knum = close_face_idx.size(-1)
+    check_size(fn, args[0], [batch_size, height, width])
+    check_size(fn, args[1], [batch_size, height, width])
+    check_size(fn, args[2], [batch_size, height, width])
+    check_size(fn, args[3], [batch_size, height, width, knum])
+    check_size(fn, args[4], [batch_size, height, width, knum])
+    check_size(fn, args[5], [batch_size, height, width, knum])
+    check_size(fn, args[6], [batch_size, num_faces, 3, 2])
+    dtype, device = face_vertices_image.dtype, face_vertices_image.device
+    sfx = _lib.dtype_suffix(dtype, 'dibr_soft_mask_backward_cuda')
+    lib = _lib.load()
+    with torch.cuda.device(device):
+        g_img = torch.zeros_like(face_vertices_image)
+        st = getattr(lib, f'kamd_dibr_soft_mask_backward_{sfx}')(
+            _lib.stream_ptr(device), batch_size, height, width, num_faces, knum,
+            _lib.ptr(grad_soft_mask), _lib.ptr(soft_mask), _lib.ptr(selected_face_idx), _lib.ptr(close_face_prob),
+            _lib.ptr(close_face_idx), _lib.ptr(close_face_dist_type), _lib.ptr(face_vertices_image),
+            float(sigmainv), float(multiplier), _lib.ptr(g_img))
+    _lib.check(st, fn)
+    return g_img

@@ -25,8 +25,8 @@ _sz = ctypes.c_size_t
 SIGNATURES = {
     'kamd_version': (ctypes.c_char_p, []),
     'kamd_sided_distance_forward_workspace': (_sz, [_i, _i, _i, _i]),
-    'kamd_rasterize_forward_workspace': (_sz, [_i, _i, _i, _i64]),
-    'kamd_dibr_soft_mask_forward_workspace': (_sz, [_i, _i, _i, _i]),
+    'kamd_rasterize_forward_workspace': (_sz, [_i, _i, _i, _i64, _i]),
+    'kamd_dibr_soft_mask_forward_workspace': (_sz, [_i, _i, _i, _i, _i]),
     'kamd_triangle_distance_forward_workspace': (_sz, [_i, _i, _i]),
 }
 for _t in ('f32', 'f64', 'f16'):

@@ -14,8 +14,8 @@
 #define KAMD_RETURN_LAST_ERROR() return (int)hipGetLastError()
 #define KAMD_CHECK(expr)                      \
   do {                                        \
-    hipError_t _e = (expr);                   \
-    if (_e != hipSuccess) return (int)_e;     \
+    int _e = (int)(expr);                     \
+    if (_e != 0) return _e;                   \
   } while (0)
 
 static inline int kamd_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,262 @@
+// DIB-R rasterizer forward / backward for MI355X (gfx950).
+//
+// Replaces kaolin/csrc/render/mesh/rasterization_cuda.cu:43-236 (K1) and :238-442 (K2) behind the C ABI
+// of include/kaolin_amd.h.  Semantics kept from the reference (restated in oracle/dibr_oracle.inc):
+//   K1  per pixel, faces in ascending packed index: half-open bbox reject, edge functions on
+//       (vertex - pixel), norm += copysign((double)eps, norm), inside iff all w >= 0,
+//       z0 = w0*az + w1*bz + w2*cz, strictly larger z0 wins (ties keep the lowest index).
+//   K2  per covered pixel: grad*w into the face's 3xD feature slots, barycentric Jacobian into its
+//       3x2 vertex slots (atomic accumulation into caller-zeroed outputs).
+// Arithmetic: compiled with -ffp-contract=off, every expression in the reference's operand order and
+// types, so face_idx is bit-exact against the oracle.
+//
+// MI355X design: see tile_bins.h.  K1 is two launches, bin_faces_kernel + raster_tile_kernel; every
+// output element is written by raster_tile_kernel (uncovered pixels get -1 / 0), so no pre-fill pass over
+// the G-buffer is needed.  A 16x4-pixel sub-tile per wavefront makes each row of the G-buffer a 128-B
+// (idx), 192-B (weights) or 64*D/4-B (features) contiguous store per wavefront.
+#include "common.h"
+#include "tile_bins.h"
+#include "../../include/kaolin_amd.h"
+
+namespace {
+using namespace kamd;
+
+template <typename T> struct RasterCap;  // faces staged in LDS per round (32 KiB of records)
+template <> struct RasterCap<float> { static constexpr int value = 512; };
+template <> struct RasterCap<double> { static constexpr int value = 256; };
+
+template <typename T>
+__global__ __launch_bounds__(TILE_THREADS) void raster_tile_kernel(
+    int B, int F_dense, const int64_t* __restrict__ first, TileGeom g, int D, float multiplier, float eps,
+    const T* __restrict__ rec, const unsigned int* __restrict__ masks, const T* __restrict__ feat,
+    T* __restrict__ interp, int64_t* __restrict__ sel_idx, T* __restrict__ weights) {
+  constexpr int CAP = RasterCap<T>::value;
+  __shared__ __attribute__((aligned(16))) T s_bbox[CAP * 4];
+  __shared__ __attribute__((aligned(16))) T s_rest[CAP * 12];  // a.xy b.xy c.xy z.abc pad3
+  __shared__ int s_ids[CAP];
+  __shared__ int s_scan[TILE_THREADS / 64 + 1];
+
+  const int b = blockIdx.x % B;  // consecutive workgroups -> consecutive XCDs: with B % 8 == 0 a view stays on one XCD's L2
+  const int tile = blockIdx.x / B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t first_b = first ? first[b] : (int64_t)b * F_dense;
+  const int n_b = first ? (int)(first[b + 1] - first_b) : F_dense;
+  const int stride_b = (n_b + 31) / 32;
+  const unsigned int* tmask = masks + mask_base(g.ntiles, first_b, b, tile, stride_b);
+
+  const int tile_x = (tile % g.tiles_x) * TILE_W, tile_y = (tile / g.tiles_x) * TILE_H;
+  const int sub_x = tile_x + (wave & 1) * SUB_W, sub_y = tile_y + (wave >> 1) * SUB_H;
+  const int col = sub_x + (lane & 15), row = sub_y + (lane >> 4);
+  const bool in_image = col < g.W && row < g.H;
+  const T x0 = pixel_x(multiplier, g.W, col);
+  const T y0 = pixel_y(multiplier, g.H, row);
+  // sub-tile extent in pixel-centre coordinates (clamped to the image); x grows with col, y falls with row
+  const T sx_min = pixel_x(multiplier, g.W, sub_x), sx_max = pixel_x(multiplier, g.W, min(sub_x + SUB_W, g.W) - 1);
+  const T sy_max = pixel_y(multiplier, g.H, sub_y), sy_min = pixel_y(multiplier, g.H, min(sub_y + SUB_H, g.H) - 1);
+  const bool sub_in_image = sub_x < g.W && sub_y < g.H;
+
+  T best_z = -INFINITY, bw0 = 0, bw1 = 0, bw2 = 0;
+  int best = -1;
+
+  for (int seg0 = 0; seg0 < stride_b; seg0 += TILE_THREADS) {
+    const int wi = seg0 + tid;
+    unsigned int word = wi < stride_b ? tmask[wi] : 0u;
+    int total;
+    const int excl = block_exclusive_scan(__popc(word), s_scan, &total);
+    for (int c0 = 0; c0 < total; c0 += CAP) {
+      __syncthreads();  // previous round's readers are done with the LDS lists
+      {
+        unsigned int wv = word;
+        int pos = excl;
+        while (wv) {
+          const int bit = __ffs(wv) - 1;
+          wv &= wv - 1;
+          if (pos >= c0 && pos < c0 + CAP) s_ids[pos - c0] = wi * 32 + bit;
+          ++pos;
+        }
+      }
+      __syncthreads();
+      const int n = min(CAP, total - c0);
+      for (int i = tid; i < n * REC_STRIDE; i += TILE_THREADS) {
+        const int k = i / REC_STRIDE, e = i % REC_STRIDE;
+        const T v = rec[((size_t)first_b + s_ids[k]) * REC_STRIDE + e];
+        if (e < 4)
+          s_bbox[k * 4 + e] = v;
+        else
+          s_rest[k * 12 + (e - 4)] = v;
+      }
+      __syncthreads();
+      if (sub_in_image) {
+        for (int k0 = 0; k0 < n; k0 += 64) {
+          const int k = k0 + lane;
+          bool keep = false;
+          if (k < n) {
+            const T xmin = s_bbox[k * 4 + 0], ymin = s_bbox[k * 4 + 1], xmax = s_bbox[k * 4 + 2], ymax = s_bbox[k * 4 + 3];
+            // a face is dropped only if NO pixel centre of the sub-tile can pass the reference's reject test
+            keep = !(sx_max < xmin || sx_min >= xmax || sy_max < ymin || sy_min >= ymax);
+          }
+          unsigned long long m = __ballot(keep);
+          while (m) {
+            const int j = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int kk = k0 + j;
+            const T xmin = s_bbox[kk * 4 + 0], ymin = s_bbox[kk * 4 + 1], xmax = s_bbox[kk * 4 + 2], ymax = s_bbox[kk * 4 + 3];
+            if (x0 < xmin || x0 >= xmax || y0 < ymin || y0 >= ymax) continue;
+            const T* v = s_rest + kk * 12;
+            const T aex = v[0] - x0, aey = v[1] - y0;
+            const T bex = v[2] - x0, bey = v[3] - y0;
+            const T cex = v[4] - x0, cey = v[5] - y0;
+            T w0 = bex * cey - bey * cex;
+            T w1 = cex * aey - cey * aex;
+            T w2 = aex * bey - aey * bex;
+            T norm = w0 + w1 + w2;
+            norm = (T)((double)norm + copysign((double)eps, (double)norm));
+            w0 /= norm;
+            w1 /= norm;
+            w2 /= norm;
+            if (w0 < 0. || w1 < 0. || w2 < 0.) continue;
+            const T z0 = w0 * v[6] + w1 * v[7] + w2 * v[8];
+            if (z0 <= best_z) continue;
+            best_z = z0;
+            best = s_ids[kk];
+            bw0 = w0;
+            bw1 = w1;
+            bw2 = w2;
+          }
+        }
+      }
+    }
+  }
+
+  if (!in_image) return;
+  const size_t p = ((size_t)b * g.H + row) * g.W + col;
+  sel_idx[p] = best;  // relative to the mesh's first packed face, -1 = no face
+  weights[p * 3 + 0] = bw0;
+  weights[p * 3 + 1] = bw1;
+  weights[p * 3 + 2] = bw2;
+  if (best >= 0) {
+    const T* ff = feat + ((size_t)first_b + best) * 3 * D;
+    for (int d = 0; d < D; ++d) interp[p * D + d] = bw0 * ff[d] + bw1 * ff[D + d] + bw2 * ff[2 * D + d];
+  } else {
+    for (int d = 0; d < D; ++d) interp[p * D + d] = 0;
+  }
+}
+
+// ---- K2 -------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void raster_backward_kernel(
+    long long total_pixels, int P, int F, int D, const T* __restrict__ grad, const int64_t* __restrict__ face_idx,
+    const T* __restrict__ weights, const T* __restrict__ img, const T* __restrict__ feat, float eps,
+    T* __restrict__ g_img, T* __restrict__ g_feat) {
+  const long long tp = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (tp >= total_pixels) return;
+  const int64_t f = face_idx[tp];
+  if (f < 0) return;
+  const int b = (int)(tp / P);
+  const size_t tf = (size_t)b * F + (size_t)f;
+  const T* g = grad + tp * D;
+  const T aw = weights[tp * 3 + 0], bw = weights[tp * 3 + 1], cw = weights[tp * 3 + 2];
+  const T w3[3] = {aw, bw, cw};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    for (int d = 0; d < D; ++d) kamd_atomic_add(g_feat + (tf * 3 + i) * D + d, (T)(g[d] * w3[i]));
+
+  const T* v = img + tf * 6;
+  const T ax = v[0], ay = v[1], bx = v[2], by = v[3], cx = v[4], cy = v[5];
+  const T x0 = aw * ax + bw * bx + cw * cx;
+  const T y0 = aw * ay + bw * by + cw * cy;
+  const T m = bx - ax, p = by - ay, n = cx - ax, q = cy - ay, s = x0 - ax, t = y0 - ay;
+  const T k1 = s * q - n * t;
+  const T k2 = m * t - s * p;
+  T k3 = m * q - n * p;
+  k3 = (T)((double)k3 + copysign((double)eps, (double)k3));
+  // numerators of d(w1), d(w2) w.r.t. (m, n, p, q, s, t): dk_i * k3 - dk3 * k_i, with the reference's explicit
+  // zero terms kept (0 * k3 - q * k1 etc.) so that signed zeros and roundings match the oracle
+  const T zero = 0;
+  const T dw1dm = zero * k3 - q * k1, dw1dn = (-t) * k3 - (-p) * k1;
+  const T dw1dp = zero * k3 - (-n) * k1, dw1dq = s * k3 - m * k1;
+  const T dw1ds = q * k3 - zero * k1, dw1dt = (-n) * k3 - zero * k1;
+  const T dw2dm = t * k3 - q * k2, dw2dn = zero * k3 - (-p) * k2;
+  const T dw2dp = (-s) * k3 - (-n) * k2, dw2dq = zero * k3 - m * k2;
+  const T dw2ds = (-p) * k3 - zero * k2, dw2dt = m * k3 - zero * k2;
+  const T dw1[6] = {-(dw1dm + dw1dn + dw1ds), -(dw1dp + dw1dq + dw1dt), dw1dm, dw1dp, dw1dn, dw1dq};
+  const T dw2[6] = {-(dw2dm + dw2dn + dw2ds), -(dw2dp + dw2dq + dw2dt), dw2dm, dw2dp, dw2dn, dw2dq};
+  const T* ff = feat + tf * 3 * D;
+  for (int d = 0; d < D; ++d) {
+    const T c0 = ff[d], c1 = ff[D + d], c2 = ff[2 * D + d];
+    const T dldI = g[d] / (k3 * k3);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const T dI = (c1 - c0) * dw1[j] + (c2 - c0) * dw2[j];
+      kamd_atomic_add(g_img + tf * 6 + j, (T)(dldI * dI));
+    }
+  }
+}
+
+template <typename T>
+int rasterize_forward_launch(hipStream_t st, int B, int H, int W, int D, int64_t total_faces, const T* z, const T* img,
+                             const T* bbox, const T* feat, const int64_t* first_idx, float multiplier, float eps,
+                             T* interp, int64_t* sel_idx, T* weights, void* workspace) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  const TileGeom g = tile_geom(H, W);
+  if (total_faces > 0 && workspace == nullptr) return (int)hipErrorInvalidValue;
+  T* rec = (T*)workspace;
+  unsigned int* masks = (unsigned int*)((char*)workspace + align256((size_t)total_faces * REC_STRIDE * sizeof(T)));
+  if (total_faces > 0) {
+    KAMD_CHECK(hipMemsetAsync(masks, 0, mask_words(g.ntiles, B, total_faces) * 4, st));
+    hipLaunchKernelGGL(bin_faces_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, 0,
+                       (long long)total_faces, first_idx, bbox, img, z, g, multiplier, rec, masks);
+    KAMD_CHECK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(raster_tile_kernel<T>, dim3(g.ntiles * B), dim3(TILE_THREADS), 0, st, B, 0, first_idx, g, D,
+                     multiplier, eps, rec, masks, feat, interp, sel_idx, weights);
+  KAMD_RETURN_LAST_ERROR();
+}
+
+template <typename T>
+int rasterize_backward_launch(hipStream_t st, int B, int H, int W, int F, int D, const T* grad, const int64_t* face_idx,
+                              const T* weights, const T* img, const T* feat, float eps, T* g_img, T* g_feat) {
+  const long long total = (long long)B * H * W;
+  if (total <= 0 || F <= 0) return 0;
+  hipLaunchKernelGGL(raster_backward_kernel<T>, dim3(kamd_cdiv(total, 256)), dim3(256), 0, st, total, H * W, F, D, grad,
+                     face_idx, weights, img, feat, eps, g_img, g_feat);
+  KAMD_RETURN_LAST_ERROR();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t kamd_rasterize_forward_workspace(int B, int H, int W, int64_t total_faces, int elem_size) {
+  if (B <= 0 || H <= 0 || W <= 0 || total_faces <= 0) return 0;
+  return kamd::bins_workspace_bytes(B, H, W, total_faces, elem_size);
+}
+
+int kamd_packed_rasterize_forward_f32(void* stream, int B, int H, int W, int D, int64_t total_faces, const float* z,
+                                      const float* img, const float* bbox, const float* feat, const int64_t* first_idx,
+                                      float multiplier, float eps, float* interp, int64_t* sel_idx, float* weights,
+                                      void* workspace) {
+  return rasterize_forward_launch<float>((hipStream_t)stream, B, H, W, D, total_faces, z, img, bbox, feat, first_idx,
+                                         multiplier, eps, interp, sel_idx, weights, workspace);
+}
+int kamd_packed_rasterize_forward_f64(void* stream, int B, int H, int W, int D, int64_t total_faces, const double* z,
+                                      const double* img, const double* bbox, const double* feat,
+                                      const int64_t* first_idx, float multiplier, float eps, double* interp,
+                                      int64_t* sel_idx, double* weights, void* workspace) {
+  return rasterize_forward_launch<double>((hipStream_t)stream, B, H, W, D, total_faces, z, img, bbox, feat, first_idx,
+                                          multiplier, eps, interp, sel_idx, weights, workspace);
+}
+int kamd_rasterize_backward_f32(void* stream, int B, int H, int W, int F, int D, const float* grad,
+                                const int64_t* face_idx, const float* weights, const float* img, const float* feat,
+                                float eps, float* g_img, float* g_feat) {
+  return rasterize_backward_launch<float>((hipStream_t)stream, B, H, W, F, D, grad, face_idx, weights, img, feat, eps,
+                                          g_img, g_feat);
+}
+int kamd_rasterize_backward_f64(void* stream, int B, int H, int W, int F, int D, const double* grad,
+                                const int64_t* face_idx, const double* weights, const double* img, const double* feat,
+                                float eps, double* g_img, double* g_feat) {
+  return rasterize_backward_launch<double>((hipStream_t)stream, B, H, W, F, D, grad, face_idx, weights, img, feat, eps,
+                                           g_img, g_feat);
+}
+
+}  // extern "C"

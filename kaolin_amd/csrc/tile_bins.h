@@ -1,0 +1,156 @@
+// Screen-tile face binning shared by the DIB-R rasterizer and the soft-mask kernels (gfx950).
+//
+// The reference tests every pixel against every face (rasterization_cuda.cu:88-170,
+// dibr_soft_mask_cuda.cu:80-172).  Both kernels only ever let a face act on a pixel whose centre lies
+// inside the face's (possibly enlarged) bounding box, and both visit faces in ascending index.  We keep
+// exactly that semantics but make the search sub-linear:
+//
+//   1. bin kernel: one thread per face sets the face's bit in the bitmask of every 32x32-pixel tile its
+//      bbox can touch (conservative: +-1 pixel, NaN boxes go everywhere).  A bitmask -- not an append
+//      list -- so that "ascending face index" is free and the workspace size does not depend on the data.
+//   2. tile kernel: one 1024-thread workgroup per tile expands the tile's bitmask (popcount + block scan)
+//      into an ascending face list, stages the face records in LDS, and each of its 16 wavefronts culls
+//      the list against its own 16x4-pixel sub-tile with one ballot per 64 faces before any per-pixel
+//      work happens.
+//
+// Workspace layout (all offsets 256-B aligned):
+//   records : total_faces x 16 x sizeof(T)   {bbox[4], a.xy, b.xy, c.xy, z[3], pad[3]}
+//   masks   : ntiles x (total_faces/32 + B + 1) 32-bit words; mesh b owns the word range
+//             ntiles*(first[b]/32 + b) .. , tile t of mesh b starts at  + t*stride_b,
+//             stride_b = ceil(n_b/32)  (regions provably do not overlap).
+#pragma once
+#include "common.h"
+
+namespace kamd {
+
+constexpr int TILE_W = 32, TILE_H = 32;  // pixels per workgroup tile
+constexpr int SUB_W = 16, SUB_H = 4;     // pixels per wavefront sub-tile (64 lanes)
+constexpr int TILE_THREADS = 1024;       // 16 wavefronts: 2 x 8 sub-tiles
+constexpr int REC_STRIDE = 16;           // scalars per face record
+
+struct TileGeom {
+  int H, W, tiles_x, tiles_y, ntiles;
+};
+__host__ __device__ inline TileGeom tile_geom(int H, int W) {
+  TileGeom g;
+  g.H = H;
+  g.W = W;
+  g.tiles_x = (W + TILE_W - 1) / TILE_W;
+  g.tiles_y = (H + TILE_H - 1) / TILE_H;
+  g.ntiles = g.tiles_x * g.tiles_y;
+  return g;
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline size_t mask_words(int ntiles, int B, long long total_faces) {
+  return (size_t)ntiles * (size_t)(total_faces / 32 + B + 1);
+}
+inline size_t bins_workspace_bytes(int B, int H, int W, long long total_faces, int elem_size) {
+  TileGeom g = tile_geom(H, W);
+  return align256((size_t)total_faces * REC_STRIDE * elem_size) + align256(mask_words(g.ntiles, B, total_faces) * 4);
+}
+
+// pixel centre in the reference's float arithmetic (rasterization_cuda.cu:85-86, dibr_soft_mask_cuda.cu:75-76):
+//   x0 = multiplier / width * (2*col + 1 - width),  y0 = multiplier / height * (height - 2*row - 1)
+__device__ __forceinline__ float pixel_x(float multiplier, int W, int col) { return multiplier / W * (2 * col + 1 - W); }
+__device__ __forceinline__ float pixel_y(float multiplier, int H, int row) { return multiplier / H * (H - 2 * row - 1); }
+
+// word offset of (mesh b, tile t) in the mask area
+__device__ __forceinline__ size_t mask_base(int ntiles, long long first_b, int b, int t, int stride_b) {
+  return (size_t)ntiles * (size_t)(first_b / 32 + b) + (size_t)t * stride_b;
+}
+
+// ---- bin kernel -----------------------------------------------------------------------------------
+// One thread per face of the (packed) face list.  `first` (B+1, device) gives each mesh's face range;
+// first == nullptr means a dense batch: mesh b owns faces [b*F, (b+1)*F).  Copies bbox / vertices / z
+// into the record array and sets the face's bit in every tile its bbox can touch.
+template <typename T>
+__global__ __launch_bounds__(256) void bin_faces_kernel(
+    int B, int F_dense, long long total_faces, const int64_t* __restrict__ first,
+    const T* __restrict__ bbox, const T* __restrict__ img, const T* __restrict__ z,
+    TileGeom g, float multiplier, T* __restrict__ rec, unsigned int* __restrict__ masks) {
+  const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (f >= total_faces) return;
+  int b;
+  long long first_b, n_b;
+  if (first == nullptr) {
+    b = (int)(f / F_dense);
+    first_b = (long long)b * F_dense;
+    n_b = F_dense;
+  } else {
+    b = 0;
+    while (b + 1 < B && first[b + 1] <= f) ++b;
+    first_b = first[b];
+    n_b = first[b + 1] - first_b;
+    if (f >= first[B]) return;
+  }
+  const T xmin = bbox[f * 4 + 0], ymin = bbox[f * 4 + 1], xmax = bbox[f * 4 + 2], ymax = bbox[f * 4 + 3];
+  T* r = rec + (size_t)f * REC_STRIDE;
+  r[0] = xmin;
+  r[1] = ymin;
+  r[2] = xmax;
+  r[3] = ymax;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r[4 + i] = img[f * 6 + i];
+  if (z != nullptr) {
+    r[10] = z[f * 3 + 0];
+    r[11] = z[f * 3 + 1];
+    r[12] = z[f * 3 + 2];
+  }
+  // conservative pixel range of the half-open box [xmin,xmax) x [ymin,ymax):
+  //   col(x) = (x*W/mult + W - 1)/2 increasing in x, row(y) = (H - 1 - y*H/mult)/2 decreasing in y
+  int c_lo = 0, c_hi = g.W - 1, r_lo = 0, r_hi = g.H - 1;
+  const double dxmin = (double)xmin, dxmax = (double)xmax, dymin = (double)ymin, dymax = (double)ymax;
+  const bool has_nan = !(multiplier > 0.f) || !(dxmin == dxmin) || !(dxmax == dxmax) || !(dymin == dymin) || !(dymax == dymax);
+  if (!has_nan) {
+    const double sx = (double)g.W / (double)multiplier, sy = (double)g.H / (double)multiplier;
+    const double cl = floor((dxmin * sx + g.W - 1) * 0.5) - 1.0, ch = ceil((dxmax * sx + g.W - 1) * 0.5) + 1.0;
+    const double rl = floor((g.H - 1 - dymax * sy) * 0.5) - 1.0, rh = ceil((g.H - 1 - dymin * sy) * 0.5) + 1.0;
+    if (ch < 0.0 || cl > (double)(g.W - 1) || rh < 0.0 || rl > (double)(g.H - 1)) return;
+    c_lo = (int)fmax(cl, 0.0);
+    c_hi = (int)fmin(ch, (double)(g.W - 1));
+    r_lo = (int)fmax(rl, 0.0);
+    r_hi = (int)fmin(rh, (double)(g.H - 1));
+  }
+  const int tx0 = c_lo / TILE_W, tx1 = c_hi / TILE_W, ty0 = r_lo / TILE_H, ty1 = r_hi / TILE_H;
+  const long long j = f - first_b;
+  const int stride_b = (int)((n_b + 31) / 32);
+  const unsigned int bit = 1u << (unsigned)(j & 31);
+  for (int ty = ty0; ty <= ty1; ++ty)
+    for (int tx = tx0; tx <= tx1; ++tx)
+      atomicOr(masks + mask_base(g.ntiles, first_b, b, ty * g.tiles_x + tx, stride_b) + (size_t)(j >> 5), bit);
+}
+
+// ---- block-wide exclusive scan over 1024 threads (16 wavefronts) -------------------------------------
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+// returns the exclusive prefix of v over the block; *total = block sum.  `scratch` holds 17 ints.
+__device__ __forceinline__ int block_exclusive_scan(int v, int* scratch, int* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int inc = wave_inclusive_scan(v);
+  __syncthreads();  // scratch may still be read by the previous round
+  if (lane == 63) scratch[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+#pragma unroll
+    for (int w = 0; w < TILE_THREADS / 64; ++w) {
+      const int s = scratch[w];
+      scratch[w] = run;
+      run += s;
+    }
+    scratch[TILE_THREADS / 64] = run;
+  }
+  __syncthreads();
+  *total = scratch[TILE_THREADS / 64];
+  return scratch[wave] + inc - v;
+}
+
+}  // namespace kamd

@@ -1,0 +1,2 @@
+from . import camera  # noqa: F401
+from . import mesh  # noqa: F401

@@ -1,0 +1,68 @@
+"""``dibr_soft_mask`` and ``dibr_rasterization`` (API mirror of kaolin/render/mesh/dibr.py:27-209)."""
+import torch
+
+from ... import _C
+from .rasterization import rasterize
+
+__all__ = ['dibr_soft_mask', 'dibr_rasterization']
+
+
+class DibrSoftMaskCuda(torch.autograd.Function):
+    """Same contract as the reference's DibrSoftMaskCuda (dibr.py:27-73): the vertices are scaled by
+    ``multiplier`` (and saved scaled), the boxes enlarged by ``boxlen * multiplier``, the K-buffers are
+    kept for backward, whose result is the gradient w.r.t. the unscaled vertices."""
+
+    @staticmethod
+    def forward(ctx, face_vertices_image, selected_face_idx, sigmainv, boxlen, knum, multiplier):
+        scaled = face_vertices_image.contiguous() * multiplier
+        selected_face_idx = selected_face_idx.contiguous()
+        lo = torch.min(scaled, dim=-2)[0] - boxlen * multiplier
+        hi = torch.max(scaled, dim=-2)[0] + boxlen * multiplier
+        large_bboxes = torch.cat([lo, hi], dim=-1)
+        soft_mask, prob, idx, dist_type = _C.render.mesh.dibr_soft_mask_forward_cuda(
+            scaled, large_bboxes.contiguous(), selected_face_idx, sigmainv, knum, multiplier)
+        ctx.multiplier, ctx.sigmainv = multiplier, sigmainv
+        ctx.save_for_backward(soft_mask, scaled, selected_face_idx, prob, idx, dist_type)
+        return soft_mask
+
+    @staticmethod
+    def backward(ctx, grad_soft_mask):
+        soft_mask, scaled, selected_face_idx, prob, idx, dist_type = ctx.saved_tensors
+        grad = _C.render.mesh.dibr_soft_mask_backward_cuda(
+            grad_soft_mask.contiguous(), soft_mask, selected_face_idx, prob, idx, dist_type, scaled,
+            ctx.sigmainv, ctx.multiplier)
+        return grad, None, None, None, None, None
+
+
+def dibr_soft_mask(face_vertices_image, selected_face_idx, sigmainv=7000, boxlen=0.02, knum=30, multiplier=1000.):
+    r"""Soft silhouette mask of DIB-R, generally paired with :func:`kaolin_amd.metrics.render.mask_iou`
+    (reference: kaolin/render/mesh/dibr.py:75-117).
+
+    Args:
+        face_vertices_image (torch.Tensor): 2D vertex positions in [-1, 1], (B, F, 3, 2).
+        selected_face_idx (torch.LongTensor): rendered face index (B, H, W) from :func:`rasterize`.
+        sigmainv (float): sharpness; recommended [1/3e-4, 1/3e-5]. Default: 7000.
+        boxlen (float): bbox margin deciding which pixels a face influences. Default: 0.02.
+        knum (int): maximum number of faces influencing one pixel. Default: 30.
+        multiplier (float): internal coordinate scale. Default: 1000.
+
+    Returns:
+        (torch.FloatTensor): the soft mask, (B, H, W).
+    """
+    return DibrSoftMaskCuda.apply(face_vertices_image, selected_face_idx, sigmainv, boxlen, knum, multiplier)
+
+
+def dibr_rasterization(height, width, face_vertices_z, face_vertices_image, face_features, face_normals_z,
+                       sigmainv=7000, boxlen=0.02, knum=30, multiplier=None, eps=None, rast_backend='cuda'):
+    r"""DIB-R rasterization: :func:`rasterize` restricted to front faces (``face_normals_z >= 0``) followed
+    by :func:`dibr_soft_mask` over ALL faces (reference: kaolin/render/mesh/dibr.py:119-209).
+
+    Returns:
+        (torch.Tensor or tuple, torch.Tensor, torch.LongTensor): features (B, H, W, D), soft mask (B, H, W),
+        face index (B, H, W).
+    """
+    interpolated_features, face_idx = rasterize(height, width, face_vertices_z, face_vertices_image,
+                                                face_features, face_normals_z >= 0., multiplier, eps, rast_backend)
+    _multiplier = 1000. if multiplier is None else multiplier
+    soft_mask = dibr_soft_mask(face_vertices_image, face_idx, sigmainv, boxlen, knum, _multiplier)
+    return interpolated_features, soft_mask, face_idx
