@@ -1,0 +1,364 @@
+// Point -> triangle-soup distance forward / backward for MI355X (gfx950).
+//
+// Replaces kaolin/csrc/metrics/unbatched_triangle_distance_cuda.cu:237-317 (K7) and :319-416 (K8) behind the C
+// ABI of include/kaolin_amd.h.  Semantics kept from the reference (restated in oracle/tridist_oracle.inc):
+//   K7  per point, faces in ascending index: edge parameters uab/ubc/uca = dot(p - v, e) / dot(e, e); vertex
+//       regions (type 1-3), edge regions (4-6, closed [0,1] parameter and "not above" the edge), otherwise the
+//       plane projection (0); dist = |p - closest|^2 ROUNDED TO float (even for double inputs, :302); a face
+//       wins only if strictly closer => lowest index on ties; face 0 seeds unconditionally (:303,:309).
+//   K8  analytic gradient of the stored region: plane (:342-373), vertex (:374-397), edge (:176-233).
+// Arithmetic: -ffp-contract=off, dot() evaluated x*x' + y*y' + z*z' left to right, point_at's parameter is a
+// float (:172).  The reference's rsqrt() (:144) is evaluated as 1 / sqrt() (IEEE), the same pin as the oracle.
+// Deviation (documented in DESIGN.md): the reference re-seeds its running best at every 1024-face (512 for
+// double) tile, which only matters when a tile's first face yields a NaN distance; here only face 0 seeds.
+//
+// MI355X design.  This is an all-pairs search (N x F closest-point evaluations, ~90 VALU each with three IEEE
+// divides): VALU-bound by orders of magnitude, so the work is cut rather than the bytes:
+//   * per-face invariants (edges, normal, edge normals, unit normal, edge lengths) are computed ONCE per face by
+//     td_prep_kernel with the exact expressions the per-pair code would use (bit-identical results), leaving
+//     ~45 VALU per evaluated pair;
+//   * every face record carries a bounding sphere (centre, radius + rounding margin); a lane skips a face when
+//     |p - c| - r exceeds sqrt(best) by more than a conservative margin (such a face cannot win, not even a
+//     tie), and a wavefront skips it when all 64 lanes do: 11 VALU instead of the full evaluation;
+//   * face records are staged through LDS in tiles and read with broadcast ds_read_b128;
+//   * when N alone cannot fill 256 CUs the face range is split over blockIdx.y and merged in index order.
+#include "common.h"
+#include "../../include/kaolin_amd.h"
+
+namespace {
+
+constexpr int TD_REC = 40;       // scalars per face record
+constexpr int TD_TILE = 64;      // faces per LDS tile
+constexpr int TD_THREADS = 256;
+
+template <typename T> struct V3 { T x, y, z; };
+template <typename T> __device__ __forceinline__ V3<T> mk(T x, T y, T z) { return V3<T>{x, y, z}; }
+template <typename T> __device__ __forceinline__ V3<T> operator-(V3<T> a, V3<T> b) { return mk<T>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <typename T> __device__ __forceinline__ V3<T> operator+(V3<T> a, V3<T> b) { return mk<T>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <typename T> __device__ __forceinline__ V3<T> operator*(V3<T> a, T s) { return mk<T>(a.x * s, a.y * s, a.z * s); }
+template <typename T> __device__ __forceinline__ V3<T> operator/(V3<T> a, T s) { return mk<T>(a.x / s, a.y / s, a.z / s); }
+template <typename T> __device__ __forceinline__ T dot(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename T> __device__ __forceinline__ V3<T> cross(V3<T> a, V3<T> b) {
+  return mk<T>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+template <typename T> __device__ __forceinline__ V3<T> ld3(const T* p) { return mk<T>(p[0], p[1], p[2]); }
+template <typename T> __device__ __forceinline__ void st3(T* p, V3<T> v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+__device__ __forceinline__ float td_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double td_sqrt(double x) { return sqrt(x); }
+template <typename T> __device__ __forceinline__ T td_abs(T x) { return x < 0 ? -x : x; }
+template <typename T> __device__ __forceinline__ T max3abs(V3<T> v) { return fmax(td_abs(v.x), fmax(td_abs(v.y), td_abs(v.z))); }
+
+// ---- per-face invariants ----------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void td_prep_kernel(int F, const T* __restrict__ faces, T* __restrict__ rec) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= F) return;
+  const T* fv = faces + (size_t)f * 9;
+  const V3<T> v1 = ld3(fv), v2 = ld3(fv + 3), v3 = ld3(fv + 6);
+  const V3<T> e12 = v2 - v1, e23 = v3 - v2, e31 = v1 - v3;
+  const V3<T> normal = cross(v1 - v2, e31);
+  const T inv_len = (T)1 / td_sqrt(dot(normal, normal));
+  T* r = rec + (size_t)f * TD_REC;
+  st3(r + 0, v1);
+  st3(r + 3, v2);
+  st3(r + 6, v3);
+  st3(r + 9, e12);
+  st3(r + 12, e23);
+  st3(r + 15, e31);
+  st3(r + 18, normal);
+  r[21] = dot(e12, e12);
+  r[22] = dot(e23, e23);
+  r[23] = dot(e31, e31);
+  st3(r + 24, cross(normal, e12));
+  st3(r + 27, cross(normal, e23));
+  st3(r + 30, cross(normal, e31));
+  st3(r + 33, normal * inv_len);
+  // bounding sphere with rounding head-room: radius inflated, plus 1e-5 of the coordinate magnitude
+  const V3<T> c = mk<T>((v1.x + v2.x + v3.x) / 3, (v1.y + v2.y + v3.y) / 3, (v1.z + v2.z + v3.z) / 3);
+  const T r2 = fmax(dot(v1 - c, v1 - c), fmax(dot(v2 - c, v2 - c), dot(v3 - c, v3 - c)));
+  const T rad = td_sqrt(r2) * (T)1.0001;
+  st3(r + 36, c);
+  r[39] = rad + (T)1e-5 * (max3abs(c) + rad);
+}
+
+// closest-point evaluation of one (point, face record) pair; returns the float-rounded squared distance
+template <typename T>
+__device__ __forceinline__ float td_eval(const T* __restrict__ r, V3<T> p, int* type_out) {
+  const V3<T> v1 = ld3(r), v2 = ld3(r + 3), v3 = ld3(r + 6);
+  const V3<T> e12 = ld3(r + 9), e31 = ld3(r + 15);
+  const V3<T> pv1 = p - v1, pv3 = p - v3;
+  const T uab = dot(pv1, e12) / r[21];
+  const T uca = dot(pv3, e31) / r[23];
+  V3<T> closest;
+  int type;
+  if (uca > 1 && uab < 0) {
+    closest = v1;
+    type = 1;
+  } else {
+    const V3<T> e23 = ld3(r + 12);
+    const V3<T> pv2 = p - v2;
+    const T ubc = dot(pv2, e23) / r[22];
+    if (uab > 1 && ubc < 0) {
+      closest = v2;
+      type = 2;
+    } else if (ubc > 1 && uca < 0) {
+      closest = v3;
+      type = 3;
+    } else if ((uab <= 1 && uab >= 0) && dot(ld3(r + 24), pv1) <= 0) {
+      const float t = (float)uab;
+      closest = v1 + mk<T>(e12.x * t, e12.y * t, e12.z * t);
+      type = 4;
+    } else if ((ubc <= 1 && ubc >= 0) && dot(ld3(r + 27), pv2) <= 0) {
+      const float t = (float)ubc;
+      closest = v2 + mk<T>(e23.x * t, e23.y * t, e23.z * t);
+      type = 5;
+    } else if ((uca <= 1 && uca >= 0) && dot(ld3(r + 30), pv3) <= 0) {
+      const float t = (float)uca;
+      closest = v3 + mk<T>(e31.x * t, e31.y * t, e31.z * t);
+      type = 6;
+    } else {
+      const V3<T> un = ld3(r + 33);
+      const T dist = (p.x - v1.x) * un.x + (p.y - v1.y) * un.y + (p.z - v1.z) * un.z;
+      closest = p - un * dist;
+      type = 0;
+    }
+  }
+  const V3<T> dv = p - closest;
+  *type_out = type;
+  return (float)dot(dv, dv);
+}
+
+template <typename T>
+__global__ __launch_bounds__(TD_THREADS) void td_main_kernel(
+    int N, int F, int Fs, const T* __restrict__ points, const T* __restrict__ rec,
+    T* __restrict__ out_dist, int* __restrict__ out_idx, int* __restrict__ out_type) {
+  __shared__ __attribute__((aligned(16))) T tile[TD_TILE * TD_REC];
+  const int s = blockIdx.y;
+  const int i = blockIdx.x * TD_THREADS + threadIdx.x;
+  const bool active = i < N;
+  const V3<T> p = active ? ld3(points + (size_t)i * 3) : mk<T>(0, 0, 0);
+  const T pmag = (T)1e-5 * max3abs(p);
+  T best = INFINITY;
+  T bound = INFINITY;  // sqrt(best) with head-room; a face whose sphere is farther than this cannot win
+  int best_face = s * Fs, best_type = 0;
+  const int f0 = s * Fs, f1 = min(F, f0 + Fs);
+  for (int t0 = f0; t0 < f1; t0 += TD_TILE) {
+    const int cnt = min(TD_TILE, f1 - t0);
+    __syncthreads();
+    for (int k = threadIdx.x; k < cnt * TD_REC; k += TD_THREADS) tile[k] = rec[(size_t)t0 * TD_REC + k];
+    __syncthreads();
+    for (int k = 0; k < cnt; ++k) {
+      const T* r = tile + k * TD_REC;
+      const V3<T> pc = p - ld3(r + 36);
+      const T d2c = dot(pc, pc);
+      const T reach = bound + r[39];
+      const bool skip = d2c > reach * reach;  // false for NaN / inf: then the face is evaluated
+      if (!__any(active && !skip)) continue;
+      if (!active || skip) continue;
+      int type;
+      const float dist = td_eval<T>(r, p, &type);
+      if ((t0 + k) == 0 || best > dist) {
+        best = dist;
+        best_type = type;
+        best_face = t0 + k;
+        bound = td_sqrt(best) * (T)1.001 + pmag;
+      }
+    }
+  }
+  if (active) {
+    const size_t o = (size_t)s * N + i;
+    out_dist[o] = best;
+    out_idx[o] = best_face;
+    out_type[o] = best_type;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void td_final_kernel(int N, int S, const T* __restrict__ part_d,
+                                                       const int* __restrict__ part_i, const int* __restrict__ part_t,
+                                                       T* __restrict__ dist, int64_t* __restrict__ idx,
+                                                       int32_t* __restrict__ type) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  T best = part_d[i];
+  int bi = part_i[i], bt = part_t[i];
+  for (int s = 1; s < S; ++s) {
+    const T d = part_d[(size_t)s * N + i];
+    if (best > d) {  // strict: the lower split (lower face indices) keeps ties
+      best = d;
+      bi = part_i[(size_t)s * N + i];
+      bt = part_t[(size_t)s * N + i];
+    }
+  }
+  dist[i] = best;
+  idx[i] = bi;
+  type[i] = bt;
+}
+
+// ---- K8 ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void td_edge_backward(V3<T> vab, V3<T> pb, T* g_va, T* g_vb, T* g_p, T grad) {
+  const T l = dot(vab, pb);
+  const T m = dot(vab, vab);
+  const T k = l / m;
+  const T j = fmax((T)0.0, fmin((T)1.0, k));
+  const V3<T> i = (vab * j) - pb;
+  const V3<T> i_bar = i * grad;
+  const T j_bar = dot(i_bar, vab);
+  const T dj_dk = (k > 0 && k < 1) ? 1 : 0;
+  const T k_bar = j_bar * dj_dk;
+  const T m_bar = k_bar * (-l / (m * m));
+  const T l_bar = k_bar * (1 / m);
+  const V3<T> di_dpb = mk<T>(-i_bar.x, -i_bar.y, -i_bar.z);
+  const V3<T> pb_bar = vab * l_bar + di_dpb;
+  const V3<T> dm_dvab = vab * (T)2.;
+  const V3<T> vab_bar = ((dm_dvab * m_bar) + (pb * l_bar)) + (i_bar * j);
+  const V3<T> vb_bar = mk<T>(-vab_bar.x - pb_bar.x, -vab_bar.y - pb_bar.y, -vab_bar.z - pb_bar.z);
+  st3(g_p, pb_bar);
+  kamd_atomic_add(g_va + 0, vab_bar.x);
+  kamd_atomic_add(g_va + 1, vab_bar.y);
+  kamd_atomic_add(g_va + 2, vab_bar.z);
+  kamd_atomic_add(g_vb + 0, vb_bar.x);
+  kamd_atomic_add(g_vb + 1, vb_bar.y);
+  kamd_atomic_add(g_vb + 2, vb_bar.z);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void td_backward_kernel(
+    int N, const T* __restrict__ grad_dist, const T* __restrict__ points, const T* __restrict__ faces,
+    const int64_t* __restrict__ face_idx, const int32_t* __restrict__ dist_type, T* __restrict__ g_points,
+    T* __restrict__ g_faces) {
+  const int pi = blockIdx.x * 256 + threadIdx.x;
+  if (pi >= N) return;
+  const int type = dist_type[pi];
+  const int64_t f = face_idx[pi];
+  const V3<T> p = ld3(points + (size_t)pi * 3);
+  const T* fv = faces + (size_t)f * 9;
+  const V3<T> v1 = ld3(fv), v2 = ld3(fv + 3), v3 = ld3(fv + 6);
+  const V3<T> e12 = v2 - v1, e23 = v3 - v2, e31 = v1 - v3;
+  const T grad_out = (T)(2. * grad_dist[pi]);
+  T* a = g_faces + (size_t)f * 9;
+  T* gp = g_points + (size_t)pi * 3;
+  if (type == 0) {
+    const V3<T> pv = p - v1;
+    const V3<T> e21 = v1 - v2;
+    const V3<T> normal = cross(e21, e31);
+    const T len = td_sqrt(dot(normal, normal));
+    const V3<T> un = normal / len;
+    const T dist = dot(pv, un);
+    const V3<T> gdv = un * (dist * grad_out);
+    const T gd = dot(un, gdv);
+    const V3<T> gpv = un * gd;
+    const V3<T> gun = gdv * dist + pv * gd;
+    const T glen = -dot(normal, gun) / (len * len);
+    const T gdot2 = glen / (2 * td_sqrt(dot(normal, normal)));
+    const V3<T> gn = (gun / len) + normal * (gdot2 * (T)2.);
+    const V3<T> ge31 = cross(gn, e21);
+    const V3<T> ge21 = cross(e31, gn);
+    st3(gp, gpv);
+    const V3<T> tmp = ge31 + ge21 - gpv;
+    kamd_atomic_add(a + 0, tmp.x);
+    kamd_atomic_add(a + 1, tmp.y);
+    kamd_atomic_add(a + 2, tmp.z);
+    kamd_atomic_add(a + 3, -ge21.x);
+    kamd_atomic_add(a + 4, -ge21.y);
+    kamd_atomic_add(a + 5, -ge21.z);
+    kamd_atomic_add(a + 6, -ge31.x);
+    kamd_atomic_add(a + 7, -ge31.y);
+    kamd_atomic_add(a + 8, -ge31.z);
+  } else if (type >= 1 && type <= 3) {
+    const V3<T> v = type == 1 ? v1 : (type == 2 ? v2 : v3);
+    const V3<T> g = (p - v) * grad_out;
+    T* av = a + (type - 1) * 3;
+    kamd_atomic_add(av + 0, -g.x);
+    kamd_atomic_add(av + 1, -g.y);
+    kamd_atomic_add(av + 2, -g.z);
+    st3(gp, g);
+  } else if (type == 4) {
+    td_edge_backward<T>(e12, p - v1, a + 3, a, gp, grad_out);
+  } else if (type == 5) {
+    td_edge_backward<T>(e23, p - v2, a + 6, a + 3, gp, grad_out);
+  } else {
+    td_edge_backward<T>(e31, p - v3, a, a + 6, gp, grad_out);
+  }
+}
+
+struct TdPlan {
+  int nx, S, Fs;
+};
+inline TdPlan td_plan(int N, int F) {
+  TdPlan p;
+  p.nx = kamd_cdiv(N, TD_THREADS);
+  const int ntiles = kamd_cdiv(F, TD_TILE);
+  int S = (KAMD_NUM_CU * 8 + p.nx - 1) / p.nx;  // aim at >= 8 workgroups per CU
+  if (S > ntiles / 4) S = ntiles / 4;           // but keep >= 4 LDS tiles per split
+  if (S < 1) S = 1;
+  p.Fs = kamd_cdiv(ntiles, S) * TD_TILE;
+  p.S = kamd_cdiv(F, p.Fs);
+  return p;
+}
+inline size_t td_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+template <typename T>
+int td_forward_launch(hipStream_t st, int N, int F, const T* points, const T* faces, T* dist, int64_t* face_idx,
+                      int32_t* dist_type, void* workspace) {
+  if (N <= 0 || F <= 0) return 0;  // the caller's zero-initialised outputs stay (reference: the loops never run)
+  if (workspace == nullptr) return (int)hipErrorInvalidValue;
+  const TdPlan p = td_plan(N, F);
+  T* rec = (T*)workspace;
+  char* w = (char*)workspace + td_align((size_t)F * TD_REC * sizeof(T));
+  T* part_d = (T*)w;
+  w += td_align((size_t)p.S * N * sizeof(T));
+  int* part_i = (int*)w;
+  w += td_align((size_t)p.S * N * sizeof(int));
+  int* part_t = (int*)w;
+  hipLaunchKernelGGL(td_prep_kernel<T>, dim3(kamd_cdiv(F, 256)), dim3(256), 0, st, F, faces, rec);
+  KAMD_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(td_main_kernel<T>, dim3(p.nx, p.S), dim3(TD_THREADS), 0, st, N, F, p.Fs, points, rec, part_d,
+                     part_i, part_t);
+  KAMD_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(td_final_kernel<T>, dim3(kamd_cdiv(N, 256)), dim3(256), 0, st, N, p.S, part_d, part_i, part_t,
+                     dist, face_idx, dist_type);
+  KAMD_RETURN_LAST_ERROR();
+}
+
+template <typename T>
+int td_backward_launch(hipStream_t st, int N, int F, const T* grad, const T* points, const T* faces,
+                       const int64_t* face_idx, const int32_t* dist_type, T* g_points, T* g_faces) {
+  if (N <= 0 || F <= 0) return 0;
+  hipLaunchKernelGGL(td_backward_kernel<T>, dim3(kamd_cdiv(N, 256)), dim3(256), 0, st, N, grad, points, faces,
+                     face_idx, dist_type, g_points, g_faces);
+  KAMD_RETURN_LAST_ERROR();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t kamd_triangle_distance_forward_workspace(int N, int F, int elem_size) {
+  if (N <= 0 || F <= 0) return 0;
+  const TdPlan p = td_plan(N, F);
+  return td_align((size_t)F * TD_REC * elem_size) + td_align((size_t)p.S * N * elem_size) +
+         2 * td_align((size_t)p.S * N * sizeof(int));
+}
+int kamd_triangle_distance_forward_f32(void* stream, int N, int F, const float* points, const float* faces, float* dist,
+                                       int64_t* face_idx, int32_t* dist_type, void* workspace) {
+  return td_forward_launch<float>((hipStream_t)stream, N, F, points, faces, dist, face_idx, dist_type, workspace);
+}
+int kamd_triangle_distance_forward_f64(void* stream, int N, int F, const double* points, const double* faces,
+                                       double* dist, int64_t* face_idx, int32_t* dist_type, void* workspace) {
+  return td_forward_launch<double>((hipStream_t)stream, N, F, points, faces, dist, face_idx, dist_type, workspace);
+}
+int kamd_triangle_distance_backward_f32(void* stream, int N, int F, const float* grad, const float* points,
+                                        const float* faces, const int64_t* face_idx, const int32_t* dist_type,
+                                        float* g_points, float* g_faces) {
+  return td_backward_launch<float>((hipStream_t)stream, N, F, grad, points, faces, face_idx, dist_type, g_points, g_faces);
+}
+int kamd_triangle_distance_backward_f64(void* stream, int N, int F, const double* grad, const double* points,
+                                        const double* faces, const int64_t* face_idx, const int32_t* dist_type,
+                                        double* g_points, double* g_faces) {
+  return td_backward_launch<double>((hipStream_t)stream, N, F, grad, points, faces, face_idx, dist_type, g_points,
+                                    g_faces);
+}
+
+}  // extern "C"

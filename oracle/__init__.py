@@ -197,3 +197,34 @@ def dibr_rasterization(height, width, face_vertices_z, face_vertices_image, face
                                                 1000. if multiplier is None else multiplier, omp=omp)
     return {'features': feats, 'face_idx': face_idx, 'weights': wts, 'soft_mask': soft, 'close_face_prob': prob,
             'close_face_idx': idx, 'close_face_dist_type': typ, 'scaled_vertices': simg}
+
+
+# ---- point -> triangle-soup distance (reference `_C.metrics.unbatched_triangle_distance_*`) ----------
+def triangle_distance_forward(points, face_vertices, omp=False):
+    """unbatched_triangle_distance.cpp:43-72 (outputs are caller-allocated there): returns (dist (N),
+    face_idx (N) int64, dist_type (N) int32: 0 plane, 1-3 vertex, 4-6 edge)."""
+    pts, fv = _cpu(points), _cpu(face_vertices)
+    N, F = pts.shape[0], fv.shape[0]
+    dist = torch.zeros(N, dtype=pts.dtype)
+    idx = torch.zeros(N, dtype=torch.long)
+    typ = torch.zeros(N, dtype=torch.int32)
+    f = getattr(lib(omp), f'oracle_triangle_distance_forward_{_SFX[pts.dtype]}')
+    f(_ci(N), _ci(F), _p(pts), _p(fv), _p(dist), _p(idx), _p(typ))
+    return dist, idx, typ
+
+
+def triangle_distance_backward(grad_dist, points, face_vertices, face_idx, dist_type):
+    """unbatched_triangle_distance.cpp:74-114 -> (grad_points (N,3), grad_face_vertices (F,3,3))."""
+    g, pts, fv = _cpu(grad_dist), _cpu(points), _cpu(face_vertices)
+    idx, typ = _cpu(face_idx, torch.long), _cpu(dist_type, torch.int32)
+    N, F = pts.shape[0], fv.shape[0]
+    gp, gf = torch.zeros_like(pts), torch.zeros_like(fv)
+    f = getattr(lib(False), f'oracle_triangle_distance_backward_{_SFX[pts.dtype]}')
+    f(_ci(N), _ci(F), _p(g), _p(pts), _p(fv), _p(idx), _p(typ), _p(gp), _p(gf))
+    return gp, gf
+
+
+def point_to_mesh_distance(pointclouds, face_vertices, omp=False):
+    """kaolin/metrics/trianglemesh.py:20-99: per-batch loop, stacked results."""
+    out = [triangle_distance_forward(pointclouds[i], face_vertices[i], omp=omp) for i in range(pointclouds.shape[0])]
+    return tuple(torch.stack([o[k] for o in out], dim=0) for k in range(3))

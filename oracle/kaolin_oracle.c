@@ -229,3 +229,23 @@ DEFINE_SIDED_BWD(oracle_sided_distance_backward_f64, double)
 #undef T
 #undef FN
 #undef EXPFN
+
+/* ---- triangle distance K7/K8, instantiated for float and double ----------------- */
+#define T float
+#define FN(n) n##_f32
+#define SQRTFN sqrtf
+#define REF_TILE 1024
+#include "tridist_oracle.inc"
+#undef T
+#undef FN
+#undef SQRTFN
+#undef REF_TILE
+#define T double
+#define FN(n) n##_f64
+#define SQRTFN sqrt
+#define REF_TILE 512
+#include "tridist_oracle.inc"
+#undef T
+#undef FN
+#undef SQRTFN
+#undef REF_TILE

@@ -48,8 +48,14 @@ def load_reference():
     sys.modules['kaolin.rep.spc'] = types.ModuleType('kaolin.rep.spc')
     sys.modules['kaolin.rep.spc'].Spc = None
     sys.modules['kaolin.rep'].Spc = None
+    # metrics/trianglemesh.py imports ..ops.mesh.uniform_laplacian (unused on our path) and its oracle calls
+    # torch.cuda.synchronize() (metrics/trianglemesh.py:232), which raises on a GPU-less box -> no-op it here
+    sys.modules['kaolin.ops.mesh'].uniform_laplacian = None
+    if not torch.cuda.is_available():
+        torch.cuda.synchronize = lambda *a, **k: None
     mods['legacy_camera'] = _load('kaolin.render.camera.legacy', 'kaolin/render/camera/legacy.py')
     mods['pointcloud'] = _load('kaolin.metrics.pointcloud', 'kaolin/metrics/pointcloud.py')
     mods['deftet'] = _load('kaolin.render.mesh.deftet', 'kaolin/render/mesh/deftet.py')
+    mods['trianglemesh'] = _load('kaolin.metrics.trianglemesh', 'kaolin/metrics/trianglemesh.py')
     k._mods = mods
     return mods

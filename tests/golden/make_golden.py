@@ -147,6 +147,36 @@ def rasterize_backward():
     save('rasterize_backward', **out)
 
 
+@section
+def triangle_distance():
+    """reference oracle: _unbatched_naive_point_to_mesh_distance (kaolin/metrics/trianglemesh.py:151-276) on
+    seeded random points/faces (shape of test_trianglemesh.py:81-122: 1025 x 1025, crossing the 1024/512 face
+    tile) and on a small sphere mesh; gradients by autograd through the oracle with a seeded grad_out."""
+    tm = _refload.load_reference()['trianglemesh']
+    sys.path.insert(0, os.path.join(HERE, os.pardir, os.pardir))
+    from kaolin_amd.utils.testing import geodesic_sphere
+    out = {}
+    for tag in ('rand', 'sphere'):
+        for dn, dtype in (('f32', torch.float), ('f64', torch.double)):
+            torch.manual_seed(0)
+            if tag == 'rand':
+                pts = torch.randn(1025, 3, dtype=dtype)
+                fv = torch.randn(1025, 3, 3, dtype=dtype)
+            else:
+                v, f = geodesic_sphere(4)
+                fv = v.to(dtype)[f]
+                pts = torch.rand(700, 3, dtype=dtype) * 1.4 - 0.7
+            a, b = pts.clone().requires_grad_(), fv.clone().requires_grad_()
+            dist, idx, typ = tm._unbatched_naive_point_to_mesh_distance(a, b)
+            g = torch.rand(dist.shape, dtype=dtype)
+            dist.backward(g)
+            k = f'{tag}_{dn}'
+            out[k + '_points'], out[k + '_faces'], out[k + '_grad_out'] = pts, fv, g
+            out[k + '_dist'], out[k + '_idx'], out[k + '_type'] = dist, idx, typ.to(torch.int32)
+            out[k + '_g_points'], out[k + '_g_faces'] = a.grad, b.grad
+    save('triangle_distance', **out)
+
+
 def _dibr_gt(sub, stem, H, W, sigmainv, boxlen):
     return torch.load(os.path.join(_refload.REF, 'tests/samples/dibr', sub, f'{stem}_{H}_{W}_{int(sigmainv)}_{boxlen}.pt'),
                       map_location='cpu')

@@ -1,0 +1,179 @@
+"""point_to_mesh_distance / unbatched_triangle_distance.
+
+CPU part: pins oracle/tridist_oracle.inc against the reference's hand table with all 7 region codes
+(tests/python/kaolin/metrics/test_trianglemesh.py:26-79) and against golden outputs of the reference's own
+torch oracle `_unbatched_naive_point_to_mesh_distance` incl. autograd gradients (tests/golden/make_golden.py).
+GPU part: the HIP path through the C ABI vs the same goldens and vs the oracle (idx / type bit-exact)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import GOLDEN_DIR
+
+PC = [[0., -1., -1.], [1., -1., -1.], [-1., -1., -1.], [0., -1., 2.], [1., -1., 2.], [-1, -1., 2.], [0., 2., 0.5],
+      [1., 2., 0.5], [-1., 2., 0.5], [0., -1., 0.5], [1., -1., 0.5], [-1., -1., 0.5], [0., 1., 1.], [1., 1., 1.],
+      [-1., 1., 1.], [0., 1., 0.], [1., 1., 0.], [-1., 1., 0.], [1., 0.5, 0.5], [-1., 0.5, 0.5]]
+VERTS = [[0., 0., 0.], [0., 0., 1.], [0., 1., 0.5], [0.5, 0., 0.], [0.5, 0., 1.], [0.5, 1., 0.5]]
+KAT_DIST = [2.0000, 2.2500, 3.0000, 2.0000, 2.2500, 3.0000, 1.0000, 1.2500, 2.0000, 1.0000, 1.2500, 2.0000, 0.2000, 0.4500,
+            1.2000, 0.2000, 0.4500, 1.2000, 0.2500, 1.0000]
+KAT_IDX = [0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 1, 0, 1, 0]
+KAT_TYPE = [1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5, 6, 6, 6, 0, 0]
+
+
+def kat_inputs(dtype):
+    v = torch.tensor(VERTS, dtype=dtype)
+    return torch.tensor(PC, dtype=dtype), v[torch.tensor([[0, 1, 2], [3, 4, 5]])]
+
+
+@pytest.fixture(scope='module')
+def gold():
+    return np.load(os.path.join(GOLDEN_DIR, 'triangle_distance.npz'))
+
+
+def _check_against_golden(gold, tag, dn, fwd, bwd):
+    dtype = {'f32': torch.float, 'f64': torch.double}[dn]
+    t = lambda k: torch.from_numpy(gold[f'{tag}_{dn}_{k}'])  # noqa: E731
+    dist, idx, typ = fwd(t('points'), t('faces'))
+    # test_trianglemesh.py:98-100 uses allclose defaults; squared distances of points that almost touch a
+    # triangle (1e-5 for unit-scale data) carry ~1e-9 absolute rounding noise in ANY fp32 evaluation order,
+    # so the absolute tolerance is tied to the coordinate scale^2 (1e-7) instead of 1e-8
+    assert torch.allclose(dist.cpu(), t('dist'), rtol=1e-5, atol=1e-7)
+    if tag == 'rand':   # triangle soup, as in the reference's test: no exact ties
+        assert torch.equal(idx.cpu(), t('idx')) and torch.equal(typ.cpu(), t('type'))
+    else:
+        # connected mesh: a point whose closest feature is a SHARED edge / vertex is equidistant from the
+        # adjacent faces; the kernel's `float dist` (unbatched_triangle_distance_cuda.cu:302) makes that an
+        # exact tie (-> lowest index) while the torch oracle breaks it by double-precision noise.  Same
+        # distances, index may differ on those points only.
+        same = idx.cpu() == t('idx')
+        assert float(same.float().mean()) > 0.9
+        assert bool((idx.cpu()[~same] < t('idx')[~same]).all()) or dn == 'f32'
+    gp, gf = bwd(t('grad_out'), t('points'), t('faces'), idx, typ)
+    assert torch.allclose(gp.cpu(), t('g_points'), rtol=1e-5, atol=1e-5)   # test_trianglemesh.py:119-122
+    if tag == 'rand':
+        assert torch.allclose(gf.cpu(), t('g_faces'), rtol=1e-5, atol=1e-5)
+    assert dist.dtype == dtype
+
+
+# ------------------------------------------------------------------ CPU: oracle pins
+@pytest.mark.parametrize('dtype', [torch.float, torch.double])
+def test_oracle_kat_table(dtype):
+    pts, fv = kat_inputs(dtype)
+    dist, idx, typ = oracle.triangle_distance_forward(pts, fv)
+    assert torch.allclose(dist, torch.tensor(KAT_DIST, dtype=dtype))
+    assert torch.equal(idx, torch.tensor(KAT_IDX)) and torch.equal(typ, torch.tensor(KAT_TYPE, dtype=torch.int32))
+
+
+@pytest.mark.parametrize('tag', ['rand', 'sphere'])
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+def test_oracle_vs_reference_golden(gold, tag, dn):
+    _check_against_golden(gold, tag, dn, oracle.triangle_distance_forward, oracle.triangle_distance_backward)
+
+
+def test_oracle_docstring_example():
+    """kaolin/metrics/trianglemesh.py:61-75."""
+    v = torch.tensor([[0, 0, 0], [0, 1, 0], [0, 0, 1]], dtype=torch.float)
+    fv = v[torch.tensor([[0, 1, 2]])]
+    pts = torch.tensor([[2, 0.5, 0.5], [0.5, 0.5, 0.5], [0.5, 0.5, -0.5]])   # wait: reference lists 3 points
+    dist, idx, typ = oracle.triangle_distance_forward(pts, fv)
+    assert torch.allclose(dist[:2], torch.tensor([4.0, 0.25])) and int(idx.max()) == 0
+
+
+# ------------------------------------------------------------------ GPU
+def _tm():
+    from kaolin_amd.metrics import trianglemesh
+    return trianglemesh
+
+
+def _gpu_fwd(pts, fv):
+    return _tm()._UnbatchedTriangleDistanceCuda.apply(pts.cuda(), fv.cuda())
+
+
+def _gpu_bwd(grad_out, pts, fv, idx, typ):
+    a, b = pts.cuda().requires_grad_(), fv.cuda().requires_grad_()
+    dist, _, _ = _tm()._UnbatchedTriangleDistanceCuda.apply(a, b)
+    dist.backward(grad_out.cuda())
+    return a.grad, b.grad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float, torch.double])
+def test_gpu_kat_table(dtype):
+    pts, fv = kat_inputs(dtype)
+    dist, idx, typ = _tm().point_to_mesh_distance(pts[None].cuda(), fv[None].cuda())
+    assert torch.allclose(dist[0].cpu(), torch.tensor(KAT_DIST, dtype=dtype))
+    assert torch.equal(idx[0].cpu(), torch.tensor(KAT_IDX)) and torch.equal(typ[0].cpu(), torch.tensor(KAT_TYPE, dtype=torch.int32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['rand', 'sphere'])
+@pytest.mark.parametrize('dn', ['f32', 'f64'])
+def test_gpu_vs_reference_golden(gold, tag, dn):
+    _check_against_golden(gold, tag, dn, _gpu_fwd, _gpu_bwd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float, torch.double])
+@pytest.mark.parametrize('N,F', [(1, 1), (777, 3), (5000, 1300), (64, 20480), (30000, 5120)])
+def test_gpu_vs_oracle(dtype, N, F):
+    """dist / face_idx / dist_type bit-exact vs the oracle (same IEEE operations incl. the 1/sqrt pin);
+    gradients 1e-5 relative (atomic order)."""
+    from kaolin_amd.utils.testing import geodesic_sphere
+    torch.manual_seed(N + F)
+    if F in (20480, 5120):
+        v, f = geodesic_sphere({20480: 32, 5120: 16}[F])
+        fv = v.to(dtype)[f]
+        pts = torch.rand(N, 3, dtype=dtype) * 1.2 - 0.6
+    else:
+        fv = torch.randn(F, 3, 3, dtype=dtype)
+        pts = torch.randn(N, 3, dtype=dtype)
+    d_ref, i_ref, t_ref = oracle.triangle_distance_forward(pts, fv, omp=True)
+    a, b = pts.cuda().requires_grad_(), fv.cuda().requires_grad_()
+    dist, idx, typ = _tm()._UnbatchedTriangleDistanceCuda.apply(a, b)
+    assert torch.equal(idx.cpu(), i_ref) and torch.equal(typ.cpu(), t_ref)
+    assert torch.equal(dist.detach().cpu(), d_ref)
+    g = torch.rand(N, dtype=dtype)
+    dist.backward(g.cuda())
+    gp, gf = oracle.triangle_distance_backward(g, pts, fv, i_ref, t_ref)
+    assert float((a.grad.cpu() - gp).abs().max()) <= 1e-5 * max(float(gp.abs().max()), 1e-30)
+    assert float((b.grad.cpu() - gf).abs().max()) <= 1e-5 * max(float(gf.abs().max()), 1e-30)
+
+
+@pytest.mark.gpu
+def test_gpu_batched_api_and_errors():
+    tm = _tm()
+    torch.manual_seed(0)
+    pts, fv = torch.randn(3, 100, 3), torch.randn(3, 50, 3, 3)
+    dist, idx, typ = tm.point_to_mesh_distance(pts.cuda(), fv.cuda())
+    r = oracle.point_to_mesh_distance(pts, fv)
+    assert dist.shape == (3, 100) and idx.dtype == torch.long and typ.dtype == torch.int32
+    assert torch.equal(dist.cpu(), r[0]) and torch.equal(idx.cpu(), r[1]) and torch.equal(typ.cpu(), r[2])
+    with pytest.raises(RuntimeError, match='points must be a CUDA tensor'):
+        from kaolin_amd import _C
+        _C.metrics.unbatched_triangle_distance_forward_cuda(pts[0], fv[0].cuda(), torch.zeros(100).cuda(),
+                                                            torch.zeros(100, dtype=torch.long).cuda(),
+                                                            torch.zeros(100, dtype=torch.int32).cuda())
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_properties():
+    """C5 shape (1M queries x 50k-face sphere): (i) a random subset of queries agrees bit-for-bit with the
+    oracle; (ii) for the unit-radius-0.5 sphere the distance is close to (|p| - 0.5)^2; (iii) splitting
+    the queries in two halves gives the same answers (queries are independent)."""
+    from kaolin_amd.utils.testing import geodesic_sphere
+    v, f = geodesic_sphere(50)
+    fv = v.float()[f].cuda()
+    torch.manual_seed(0)
+    pts = (torch.rand(1000000, 3) * 1.2 - 0.6).cuda()
+    dist, idx, typ = _tm().point_to_mesh_distance(pts[None], fv[None])
+    sel = torch.randperm(1000000)[:300]
+    d_ref, i_ref, t_ref = oracle.triangle_distance_forward(pts[sel.cuda()].cpu(), fv.cpu(), omp=True)
+    assert torch.equal(dist[0, sel.cuda()].cpu(), d_ref) and torch.equal(idx[0, sel.cuda()].cpu(), i_ref)
+    assert torch.equal(typ[0, sel.cuda()].cpu(), t_ref)
+    approx = (pts.norm(dim=1) - 0.5) ** 2
+    assert float((dist[0] - approx).abs().max()) < 2e-3
+    d2, i2, t2 = _tm().point_to_mesh_distance(pts[None, 500000:], fv[None])
+    assert torch.equal(d2[0], dist[0, 500000:]) and torch.equal(i2[0], idx[0, 500000:])
