@@ -1,0 +1,181 @@
+// trianglemeshes_to_voxelgrids (dense) for MI355X (gfx950).
+//
+// The reference has NO native kernel for this op: it is pure PyTorch
+// (kaolin/ops/conversions/trianglemesh.py:29-110, ops/mesh/trianglemesh.py:410-458,
+// ops/conversions/pointcloud.py:42-75): repeat { keep triangles whose largest squared edge exceeds
+// ((R-1)/R^2)^2; add the three edge midpoints to the vertex set; split into 4 } with a sort-based
+// torch.unique and a host sync per round, then round(p*(R-1)), unique again, scatter into a dense grid.
+// The result only depends on the SET {original vertices} U {all midpoints}, and marking a voxel is
+// idempotent, so the whole op becomes one streaming pass with no sort, no de-duplication and no host sync:
+//   vox_vertices_kernel : one thread per vertex marks its voxel;
+//   vox_faces_kernel    : the subdivision tree of a face is deterministic, so a thread is given
+//                         (face, a base-4 path of L0 levels): it re-derives its sub-triangle by descending
+//                         the path (the thread whose remaining path digits are all 0 marks the ancestors'
+//                         midpoints, exactly once), then finishes the subtree depth-first with a small
+//                         per-level stack.  L0 is picked on the host from B*F alone so that ~2M threads exist
+//                         whatever the mesh (12 huge faces or 10^6 tiny ones).
+// Arithmetic as the reference's torch ops, in the tensor's dtype: midpoint (a+b)/2, squared edge
+// (dx*dx + dy*dy) + dz*dz (torch.sum's order for 3 elements), threshold rounded to the dtype,
+// round-half-even of p*(R-1).  -ffp-contract=off.
+#include "common.h"
+#include "../../include/kaolin_amd.h"
+
+namespace {
+
+constexpr int VOX_MAXD = 20;   // depth-first levels below L0 (edges halve per level)
+constexpr int VOX_MAXL0 = 10;
+
+template <typename T> __device__ __forceinline__ T vox_rint(T x);
+template <> __device__ __forceinline__ float vox_rint<float>(float x) { return rintf(x); }
+template <> __device__ __forceinline__ double vox_rint<double>(double x) { return rint(x); }
+
+template <typename T>
+__device__ __forceinline__ void vox_mark(T* __restrict__ grid, int R, T x, T y, T z) {
+  const T s = (T)(R - 1);
+  const T rx = vox_rint<T>(x * s), ry = vox_rint<T>(y * s), rz = vox_rint<T>(z * s);
+  if (rx >= 0 && rx <= s && ry >= 0 && ry <= s && rz >= 0 && rz <= s)
+    grid[((size_t)(int)rx * R + (int)ry) * R + (int)rz] = (T)1;
+}
+
+template <typename T>
+__device__ __forceinline__ T vox_edge2(const T* a, const T* b) {
+  const T dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+  return (dx * dx + dy * dy) + dz * dz;
+}
+// t = {v1, v2, v3}; true when the triangle must be subdivided
+template <typename T>
+__device__ __forceinline__ bool vox_keep(const T* t, T thr) {
+  T m = vox_edge2(t, t + 3);
+  const T e2 = vox_edge2(t + 3, t + 6), e3 = vox_edge2(t + 6, t);
+  if (e2 > m) m = e2;
+  if (e3 > m) m = e3;
+  return m > thr;
+}
+// mids = {v4 = (v1+v3)/2, v5 = (v1+v2)/2, v6 = (v2+v3)/2}
+template <typename T>
+__device__ __forceinline__ void vox_mids(const T* t, T* m) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    m[i] = (t[i] + t[6 + i]) / (T)2;
+    m[3 + i] = (t[i] + t[3 + i]) / (T)2;
+    m[6 + i] = (t[3 + i] + t[6 + i]) / (T)2;
+  }
+}
+// children: 0 (v1,v4,v5)  1 (v2,v5,v6)  2 (v4,v5,v6)  3 (v3,v4,v6)
+template <typename T>
+__device__ __forceinline__ void vox_child(const T* t, const T* m, int c, T* out) {
+  const T* a = c == 0 ? t : (c == 1 ? t + 3 : (c == 2 ? m : t + 6));
+  const T* b = (c == 1 || c == 2) ? m + 3 : m;
+  const T* d = c == 0 ? m + 3 : m + 6;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    out[i] = a[i];
+    out[3 + i] = b[i];
+    out[6 + i] = d[i];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void vox_vertices_kernel(long long total, int V, int R, const T* __restrict__ vertices,
+                                                           T* __restrict__ grid) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int b = (int)(i / V);
+  vox_mark<T>(grid + (size_t)b * R * R * R, R, vertices[i * 3], vertices[i * 3 + 1], vertices[i * 3 + 2]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void vox_faces_kernel(long long total, int V, int F, int R, int L0, double thr_d,
+                                                        const T* __restrict__ vertices,
+                                                        const int64_t* __restrict__ faces, T* __restrict__ grid_all) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const unsigned int npath = 1u << (2 * L0);
+  const unsigned int path = (unsigned int)(gid % npath);
+  const long long bf = gid / npath;
+  const int f = (int)(bf % F), b = (int)(bf / F);
+  const T thr = (T)thr_d;
+  T* grid = grid_all + (size_t)b * R * R * R;
+  const T* vb = vertices + (size_t)b * V * 3;
+  T tri[VOX_MAXD + 1][9], mid[VOX_MAXD + 1][9];
+  int next[VOX_MAXD + 1];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int64_t vi = faces[(size_t)f * 3 + k];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tri[0][k * 3 + i] = vb[vi * 3 + i];
+  }
+  // descend the path prefix
+  for (int l = 0; l < L0; ++l) {
+    if (!vox_keep<T>(tri[0], thr)) return;
+    vox_mids<T>(tri[0], mid[0]);
+    const int shift = 2 * (L0 - 1 - l);
+    if ((path & ((1u << (shift + 2)) - 1u)) == 0u) {
+      vox_mark<T>(grid, R, mid[0][0], mid[0][1], mid[0][2]);
+      vox_mark<T>(grid, R, mid[0][3], mid[0][4], mid[0][5]);
+      vox_mark<T>(grid, R, mid[0][6], mid[0][7], mid[0][8]);
+    }
+    T child[9];
+    vox_child<T>(tri[0], mid[0], (int)((path >> shift) & 3u), child);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tri[0][i] = child[i];
+  }
+  // depth-first below L0
+  int d = 0;
+  next[0] = -1;
+  while (d >= 0) {
+    if (next[d] < 0) {
+      if (!vox_keep<T>(tri[d], thr)) {
+        --d;
+        continue;
+      }
+      vox_mids<T>(tri[d], mid[d]);
+      vox_mark<T>(grid, R, mid[d][0], mid[d][1], mid[d][2]);
+      vox_mark<T>(grid, R, mid[d][3], mid[d][4], mid[d][5]);
+      vox_mark<T>(grid, R, mid[d][6], mid[d][7], mid[d][8]);
+      next[d] = 0;
+    }
+    if (next[d] >= 4 || d >= VOX_MAXD) {
+      --d;
+      continue;
+    }
+    const int c = next[d]++;
+    vox_child<T>(tri[d], mid[d], c, tri[d + 1]);
+    next[d + 1] = -1;
+    ++d;
+  }
+}
+
+template <typename T>
+int vox_launch(hipStream_t st, int B, int V, int F, int R, const T* vertices, const int64_t* faces, T* grid) {
+  if (B <= 0 || R <= 1) return 0;
+  KAMD_CHECK(hipMemsetAsync(grid, 0, (size_t)B * R * R * R * sizeof(T), st));
+  if (V > 0) {
+    const long long tv = (long long)B * V;
+    hipLaunchKernelGGL(vox_vertices_kernel<T>, dim3(kamd_cdiv(tv, 256)), dim3(256), 0, st, tv, V, R, vertices, grid);
+    KAMD_CHECK(hipGetLastError());
+  }
+  if (F > 0 && V > 0) {
+    int L0 = 0;
+    while (L0 < VOX_MAXL0 && (long long)B * F * (1ll << (2 * L0)) < (1ll << 21)) ++L0;
+    const long long total = (long long)B * F * (1ll << (2 * L0));
+    const double thr = ((double)(R - 1) / ((double)R * (double)R)) * ((double)(R - 1) / ((double)R * (double)R));
+    hipLaunchKernelGGL(vox_faces_kernel<T>, dim3(kamd_cdiv(total, 256)), dim3(256), 0, st, total, V, F, R, L0, thr,
+                       vertices, faces, grid);
+    KAMD_CHECK(hipGetLastError());
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+int kamd_trianglemeshes_to_voxelgrids_f32(void* stream, int B, int V, int F, int R, const float* vertices,
+                                          const int64_t* faces, float* grid) {
+  return vox_launch<float>((hipStream_t)stream, B, V, F, R, vertices, faces, grid);
+}
+int kamd_trianglemeshes_to_voxelgrids_f64(void* stream, int B, int V, int F, int R, const double* vertices,
+                                          const int64_t* faces, double* grid) {
+  return vox_launch<double>((hipStream_t)stream, B, V, F, R, vertices, faces, grid);
+}
+}  // extern "C"

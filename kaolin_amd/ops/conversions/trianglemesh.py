@@ -1,0 +1,66 @@
+"""``trianglemeshes_to_voxelgrids`` (API mirror of kaolin/ops/conversions/trianglemesh.py:29-110)."""
+import torch
+
+from ... import _C
+
+__all__ = ['trianglemeshes_to_voxelgrids']
+
+
+def _torch_dense(points_per_item, faces, resolution):
+    """Device-agnostic torch path for non-GPU tensors (the reference op is itself plain torch and accepts CPU
+    tensors): level-synchronous subdivision collecting the midpoint SET, then round + scatter."""
+    thr = ((resolution - 1) / (resolution ** 2)) ** 2
+    grids = []
+    for verts in points_per_item:
+        pts = [verts]
+        v1, v2, v3 = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
+        while v1.shape[0] > 0:
+            e = torch.stack([torch.sum((v1 - v2) ** 2, dim=1), torch.sum((v2 - v3) ** 2, dim=1),
+                             torch.sum((v3 - v1) ** 2, dim=1)], dim=1)
+            keep = e.max(dim=1)[0] > thr
+            if not bool(keep.any()):
+                break
+            v1, v2, v3 = v1[keep], v2[keep], v3[keep]
+            v4, v5, v6 = (v1 + v3) / 2, (v1 + v2) / 2, (v2 + v3) / 2
+            pts += [v4, v5, v6]
+            v1, v2, v3 = torch.cat((v1, v2, v4, v3)), torch.cat((v4, v5, v5, v4)), torch.cat((v5, v6, v6, v6))
+        idx = torch.round(torch.cat(pts) * (resolution - 1)).long()
+        idx = idx[((idx >= 0) & (idx <= resolution - 1)).all(dim=1)]
+        g = torch.zeros((resolution,) * 3, dtype=verts.dtype, device=verts.device)
+        g[idx[:, 0], idx[:, 1], idx[:, 2]] = 1
+        grids.append(g)
+    return torch.stack(grids)
+
+
+def trianglemeshes_to_voxelgrids(vertices, faces, resolution, origin=None, scale=None, return_sparse=False):
+    r"""Converts meshes to surface voxelgrids of a given resolution: vertices are normalised with
+    ``(vertices - origin) / scale``, every triangle is subdivided until its longest edge is below the voxel
+    size, and each resulting point marks the voxel ``round(p * (resolution - 1))``
+    (reference: kaolin/ops/conversions/trianglemesh.py:29-110).
+
+    Args:
+        vertices (torch.Tensor): (B, V, 3).
+        faces (torch.LongTensor): (F, 3), shared by the batch.
+        resolution (int): grid size along each axis.
+        origin (torch.Tensor): (B, 3) origin of the grid. Default: per-mesh minimum.
+        scale (torch.Tensor): (B) scale of the grid. Default: largest per-mesh extent.
+        return_sparse (bool): return a sparse COO tensor instead of a dense one.
+
+    Returns:
+        (torch.Tensor): binary voxelgrids (B, R, R, R) in the dtype of ``vertices``.
+    """
+    if not isinstance(resolution, int):
+        raise TypeError(f"Expected resolution to be int "
+                        f"but got {type(resolution)}.")
+    if origin is None:
+        origin = torch.min(vertices, dim=1)[0]
+    if scale is None:
+        scale = torch.max(torch.max(vertices, dim=1)[0] - origin, dim=1)[0]
+    normalized = (vertices - origin.unsqueeze(1)) / scale.view(-1, 1, 1)
+    if vertices.is_cuda and vertices.dtype in (torch.float32, torch.float64):
+        assert resolution > 1
+        dense = _C.ops.trianglemeshes_to_voxelgrids_cuda(normalized, faces, resolution)
+    else:
+        assert resolution > 1
+        dense = _torch_dense(normalized, faces, resolution)
+    return dense.to_sparse() if return_sparse else dense

@@ -43,8 +43,11 @@ def load_reference():
     # stubs for imports the oracle files do not use on our path
     sys.modules['kaolin.ops.spc'].points = types.ModuleType('points')
     sys.modules['kaolin.ops.spc.points'] = sys.modules['kaolin.ops.spc'].points
-    sys.modules['kaolin.ops.spc.points'].quantize_points = None
-    sys.modules['kaolin.ops.spc.points'].unbatched_points_to_octree = None
+    for n in ('quantize_points', 'points_to_morton', 'morton_to_points', 'unbatched_points_to_octree'):
+        setattr(sys.modules['kaolin.ops.spc.points'], n, None)
+    sys.modules['kaolin.ops.batch'] = types.ModuleType('kaolin.ops.batch')
+    for n in ('tile_to_packed', 'packed_to_padded', 'get_first_idx'):
+        setattr(sys.modules['kaolin.ops.batch'], n, None)
     sys.modules['kaolin.rep.spc'] = types.ModuleType('kaolin.rep.spc')
     sys.modules['kaolin.rep.spc'].Spc = None
     sys.modules['kaolin.rep'].Spc = None
@@ -56,6 +59,9 @@ def load_reference():
     mods['legacy_camera'] = _load('kaolin.render.camera.legacy', 'kaolin/render/camera/legacy.py')
     mods['pointcloud'] = _load('kaolin.metrics.pointcloud', 'kaolin/metrics/pointcloud.py')
     mods['deftet'] = _load('kaolin.render.mesh.deftet', 'kaolin/render/mesh/deftet.py')
+    mods['ops_trianglemesh'] = _load('kaolin.ops.mesh.trianglemesh', 'kaolin/ops/mesh/trianglemesh.py')
+    mods['conv_pointcloud'] = _load('kaolin.ops.conversions.pointcloud', 'kaolin/ops/conversions/pointcloud.py')
+    mods['conv_trianglemesh'] = _load('kaolin.ops.conversions.trianglemesh', 'kaolin/ops/conversions/trianglemesh.py')
     mods['trianglemesh'] = _load('kaolin.metrics.trianglemesh', 'kaolin/metrics/trianglemesh.py')
     k._mods = mods
     return mods

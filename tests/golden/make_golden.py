@@ -177,6 +177,43 @@ def triangle_distance():
     save('triangle_distance', **out)
 
 
+@section
+def voxelgrid():
+    """reference: trianglemeshes_to_voxelgrids (kaolin/ops/conversions/trianglemesh.py:29-110, pure torch, run
+    here on CPU) on the inputs of its own tests (tests/python/kaolin/ops/conversions/test_trianglemesh.py:45-242)
+    and on seeded random / sphere meshes; dense outputs stored bit-packed."""
+    conv = _refload.load_reference()['conv_trianglemesh'].trianglemeshes_to_voxelgrids
+    sys.path.insert(0, os.path.join(HERE, os.pardir, os.pardir))
+    from kaolin_amd.utils.testing import geodesic_sphere
+    out = {}
+    cases = []
+    tri = torch.tensor([[[0, 0, 0], [1, 0, 0], [0, 0, 1]], [[0, 0, 0], [0, 1, 0], [1, 0, 1]]], dtype=torch.float)
+    f1 = torch.tensor([[0, 1, 2]])
+    cases.append(('batched', tri, f1, 3, torch.zeros(2, 3), torch.ones(2)))
+    cases.append(('origins', tri[:1], f1, 3, torch.tensor([[0., 0.5, 0.]]), torch.ones(1)))      # shape of :93-123
+    cases.append(('scale', tri[:1], f1, 3, torch.zeros(1, 3), torch.ones(1) * 2))                 # shape of :125-154
+    cases.append(('res4', tri[:1], f1, 4, None, None))
+    rect_v = torch.tensor([[[0, 0, 0], [8, 0, 0], [0, 8, 0], [8, 8, 0], [0, 0, 12], [8, 0, 12], [0, 8, 12], [8, 8, 12]]],
+                          dtype=torch.float)
+    rect_f = torch.tensor([[0, 3, 1], [0, 2, 3], [0, 1, 5], [0, 5, 4], [6, 7, 3], [6, 3, 2], [1, 3, 7], [1, 7, 5],
+                           [4, 5, 7], [4, 7, 6], [4, 6, 2], [4, 2, 0]])
+    cases.append(('rect', rect_v, rect_f, 16, None, None))
+    torch.manual_seed(0)
+    cases.append(('rand', torch.rand(2, 40, 3), torch.randint(0, 40, (60, 3)), 32, None, None))
+    cases.append(('rand_out', torch.rand(1, 30, 3) * 2 - 0.5, torch.randint(0, 30, (40, 3)), 24, torch.zeros(1, 3), torch.ones(1)))
+    v, f = geodesic_sphere(4)
+    cases.append(('sphere64', v.float()[None], f, 64, None, None))
+    cases.append(('sphere40_f64', v[None], f, 40, None, None))
+    for name, vv, ff, res, org, sc in cases:
+        dense = conv(vv, ff, res, org, sc, False)
+        out[name + '_vertices'], out[name + '_faces'], out[name + '_res'] = vv, ff, res
+        if org is not None:
+            out[name + '_origin'], out[name + '_scale'] = org, sc
+        out[name + '_packed'] = np.packbits(dense.numpy().astype(np.uint8).reshape(-1))
+        out[name + '_count'] = int(dense.sum())
+    save('voxelgrid', **out)
+
+
 def _dibr_gt(sub, stem, H, W, sigmainv, boxlen):
     return torch.load(os.path.join(_refload.REF, 'tests/samples/dibr', sub, f'{stem}_{H}_{W}_{int(sigmainv)}_{boxlen}.pt'),
                       map_location='cpu')
