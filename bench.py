@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""bench.py -- the hot path's headline benchmark on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Headline metric (BASELINE.json): Mpixels/s of DIB-R forward+backward at 1024x1024.  One "step" is one pass of
+the hot path over one batch of synthetic camera views on every rank (config C4 of SURVEY.md 8(d)):
+    prepare_vertices(shared vertices) -> dibr_rasterization(8 views/GPU of a 50 000-triangle geodesic sphere,
+    D = 3 features, knum = 30, sigmainv = 7000, boxlen = 0.02) -> backward of (features*G1).sum() +
+    (soft_mask*G2).sum() down to the shared vertices -> ONE all-reduce of the vertex gradient (N > 1).
+Views are sharded over ranks (weak scaling: 8 views per GPU), no collective on the data path.  Inputs are
+resident in HBM when the timed region starts.  The same run also times chamfer_distance fwd+bwd at
+100k x 100k (config C3, one batch item per GPU) and reports it under "chamfer".
+
+Rank 0 prints ONE JSON line.  "roofline" describes the kernel with the largest share of the DIB-R step, timed
+live with HIP events on the launch stream (libkaolin_amd's kamd_profile_* hooks); "cpu_baseline" is the CPU
+oracle (OpenMP) timed on a bounded sample on this box's host cores (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import kaolin_amd as kal  # noqa: E402
+from kaolin_amd import _lib, distributed as D  # noqa: E402
+from kaolin_amd.utils import testing as T  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is what a streaming copy reaches
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--views-per-gpu', type=int, default=8)
+    ap.add_argument('--res', type=int, default=1024)
+    ap.add_argument('--sphere-frequency', type=int, default=50, help='20*f^2 triangles (50 -> 50 000)')
+    ap.add_argument('--chamfer-points', type=int, default=100000)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-chamfer', action='store_true')
+    return ap.parse_args()
+
+
+def algorithmic_bytes(kernel, B, P, F, Fv, D, K, esz=4):
+    """Contract bytes per launch: every operator input read once, every output written once."""
+    per = {
+        'raster_tile_kernel': P * (8 + 3 * esz + D * esz) + Fv * (13 * esz + 3 * D * esz),
+        'raster_backward_kernel': P * (8 + 3 * esz + D * esz) + F * (6 * esz * 2 + 3 * D * esz * 2),
+        'fill_regions_kernel': P * K * (esz + 8 + 1),
+        'soft_mask_tile_kernel': P * (8 + esz) + F * 10 * esz,
+        'soft_mask_backward_kernel': P * (8 + 2 * esz) + F * 6 * esz * 2,
+        'bin_faces_kernel': F * (13 * esz + 16 * esz),
+    }
+    return B * per[kernel] if kernel in per else None
+
+
+def main():
+    args = parse()
+    D.init_from_env()
+    rank, world = D.rank(), D.world_size()
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP operators have no CPU fallback)'
+    dev = torch.device('cuda', torch.cuda.current_device())
+    lib = _lib.load()
+    H = W = args.res
+    V = args.views_per_gpu
+
+    # ---------------- synthetic scene (config C4): shared mesh, this rank's slice of the camera ring
+    verts, faces = T.geodesic_sphere(args.sphere_frequency)
+    verts = verts.float().to(dev).requires_grad_()
+    faces = faces.to(dev)
+    F = faces.shape[0]
+    cams_all = T.fibonacci_cameras(V * world, 2.5)
+    cams = cams_all[rank * V:(rank + 1) * V].to(dev)
+    look_at = torch.zeros((V, 3), device=dev)
+    up = torch.tensor([[0., 1., 0.]], device=dev).repeat(V, 1)
+    rot, trans = kal.render.camera.generate_rotate_translate_matrices(cams, look_at, up)
+    proj = kal.render.camera.generate_perspective_projection(math.pi / 4).to(dev)
+    g = torch.Generator().manual_seed(0)
+    uv = torch.rand((1, F, 3, 2), generator=g).to(dev).expand(V, -1, -1, -1).contiguous()
+    ones = torch.ones((V, F, 3, 1), device=dev)
+    G1 = torch.rand((V, H, W, 3), generator=g).to(dev)
+    G2 = torch.rand((V, H, W), generator=g).to(dev)
+
+    def dibr_step():
+        verts.grad = None
+        fv_cam, fv_img, normals = kal.render.mesh.prepare_vertices(
+            verts.unsqueeze(0).expand(V, -1, -1), faces, proj, camera_rot=rot, camera_trans=trans)
+        (f_uv, f_one), soft, face_idx = kal.render.mesh.dibr_rasterization(
+            H, W, fv_cam[..., 2], fv_img, [uv, ones], normals[..., 2])
+        loss = (f_uv * G1[..., :2]).sum() + (f_one * G1[..., 2:]).sum() + (soft * G2).sum()
+        loss.backward()
+        D.all_reduce_gradients([verts])
+        return face_idx
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        D.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        D.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.double)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    # ---------------- DIB-R: the timed region (per-kernel HIP-event timing switched on inside it)
+    for _ in range(args.warmup):
+        face_idx = dibr_step()
+    lib.kamd_profile_reset()
+    lib.kamd_profile_enable(1)
+    dt = timed(dibr_step, args.steps, 0)
+    lib.kamd_profile_enable(0)
+    prof = _lib.kernel_profile(reset=True)
+    ms_per_step = dt / args.steps * 1e3
+    mpix = world * V * H * W * args.steps / dt / 1e6
+
+    covered = float((face_idx >= 0).float().mean())
+    Fv = F // 2  # front-facing faces of a closed convex mesh
+    kernels = {}
+    for name, (ms, n) in prof.items():
+        avg_us = ms / n * 1e3
+        ab = algorithmic_bytes(name, V, H * W, F, Fv, 3, 30)
+        kernels[name] = {'avg_us': round(avg_us, 2), 'launches_per_step': round(n / args.steps, 2),
+                         'share_of_step': round(ms / args.steps / ms_per_step, 4),
+                         'algorithmic_GBps': None if ab is None else round(ab / (avg_us * 1e-6) / 1e9, 1)}
+    dom = max((k for k in kernels if kernels[k]['algorithmic_GBps'] is not None),
+              key=lambda k: kernels[k]['share_of_step'] * 1.0, default=None)
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if dom and os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get(dom)
+    roofline = None
+    if dom:
+        roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': kernels[dom]['algorithmic_GBps'], 'peak': HBM_PEAK_GBS,
+                    'unit': 'GB/s', 'frac': round(kernels[dom]['algorithmic_GBps'] / HBM_PEAK_GBS, 4),
+                    'traffic': traffic, 'avg_launch_us': kernels[dom]['avg_us'],
+                    'algorithmic_bytes_per_launch': algorithmic_bytes(dom, V, H * W, F, Fv, 3, 30)}
+    # whole-step figure against the contract bytes of SURVEY.md 8(d): 872 B/pixel + 296 B/face (D=3, K=30, fp32)
+    contract = V * (H * W * 872 + F * 296)
+    lean = V * (H * W * 48 + F * 136)
+    step_roofline = {'contract_bytes_per_step': contract, 'contract_GBps': round(contract / (ms_per_step * 1e-3) / 1e9, 1),
+                     'contract_frac_of_8TBps': round(contract / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     'lean_bytes_per_step': lean}
+
+    # ---------------- chamfer 100k x 100k fwd+bwd (config C3: one batch item per rank + shared offset)
+    chamfer = None
+    if not args.no_chamfer:
+        n = args.chamfer_points
+        gen = torch.Generator().manual_seed(rank)
+        base = torch.rand((1, n, 3), generator=gen).to(dev)
+        p2 = torch.rand((1, n, 3), generator=gen).to(dev).requires_grad_()
+        offset = torch.zeros(3, device=dev, requires_grad=True)
+
+        def chamfer_step():
+            offset.grad = None
+            p2.grad = None
+            kal.metrics.pointcloud.chamfer_distance(base + offset, p2).sum().backward()
+            D.all_reduce_gradients([offset])
+
+        lib.kamd_profile_reset()
+        lib.kamd_profile_enable(1)
+        cdt = timed(chamfer_step, args.steps, args.warmup)
+        lib.kamd_profile_enable(0)
+        cprof = _lib.kernel_profile(reset=True)
+        pairs = 2.0 * world * n * n * args.steps
+        main_ms, main_n = cprof.get('sd_main_f32', (0.0, 1))
+        chamfer = {'metric': 'Mpoint-pairs/s chamfer fwd+bwd', 'value': round(pairs / cdt / 1e6, 1),
+                   'ms_per_step': round(cdt / args.steps * 1e3, 4), 'points': n,
+                   'sd_main_avg_us': round(main_ms / max(main_n, 1) * 1e3, 2),
+                   # 6.7 VALU lane-ops per pair in sd_main_f32 (kaolin_amd/csrc/sided_distance.hip header)
+                   'valu_Tlaneops_per_s': round(6.7 * n * n / (main_ms / max(main_n, 1) * 1e-3) / 1e12, 2) if main_ms else None,
+                   'hbm_frac_of_8TBps': round(192.0 * n / (cdt / args.steps) / 1e9 / HBM_PEAK_GBS, 6)}
+
+    # ---------------- CPU baseline: the oracle (OpenMP) on a bounded sample, rank 0 at N = 1 only
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        import oracle
+        oracle.build()
+        with torch.no_grad():
+            fv_cam, fv_img, normals = kal.render.mesh.prepare_vertices(
+                verts.detach().unsqueeze(0), faces, proj, camera_rot=rot[:1], camera_trans=trans[:1])
+        sH = sW = 256
+        fz, fimg, nz = fv_cam[..., 2].cpu(), fv_img.cpu(), normals[..., 2].cpu()
+        feat = torch.cat([uv[:1], ones[:1]], -1).cpu()
+        t0 = time.perf_counter()
+        ref = oracle.dibr_rasterization(sH, sW, fz, fimg, feat, nz, omp=True)
+        oracle.rasterize_backward(torch.ones_like(ref['features']), ref['face_idx'], ref['weights'], fimg, feat, 1e-8)
+        oracle.dibr_soft_mask_backward(torch.ones_like(ref['soft_mask']), ref['soft_mask'], ref['face_idx'],
+                                       ref['close_face_prob'], ref['close_face_idx'], ref['close_face_dist_type'],
+                                       ref['scaled_vertices'], 7000, 1000.)
+        cdt = time.perf_counter() - t0
+        cpu = {'value': round(sH * sW / cdt / 1e6, 4), 'unit': 'Mpixels/s', 'cores': oracle.num_threads(True),
+               'kind': 'port',
+               'sample': f'1 view of the same {F}-triangle mesh at {sH}x{sW} (the brute-force reference algorithm costs '
+                         f'O(faces) per pixel at any resolution), oracle forward (OpenMP) + both backwards, {cdt:.1f} s'}
+
+    if rank == 0:
+        out = {
+            'metric': 'Mpixels/s DIB-R fwd+bwd @1024^2', 'value': round(mpix, 2), 'unit': 'Mpixels/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'C4: dibr_rasterization fwd+bwd, {V} views/GPU at {H}x{W} of a {F}-triangle geodesic '
+                                   f'sphere (shared vertices), D=3 features, knum=30, sigmainv=7000, boxlen=0.02, '
+                                   f'prepare_vertices + vertex-gradient all-reduce inside the step',
+                       'views_per_gpu': V, 'global_views': V * world, 'height': H, 'width': W, 'faces': F,
+                       'covered_pixel_fraction': round(covered, 4), 'parallelism': f'views sharded {world}-way'},
+            'roofline': roofline, 'step_roofline': step_roofline, 'kernels': kernels,
+            'cpu_baseline': cpu, 'chamfer': chamfer,
+        }
+        print(json.dumps(out))
+    if D.is_distributed():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -195,6 +195,17 @@ int kamd_trianglemeshes_to_voxelgrids_f64(void* stream, int B, int V, int F, int
                                           const double* vertices, const int64_t* faces,
                                           double* grid);
 
+/* ------------------------------------------------------------------------- */
+/* Optional per-kernel timing (HIP events recorded on the launch stream).      */
+/* Not part of the reference's interface: used by bench.py for its roofline    */
+/* line; off by default.  kamd_profile_read synchronises the pending events.  */
+/* ------------------------------------------------------------------------- */
+int kamd_profile_enable(int on);
+int kamd_profile_reset(void);
+int kamd_profile_num_kernels(void);
+const char* kamd_profile_kernel_name(int id);
+int kamd_profile_read(int id, double* total_ms, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

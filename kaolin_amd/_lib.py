@@ -28,6 +28,11 @@ SIGNATURES = {
     'kamd_rasterize_forward_workspace': (_sz, [_i, _i, _i, _i64, _i]),
     'kamd_dibr_soft_mask_forward_workspace': (_sz, [_i, _i, _i, _i, _i]),
     'kamd_triangle_distance_forward_workspace': (_sz, [_i, _i, _i]),
+    'kamd_profile_enable': (_i, [_i]),
+    'kamd_profile_reset': (_i, []),
+    'kamd_profile_num_kernels': (_i, []),
+    'kamd_profile_kernel_name': (ctypes.c_char_p, [_i]),
+    'kamd_profile_read': (_i, [_i, _vp, _vp]),
 }
 for _t in ('f32', 'f64', 'f16'):
     SIGNATURES[f'kamd_sided_distance_forward_{_t}'] = (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp])
@@ -103,3 +108,18 @@ def workspace(nbytes, device):
     if nbytes <= 0:
         return None
     return torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=device)
+
+
+def kernel_profile(reset=False):
+    """{kernel name: (total_ms, launches)} accumulated since the last reset while profiling was enabled
+    (kamd_profile_enable).  Synchronises the recorded events."""
+    lib = load()
+    out = {}
+    for k in range(lib.kamd_profile_num_kernels()):
+        ms, n = ctypes.c_double(0), ctypes.c_int64(0)
+        lib.kamd_profile_read(k, ctypes.byref(ms), ctypes.byref(n))
+        if n.value:
+            out[lib.kamd_profile_kernel_name(k).decode()] = (ms.value, n.value)
+    if reset:
+        lib.kamd_profile_reset()
+    return out

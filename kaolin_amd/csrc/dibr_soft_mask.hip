@@ -16,6 +16,7 @@
 // pixel, 390 B at knum = 30) dominate HBM traffic: they are initialised by one streaming fill kernel
 // (16-byte stores), after which the tile kernel only touches the entries of actual hits.
 #include "common.h"
+#include "profile.h"
 #include "tile_bins.h"
 #include "../../include/kaolin_amd.h"
 
@@ -289,8 +290,11 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
     const size_t most = pb.n16 > pa.n16 ? pb.n16 : pa.n16;
     int blocks = (int)((most + 255) / 256 < (size_t)KAMD_NUM_CU * 16 ? (most + 255) / 256 : (size_t)KAMD_NUM_CU * 16);
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(fill_regions_kernel, dim3(blocks), dim3(256), 0, st, pa.body, pa.n16, 0u, pb.body, pb.n16,
+    {
+      kamd::ProfScope prof_(kamd::K_SOFT_FILL, st);
+      hipLaunchKernelGGL(fill_regions_kernel, dim3(blocks), dim3(256), 0, st, pa.body, pa.n16, 0u, pb.body, pb.n16,
                        0xFFFFFFFFu, pc.body, pc.n16, 0u);
+    }
     KAMD_CHECK(hipGetLastError());
   }
   // 2. bin the enlarged boxes, 3. search
@@ -298,12 +302,18 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
   unsigned int* masks = (unsigned int*)((char*)workspace + align256((size_t)total_faces * REC_STRIDE * sizeof(T)));
   if (total_faces > 0) {
     KAMD_CHECK(hipMemsetAsync(masks, 0, mask_words(g.ntiles, B, total_faces) * 4, st));
-    hipLaunchKernelGGL(bin_faces_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, F, total_faces,
+    {
+      kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
+      hipLaunchKernelGGL(bin_faces_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, F, total_faces,
                        (const int64_t*)nullptr, large_bbox, img, (const T*)nullptr, g, multiplier, rec, masks);
+    }
     KAMD_CHECK(hipGetLastError());
   }
-  hipLaunchKernelGGL(soft_mask_tile_kernel<T>, dim3(g.ntiles * B), dim3(TILE_THREADS), 0, st, B, F, g, K, sigmainv,
+  {
+    kamd::ProfScope prof_(kamd::K_SOFT_TILE, st);
+    hipLaunchKernelGGL(soft_mask_tile_kernel<T>, dim3(g.ntiles * B), dim3(TILE_THREADS), 0, st, B, F, g, K, sigmainv,
                      multiplier, rec, masks, sel_idx, soft_mask, prob, idx, type);
+  }
   KAMD_RETURN_LAST_ERROR();
 }
 
@@ -313,8 +323,11 @@ int soft_mask_backward_launch(hipStream_t st, int B, int H, int W, int F, int K,
                               const T* img, float sigmainv, float multiplier, T* g_img) {
   const long long total = (long long)B * H * W;
   if (total <= 0 || F <= 0 || K <= 0) return 0;
-  hipLaunchKernelGGL(soft_mask_backward_kernel<T>, dim3(kamd_cdiv(total, 256)), dim3(256), 0, st, total, H, W, F, K,
+  {
+    kamd::ProfScope prof_(kamd::K_SOFT_BACKWARD, st);
+    hipLaunchKernelGGL(soft_mask_backward_kernel<T>, dim3(kamd_cdiv(total, 256)), dim3(256), 0, st, total, H, W, F, K,
                      grad, soft_mask, sel_idx, prob, idx, type, img, sigmainv, multiplier, g_img);
+  }
   KAMD_RETURN_LAST_ERROR();
 }
 

@@ -1,0 +1,34 @@
+// Optional per-kernel timing with HIP events recorded on the launch stream (off by default, zero cost then).
+// bench.py switches it on around its timed region to obtain each kernel's average launch duration for the
+// roofline line; the same figures come out of `rocprofv3 --kernel-trace --stats` (profiles/).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace kamd {
+
+enum KernelId {
+  K_SD_MAIN = 0, K_SD_FINAL, K_SD_GENERIC, K_SD_BACKWARD,
+  K_BIN_FACES, K_RASTER_TILE, K_RASTER_BACKWARD,
+  K_SOFT_FILL, K_SOFT_TILE, K_SOFT_BACKWARD,
+  K_TD_PREP, K_TD_MAIN, K_TD_FINAL, K_TD_BACKWARD,
+  K_VOX_VERTICES, K_VOX_FACES, K_MEMSET,
+  K_NUM
+};
+
+bool prof_enabled();
+void prof_begin(int id, hipStream_t st);
+void prof_end(int id, hipStream_t st);
+
+struct ProfScope {
+  int id;
+  hipStream_t st;
+  bool on;
+  ProfScope(int id_, hipStream_t st_) : id(id_), st(st_), on(prof_enabled()) {
+    if (on) prof_begin(id, st);
+  }
+  ~ProfScope() {
+    if (on) prof_end(id, st);
+  }
+};
+
+}  // namespace kamd

@@ -15,6 +15,7 @@
 // the G-buffer is needed.  A 16x4-pixel sub-tile per wavefront makes each row of the G-buffer a 128-B
 // (idx), 192-B (weights) or 64*D/4-B (features) contiguous store per wavefront.
 #include "common.h"
+#include "profile.h"
 #include "tile_bins.h"
 #include "../../include/kaolin_amd.h"
 
@@ -204,12 +205,18 @@ int rasterize_forward_launch(hipStream_t st, int B, int H, int W, int D, int64_t
   unsigned int* masks = (unsigned int*)((char*)workspace + align256((size_t)total_faces * REC_STRIDE * sizeof(T)));
   if (total_faces > 0) {
     KAMD_CHECK(hipMemsetAsync(masks, 0, mask_words(g.ntiles, B, total_faces) * 4, st));
-    hipLaunchKernelGGL(bin_faces_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, 0,
+    {
+      kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
+      hipLaunchKernelGGL(bin_faces_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, 0,
                        (long long)total_faces, first_idx, bbox, img, z, g, multiplier, rec, masks);
+    }
     KAMD_CHECK(hipGetLastError());
   }
-  hipLaunchKernelGGL(raster_tile_kernel<T>, dim3(g.ntiles * B), dim3(TILE_THREADS), 0, st, B, 0, first_idx, g, D,
+  {
+    kamd::ProfScope prof_(kamd::K_RASTER_TILE, st);
+    hipLaunchKernelGGL(raster_tile_kernel<T>, dim3(g.ntiles * B), dim3(TILE_THREADS), 0, st, B, 0, first_idx, g, D,
                      multiplier, eps, rec, masks, feat, interp, sel_idx, weights);
+  }
   KAMD_RETURN_LAST_ERROR();
 }
 
@@ -218,8 +225,11 @@ int rasterize_backward_launch(hipStream_t st, int B, int H, int W, int F, int D,
                               const T* weights, const T* img, const T* feat, float eps, T* g_img, T* g_feat) {
   const long long total = (long long)B * H * W;
   if (total <= 0 || F <= 0) return 0;
-  hipLaunchKernelGGL(raster_backward_kernel<T>, dim3(kamd_cdiv(total, 256)), dim3(256), 0, st, total, H * W, F, D, grad,
+  {
+    kamd::ProfScope prof_(kamd::K_RASTER_BACKWARD, st);
+    hipLaunchKernelGGL(raster_backward_kernel<T>, dim3(kamd_cdiv(total, 256)), dim3(256), 0, st, total, H * W, F, D, grad,
                      face_idx, weights, img, feat, eps, g_img, g_feat);
+  }
   KAMD_RETURN_LAST_ERROR();
 }
 

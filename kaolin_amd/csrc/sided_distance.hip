@@ -25,6 +25,7 @@
 //     chunk with the identical arithmetic (kernel sd_final_f32).
 // That is 6.7 VALU/pair instead of 9 for the compare+2xselect formulation.
 #include "common.h"
+#include "profile.h"
 #include "../../include/kaolin_amd.h"
 
 namespace {
@@ -261,7 +262,10 @@ template <typename T>
 int sd_forward_generic_launch(hipStream_t st, int B, int N, int M, const T* p1, const T* p2, T* dist, int64_t* idx) {
   if (B <= 0 || N <= 0 || M <= 0) return 0;  // M == 0: outputs keep the caller's zeros
   dim3 grid(kamd_cdiv(N, SDG_THREADS), B);
-  hipLaunchKernelGGL(sd_forward_generic<T>, grid, dim3(SDG_THREADS), 0, st, N, M, p1, p2, dist, idx);
+  {
+    kamd::ProfScope prof_(kamd::K_SD_GENERIC, st);
+    hipLaunchKernelGGL(sd_forward_generic<T>, grid, dim3(SDG_THREADS), 0, st, N, M, p1, p2, dist, idx);
+  }
   KAMD_RETURN_LAST_ERROR();
 }
 
@@ -297,7 +301,10 @@ int sd_backward_launch(hipStream_t st, int B, int N, int M, const T* grad, const
                        const int64_t* idx, T* g1, T* g2) {
   if (B <= 0 || N <= 0 || M <= 0) return 0;
   dim3 grid(kamd_cdiv(N, 256), B);
-  hipLaunchKernelGGL(sd_backward<T>, grid, dim3(256), 0, st, N, M, grad, p1, p2, idx, g1, g2);
+  {
+    kamd::ProfScope prof_(kamd::K_SD_BACKWARD, st);
+    hipLaunchKernelGGL(sd_backward<T>, grid, dim3(256), 0, st, N, M, grad, p1, p2, idx, g1, g2);
+  }
   KAMD_RETURN_LAST_ERROR();
 }
 
@@ -320,10 +327,16 @@ int kamd_sided_distance_forward_f32(void* stream, int B, int N, int M, const flo
   if (!p.fast || workspace == nullptr) return sd_forward_generic_launch<float>(st, B, N, M, p1, p2, dist, idx);
   float* part_d = (float*)workspace;
   int* part_c = (int*)(part_d + (size_t)p.S * B * N);
-  hipLaunchKernelGGL(sd_main_f32, dim3(p.nx, p.S, B), dim3(SD_THREADS), 0, st, B, N, M, p.Ms, p1, p2, part_d, part_c);
+  {
+    kamd::ProfScope prof_(kamd::K_SD_MAIN, st);
+    hipLaunchKernelGGL(sd_main_f32, dim3(p.nx, p.S, B), dim3(SD_THREADS), 0, st, B, N, M, p.Ms, p1, p2, part_d, part_c);
+  }
   KAMD_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(sd_final_f32, dim3(kamd_cdiv((long long)B * N, 256)), dim3(256), 0, st, B, N, M, p.S, p1, p2,
+  {
+    kamd::ProfScope prof_(kamd::K_SD_FINAL, st);
+    hipLaunchKernelGGL(sd_final_f32, dim3(kamd_cdiv((long long)B * N, 256)), dim3(256), 0, st, B, N, M, p.S, p1, p2,
                      part_d, part_c, dist, idx);
+  }
   KAMD_RETURN_LAST_ERROR();
 }
 

@@ -23,6 +23,7 @@
 //   * face records are staged through LDS in tiles and read with broadcast ds_read_b128;
 //   * when N alone cannot fill 256 CUs the face range is split over blockIdx.y and merged in index order.
 #include "common.h"
+#include "profile.h"
 #include "../../include/kaolin_amd.h"
 
 namespace {
@@ -312,13 +313,22 @@ int td_forward_launch(hipStream_t st, int N, int F, const T* points, const T* fa
   int* part_i = (int*)w;
   w += td_align((size_t)p.S * N * sizeof(int));
   int* part_t = (int*)w;
-  hipLaunchKernelGGL(td_prep_kernel<T>, dim3(kamd_cdiv(F, 256)), dim3(256), 0, st, F, faces, rec);
+  {
+    kamd::ProfScope prof_(kamd::K_TD_PREP, st);
+    hipLaunchKernelGGL(td_prep_kernel<T>, dim3(kamd_cdiv(F, 256)), dim3(256), 0, st, F, faces, rec);
+  }
   KAMD_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(td_main_kernel<T>, dim3(p.nx, p.S), dim3(TD_THREADS), 0, st, N, F, p.Fs, points, rec, part_d,
+  {
+    kamd::ProfScope prof_(kamd::K_TD_MAIN, st);
+    hipLaunchKernelGGL(td_main_kernel<T>, dim3(p.nx, p.S), dim3(TD_THREADS), 0, st, N, F, p.Fs, points, rec, part_d,
                      part_i, part_t);
+  }
   KAMD_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(td_final_kernel<T>, dim3(kamd_cdiv(N, 256)), dim3(256), 0, st, N, p.S, part_d, part_i, part_t,
+  {
+    kamd::ProfScope prof_(kamd::K_TD_FINAL, st);
+    hipLaunchKernelGGL(td_final_kernel<T>, dim3(kamd_cdiv(N, 256)), dim3(256), 0, st, N, p.S, part_d, part_i, part_t,
                      dist, face_idx, dist_type);
+  }
   KAMD_RETURN_LAST_ERROR();
 }
 
@@ -326,8 +336,11 @@ template <typename T>
 int td_backward_launch(hipStream_t st, int N, int F, const T* grad, const T* points, const T* faces,
                        const int64_t* face_idx, const int32_t* dist_type, T* g_points, T* g_faces) {
   if (N <= 0 || F <= 0) return 0;
-  hipLaunchKernelGGL(td_backward_kernel<T>, dim3(kamd_cdiv(N, 256)), dim3(256), 0, st, N, grad, points, faces,
+  {
+    kamd::ProfScope prof_(kamd::K_TD_BACKWARD, st);
+    hipLaunchKernelGGL(td_backward_kernel<T>, dim3(kamd_cdiv(N, 256)), dim3(256), 0, st, N, grad, points, faces,
                      face_idx, dist_type, g_points, g_faces);
+  }
   KAMD_RETURN_LAST_ERROR();
 }
 

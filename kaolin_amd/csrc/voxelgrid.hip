@@ -18,6 +18,7 @@
 // (dx*dx + dy*dy) + dz*dz (torch.sum's order for 3 elements), threshold rounded to the dtype,
 // round-half-even of p*(R-1).  -ffp-contract=off.
 #include "common.h"
+#include "profile.h"
 #include "../../include/kaolin_amd.h"
 
 namespace {
@@ -152,7 +153,10 @@ int vox_launch(hipStream_t st, int B, int V, int F, int R, const T* vertices, co
   KAMD_CHECK(hipMemsetAsync(grid, 0, (size_t)B * R * R * R * sizeof(T), st));
   if (V > 0) {
     const long long tv = (long long)B * V;
-    hipLaunchKernelGGL(vox_vertices_kernel<T>, dim3(kamd_cdiv(tv, 256)), dim3(256), 0, st, tv, V, R, vertices, grid);
+    {
+      kamd::ProfScope prof_(kamd::K_VOX_VERTICES, st);
+      hipLaunchKernelGGL(vox_vertices_kernel<T>, dim3(kamd_cdiv(tv, 256)), dim3(256), 0, st, tv, V, R, vertices, grid);
+    }
     KAMD_CHECK(hipGetLastError());
   }
   if (F > 0 && V > 0) {
@@ -160,8 +164,11 @@ int vox_launch(hipStream_t st, int B, int V, int F, int R, const T* vertices, co
     while (L0 < VOX_MAXL0 && (long long)B * F * (1ll << (2 * L0)) < (1ll << 21)) ++L0;
     const long long total = (long long)B * F * (1ll << (2 * L0));
     const double thr = ((double)(R - 1) / ((double)R * (double)R)) * ((double)(R - 1) / ((double)R * (double)R));
-    hipLaunchKernelGGL(vox_faces_kernel<T>, dim3(kamd_cdiv(total, 256)), dim3(256), 0, st, total, V, F, R, L0, thr,
+    {
+      kamd::ProfScope prof_(kamd::K_VOX_FACES, st);
+      hipLaunchKernelGGL(vox_faces_kernel<T>, dim3(kamd_cdiv(total, 256)), dim3(256), 0, st, total, V, F, R, L0, thr,
                        vertices, faces, grid);
+    }
     KAMD_CHECK(hipGetLastError());
   }
   return 0;

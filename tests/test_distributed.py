@@ -1,0 +1,91 @@
+"""N > 1 path on CPU: two gloo processes.  Config C3's structure: every rank owns some batch
+items of a chamfer problem, a parameter `shared_offset` is replicated, per-item gradients stay local and ONE
+all-reduce carries the shared gradient; the sharded result must equal the single-process full-batch result.
+The per-item compute here is the CPU oracle (tests may use it); on the GPU box the same harness calls the HIP ops."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _chamfer_grad_wrt_offset(base, p2, offset):
+    """d/d(offset) of sum_b chamfer(base + offset, p2) via the oracle's sided-distance backward."""
+    import oracle
+    p1 = base + offset
+    B, N, M = p1.shape[0], p1.shape[1], p2.shape[1]
+    d12, i12 = oracle.sided_distance_forward(p1, p2)
+    d21, i21 = oracle.sided_distance_forward(p2, p1)
+    g1a, _ = oracle.sided_distance_backward(torch.full((B, N), 1.0 / N, dtype=p1.dtype), p1, p2, i12)
+    _, g1b = oracle.sided_distance_backward(torch.full((B, M), 1.0 / M, dtype=p1.dtype), p2, p1, i21)
+    loss = d12.mean(-1).sum() + d21.mean(-1).sum()
+    return (g1a + g1b).sum(dim=(0, 1)), loss
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from kaolin_amd import distributed as D
+    assert D.init_from_env('gloo')
+    assert D.rank() == rank and D.world_size() == world
+    torch.manual_seed(0)
+    B = 5  # ragged: 3 + 2 items
+    base, p2 = torch.rand(B, 300, 3, dtype=torch.double), torch.rand(B, 200, 3, dtype=torch.double)
+    offset = torch.zeros(3, dtype=torch.double, requires_grad=True)
+    b, e = D.shard_range(B)
+    assert (b, e) == ((0, 3) if rank == 0 else (3, 5))
+    g, loss = _chamfer_grad_wrt_offset(D.shard(base), D.shard(p2), offset.detach())
+    offset.grad = g.clone()
+    unused = torch.zeros(2, requires_grad=True, dtype=torch.double)  # a parameter with no grad on this rank
+    D.all_reduce_gradients([offset, unused])
+    gathered = D.all_gather_batch(torch.full((2, 1), float(rank)))
+    D.barrier()
+    if rank == 0:
+        torch.save({'grad': offset.grad, 'unused': unused.grad, 'gathered': gathered}, out)
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo_sharded_chamfer_matches_full_batch(tmp_path):
+    out = str(tmp_path / 'r0.pt')
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out)
+    torch.manual_seed(0)
+    base, p2 = torch.rand(5, 300, 3, dtype=torch.double), torch.rand(5, 200, 3, dtype=torch.double)
+    g_full, _ = _chamfer_grad_wrt_offset(base, p2, torch.zeros(3, dtype=torch.double))
+    assert torch.allclose(res['grad'], g_full, rtol=1e-12, atol=1e-14)
+    assert torch.equal(res['unused'], torch.zeros(2, dtype=torch.double))
+    assert torch.equal(res['gathered'], torch.tensor([[0.], [0.], [1.], [1.]]))
+
+
+def test_shard_range_covers_everything():
+    from kaolin_amd import distributed as D
+    for n in (0, 1, 7, 8, 64, 65):
+        for w in (1, 2, 3, 8):
+            spans = [D.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_single_process_is_a_noop():
+    from kaolin_amd import distributed as D
+    assert not D.is_distributed() and D.world_size() == 1 and D.rank() == 0
+    p = torch.ones(3, requires_grad=True)
+    p.grad = torch.full((3,), 2.0)
+    D.all_reduce_gradients([p])
+    assert torch.equal(p.grad, torch.full((3,), 2.0))
+    assert D.shard(torch.arange(10)).tolist() == list(range(10))
