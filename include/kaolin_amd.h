@@ -119,18 +119,21 @@ int kamd_rasterize_backward_f64(void* stream, int B, int H, int W, int F, int D,
 /* img (B,F,3,2) scaled, large_bbox (B,F,4), sel_idx (B,H,W) int64.           */
 /* Outputs fully written: soft_mask (B,H,W), prob (B,H,W,K) (0 fill),         */
 /* idx (B,H,W,K) int64 (-1 fill), type (B,H,W,K) uint8 (0 fill).              */
+/* hit_count (B,H,W) uint8 is OPTIONAL (NULL = not produced; not part of the  */
+/* reference's interface): number of K-buffer entries written per pixel,      */
+/* saturated at 255; the backward uses it to skip pixels without hits.        */
 /* ------------------------------------------------------------------------- */
 size_t kamd_dibr_soft_mask_forward_workspace(int B, int H, int W, int F, int elem_size);
 int kamd_dibr_soft_mask_forward_f32(void* stream, int B, int H, int W, int F, int K,
                                     const float* img, const float* large_bbox,
                                     const int64_t* sel_idx, float sigmainv, float multiplier,
                                     float* soft_mask, float* prob, int64_t* idx, uint8_t* type,
-                                    void* workspace);
+                                    void* workspace, uint8_t* hit_count);
 int kamd_dibr_soft_mask_forward_f64(void* stream, int B, int H, int W, int F, int K,
                                     const double* img, const double* large_bbox,
                                     const int64_t* sel_idx, float sigmainv, float multiplier,
                                     double* soft_mask, double* prob, int64_t* idx, uint8_t* type,
-                                    void* workspace);
+                                    void* workspace, uint8_t* hit_count);
 
 /* render.mesh.dibr_soft_mask_backward_cuda(grad, soft_mask, sel_idx, prob,   */
 /*     idx, type, img*mult, sigmainv, multiplier) -> g_img                    */
@@ -140,12 +143,14 @@ int kamd_dibr_soft_mask_backward_f32(void* stream, int B, int H, int W, int F, i
                                      const float* grad, const float* soft_mask,
                                      const int64_t* sel_idx, const float* prob,
                                      const int64_t* idx, const uint8_t* type, const float* img,
-                                     float sigmainv, float multiplier, float* g_img);
+                                     float sigmainv, float multiplier, float* g_img,
+                                     const uint8_t* hit_count);
 int kamd_dibr_soft_mask_backward_f64(void* stream, int B, int H, int W, int F, int K,
                                      const double* grad, const double* soft_mask,
                                      const int64_t* sel_idx, const double* prob,
                                      const int64_t* idx, const uint8_t* type, const double* img,
-                                     float sigmainv, float multiplier, double* g_img);
+                                     float sigmainv, float multiplier, double* g_img,
+                                     const uint8_t* hit_count);
 
 /* ------------------------------------------------------------------------- */
 /* metrics.unbatched_triangle_distance_forward_cuda(points, faces, dist,      */

@@ -83,10 +83,12 @@ def rasterize_backward_cuda(grad_interpolated_features, interpolated_features, s
 
 
 def dibr_soft_mask_forward_cuda(face_vertices_image, face_large_bboxes, selected_face_idx, sigmainv, knum,
-                                multiplier):
+                                multiplier, _with_hit_count=False):
     """reference: kaolin/csrc/render/mesh/dibr_soft_mask.cpp:48-108
     -> [soft_mask (B,H,W), close_face_prob (B,H,W,K), close_face_idx (B,H,W,K) int64,
-        close_face_dist_type (B,H,W,K) uint8]; face_vertices_image is already scaled by `multiplier`."""
+        close_face_dist_type (B,H,W,K) uint8]; face_vertices_image is already scaled by `multiplier`.
+    `_with_hit_count` (ours, not in the reference) appends a (B,H,W) uint8 tensor holding the number of K-buffer
+    entries written per pixel, which lets the backward skip pixels without hits."""
     fn = 'dibr_soft_mask_forward_cuda'
     args = [Arg(face_vertices_image, 'face_vertices_image', 1), Arg(face_large_bboxes, 'face_bboxes', 2),
             Arg(selected_face_idx, 'selected_face_idx', 3)]
@@ -107,19 +109,20 @@ def dibr_soft_mask_forward_cuda(face_vertices_image, face_large_bboxes, selected
         prob = torch.empty((batch_size, height, width, knum), dtype=dtype, device=device)
         idx = torch.empty((batch_size, height, width, knum), dtype=torch.long, device=device)
         typ = torch.empty((batch_size, height, width, knum), dtype=torch.uint8, device=device)
+        hits = torch.empty((batch_size, height, width), dtype=torch.uint8, device=device) if _with_hit_count else None
         ws = _lib.workspace(lib.kamd_dibr_soft_mask_forward_workspace(batch_size, height, width, num_faces,
                                                                       face_vertices_image.element_size()), device)
         st = getattr(lib, f'kamd_dibr_soft_mask_forward_{sfx}')(
             _lib.stream_ptr(device), batch_size, height, width, num_faces, knum,
             _lib.ptr(face_vertices_image), _lib.ptr(face_large_bboxes), _lib.ptr(selected_face_idx),
             float(sigmainv), float(multiplier), _lib.ptr(soft_mask), _lib.ptr(prob), _lib.ptr(idx), _lib.ptr(typ),
-            _lib.ptr(ws))
+            _lib.ptr(ws), _lib.ptr(hits))
     _lib.check(st, fn)
-    return [soft_mask, prob, idx, typ]
+    return [soft_mask, prob, idx, typ, hits] if _with_hit_count else [soft_mask, prob, idx, typ]
 
 
 def dibr_soft_mask_backward_cuda(grad_soft_mask, soft_mask, selected_face_idx, close_face_prob, close_face_idx,
-                                 close_face_dist_type, face_vertices_image, sigmainv, multiplier):
+                                 close_face_dist_type, face_vertices_image, sigmainv, multiplier, _hit_count=None):
     """reference: dibr_soft_mask.cpp:110-183 -> grad_face_vertices_image (B,F,3,2) (w.r.t. the UNSCALED input)"""
     fn = 'dibr_soft_mask_backward_cuda'
     args = [Arg(grad_soft_mask, 'grad_soft_mask', 1), Arg(soft_mask, 'soft_mask', 2),
@@ -147,6 +150,6 @@ def dibr_soft_mask_backward_cuda(grad_soft_mask, soft_mask, selected_face_idx, c
             _lib.stream_ptr(device), batch_size, height, width, num_faces, knum,
             _lib.ptr(grad_soft_mask), _lib.ptr(soft_mask), _lib.ptr(selected_face_idx), _lib.ptr(close_face_prob),
             _lib.ptr(close_face_idx), _lib.ptr(close_face_dist_type), _lib.ptr(face_vertices_image),
-            float(sigmainv), float(multiplier), _lib.ptr(g_img))
+            float(sigmainv), float(multiplier), _lib.ptr(g_img), _lib.ptr(_hit_count))
     _lib.check(st, fn)
     return g_img

@@ -29,27 +29,57 @@ template <typename T> __device__ __forceinline__ T dibr_exp(T x);
 template <> __device__ __forceinline__ float dibr_exp<float>(float x) { return expf(x); }
 template <> __device__ __forceinline__ double dibr_exp<double>(double x) { return exp(x); }
 
+// Per-face, per-edge quantities that do not depend on the pixel (dibr_soft_mask_cuda.cu:112-125): the line
+// coefficients, the products the foot-point numerators are built from, and the divisor (down + EPS) -- a double
+// -- with its correctly rounded reciprocal.  Computed once per face and tile while the records are staged into
+// LDS, with the very expressions the per-pixel code of the reference evaluates, so nothing changes numerically.
+template <typename T>
+struct EdgeInv {
+  T A, B, C, AA, BB, AB, AC, BC;
+};
+template <typename T>
+__device__ __forceinline__ void edge_invariants(T x1, T y1, T x2, T y2, EdgeInv<T>* e, double* den, double* rcp) {
+  const T A = y2 - y1, Bc = x1 - x2, C = x2 * y1 - x1 * y2;
+  const T down = A * A + Bc * Bc;
+  e->A = A;
+  e->B = Bc;
+  e->C = C;
+  e->AA = A * A;
+  e->BB = Bc * Bc;
+  e->AB = A * Bc;
+  e->AC = A * C;
+  e->BC = Bc * C;
+  *den = (double)down + DIBR_EPS;
+  *rcp = 1.0 / *den;
+}
+// num / den for a divisor whose correctly rounded reciprocal r is known: q = num*r, one exact-residual
+// correction (Markstein): the correctly rounded double quotient in 3 operations instead of a full IEEE divide
+__device__ __forceinline__ double div_by_invariant(double num, double den, double r) {
+  const double q = num * r;
+  const double rem = __builtin_fma(-q, den, num);
+  return __builtin_fma(rem, r, q);
+}
+
 // squared distance of pixel (x0,y0) to the triangle's 3 edges / 3 vertices; returns the first minimum and
 // its slot 0..5 (dibr_soft_mask_cuda.cu:98-159)
 template <typename T>
-__device__ __forceinline__ T closest_of_six(const T* v, T x0, T y0, float multiplier, int* which) {
+__device__ __forceinline__ T closest_of_six(const T* v, const EdgeInv<T>* e, const double* den, const double* rcp,
+                                            T x0, T y0, float multiplier, int* which) {
   T pdis[6];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const T x1 = v[i * 2], y1 = v[i * 2 + 1];
     const T x2 = v[((i + 1) % 3) * 2], y2 = v[((i + 1) % 3) * 2 + 1];
-    const T A = y2 - y1, Bc = x1 - x2, C = x2 * y1 - x1 * y2;
-    const T up = A * x0 + Bc * y0 + C;
-    const T down = A * A + Bc * Bc;
-    T x3 = Bc * Bc * x0 - A * Bc * y0 - A * C;
-    T y3 = A * A * y0 - A * Bc * x0 - Bc * C;
-    x3 = x3 / (down + DIBR_EPS);
-    y3 = y3 / (down + DIBR_EPS);
+    const T up = e[i].A * x0 + e[i].B * y0 + e[i].C;
+    const T x3n = e[i].BB * x0 - e[i].AB * y0 - e[i].AC;
+    const T y3n = e[i].AA * y0 - e[i].AB * x0 - e[i].BC;
+    const T x3 = (T)div_by_invariant((double)x3n, den[i], rcp[i]);
+    const T y3 = (T)div_by_invariant((double)y3n, den[i], rcp[i]);
     const T direct = (x3 - x1) * (x3 - x2) + (y3 - y1) * (y3 - y2);
     if (direct > 0)
       pdis[i] = 4 * multiplier * multiplier;
     else
-      pdis[i] = up * up / (down + DIBR_EPS);
+      pdis[i] = (T)div_by_invariant((double)(T)(up * up), den[i], rcp[i]);
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -68,9 +98,9 @@ __device__ __forceinline__ T closest_of_six(const T* v, T x0, T y0, float multip
   return d2;
 }
 
-template <typename T> struct SoftCap;
-template <> struct SoftCap<float> { static constexpr int value = 512; };
-template <> struct SoftCap<double> { static constexpr int value = 256; };
+template <typename T> struct SoftCap;  // faces staged in LDS per round
+template <> struct SoftCap<float> { static constexpr int value = 256; };   // 184 B per face
+template <> struct SoftCap<double> { static constexpr int value = 128; };  // 320 B per face
 
 // ---- K-buffer fill: prob = 0, idx = -1, type = 0 (dibr_soft_mask.cpp:86-96) ----------------------------
 __global__ __launch_bounds__(256) void fill_regions_kernel(uint4* __restrict__ a, size_t na, unsigned int va,
@@ -107,10 +137,14 @@ template <typename T>
 __global__ __launch_bounds__(TILE_THREADS) void soft_mask_tile_kernel(
     int B, int F, TileGeom g, int K, float sigmainv, float multiplier, const T* __restrict__ rec,
     const unsigned int* __restrict__ masks, const int64_t* __restrict__ sel_idx, T* __restrict__ soft_mask,
-    T* __restrict__ prob_out, int64_t* __restrict__ idx_out, uint8_t* __restrict__ type_out) {
+    T* __restrict__ prob_out, int64_t* __restrict__ idx_out, uint8_t* __restrict__ type_out,
+    const unsigned int* __restrict__ tile_flags, uint8_t* __restrict__ hit_count) {
   constexpr int CAP = SoftCap<T>::value;
   __shared__ __attribute__((aligned(16))) T s_bbox[CAP * 4];
   __shared__ __attribute__((aligned(16))) T s_vert[CAP * 6];
+  __shared__ __attribute__((aligned(16))) EdgeInv<T> s_edge[CAP * 3];
+  __shared__ __attribute__((aligned(16))) double s_den[CAP * 3];
+  __shared__ __attribute__((aligned(16))) double s_rcp[CAP * 3];
   __shared__ int s_ids[CAP];
   __shared__ int s_scan[TILE_THREADS / 64 + 1];
   __shared__ int s_any_uncovered;
@@ -135,8 +169,12 @@ __global__ __launch_bounds__(TILE_THREADS) void soft_mask_tile_kernel(
   const bool wave_has_work = __any(uncovered);
   if (wave_has_work && lane == 0) s_any_uncovered = 1;
   __syncthreads();
-  if (in_image && !uncovered) soft_mask[p1] = (T)1.0;
+  if (in_image && !uncovered) {
+    soft_mask[p1] = (T)1.0;
+    if (hit_count) hit_count[p1] = 0;
+  }
   if (!s_any_uncovered) return;  // fully covered tile: nothing to search (uniform for the workgroup)
+  const int nwords = (tile_flags != nullptr && tile_flags[(size_t)b * g.ntiles + tile]) ? stride_b : 0;
 
   const T x0 = pixel_x(multiplier, g.W, col);
   const T y0 = pixel_y(multiplier, g.H, row);
@@ -155,9 +193,9 @@ __global__ __launch_bounds__(TILE_THREADS) void soft_mask_tile_kernel(
   T all = 1.0;
   bool active = uncovered && K > 0;
 
-  for (int seg0 = 0; seg0 < stride_b; seg0 += TILE_THREADS) {
+  for (int seg0 = 0; seg0 < nwords; seg0 += TILE_THREADS) {
     const int wi = seg0 + tid;
-    unsigned int word = wi < stride_b ? tmask[wi] : 0u;
+    unsigned int word = wi < nwords ? tmask[wi] : 0u;
     int total;
     const int excl = block_exclusive_scan(__popc(word), s_scan, &total);
     for (int c0 = 0; c0 < total; c0 += CAP) {
@@ -183,6 +221,13 @@ __global__ __launch_bounds__(TILE_THREADS) void soft_mask_tile_kernel(
           s_vert[k * 6 + (e - 4)] = v;
       }
       __syncthreads();
+      for (int i = tid; i < n * 3; i += TILE_THREADS) {  // one thread per (face, edge)
+        const int k = i / 3, ed = i % 3;
+        const T* v = s_vert + k * 6;
+        edge_invariants<T>(v[ed * 2], v[ed * 2 + 1], v[((ed + 1) % 3) * 2], v[((ed + 1) % 3) * 2 + 1], &s_edge[i],
+                           &s_den[i], &s_rcp[i]);
+      }
+      __syncthreads();
       if (wave_has_work) {
         for (int k0 = 0; k0 < n; k0 += 64) {
           if (!__any(active)) break;
@@ -201,7 +246,7 @@ __global__ __launch_bounds__(TILE_THREADS) void soft_mask_tile_kernel(
             const T xmin = s_bbox[kk * 4 + 0], ymin = s_bbox[kk * 4 + 1], xmax = s_bbox[kk * 4 + 2], ymax = s_bbox[kk * 4 + 3];
             if (x0 < xmin || x0 >= xmax || y0 < ymin || y0 >= ymax) continue;
             int which;
-            const T d2 = closest_of_six<T>(s_vert + kk * 6, x0, y0, multiplier, &which);
+            const T d2 = closest_of_six<T>(s_vert + kk * 6, s_edge + kk * 3, s_den + kk * 3, s_rcp + kk * 3, x0, y0, multiplier, &which);
             const T zz = sigmainv * d2 / multiplier / multiplier;
             const T pr = dibr_exp<T>(-zz);
             prob_out[pk + kid] = pr;
@@ -215,7 +260,10 @@ __global__ __launch_bounds__(TILE_THREADS) void soft_mask_tile_kernel(
       }
     }
   }
-  if (uncovered) soft_mask[p1] = (T)(1.0 - (double)all);
+  if (uncovered) {
+    soft_mask[p1] = (T)(1.0 - (double)all);
+    if (hit_count) hit_count[p1] = (uint8_t)(kid > 255 ? 255 : kid);
+  }
 }
 
 // ---- K4 ---------------------------------------------------------------------------------------------------
@@ -224,9 +272,17 @@ __global__ __launch_bounds__(256) void soft_mask_backward_kernel(
     long long total_pixels, int H, int W, int F, int K, const T* __restrict__ grad, const T* __restrict__ soft_mask,
     const int64_t* __restrict__ sel_idx, const T* __restrict__ prob_in, const int64_t* __restrict__ idx_in,
     const uint8_t* __restrict__ type_in, const T* __restrict__ img, float sigmainv, float multiplier,
-    T* __restrict__ g_img) {
+    T* __restrict__ g_img, const uint8_t* __restrict__ hit_count) {
   const long long p1 = (long long)blockIdx.x * 256 + threadIdx.x;
   if (p1 >= total_pixels) return;
+  // hit_count (optional, produced by our own forward): pixels without hits never touch the K-buffers; a stored
+  // 255 means "255 or more", then the -1 terminator decides as in the reference
+  int limit = K;
+  if (hit_count) {
+    const int hc = hit_count[p1];
+    if (hc == 0) return;
+    if (hc < 255 && hc < K) limit = hc;
+  }
   if ((int)sel_idx[p1] >= 0) return;
   const size_t pk = (size_t)p1 * K;
   const int col = (int)(p1 % W);
@@ -236,7 +292,7 @@ __global__ __launch_bounds__(256) void soft_mask_backward_kernel(
   const T y0 = pixel_y(multiplier, H, row);
   const T dLdp = grad[p1];
   const T all = soft_mask[p1];
-  for (int kid = 0; kid < K; ++kid) {
+  for (int kid = 0; kid < limit; ++kid) {
     const int f = (int)idx_in[pk + kid];
     if (f < 0) break;
     const size_t s6 = ((size_t)b * F + f) * 6;
@@ -275,7 +331,7 @@ __global__ __launch_bounds__(256) void soft_mask_backward_kernel(
 template <typename T>
 int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, const T* img, const T* large_bbox,
                              const int64_t* sel_idx, float sigmainv, float multiplier, T* soft_mask, T* prob,
-                             int64_t* idx, uint8_t* type, void* workspace) {
+                             int64_t* idx, uint8_t* type, void* workspace, uint8_t* hit_count) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
   const TileGeom g = tile_geom(H, W);
   const long long total_faces = (long long)B * F;
@@ -300,19 +356,20 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
   // 2. bin the enlarged boxes, 3. search
   T* rec = (T*)workspace;
   unsigned int* masks = (unsigned int*)((char*)workspace + align256((size_t)total_faces * REC_STRIDE * sizeof(T)));
+  unsigned int* flags = total_faces > 0 ? masks + mask_words(g.ntiles, B, total_faces) : nullptr;
   if (total_faces > 0) {
-    KAMD_CHECK(hipMemsetAsync(masks, 0, mask_words(g.ntiles, B, total_faces) * 4, st));
+    KAMD_CHECK(hipMemsetAsync(masks, 0, (mask_words(g.ntiles, B, total_faces) + flag_words(g.ntiles, B)) * 4, st));
     {
       kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
       hipLaunchKernelGGL(bin_faces_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, F, total_faces,
-                       (const int64_t*)nullptr, large_bbox, img, (const T*)nullptr, g, multiplier, rec, masks);
+                       (const int64_t*)nullptr, large_bbox, img, (const T*)nullptr, g, multiplier, rec, masks, flags);
     }
     KAMD_CHECK(hipGetLastError());
   }
   {
     kamd::ProfScope prof_(kamd::K_SOFT_TILE, st);
     hipLaunchKernelGGL(soft_mask_tile_kernel<T>, dim3(g.ntiles * B), dim3(TILE_THREADS), 0, st, B, F, g, K, sigmainv,
-                     multiplier, rec, masks, sel_idx, soft_mask, prob, idx, type);
+                     multiplier, rec, masks, sel_idx, soft_mask, prob, idx, type, flags, hit_count);
   }
   KAMD_RETURN_LAST_ERROR();
 }
@@ -320,13 +377,13 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
 template <typename T>
 int soft_mask_backward_launch(hipStream_t st, int B, int H, int W, int F, int K, const T* grad, const T* soft_mask,
                               const int64_t* sel_idx, const T* prob, const int64_t* idx, const uint8_t* type,
-                              const T* img, float sigmainv, float multiplier, T* g_img) {
+                              const T* img, float sigmainv, float multiplier, T* g_img, const uint8_t* hit_count) {
   const long long total = (long long)B * H * W;
   if (total <= 0 || F <= 0 || K <= 0) return 0;
   {
     kamd::ProfScope prof_(kamd::K_SOFT_BACKWARD, st);
     hipLaunchKernelGGL(soft_mask_backward_kernel<T>, dim3(kamd_cdiv(total, 256)), dim3(256), 0, st, total, H, W, F, K,
-                     grad, soft_mask, sel_idx, prob, idx, type, img, sigmainv, multiplier, g_img);
+                     grad, soft_mask, sel_idx, prob, idx, type, img, sigmainv, multiplier, g_img, hit_count);
   }
   KAMD_RETURN_LAST_ERROR();
 }
@@ -342,29 +399,31 @@ size_t kamd_dibr_soft_mask_forward_workspace(int B, int H, int W, int F, int ele
 
 int kamd_dibr_soft_mask_forward_f32(void* stream, int B, int H, int W, int F, int K, const float* img,
                                     const float* large_bbox, const int64_t* sel_idx, float sigmainv, float multiplier,
-                                    float* soft_mask, float* prob, int64_t* idx, uint8_t* type, void* workspace) {
+                                    float* soft_mask, float* prob, int64_t* idx, uint8_t* type, void* workspace,
+                                    uint8_t* hit_count) {
   return soft_mask_forward_launch<float>((hipStream_t)stream, B, H, W, F, K, img, large_bbox, sel_idx, sigmainv,
-                                         multiplier, soft_mask, prob, idx, type, workspace);
+                                         multiplier, soft_mask, prob, idx, type, workspace, hit_count);
 }
 int kamd_dibr_soft_mask_forward_f64(void* stream, int B, int H, int W, int F, int K, const double* img,
                                     const double* large_bbox, const int64_t* sel_idx, float sigmainv, float multiplier,
-                                    double* soft_mask, double* prob, int64_t* idx, uint8_t* type, void* workspace) {
+                                    double* soft_mask, double* prob, int64_t* idx, uint8_t* type, void* workspace,
+                                    uint8_t* hit_count) {
   return soft_mask_forward_launch<double>((hipStream_t)stream, B, H, W, F, K, img, large_bbox, sel_idx, sigmainv,
-                                          multiplier, soft_mask, prob, idx, type, workspace);
+                                          multiplier, soft_mask, prob, idx, type, workspace, hit_count);
 }
 int kamd_dibr_soft_mask_backward_f32(void* stream, int B, int H, int W, int F, int K, const float* grad,
                                      const float* soft_mask, const int64_t* sel_idx, const float* prob,
                                      const int64_t* idx, const uint8_t* type, const float* img, float sigmainv,
-                                     float multiplier, float* g_img) {
+                                     float multiplier, float* g_img, const uint8_t* hit_count) {
   return soft_mask_backward_launch<float>((hipStream_t)stream, B, H, W, F, K, grad, soft_mask, sel_idx, prob, idx, type,
-                                          img, sigmainv, multiplier, g_img);
+                                          img, sigmainv, multiplier, g_img, hit_count);
 }
 int kamd_dibr_soft_mask_backward_f64(void* stream, int B, int H, int W, int F, int K, const double* grad,
                                      const double* soft_mask, const int64_t* sel_idx, const double* prob,
                                      const int64_t* idx, const uint8_t* type, const double* img, float sigmainv,
-                                     float multiplier, double* g_img) {
+                                     float multiplier, double* g_img, const uint8_t* hit_count) {
   return soft_mask_backward_launch<double>((hipStream_t)stream, B, H, W, F, K, grad, soft_mask, sel_idx, prob, idx,
-                                           type, img, sigmainv, multiplier, g_img);
+                                           type, img, sigmainv, multiplier, g_img, hit_count);
 }
 
 }  // extern "C"

@@ -29,8 +29,8 @@ template <> struct RasterCap<double> { static constexpr int value = 256; };
 template <typename T>
 __global__ __launch_bounds__(TILE_THREADS) void raster_tile_kernel(
     int B, int F_dense, const int64_t* __restrict__ first, TileGeom g, int D, float multiplier, float eps,
-    const T* __restrict__ rec, const unsigned int* __restrict__ masks, const T* __restrict__ feat,
-    T* __restrict__ interp, int64_t* __restrict__ sel_idx, T* __restrict__ weights) {
+    const T* __restrict__ rec, const unsigned int* __restrict__ masks, const unsigned int* __restrict__ tile_flags,
+    const T* __restrict__ feat, T* __restrict__ interp, int64_t* __restrict__ sel_idx, T* __restrict__ weights) {
   constexpr int CAP = RasterCap<T>::value;
   __shared__ __attribute__((aligned(16))) T s_bbox[CAP * 4];
   __shared__ __attribute__((aligned(16))) T s_rest[CAP * 12];  // a.xy b.xy c.xy z.abc pad3
@@ -58,10 +58,11 @@ __global__ __launch_bounds__(TILE_THREADS) void raster_tile_kernel(
 
   T best_z = -INFINITY, bw0 = 0, bw1 = 0, bw2 = 0;
   int best = -1;
+  const int nwords = (tile_flags != nullptr && tile_flags[(size_t)b * g.ntiles + tile]) ? stride_b : 0;  // untouched tile: background only
 
-  for (int seg0 = 0; seg0 < stride_b; seg0 += TILE_THREADS) {
+  for (int seg0 = 0; seg0 < nwords; seg0 += TILE_THREADS) {
     const int wi = seg0 + tid;
-    unsigned int word = wi < stride_b ? tmask[wi] : 0u;
+    unsigned int word = wi < nwords ? tmask[wi] : 0u;
     int total;
     const int excl = block_exclusive_scan(__popc(word), s_scan, &total);
     for (int c0 = 0; c0 < total; c0 += CAP) {
@@ -144,25 +145,25 @@ __global__ __launch_bounds__(TILE_THREADS) void raster_tile_kernel(
 }
 
 // ---- K2 -------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void raster_backward_kernel(
-    long long total_pixels, int P, int F, int D, const T* __restrict__ grad, const int64_t* __restrict__ face_idx,
-    const T* __restrict__ weights, const T* __restrict__ img, const T* __restrict__ feat, float eps,
-    T* __restrict__ g_img, T* __restrict__ g_feat) {
-  const long long tp = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (tp >= total_pixels) return;
-  const int64_t f = face_idx[tp];
-  if (f < 0) return;
-  const int b = (int)(tp / P);
-  const size_t tf = (size_t)b * F + (size_t)f;
-  const T* g = grad + tp * D;
-  const T aw = weights[tp * 3 + 0], bw = weights[tp * 3 + 1], cw = weights[tp * 3 + 2];
-  const T w3[3] = {aw, bw, cw};
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-    for (int d = 0; d < D; ++d) kamd_atomic_add(g_feat + (tf * 3 + i) * D + d, (T)(g[d] * w3[i]));
+// Per covered pixel the reference issues 3*D + 6*D float atomics on addresses shared by every pixel of the same
+// face (rasterization_cuda.cu:283,391-398): the run time is atomic contention.  Here a wavefront owns a 16x4
+// pixel block, finds the distinct faces among its 64 pixels (ballot on the leader's face), sums each face's
+// 6 + 3*D values across its lanes with a butterfly, and one lane issues the atomics: ~64/faces-per-wave fewer
+// atomics and no same-address pile-up.  After RB_MAX_ROUNDS distinct faces (tiny faces: nothing to merge) the
+// remaining lanes fall back to their own atomics.
+constexpr int RB_MAX_ROUNDS = 12;
 
-  const T* v = img + tf * 6;
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// numerators of d(w1)/d(.) and d(w2)/d(.) for the six vertex coordinates (ax, ay, bx, by, cx, cy), and k3
+// (rasterization_cuda.cu:287-371); the common 1/k3^2 is applied by the caller
+template <typename T>
+__device__ __forceinline__ T barycentric_jacobian(const T* v, T aw, T bw, T cw, float eps, T* dw1, T* dw2) {
   const T ax = v[0], ay = v[1], bx = v[2], by = v[3], cx = v[4], cy = v[5];
   const T x0 = aw * ax + bw * bx + cw * cx;
   const T y0 = aw * ay + bw * by + cw * cy;
@@ -171,8 +172,7 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(
   const T k2 = m * t - s * p;
   T k3 = m * q - n * p;
   k3 = (T)((double)k3 + copysign((double)eps, (double)k3));
-  // numerators of d(w1), d(w2) w.r.t. (m, n, p, q, s, t): dk_i * k3 - dk3 * k_i, with the reference's explicit
-  // zero terms kept (0 * k3 - q * k1 etc.) so that signed zeros and roundings match the oracle
+  // dk_i * k3 - dk3 * k_i with the reference's explicit zero terms kept (0 * k3 - q * k1 ...)
   const T zero = 0;
   const T dw1dm = zero * k3 - q * k1, dw1dn = (-t) * k3 - (-p) * k1;
   const T dw1dp = zero * k3 - (-n) * k1, dw1dq = s * k3 - m * k1;
@@ -180,17 +180,95 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(
   const T dw2dm = t * k3 - q * k2, dw2dn = zero * k3 - (-p) * k2;
   const T dw2dp = (-s) * k3 - (-n) * k2, dw2dq = zero * k3 - m * k2;
   const T dw2ds = (-p) * k3 - zero * k2, dw2dt = m * k3 - zero * k2;
-  const T dw1[6] = {-(dw1dm + dw1dn + dw1ds), -(dw1dp + dw1dq + dw1dt), dw1dm, dw1dp, dw1dn, dw1dq};
-  const T dw2[6] = {-(dw2dm + dw2dn + dw2ds), -(dw2dp + dw2dq + dw2dt), dw2dm, dw2dp, dw2dn, dw2dq};
-  const T* ff = feat + tf * 3 * D;
-  for (int d = 0; d < D; ++d) {
-    const T c0 = ff[d], c1 = ff[D + d], c2 = ff[2 * D + d];
-    const T dldI = g[d] / (k3 * k3);
+  dw1[0] = -(dw1dm + dw1dn + dw1ds);
+  dw1[1] = -(dw1dp + dw1dq + dw1dt);
+  dw1[2] = dw1dm;
+  dw1[3] = dw1dp;
+  dw1[4] = dw1dn;
+  dw1[5] = dw1dq;
+  dw2[0] = -(dw2dm + dw2dn + dw2ds);
+  dw2[1] = -(dw2dp + dw2dq + dw2dt);
+  dw2[2] = dw2dm;
+  dw2[3] = dw2dp;
+  dw2[4] = dw2dn;
+  dw2[5] = dw2dq;
+  return k3;
+}
+
+// DT > 0: feature count known at compile time (values live in registers, wave-merged); DT == 0: any D, per-lane atomics
+template <typename T, int DT>
+__global__ __launch_bounds__(256) void raster_backward_kernel(
+    int B, int H, int W, int F, int D, const T* __restrict__ grad, const int64_t* __restrict__ face_idx,
+    const T* __restrict__ weights, const T* __restrict__ img, const T* __restrict__ feat, float eps,
+    T* __restrict__ g_img, T* __restrict__ g_feat) {
+  // workgroup = 16x16 pixels of one image; wavefront = 16x4
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+  const int tile = blockIdx.x % (tiles_x * tiles_y), b = blockIdx.x / (tiles_x * tiles_y);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = (tile % tiles_x) * 16 + (lane & 15), row = (tile / tiles_x) * 16 + wave * 4 + (lane >> 4);
+  const bool in_image = col < W && row < H;
+  const size_t tp = ((size_t)b * H + row) * W + col;
+  const int f = in_image ? (int)face_idx[tp] : -1;
+  unsigned long long todo = __ballot(f >= 0);
+  if (todo == 0) return;
+  const size_t tf = (size_t)b * F + (size_t)(f >= 0 ? f : 0);
+
+  constexpr int NV = DT > 0 ? 6 + 3 * DT : 6;
+  T vals[NV];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const T dI = (c1 - c0) * dw1[j] + (c2 - c0) * dw2[j];
-      kamd_atomic_add(g_img + tf * 6 + j, (T)(dldI * dI));
+  for (int i = 0; i < NV; ++i) vals[i] = 0;
+  if (f >= 0) {
+    const T aw = weights[tp * 3 + 0], bw = weights[tp * 3 + 1], cw = weights[tp * 3 + 2];
+    T dw1[6], dw2[6];
+    const T k3 = barycentric_jacobian<T>(img + tf * 6, aw, bw, cw, eps, dw1, dw2);
+    const T* ff = feat + tf * 3 * D;
+    const T* g = grad + tp * D;
+    const int nd = DT > 0 ? DT : D;
+    for (int d = 0; d < nd; ++d) {
+      const T gd = g[d];
+      const T c0 = ff[d], c1 = ff[D + d], c2 = ff[2 * D + d];
+      const T dldI = gd / (k3 * k3);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) vals[j] += (T)(dldI * ((c1 - c0) * dw1[j] + (c2 - c0) * dw2[j]));
+      if constexpr (DT > 0) {
+        vals[6 + d] = (T)(gd * aw);
+        vals[6 + DT + d] = (T)(gd * bw);
+        vals[6 + 2 * DT + d] = (T)(gd * cw);
+      } else {
+        kamd_atomic_add(g_feat + (tf * 3 + 0) * D + d, (T)(gd * aw));
+        kamd_atomic_add(g_feat + (tf * 3 + 1) * D + d, (T)(gd * bw));
+        kamd_atomic_add(g_feat + (tf * 3 + 2) * D + d, (T)(gd * cw));
+      }
     }
+  }
+
+  int rounds = 0;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int lf = __shfl(f, leader, 64);
+    const bool mine = (f == lf);
+    const unsigned long long m = __ballot(mine);
+    todo &= ~m;
+    if (__popcll(m) == 1 || rounds >= RB_MAX_ROUNDS) {
+      if (mine) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) kamd_atomic_add(g_img + tf * 6 + j, vals[j]);
+#pragma unroll
+        for (int i = 6; i < NV; ++i) kamd_atomic_add(g_feat + tf * 3 * D + (i - 6), vals[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const T s = wave_sum<T>(mine ? vals[i] : (T)0);
+        if (lane == leader) {
+          if (i < 6)
+            kamd_atomic_add(g_img + tf * 6 + i, s);
+          else
+            kamd_atomic_add(g_feat + tf * 3 * D + (i - 6), s);
+        }
+      }
+    }
+    ++rounds;
   }
 }
 
@@ -203,19 +281,20 @@ int rasterize_forward_launch(hipStream_t st, int B, int H, int W, int D, int64_t
   if (total_faces > 0 && workspace == nullptr) return (int)hipErrorInvalidValue;
   T* rec = (T*)workspace;
   unsigned int* masks = (unsigned int*)((char*)workspace + align256((size_t)total_faces * REC_STRIDE * sizeof(T)));
+  unsigned int* flags = total_faces > 0 ? masks + mask_words(g.ntiles, B, total_faces) : nullptr;
   if (total_faces > 0) {
-    KAMD_CHECK(hipMemsetAsync(masks, 0, mask_words(g.ntiles, B, total_faces) * 4, st));
+    KAMD_CHECK(hipMemsetAsync(masks, 0, (mask_words(g.ntiles, B, total_faces) + flag_words(g.ntiles, B)) * 4, st));
     {
       kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
       hipLaunchKernelGGL(bin_faces_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, 0,
-                       (long long)total_faces, first_idx, bbox, img, z, g, multiplier, rec, masks);
+                       (long long)total_faces, first_idx, bbox, img, z, g, multiplier, rec, masks, flags);
     }
     KAMD_CHECK(hipGetLastError());
   }
   {
     kamd::ProfScope prof_(kamd::K_RASTER_TILE, st);
     hipLaunchKernelGGL(raster_tile_kernel<T>, dim3(g.ntiles * B), dim3(TILE_THREADS), 0, st, B, 0, first_idx, g, D,
-                     multiplier, eps, rec, masks, feat, interp, sel_idx, weights);
+                     multiplier, eps, rec, masks, flags, feat, interp, sel_idx, weights);
   }
   KAMD_RETURN_LAST_ERROR();
 }
@@ -225,12 +304,20 @@ int rasterize_backward_launch(hipStream_t st, int B, int H, int W, int F, int D,
                               const T* weights, const T* img, const T* feat, float eps, T* g_img, T* g_feat) {
   const long long total = (long long)B * H * W;
   if (total <= 0 || F <= 0) return 0;
-  {
-    kamd::ProfScope prof_(kamd::K_RASTER_BACKWARD, st);
-    hipLaunchKernelGGL(raster_backward_kernel<T>, dim3(kamd_cdiv(total, 256)), dim3(256), 0, st, total, H * W, F, D, grad,
-                     face_idx, weights, img, feat, eps, g_img, g_feat);
+  const dim3 grid((unsigned)(B * ((W + 15) / 16) * ((H + 15) / 16)));
+  kamd::ProfScope prof_(kamd::K_RASTER_BACKWARD, st);
+#define KAMD_RB(DT)                                                                                                   \
+  hipLaunchKernelGGL((raster_backward_kernel<T, DT>), grid, dim3(256), 0, st, B, H, W, F, D, grad, face_idx, weights, \
+                     img, feat, eps, g_img, g_feat)
+  switch (D) {
+    case 1: KAMD_RB(1); break;
+    case 2: KAMD_RB(2); break;
+    case 3: KAMD_RB(3); break;
+    case 4: KAMD_RB(4); break;
+    default: KAMD_RB(0); break;
   }
-  KAMD_RETURN_LAST_ERROR();
+#undef KAMD_RB
+  return (int)hipGetLastError();
 }
 
 }  // namespace

@@ -17,7 +17,8 @@
 //   records : total_faces x 16 x sizeof(T)   {bbox[4], a.xy, b.xy, c.xy, z[3], pad[3]}
 //   masks   : ntiles x (total_faces/32 + B + 1) 32-bit words; mesh b owns the word range
 //             ntiles*(first[b]/32 + b) .. , tile t of mesh b starts at  + t*stride_b,
-//             stride_b = ceil(n_b/32)  (regions provably do not overlap).
+//             stride_b = ceil(n_b/32)  (regions provably do not overlap);
+//             then B x ntiles flag words (tile touched by any face of the mesh).
 #pragma once
 #include "common.h"
 
@@ -45,9 +46,11 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline size_t mask_words(int ntiles, int B, long long total_faces) {
   return (size_t)ntiles * (size_t)(total_faces / 32 + B + 1);
 }
+// the mask area is followed by one word per (mesh, tile): non-zero when any face touches the tile
+inline size_t flag_words(int ntiles, int B) { return (size_t)ntiles * B; }
 inline size_t bins_workspace_bytes(int B, int H, int W, long long total_faces, int elem_size) {
   TileGeom g = tile_geom(H, W);
-  return align256((size_t)total_faces * REC_STRIDE * elem_size) + align256(mask_words(g.ntiles, B, total_faces) * 4);
+  return align256((size_t)total_faces * REC_STRIDE * elem_size) + align256((mask_words(g.ntiles, B, total_faces) + flag_words(g.ntiles, B)) * 4);
 }
 
 // pixel centre in the reference's float arithmetic (rasterization_cuda.cu:85-86, dibr_soft_mask_cuda.cu:75-76):
@@ -68,7 +71,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void bin_faces_kernel(
     int B, int F_dense, long long total_faces, const int64_t* __restrict__ first,
     const T* __restrict__ bbox, const T* __restrict__ img, const T* __restrict__ z,
-    TileGeom g, float multiplier, T* __restrict__ rec, unsigned int* __restrict__ masks) {
+    TileGeom g, float multiplier, T* __restrict__ rec, unsigned int* __restrict__ masks,
+    unsigned int* __restrict__ tile_flags) {
   const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
   if (f >= total_faces) return;
   int b;
@@ -117,8 +121,11 @@ __global__ __launch_bounds__(256) void bin_faces_kernel(
   const int stride_b = (int)((n_b + 31) / 32);
   const unsigned int bit = 1u << (unsigned)(j & 31);
   for (int ty = ty0; ty <= ty1; ++ty)
-    for (int tx = tx0; tx <= tx1; ++tx)
-      atomicOr(masks + mask_base(g.ntiles, first_b, b, ty * g.tiles_x + tx, stride_b) + (size_t)(j >> 5), bit);
+    for (int tx = tx0; tx <= tx1; ++tx) {
+      const int t = ty * g.tiles_x + tx;
+      atomicOr(masks + mask_base(g.ntiles, first_b, b, t, stride_b) + (size_t)(j >> 5), bit);
+      if (tile_flags[(size_t)b * g.ntiles + t] == 0u) tile_flags[(size_t)b * g.ntiles + t] = 1u;  // benign race: all writers store 1
+    }
 }
 
 // ---- block-wide exclusive scan over 1024 threads (16 wavefronts) -------------------------------------

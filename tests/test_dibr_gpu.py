@@ -283,3 +283,19 @@ def test_full_size_properties_1024():
     hi = idx.clone()
     hi[~hit] = 10 ** 9
     assert bool(((hi[..., 1:] > hi[..., :-1]) | ~hit[..., 1:]).all())   # ascending face order
+
+
+def test_backward_with_and_without_hit_count():
+    """The reference-signature backward (reads the K-buffers' -1 terminators) and our hit-count shortcut agree."""
+    fz, fimg, feats, nz = _scene(8, 2, torch.float)
+    m = kal()._C.render.mesh
+    _, face_idx = kal().render.mesh.rasterize(96, 64, fz.cuda(), fimg.cuda(), torch.cat(feats, -1).cuda(), (nz >= 0).cuda())
+    scaled = fimg.cuda() * 1000.
+    lo, hi = scaled.min(dim=-2)[0] - 20., scaled.max(dim=-2)[0] + 20.
+    soft, prob, idx, typ, hits = m.dibr_soft_mask_forward_cuda(scaled, torch.cat([lo, hi], -1), face_idx, 7000., 30, 1000.,
+                                                              _with_hit_count=True)
+    assert torch.equal(hits.long(), (idx >= 0).sum(-1))
+    g = torch.rand(soft.shape, device='cuda')
+    a = m.dibr_soft_mask_backward_cuda(g, soft, face_idx, prob, idx, typ, scaled, 7000., 1000.)
+    b = m.dibr_soft_mask_backward_cuda(g, soft, face_idx, prob, idx, typ, scaled, 7000., 1000., _hit_count=hits)
+    assert rel_close(a, b, 1e-6)
