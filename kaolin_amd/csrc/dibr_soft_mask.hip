@@ -98,10 +98,6 @@ __device__ __forceinline__ T closest_of_six(const T* v, const EdgeInv<T>* e, con
   return d2;
 }
 
-template <typename T> struct SoftCap;  // faces staged in LDS per round
-template <> struct SoftCap<float> { static constexpr int value = 256; };   // 184 B per face
-template <> struct SoftCap<double> { static constexpr int value = 128; };  // 320 B per face
-
 // ---- K-buffer fill: prob = 0, idx = -1, type = 0 (dibr_soft_mask.cpp:86-96) ----------------------------
 __global__ __launch_bounds__(256) void fill_regions_kernel(uint4* __restrict__ a, size_t na, unsigned int va,
                                                            uint4* __restrict__ b, size_t nb, unsigned int vb,
@@ -132,53 +128,56 @@ inline int fill_edges(hipStream_t st, void* p, size_t bytes, int v, FillPlan* pl
   return 0;
 }
 
-// ---- K3 tile kernel --------------------------------------------------------------------------------------
+// ---- K3 search kernel ------------------------------------------------------------------------------------
+// One 64-lane workgroup per 16x4-pixel sub-tile (a single wavefront: barriers are free and a sub-tile that owns
+// silhouette-band pixels never keeps 15 idle wavefronts resident, which is what a 32x32-pixel workgroup did:
+// SQ_WAIT_ANY was 75 % of wave time).  Wavefronts without an uncovered pixel leave after reading sel_idx.
+//   1. expand the 32x32 tile's bitmask into an ascending id list in LDS (popcount + wave scan, 64 words a step);
+//   2. 64 ids at a time: each lane culls one face against the extent of the wavefront's uncovered pixels;
+//      surviving lanes stage vertices + the per-edge invariants of "their" face in LDS (compacted, order kept);
+//   3. all lanes walk the staged faces in order with broadcast LDS reads.
+constexpr int SM_IDCAP = 2048;  // ids buffered between flushes (>= the 64*32 a single step can produce)
+
 template <typename T>
-__global__ __launch_bounds__(TILE_THREADS) void soft_mask_tile_kernel(
+__global__ __launch_bounds__(64) void soft_mask_wave_kernel(
     int B, int F, TileGeom g, int K, float sigmainv, float multiplier, const T* __restrict__ rec,
-    const unsigned int* __restrict__ masks, const int64_t* __restrict__ sel_idx, T* __restrict__ soft_mask,
-    T* __restrict__ prob_out, int64_t* __restrict__ idx_out, uint8_t* __restrict__ type_out,
-    const unsigned int* __restrict__ tile_flags, uint8_t* __restrict__ hit_count) {
-  constexpr int CAP = SoftCap<T>::value;
-  __shared__ __attribute__((aligned(16))) T s_bbox[CAP * 4];
-  __shared__ __attribute__((aligned(16))) T s_vert[CAP * 6];
-  __shared__ __attribute__((aligned(16))) EdgeInv<T> s_edge[CAP * 3];
-  __shared__ __attribute__((aligned(16))) double s_den[CAP * 3];
-  __shared__ __attribute__((aligned(16))) double s_rcp[CAP * 3];
-  __shared__ int s_ids[CAP];
-  __shared__ int s_scan[TILE_THREADS / 64 + 1];
-  __shared__ int s_any_uncovered;
+    const unsigned int* __restrict__ masks, const unsigned int* __restrict__ tile_flags,
+    const int64_t* __restrict__ sel_idx, T* __restrict__ soft_mask, T* __restrict__ prob_out,
+    int64_t* __restrict__ idx_out, uint8_t* __restrict__ type_out, uint8_t* __restrict__ hit_count) {
+  __shared__ int s_ids[SM_IDCAP];
+  __shared__ __attribute__((aligned(16))) T s_bbox[64 * 4];
+  __shared__ __attribute__((aligned(16))) T s_vert[64 * 6];
+  __shared__ __attribute__((aligned(16))) EdgeInv<T> s_edge[64 * 3];
+  __shared__ __attribute__((aligned(16))) double s_den[64 * 3];
+  __shared__ __attribute__((aligned(16))) double s_rcp[64 * 3];
+  __shared__ int s_face[64];
 
-  const int b = blockIdx.x % B;
-  const int tile = blockIdx.x / B;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t first_b = (int64_t)b * F;
-  const int stride_b = (F + 31) / 32;
-  const unsigned int* tmask = masks + mask_base(g.ntiles, first_b, b, tile, stride_b);
-
-  const int tile_x = (tile % g.tiles_x) * TILE_W, tile_y = (tile / g.tiles_x) * TILE_H;
-  const int sub_x = tile_x + (wave & 1) * SUB_W, sub_y = tile_y + (wave >> 1) * SUB_H;
+  constexpr int SUBS = (TILE_W / SUB_W) * (TILE_H / SUB_H);  // 16 sub-tiles per tile
+  const int sub = blockIdx.x % SUBS;
+  const int b = (blockIdx.x / SUBS) % B;
+  const int tile = blockIdx.x / (SUBS * B);
+  const int lane = threadIdx.x;
+  const int sub_x = (tile % g.tiles_x) * TILE_W + (sub & 1) * SUB_W;
+  const int sub_y = (tile / g.tiles_x) * TILE_H + (sub >> 1) * SUB_H;
+  if (sub_x >= g.W || sub_y >= g.H) return;
   const int col = sub_x + (lane & 15), row = sub_y + (lane >> 4);
   const bool in_image = col < g.W && row < g.H;
   const size_t p1 = ((size_t)b * g.H + row) * g.W + col;
   const size_t pk = p1 * K;
   const bool uncovered = in_image && (int)sel_idx[in_image ? p1 : 0] < 0;
-
-  if (tid == 0) s_any_uncovered = 0;
-  __syncthreads();
-  const bool wave_has_work = __any(uncovered);
-  if (wave_has_work && lane == 0) s_any_uncovered = 1;
-  __syncthreads();
   if (in_image && !uncovered) {
     soft_mask[p1] = (T)1.0;
     if (hit_count) hit_count[p1] = 0;
   }
-  if (!s_any_uncovered) return;  // fully covered tile: nothing to search (uniform for the workgroup)
+  if (!__any(uncovered)) return;
+
+  const int64_t first_b = (int64_t)b * F;
+  const int stride_b = (F + 31) / 32;
   const int nwords = (tile_flags != nullptr && tile_flags[(size_t)b * g.ntiles + tile]) ? stride_b : 0;
+  const unsigned int* tmask = masks + mask_base(g.ntiles, first_b, b, tile, stride_b);
 
   const T x0 = pixel_x(multiplier, g.W, col);
   const T y0 = pixel_y(multiplier, g.H, row);
-  // extent of this wavefront's UNCOVERED pixel centres (a face is kept if its box can hold one of them)
   T ux_min = uncovered ? x0 : (T)INFINITY, ux_max = uncovered ? x0 : (T)-INFINITY;
   T uy_min = uncovered ? y0 : (T)INFINITY, uy_max = uncovered ? y0 : (T)-INFINITY;
 #pragma unroll
@@ -193,73 +192,87 @@ __global__ __launch_bounds__(TILE_THREADS) void soft_mask_tile_kernel(
   T all = 1.0;
   bool active = uncovered && K > 0;
 
-  for (int seg0 = 0; seg0 < nwords; seg0 += TILE_THREADS) {
-    const int wi = seg0 + tid;
-    unsigned int word = wi < nwords ? tmask[wi] : 0u;
-    int total;
-    const int excl = block_exclusive_scan(__popc(word), s_scan, &total);
-    for (int c0 = 0; c0 < total; c0 += CAP) {
-      __syncthreads();
-      {
-        unsigned int wv = word;
-        int pos = excl;
-        while (wv) {
-          const int bit = __ffs(wv) - 1;
-          wv &= wv - 1;
-          if (pos >= c0 && pos < c0 + CAP) s_ids[pos - c0] = wi * 32 + bit;
-          ++pos;
-        }
+  // walks ids [0, n) of s_ids
+  auto process = [&](int n) {
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 64) {
+      if (!__any(active)) break;
+      const int k = c0 + lane;
+      bool keep = false;
+      int id = 0;
+      T bb0 = 0, bb1 = 0, bb2 = 0, bb3 = 0;
+      if (k < n) {
+        id = s_ids[k];
+        const T* r = rec + ((size_t)first_b + id) * REC_STRIDE;
+        bb0 = r[0];
+        bb1 = r[1];
+        bb2 = r[2];
+        bb3 = r[3];
+        keep = !(ux_max < bb0 || ux_min >= bb2 || uy_max < bb1 || uy_min >= bb3);
+      }
+      const unsigned long long m = __ballot(keep);
+      const int ns = __popcll(m);
+      if (keep) {
+        const int slot = __popcll(m & ((1ull << lane) - 1ull));
+        const T* r = rec + ((size_t)first_b + id) * REC_STRIDE;
+        T v[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[i] = r[4 + i];
+        s_bbox[slot * 4 + 0] = bb0;
+        s_bbox[slot * 4 + 1] = bb1;
+        s_bbox[slot * 4 + 2] = bb2;
+        s_bbox[slot * 4 + 3] = bb3;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s_vert[slot * 6 + i] = v[i];
+        s_face[slot] = id;
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+          edge_invariants<T>(v[e * 2], v[e * 2 + 1], v[((e + 1) % 3) * 2], v[((e + 1) % 3) * 2 + 1], &s_edge[slot * 3 + e],
+                             &s_den[slot * 3 + e], &s_rcp[slot * 3 + e]);
       }
       __syncthreads();
-      const int n = min(CAP, total - c0);
-      for (int i = tid; i < n * 10; i += TILE_THREADS) {
-        const int k = i / 10, e = i % 10;
-        const T v = rec[((size_t)first_b + s_ids[k]) * REC_STRIDE + e];
-        if (e < 4)
-          s_bbox[k * 4 + e] = v;
-        else
-          s_vert[k * 6 + (e - 4)] = v;
+      for (int j = 0; j < ns; ++j) {
+        if (!active) continue;
+        const T xmin = s_bbox[j * 4 + 0], ymin = s_bbox[j * 4 + 1], xmax = s_bbox[j * 4 + 2], ymax = s_bbox[j * 4 + 3];
+        if (x0 < xmin || x0 >= xmax || y0 < ymin || y0 >= ymax) continue;
+        int which;
+        const T d2 = closest_of_six<T>(s_vert + j * 6, s_edge + j * 3, s_den + j * 3, s_rcp + j * 3, x0, y0, multiplier, &which);
+        const T zz = sigmainv * d2 / multiplier / multiplier;
+        const T pr = dibr_exp<T>(-zz);
+        prob_out[pk + kid] = pr;
+        idx_out[pk + kid] = s_face[j];
+        type_out[pk + kid] = (uint8_t)(which + 1);
+        all = (T)((double)all * (1.0 - (double)pr));
+        ++kid;
+        if (kid >= K) active = false;
       }
       __syncthreads();
-      for (int i = tid; i < n * 3; i += TILE_THREADS) {  // one thread per (face, edge)
-        const int k = i / 3, ed = i % 3;
-        const T* v = s_vert + k * 6;
-        edge_invariants<T>(v[ed * 2], v[ed * 2 + 1], v[((ed + 1) % 3) * 2], v[((ed + 1) % 3) * 2 + 1], &s_edge[i],
-                           &s_den[i], &s_rcp[i]);
-      }
-      __syncthreads();
-      if (wave_has_work) {
-        for (int k0 = 0; k0 < n; k0 += 64) {
-          if (!__any(active)) break;
-          const int k = k0 + lane;
-          bool keep = false;
-          if (k < n) {
-            const T xmin = s_bbox[k * 4 + 0], ymin = s_bbox[k * 4 + 1], xmax = s_bbox[k * 4 + 2], ymax = s_bbox[k * 4 + 3];
-            keep = !(ux_max < xmin || ux_min >= xmax || uy_max < ymin || uy_min >= ymax);
-          }
-          unsigned long long m = __ballot(keep);
-          while (m) {
-            const int j = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int kk = k0 + j;
-            if (!active) continue;
-            const T xmin = s_bbox[kk * 4 + 0], ymin = s_bbox[kk * 4 + 1], xmax = s_bbox[kk * 4 + 2], ymax = s_bbox[kk * 4 + 3];
-            if (x0 < xmin || x0 >= xmax || y0 < ymin || y0 >= ymax) continue;
-            int which;
-            const T d2 = closest_of_six<T>(s_vert + kk * 6, s_edge + kk * 3, s_den + kk * 3, s_rcp + kk * 3, x0, y0, multiplier, &which);
-            const T zz = sigmainv * d2 / multiplier / multiplier;
-            const T pr = dibr_exp<T>(-zz);
-            prob_out[pk + kid] = pr;
-            idx_out[pk + kid] = s_ids[kk];
-            type_out[pk + kid] = (uint8_t)(which + 1);
-            all = (T)((double)all * (1.0 - (double)pr));
-            ++kid;
-            if (kid >= K) active = false;
-          }
-        }
-      }
     }
+  };
+
+  int count = 0;
+  for (int w0 = 0; w0 < nwords; w0 += 64) {
+    const int wi = w0 + lane;
+    unsigned int word = wi < nwords ? tmask[wi] : 0u;
+    const int c = __popc(word);
+    const int incl = wave_inclusive_scan(c);
+    const int total = __shfl(incl, 63, 64);
+    if (total == 0) continue;
+    if (count + total > SM_IDCAP) {
+      process(count);
+      count = 0;
+      if (!__any(active)) break;
+    }
+    int pos = count + incl - c;
+    while (word) {
+      const int bit = __ffs(word) - 1;
+      word &= word - 1;
+      s_ids[pos++] = wi * 32 + bit;
+    }
+    count += total;
   }
+  if (count > 0) process(count);
+
   if (uncovered) {
     soft_mask[p1] = (T)(1.0 - (double)all);
     if (hit_count) hit_count[p1] = (uint8_t)(kid > 255 ? 255 : kid);
@@ -267,48 +280,89 @@ __global__ __launch_bounds__(TILE_THREADS) void soft_mask_tile_kernel(
 }
 
 // ---- K4 ---------------------------------------------------------------------------------------------------
+// One 64-lane workgroup per 16x4-pixel sub-tile.  The reference adds every (pixel, hit) contribution to the
+// face's vertices with global atomics (dibr_soft_mask_cuda.cu:299-302,339-347); a silhouette face receives
+// hundreds of them.  Here the wavefront first sums per face in an LDS hash table (ds_add_f32), then flushes one
+// global atomic per touched (face, coordinate).
+constexpr int SB_HT = 512;  // hash slots (a wavefront rarely sees more than ~200 distinct faces)
+
 template <typename T>
-__global__ __launch_bounds__(256) void soft_mask_backward_kernel(
-    long long total_pixels, int H, int W, int F, int K, const T* __restrict__ grad, const T* __restrict__ soft_mask,
+__device__ __forceinline__ void sb_accumulate(int* s_key, T* s_acc, T* __restrict__ g_face, int f, int off, T v) {
+  // open addressing on the face id; falls back to a global atomic if the table is full
+  int slot = (int)(((unsigned)f * 2654435761u) >> 23) & (SB_HT - 1);
+  for (int probe = 0; probe < SB_HT; ++probe) {
+    const int k = atomicCAS(&s_key[slot], -1, f);
+    if (k == -1 || k == f) {
+      atomicAdd(&s_acc[slot * 6 + off], v);
+      return;
+    }
+    slot = (slot + 1) & (SB_HT - 1);
+  }
+  kamd_atomic_add(g_face + off, v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void soft_mask_backward_kernel(
+    int B, int H, int W, int F, int K, const T* __restrict__ grad, const T* __restrict__ soft_mask,
     const int64_t* __restrict__ sel_idx, const T* __restrict__ prob_in, const int64_t* __restrict__ idx_in,
     const uint8_t* __restrict__ type_in, const T* __restrict__ img, float sigmainv, float multiplier,
     T* __restrict__ g_img, const uint8_t* __restrict__ hit_count) {
-  const long long p1 = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (p1 >= total_pixels) return;
+  __shared__ int s_key[SB_HT];
+  __shared__ T s_acc[SB_HT * 6];
+  const int subs_x = (W + SUB_W - 1) / SUB_W, subs_y = (H + SUB_H - 1) / SUB_H;
+  const int sub = blockIdx.x % (subs_x * subs_y), b = blockIdx.x / (subs_x * subs_y);
+  const int lane = threadIdx.x;
+  const int col = (sub % subs_x) * SUB_W + (lane & 15), row = (sub / subs_x) * SUB_H + (lane >> 4);
+  const bool in_image = col < W && row < H;
+  const size_t p1 = ((size_t)b * H + row) * W + col;
+  const size_t pk = p1 * K;
   // hit_count (optional, produced by our own forward): pixels without hits never touch the K-buffers; a stored
   // 255 means "255 or more", then the -1 terminator decides as in the reference
-  int limit = K;
-  if (hit_count) {
-    const int hc = hit_count[p1];
-    if (hc == 0) return;
-    if (hc < 255 && hc < K) limit = hc;
+  int limit = 0;
+  if (in_image) {
+    if (hit_count) {
+      const int hc = hit_count[p1];
+      limit = hc == 255 ? K : min(hc, K);
+    } else if ((int)sel_idx[p1] < 0) {
+      limit = K;
+    }
   }
-  if ((int)sel_idx[p1] >= 0) return;
-  const size_t pk = (size_t)p1 * K;
-  const int col = (int)(p1 % W);
-  const int row = (int)((p1 / W) % H);
-  const int b = (int)(p1 / ((long long)W * H));
+  if (limit > 0 && (int)sel_idx[p1] >= 0) limit = 0;
+  if (!__any(limit > 0)) return;
+
+  for (int i = lane; i < SB_HT; i += 64) s_key[i] = -1;
+  for (int i = lane; i < SB_HT * 6; i += 64) s_acc[i] = 0;
+  __syncthreads();
+
   const T x0 = pixel_x(multiplier, W, col);
   const T y0 = pixel_y(multiplier, H, row);
-  const T dLdp = grad[p1];
-  const T all = soft_mask[p1];
-  for (int kid = 0; kid < limit; ++kid) {
+  const T dLdp = limit > 0 ? grad[p1] : (T)0;
+  const T all = limit > 0 ? soft_mask[p1] : (T)0;
+  int max_limit = limit;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) max_limit = max(max_limit, __shfl_xor(max_limit, d, 64));
+  for (int kid = 0; kid < max_limit; ++kid) {
+    if (kid >= limit) continue;
     const int f = (int)idx_in[pk + kid];
-    if (f < 0) break;
+    if (f < 0) {
+      limit = 0;
+      continue;
+    }
     const size_t s6 = ((size_t)b * F + f) * 6;
+    const int key = f;  // the table is per image: b is fixed for the workgroup
     const T pr = prob_in[pk + kid];
     const T dLdz = (T)(-1.0 * sigmainv * dLdp * (1.0 - all) / (1.0 - pr + DIBR_EPS) * pr);
     const int e = (int)type_in[pk + kid] - 1;
     if (e >= 3) {
-      const size_t ps = s6 + (size_t)(e - 3) * 2;
-      const T x1 = img[ps], y1 = img[ps + 1];
+      const int o = (e - 3) * 2;
+      const T x1 = img[s6 + o], y1 = img[s6 + o + 1];
       const T dLdx1 = dLdz * 2 * (x1 - x0);
       const T dLdy1 = dLdz * 2 * (y1 - y0);
-      kamd_atomic_add(g_img + ps, (T)(dLdx1 / multiplier));
-      kamd_atomic_add(g_img + ps + 1, (T)(dLdy1 / multiplier));
+      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o, (T)(dLdx1 / multiplier));
+      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o + 1, (T)(dLdy1 / multiplier));
     } else {
-      const size_t ps = s6 + (size_t)e * 2, ps2 = s6 + (size_t)((e + 1) % 3) * 2;
-      const T x1 = img[ps], y1 = img[ps + 1], x2 = img[ps2], y2 = img[ps2 + 1];
+      const int o = e * 2, o2 = ((e + 1) % 3) * 2;
+      const T x1 = img[s6 + o], y1 = img[s6 + o + 1], x2 = img[s6 + o2], y2 = img[s6 + o2 + 1];
       const T A = y2 - y1, Bc = x1 - x2, C = x2 * y1 - x1 * y2;
       const T up = A * x0 + Bc * y0 + C;
       const T down = A * A + Bc * Bc;
@@ -320,11 +374,17 @@ __global__ __launch_bounds__(256) void soft_mask_backward_kernel(
       const T dLdy1 = dLdz * (x2 * dzdC - dzdA);
       const T dLdx2 = dLdz * (y1 * dzdC - dzdB);
       const T dLdy2 = dLdz * (dzdA - x1 * dzdC);
-      kamd_atomic_add(g_img + ps, (T)(dLdx1 / multiplier));
-      kamd_atomic_add(g_img + ps + 1, (T)(dLdy1 / multiplier));
-      kamd_atomic_add(g_img + ps2, (T)(dLdx2 / multiplier));
-      kamd_atomic_add(g_img + ps2 + 1, (T)(dLdy2 / multiplier));
+      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o, (T)(dLdx1 / multiplier));
+      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o + 1, (T)(dLdy1 / multiplier));
+      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o2, (T)(dLdx2 / multiplier));
+      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o2 + 1, (T)(dLdy2 / multiplier));
     }
+  }
+  __syncthreads();
+  for (int i = lane; i < SB_HT * 6; i += 64) {
+    const int k = s_key[i / 6];
+    const T v = s_acc[i];
+    if (k >= 0 && v != (T)0) kamd_atomic_add(g_img + ((size_t)b * F + k) * 6 + (i % 6), v);
   }
 }
 
@@ -368,8 +428,8 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
   }
   {
     kamd::ProfScope prof_(kamd::K_SOFT_TILE, st);
-    hipLaunchKernelGGL(soft_mask_tile_kernel<T>, dim3(g.ntiles * B), dim3(TILE_THREADS), 0, st, B, F, g, K, sigmainv,
-                     multiplier, rec, masks, sel_idx, soft_mask, prob, idx, type, flags, hit_count);
+    hipLaunchKernelGGL(soft_mask_wave_kernel<T>, dim3(g.ntiles * B * 16), dim3(64), 0, st, B, F, g, K, sigmainv, multiplier,
+                       rec, masks, flags, sel_idx, soft_mask, prob, idx, type, hit_count);
   }
   KAMD_RETURN_LAST_ERROR();
 }
@@ -380,10 +440,11 @@ int soft_mask_backward_launch(hipStream_t st, int B, int H, int W, int F, int K,
                               const T* img, float sigmainv, float multiplier, T* g_img, const uint8_t* hit_count) {
   const long long total = (long long)B * H * W;
   if (total <= 0 || F <= 0 || K <= 0) return 0;
+  const long long blocks = (long long)B * ((W + SUB_W - 1) / SUB_W) * ((H + SUB_H - 1) / SUB_H);
   {
     kamd::ProfScope prof_(kamd::K_SOFT_BACKWARD, st);
-    hipLaunchKernelGGL(soft_mask_backward_kernel<T>, dim3(kamd_cdiv(total, 256)), dim3(256), 0, st, total, H, W, F, K,
-                     grad, soft_mask, sel_idx, prob, idx, type, img, sigmainv, multiplier, g_img, hit_count);
+    hipLaunchKernelGGL(soft_mask_backward_kernel<T>, dim3((unsigned)blocks), dim3(64), 0, st, B, H, W, F, K, grad,
+                       soft_mask, sel_idx, prob, idx, type, img, sigmainv, multiplier, g_img, hit_count);
   }
   KAMD_RETURN_LAST_ERROR();
 }
