@@ -152,6 +152,37 @@ int kamd_dibr_soft_mask_backward_f64(void* stream, int B, int H, int W, int F, i
                                      float sigmainv, float multiplier, double* g_img,
                                      const uint8_t* hit_count);
 
+/* Compact-list variant used by this package's own autograd Function (not part  */
+/* of the reference's interface): same search, same soft_mask, but instead of   */
+/* the (B,H,W,K) K-buffers every accepted (pixel, face) hit is appended to four */
+/* parallel arrays (capacity B*H*W*K entries, only the used prefix is touched;  */
+/* order irrelevant) and *counter (zeroed by the caller) ends up holding the    */
+/* number of hits.  Requires B*H*W < 2^31.  The backward consumes the list.     */
+int kamd_dibr_soft_mask_forward_lean_f32(void* stream, int B, int H, int W, int F, int K,
+                                         const float* img, const float* large_bbox,
+                                         const int64_t* sel_idx, float sigmainv, float multiplier,
+                                         float* soft_mask, int32_t* hit_pix, int32_t* hit_face,
+                                         float* hit_prob, uint8_t* hit_type, uint64_t* counter,
+                                         void* workspace);
+int kamd_dibr_soft_mask_forward_lean_f64(void* stream, int B, int H, int W, int F, int K,
+                                         const double* img, const double* large_bbox,
+                                         const int64_t* sel_idx, float sigmainv, float multiplier,
+                                         double* soft_mask, int32_t* hit_pix, int32_t* hit_face,
+                                         double* hit_prob, uint8_t* hit_type, uint64_t* counter,
+                                         void* workspace);
+int kamd_dibr_soft_mask_backward_lean_f32(void* stream, int B, int H, int W, int F,
+                                          const float* grad, const float* soft_mask,
+                                          const int32_t* hit_pix, const int32_t* hit_face,
+                                          const float* hit_prob, const uint8_t* hit_type,
+                                          const uint64_t* counter, const float* img,
+                                          float sigmainv, float multiplier, float* g_img);
+int kamd_dibr_soft_mask_backward_lean_f64(void* stream, int B, int H, int W, int F,
+                                          const double* grad, const double* soft_mask,
+                                          const int32_t* hit_pix, const int32_t* hit_face,
+                                          const double* hit_prob, const uint8_t* hit_type,
+                                          const uint64_t* counter, const double* img,
+                                          float sigmainv, float multiplier, double* g_img);
+
 /* ------------------------------------------------------------------------- */
 /* metrics.unbatched_triangle_distance_forward_cuda(points, faces, dist,      */
 /*     face_idx, dist_type) -> void                                           */

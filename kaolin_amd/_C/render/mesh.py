@@ -153,3 +153,66 @@ def dibr_soft_mask_backward_cuda(grad_soft_mask, soft_mask, selected_face_idx, c
             float(sigmainv), float(multiplier), _lib.ptr(g_img), _lib.ptr(_hit_count))
     _lib.check(st, fn)
     return g_img
+
+
+def dibr_soft_mask_forward_lean(face_vertices_image, face_large_bboxes, selected_face_idx, sigmainv, knum, multiplier):
+    """Our autograd path's variant of ``dibr_soft_mask_forward_cuda`` (no counterpart in the reference): the same
+    search and the same ``soft_mask``, but the per-pixel K-buffers (13*knum bytes per pixel, initialised for every
+    pixel) are replaced by a compact list of the actual (pixel, face, prob, type) hits.
+    -> (soft_mask, (hit_pix, hit_face, hit_prob, hit_type, counter))"""
+    fn = 'dibr_soft_mask_forward_lean'
+    args = [Arg(face_vertices_image, 'face_vertices_image', 1), Arg(face_large_bboxes, 'face_bboxes', 2),
+            Arg(selected_face_idx, 'selected_face_idx', 3)]
+    check_all_same_gpu(fn, args)
+    check_all_contiguous(fn, args)
+    batch_size, num_faces = face_vertices_image.size(0), face_vertices_image.size(1)
+    height, width = selected_face_idx.size(1), selected_face_idx.size(2)
+    check_size(fn, args[0], [batch_size, num_faces, 3, 2])
+    check_size(fn, args[1], [batch_size, num_faces, 4])
+    check_size(fn, args[2], [batch_size, height, width])
+    dtype, device = face_vertices_image.dtype, face_vertices_image.device
+    sfx = _lib.dtype_suffix(dtype, fn)
+    knum = int(knum)
+    cap = max(batch_size * height * width * knum, 1)
+    lib = _lib.load()
+    with torch.cuda.device(device):
+        soft_mask = torch.empty((batch_size, height, width), dtype=dtype, device=device)
+        hit_pix = torch.empty(cap, dtype=torch.int32, device=device)     # capacity only: just the used prefix is touched
+        hit_face = torch.empty(cap, dtype=torch.int32, device=device)
+        hit_prob = torch.empty(cap, dtype=dtype, device=device)
+        hit_type = torch.empty(cap, dtype=torch.uint8, device=device)
+        counter = torch.zeros(1, dtype=torch.int64, device=device)
+        ws = _lib.workspace(lib.kamd_dibr_soft_mask_forward_workspace(batch_size, height, width, num_faces,
+                                                                      face_vertices_image.element_size()), device)
+        st = getattr(lib, f'kamd_dibr_soft_mask_forward_lean_{sfx}')(
+            _lib.stream_ptr(device), batch_size, height, width, num_faces, knum,
+            _lib.ptr(face_vertices_image), _lib.ptr(face_large_bboxes), _lib.ptr(selected_face_idx),
+            float(sigmainv), float(multiplier), _lib.ptr(soft_mask), _lib.ptr(hit_pix), _lib.ptr(hit_face),
+            _lib.ptr(hit_prob), _lib.ptr(hit_type), _lib.ptr(counter), _lib.ptr(ws))
+    _lib.check(st, fn)
+    return soft_mask, (hit_pix, hit_face, hit_prob, hit_type, counter)
+
+
+def dibr_soft_mask_backward_lean(grad_soft_mask, soft_mask, hits, face_vertices_image, sigmainv, multiplier):
+    """Backward of :func:`dibr_soft_mask_forward_lean` -> grad_face_vertices_image (B,F,3,2), w.r.t. the unscaled input."""
+    fn = 'dibr_soft_mask_backward_lean'
+    hit_pix, hit_face, hit_prob, hit_type, counter = hits
+    args = [Arg(grad_soft_mask, 'grad_soft_mask', 1), Arg(soft_mask, 'soft_mask', 2),
+            Arg(face_vertices_image, 'face_vertices_image', 4)]
+    check_all_same_gpu(fn, args)
+    check_all_contiguous(fn, args)
+    batch_size, num_faces = face_vertices_image.size(0), face_vertices_image.size(1)
+    height, width = soft_mask.size(1), soft_mask.size(2)
+    check_size(fn, args[0], [batch_size, height, width])
+    dtype, device = face_vertices_image.dtype, face_vertices_image.device
+    sfx = _lib.dtype_suffix(dtype, fn)
+    lib = _lib.load()
+    with torch.cuda.device(device):
+        g_img = torch.zeros_like(face_vertices_image)
+        st = getattr(lib, f'kamd_dibr_soft_mask_backward_lean_{sfx}')(
+            _lib.stream_ptr(device), batch_size, height, width, num_faces,
+            _lib.ptr(grad_soft_mask), _lib.ptr(soft_mask), _lib.ptr(hit_pix), _lib.ptr(hit_face), _lib.ptr(hit_prob),
+            _lib.ptr(hit_type), _lib.ptr(counter), _lib.ptr(face_vertices_image), float(sigmainv), float(multiplier),
+            _lib.ptr(g_img))
+    _lib.check(st, fn)
+    return g_img

@@ -129,45 +129,59 @@ inline int fill_edges(hipStream_t st, void* p, size_t bytes, int v, FillPlan* pl
 }
 
 // ---- K3 search kernel ------------------------------------------------------------------------------------
-// One 64-lane workgroup per 16x4-pixel sub-tile (a single wavefront: barriers are free and a sub-tile that owns
-// silhouette-band pixels never keeps 15 idle wavefronts resident, which is what a 32x32-pixel workgroup did:
-// SQ_WAIT_ANY was 75 % of wave time).  Wavefronts without an uncovered pixel leave after reading sel_idx.
-//   1. expand the 32x32 tile's bitmask into an ascending id list in LDS (popcount + wave scan, 64 words a step);
-//   2. 64 ids at a time: each lane culls one face against the extent of the wavefront's uncovered pixels;
-//      surviving lanes stage vertices + the per-edge invariants of "their" face in LDS (compacted, order kept);
-//   3. all lanes walk the staged faces in order with broadcast LDS reads.
-constexpr int SM_IDCAP = 2048;  // ids buffered between flushes (>= the 64*32 a single step can produce)
+// One 64-lane workgroup (a single wavefront: barriers are free) per 16x4-pixel sub-tile; wavefronts without an
+// uncovered pixel leave after reading sel_idx.  The reference's loop "for each pixel: for each face" spends its
+// time on the few silhouette-band pixels, so inside a wavefront the roles are swapped:
+//   1. the 32x32 tile's bitmask is expanded into an ascending id list (popcount + wave scan, 64 words a step);
+//   2. 64 ids at a time, each lane culls one face against the extent of the wavefront's uncovered pixels and the
+//      survivors are compacted, in order, into a candidate queue;
+//   3. per 64 candidates: LANE = FACE.  Each lane loads its face and derives the per-edge invariants in
+//      registers once; then a scalar loop walks the still-active pixels: the pixel centre is broadcast, every
+//      lane evaluates its own face against it (full lane utilisation, no LDS traffic), a ballot gives the hits in
+//      ascending face order, the first (knum - hits so far) are accepted and written at consecutive K-buffer
+//      positions (or appended to the compact hit list), and prod(1 - prob) is continued in that same order.
+// Results are identical to the reference's pixel-major loop: same expressions per (pixel, face), same order of
+// hits per pixel, same product order.
+constexpr int SM_IDCAP = 2048;   // ids produced by one 64-word step (64 * 32)
+constexpr int SM_LISTBUF = 512;  // compact-list entries buffered per wavefront between flushes
 
 template <typename T>
-__global__ __launch_bounds__(64) void soft_mask_wave_kernel(
+struct HitList {      // compact output (our own autograd path): one record per (pixel, hit), order irrelevant
+  int* pix;           // b * H * W + row * W + col
+  int* face;
+  T* prob;
+  uint8_t* type;
+  unsigned long long* counter;  // zeroed by the caller
+};
+
+template <typename T, bool LEAN>
+__global__ __launch_bounds__(64) void soft_mask_search_kernel(
     int B, int F, TileGeom g, int K, float sigmainv, float multiplier, const T* __restrict__ rec,
     const unsigned int* __restrict__ masks, const unsigned int* __restrict__ tile_flags,
     const int64_t* __restrict__ sel_idx, T* __restrict__ soft_mask, T* __restrict__ prob_out,
-    int64_t* __restrict__ idx_out, uint8_t* __restrict__ type_out, uint8_t* __restrict__ hit_count) {
-  __shared__ int s_ids[SM_IDCAP];
-  __shared__ __attribute__((aligned(16))) T s_bbox[64 * 4];
-  __shared__ __attribute__((aligned(16))) T s_vert[64 * 6];
-  __shared__ __attribute__((aligned(16))) EdgeInv<T> s_edge[64 * 3];
-  __shared__ __attribute__((aligned(16))) double s_den[64 * 3];
-  __shared__ __attribute__((aligned(16))) double s_rcp[64 * 3];
-  __shared__ int s_face[64];
+    int64_t* __restrict__ idx_out, uint8_t* __restrict__ type_out, uint8_t* __restrict__ hit_count, HitList<T> list) {
+  __shared__ int s_tmp[SM_IDCAP];
+  __shared__ int s_cand[128];
+  __shared__ int l_pix[LEAN ? SM_LISTBUF : 1], l_face[LEAN ? SM_LISTBUF : 1];
+  __shared__ T l_prob[LEAN ? SM_LISTBUF : 1];
+  __shared__ uint8_t l_type[LEAN ? SM_LISTBUF : 1];
 
   constexpr int SUBS = (TILE_W / SUB_W) * (TILE_H / SUB_H);  // 16 sub-tiles per tile
   const int sub = blockIdx.x % SUBS;
   const int b = (blockIdx.x / SUBS) % B;
   const int tile = blockIdx.x / (SUBS * B);
   const int lane = threadIdx.x;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const int sub_x = (tile % g.tiles_x) * TILE_W + (sub & 1) * SUB_W;
   const int sub_y = (tile / g.tiles_x) * TILE_H + (sub >> 1) * SUB_H;
   if (sub_x >= g.W || sub_y >= g.H) return;
   const int col = sub_x + (lane & 15), row = sub_y + (lane >> 4);
   const bool in_image = col < g.W && row < g.H;
   const size_t p1 = ((size_t)b * g.H + row) * g.W + col;
-  const size_t pk = p1 * K;
   const bool uncovered = in_image && (int)sel_idx[in_image ? p1 : 0] < 0;
   if (in_image && !uncovered) {
     soft_mask[p1] = (T)1.0;
-    if (hit_count) hit_count[p1] = 0;
+    if (!LEAN && hit_count) hit_count[p1] = 0;
   }
   if (!__any(uncovered)) return;
 
@@ -188,94 +202,163 @@ __global__ __launch_bounds__(64) void soft_mask_wave_kernel(
     uy_max = fmax(uy_max, __shfl_xor(uy_max, d, 64));
   }
 
+  // per-PIXEL state lives in the lane that owns the pixel
   int kid = 0;
   T all = 1.0;
   bool active = uncovered && K > 0;
+  int nbuf = 0;  // entries waiting in the LDS list buffer (LEAN)
 
-  // walks ids [0, n) of s_ids
-  auto process = [&](int n) {
+  auto flush_list = [&]() {
+    if (!LEAN || nbuf == 0) return;
     __syncthreads();
-    for (int c0 = 0; c0 < n; c0 += 64) {
-      if (!__any(active)) break;
-      const int k = c0 + lane;
-      bool keep = false;
-      int id = 0;
-      T bb0 = 0, bb1 = 0, bb2 = 0, bb3 = 0;
-      if (k < n) {
-        id = s_ids[k];
-        const T* r = rec + ((size_t)first_b + id) * REC_STRIDE;
-        bb0 = r[0];
-        bb1 = r[1];
-        bb2 = r[2];
-        bb3 = r[3];
-        keep = !(ux_max < bb0 || ux_min >= bb2 || uy_max < bb1 || uy_min >= bb3);
-      }
-      const unsigned long long m = __ballot(keep);
-      const int ns = __popcll(m);
-      if (keep) {
-        const int slot = __popcll(m & ((1ull << lane) - 1ull));
-        const T* r = rec + ((size_t)first_b + id) * REC_STRIDE;
-        T v[6];
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(list.counter, (unsigned long long)nbuf);
+    base = __shfl(base, 0, 64);
+    for (int i = lane; i < nbuf; i += 64) {
+      list.pix[base + i] = l_pix[i];
+      list.face[base + i] = l_face[i];
+      list.prob[base + i] = l_prob[i];
+      list.type[base + i] = l_type[i];
+    }
+    nbuf = 0;
+    __syncthreads();
+  };
+
+  // evaluates the first n (<= 64) candidates of s_cand against every active pixel
+  auto process_chunk = [&](int n) {
+    const bool face_valid = lane < n;
+    int id = 0;
+    T bb0 = 0, bb1 = 0, bb2 = 0, bb3 = 0, v[6];
+    EdgeInv<T> e[3];
+    double den[3], rcp[3];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) v[i] = r[4 + i];
-        s_bbox[slot * 4 + 0] = bb0;
-        s_bbox[slot * 4 + 1] = bb1;
-        s_bbox[slot * 4 + 2] = bb2;
-        s_bbox[slot * 4 + 3] = bb3;
+    for (int i = 0; i < 6; ++i) v[i] = 0;
+    if (face_valid) {
+      id = s_cand[lane];
+      const T* r = rec + ((size_t)first_b + id) * REC_STRIDE;
+      bb0 = r[0];
+      bb1 = r[1];
+      bb2 = r[2];
+      bb3 = r[3];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) s_vert[slot * 6 + i] = v[i];
-        s_face[slot] = id;
+      for (int i = 0; i < 6; ++i) v[i] = r[4 + i];
+    }
 #pragma unroll
-        for (int e = 0; e < 3; ++e)
-          edge_invariants<T>(v[e * 2], v[e * 2 + 1], v[((e + 1) % 3) * 2], v[((e + 1) % 3) * 2 + 1], &s_edge[slot * 3 + e],
-                             &s_den[slot * 3 + e], &s_rcp[slot * 3 + e]);
-      }
-      __syncthreads();
-      for (int j = 0; j < ns; ++j) {
-        if (!active) continue;
-        const T xmin = s_bbox[j * 4 + 0], ymin = s_bbox[j * 4 + 1], xmax = s_bbox[j * 4 + 2], ymax = s_bbox[j * 4 + 3];
-        if (x0 < xmin || x0 >= xmax || y0 < ymin || y0 >= ymax) continue;
-        int which;
-        const T d2 = closest_of_six<T>(s_vert + j * 6, s_edge + j * 3, s_den + j * 3, s_rcp + j * 3, x0, y0, multiplier, &which);
+    for (int k = 0; k < 3; ++k)
+      edge_invariants<T>(v[k * 2], v[k * 2 + 1], v[((k + 1) % 3) * 2], v[((k + 1) % 3) * 2 + 1], &e[k], &den[k], &rcp[k]);
+    unsigned long long am = __ballot(active);
+    while (am) {
+      const int u = __ffsll((long long)am) - 1;
+      am &= am - 1;
+      const T xu = __shfl(x0, u, 64), yu = __shfl(y0, u, 64);
+      const bool pass = face_valid && !(xu < bb0 || xu >= bb2 || yu < bb1 || yu >= bb3);
+      const unsigned long long m = __ballot(pass);
+      if (m == 0) continue;
+      const int kid_u = __shfl(kid, u, 64);
+      const int room = K - kid_u;
+      T pr = 0;
+      int which = 0;
+      if (pass) {
+        const T d2 = closest_of_six<T>(v, e, den, rcp, xu, yu, multiplier, &which);
         const T zz = sigmainv * d2 / multiplier / multiplier;
-        const T pr = dibr_exp<T>(-zz);
-        prob_out[pk + kid] = pr;
-        idx_out[pk + kid] = s_face[j];
-        type_out[pk + kid] = (uint8_t)(which + 1);
-        all = (T)((double)all * (1.0 - (double)pr));
-        ++kid;
+        pr = dibr_exp<T>(-zz);
+      }
+      const int rank = __popcll(m & lt_mask);
+      const bool accept = pass && rank < room;
+      const int ucol = sub_x + (u & 15), urow = sub_y + (u >> 4);
+      const size_t p1u = ((size_t)b * g.H + urow) * g.W + ucol;
+      const int nacc = min(__popcll(m), room);
+      if (LEAN) {
+        if (nbuf + nacc > SM_LISTBUF) flush_list();
+        if (accept) {
+          l_pix[nbuf + rank] = (int)p1u;
+          l_face[nbuf + rank] = id;
+          l_prob[nbuf + rank] = pr;
+          l_type[nbuf + rank] = (uint8_t)(which + 1);
+        }
+        nbuf += nacc;
+      } else if (accept) {
+        const size_t o = p1u * K + kid_u + rank;
+        prob_out[o] = pr;
+        idx_out[o] = id;
+        type_out[o] = (uint8_t)(which + 1);
+      }
+      // continue prod(1 - prob) in hit order (dibr_soft_mask_cuda.cu:174-179)
+      T all_u = __shfl(all, u, 64);
+      unsigned long long ma = __ballot(accept);
+      while (ma) {
+        const int l = __ffsll((long long)ma) - 1;
+        ma &= ma - 1;
+        const T p = __shfl(pr, l, 64);
+        all_u = (T)((double)all_u * (1.0 - (double)p));
+      }
+      if (lane == u) {
+        kid = kid_u + nacc;
+        all = all_u;
         if (kid >= K) active = false;
       }
-      __syncthreads();
     }
   };
 
-  int count = 0;
-  for (int w0 = 0; w0 < nwords; w0 += 64) {
+  int ncand = 0;
+  bool done = false;
+  for (int w0 = 0; w0 < nwords && !done; w0 += 64) {
     const int wi = w0 + lane;
     unsigned int word = wi < nwords ? tmask[wi] : 0u;
     const int c = __popc(word);
     const int incl = wave_inclusive_scan(c);
     const int total = __shfl(incl, 63, 64);
     if (total == 0) continue;
-    if (count + total > SM_IDCAP) {
-      process(count);
-      count = 0;
-      if (!__any(active)) break;
+    __syncthreads();
+    {
+      int pos = incl - c;
+      while (word) {
+        const int bit = __ffs(word) - 1;
+        word &= word - 1;
+        s_tmp[pos++] = wi * 32 + bit;
+      }
     }
-    int pos = count + incl - c;
-    while (word) {
-      const int bit = __ffs(word) - 1;
-      word &= word - 1;
-      s_ids[pos++] = wi * 32 + bit;
+    __syncthreads();
+    for (int t0 = 0; t0 < total; t0 += 64) {
+      const int k = t0 + lane;
+      bool keep = false;
+      int id = 0;
+      if (k < total) {
+        id = s_tmp[k];
+        const T* r = rec + ((size_t)first_b + id) * REC_STRIDE;
+        const T b0 = r[0], b1 = r[1], b2 = r[2], b3 = r[3];
+        keep = !(ux_max < b0 || ux_min >= b2 || uy_max < b1 || uy_min >= b3);
+      }
+      const unsigned long long m = __ballot(keep);
+      if (m == 0) continue;
+      if (keep) s_cand[ncand + __popcll(m & lt_mask)] = id;
+      ncand += __popcll(m);
+      __syncthreads();
+      if (ncand >= 64) {
+        process_chunk(64);
+        __syncthreads();
+        const int rest = ncand - 64;
+        const int moved = lane < rest ? s_cand[64 + lane] : 0;
+        __syncthreads();
+        if (lane < rest) s_cand[lane] = moved;
+        ncand = rest;
+        __syncthreads();
+        if (!__any(active)) {
+          done = true;
+          break;
+        }
+      }
     }
-    count += total;
   }
-  if (count > 0) process(count);
+  if (!done && ncand > 0) {
+    __syncthreads();
+    process_chunk(ncand);
+  }
+  flush_list();
 
   if (uncovered) {
     soft_mask[p1] = (T)(1.0 - (double)all);
-    if (hit_count) hit_count[p1] = (uint8_t)(kid > 255 ? 255 : kid);
+    if (!LEAN && hit_count) hit_count[p1] = (uint8_t)(kid > 255 ? 255 : kid);
   }
 }
 
@@ -284,13 +367,13 @@ __global__ __launch_bounds__(64) void soft_mask_wave_kernel(
 // face's vertices with global atomics (dibr_soft_mask_cuda.cu:299-302,339-347); a silhouette face receives
 // hundreds of them.  Here the wavefront first sums per face in an LDS hash table (ds_add_f32), then flushes one
 // global atomic per touched (face, coordinate).
-constexpr int SB_HT = 512;  // hash slots (a wavefront rarely sees more than ~200 distinct faces)
+constexpr int SB_HT = 1024;  // hash slots (a wavefront rarely sees more than ~200 distinct faces)
 
 template <typename T>
 __device__ __forceinline__ void sb_accumulate(int* s_key, T* s_acc, T* __restrict__ g_face, int f, int off, T v) {
   // open addressing on the face id; falls back to a global atomic if the table is full
-  int slot = (int)(((unsigned)f * 2654435761u) >> 23) & (SB_HT - 1);
-  for (int probe = 0; probe < SB_HT; ++probe) {
+  int slot = (int)(((unsigned)f * 2654435761u) >> 22) & (SB_HT - 1);
+  for (int probe = 0; probe < 16; ++probe) {  // bounded probing: a crowded table degrades to global atomics, not to a scan
     const int k = atomicCAS(&s_key[slot], -1, f);
     if (k == -1 || k == f) {
       atomicAdd(&s_acc[slot * 6 + off], v);
@@ -388,16 +471,92 @@ __global__ __launch_bounds__(64) void soft_mask_backward_kernel(
   }
 }
 
+// ---- K4, compact-list form (our own autograd path) ---------------------------------------------------------
+// One lane per recorded (pixel, hit); the list is written wavefront by wavefront, so a workgroup's contiguous
+// slice of it touches few faces: contributions are summed per face in an LDS hash table and flushed once.
+constexpr int SL_THREADS = 256;
+constexpr int SL_BLOCKS = 4096;
+constexpr int SL_CHUNK = 1024;  // hits per workgroup round
+
+template <typename T>
+__global__ __launch_bounds__(SL_THREADS) void soft_mask_backward_list_kernel(
+    int H, int W, int F, const T* __restrict__ grad, const T* __restrict__ soft_mask, HitList<T> list,
+    const T* __restrict__ img, float sigmainv, float multiplier, T* __restrict__ g_img) {
+  __shared__ int s_key[SB_HT];
+  __shared__ T s_acc[SB_HT * 6];
+  const unsigned long long n = *list.counter;
+  const long long P = (long long)H * W;
+  // contiguous chunks of SL_CHUNK hits (the list is written wavefront by wavefront: a chunk touches few faces)
+  for (unsigned long long begin = (unsigned long long)blockIdx.x * SL_CHUNK; begin < n;
+       begin += (unsigned long long)gridDim.x * SL_CHUNK) {
+  const unsigned long long end = begin + SL_CHUNK < n ? begin + SL_CHUNK : n;
+  __syncthreads();
+  for (int i = threadIdx.x; i < SB_HT; i += SL_THREADS) s_key[i] = -1;
+  for (int i = threadIdx.x; i < SB_HT * 6; i += SL_THREADS) s_acc[i] = 0;
+  __syncthreads();
+  for (unsigned long long t = begin + threadIdx.x; t < end; t += SL_THREADS) {
+    const int pix = list.pix[t];
+    const int f = list.face[t];
+    const T pr = list.prob[t];
+    const int e = (int)list.type[t] - 1;
+    const int b = (int)(pix / P);
+    const int rem = (int)(pix - (long long)b * P);
+    const int col = rem % W, row = rem / W;
+    const T x0 = pixel_x(multiplier, W, col);
+    const T y0 = pixel_y(multiplier, H, row);
+    const T dLdp = grad[pix];
+    const T all = soft_mask[pix];
+    const size_t s6 = ((size_t)b * F + f) * 6;
+    // faces of different images never share a slice in practice, but the key must still be unique: b*F + f
+    const int key = (int)(((long long)b * F + f) & 0x7fffffff);
+    const T dLdz = (T)(-1.0 * sigmainv * dLdp * (1.0 - all) / (1.0 - pr + DIBR_EPS) * pr);
+    if (e >= 3) {
+      const int o = (e - 3) * 2;
+      const T x1 = img[s6 + o], y1 = img[s6 + o + 1];
+      const T dLdx1 = dLdz * 2 * (x1 - x0);
+      const T dLdy1 = dLdz * 2 * (y1 - y0);
+      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o, (T)(dLdx1 / multiplier));
+      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o + 1, (T)(dLdy1 / multiplier));
+    } else {
+      const int o = e * 2, o2 = ((e + 1) % 3) * 2;
+      const T x1 = img[s6 + o], y1 = img[s6 + o + 1], x2 = img[s6 + o2], y2 = img[s6 + o2 + 1];
+      const T A = y2 - y1, Bc = x1 - x2, C = x2 * y1 - x1 * y2;
+      const T up = A * x0 + Bc * y0 + C;
+      const T down = A * A + Bc * Bc;
+      const T d2 = up * up / (down + DIBR_EPS);
+      const T dzdA = 2 * (x0 * up - d2 * A) / (down + DIBR_EPS);
+      const T dzdB = 2 * (y0 * up - d2 * Bc) / (down + DIBR_EPS);
+      const T dzdC = 2 * up / (down + DIBR_EPS);
+      const T dLdx1 = dLdz * (dzdB - y2 * dzdC);
+      const T dLdy1 = dLdz * (x2 * dzdC - dzdA);
+      const T dLdx2 = dLdz * (y1 * dzdC - dzdB);
+      const T dLdy2 = dLdz * (dzdA - x1 * dzdC);
+      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o, (T)(dLdx1 / multiplier));
+      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o + 1, (T)(dLdy1 / multiplier));
+      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o2, (T)(dLdx2 / multiplier));
+      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o2 + 1, (T)(dLdy2 / multiplier));
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < SB_HT * 6; i += SL_THREADS) {
+    const int k = s_key[i / 6];
+    const T v = s_acc[i];
+    if (k >= 0 && v != (T)0) kamd_atomic_add(g_img + (size_t)k * 6 + (i % 6), v);
+  }
+  }
+}
+
 template <typename T>
 int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, const T* img, const T* large_bbox,
                              const int64_t* sel_idx, float sigmainv, float multiplier, T* soft_mask, T* prob,
-                             int64_t* idx, uint8_t* type, void* workspace, uint8_t* hit_count) {
+                             int64_t* idx, uint8_t* type, void* workspace, uint8_t* hit_count, const HitList<T>* lean) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
   const TileGeom g = tile_geom(H, W);
   const long long total_faces = (long long)B * F;
   if (total_faces > 0 && workspace == nullptr) return (int)hipErrorInvalidValue;
-  // 1. K-buffer initialisation (one streaming pass)
-  const size_t nk = (size_t)B * H * W * K;
+  if (lean != nullptr && (long long)B * H * W >= (1ll << 31)) return (int)hipErrorInvalidValue;
+  // 1. K-buffer initialisation (one streaming pass) -- reference-contract outputs only
+  const size_t nk = lean ? 0 : (size_t)B * H * W * K;
   if (nk > 0) {
     FillPlan pa, pb, pc;
     KAMD_CHECK(fill_edges(st, prob, nk * sizeof(T), 0x00, &pa));
@@ -406,30 +565,44 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
     const size_t most = pb.n16 > pa.n16 ? pb.n16 : pa.n16;
     int blocks = (int)((most + 255) / 256 < (size_t)KAMD_NUM_CU * 16 ? (most + 255) / 256 : (size_t)KAMD_NUM_CU * 16);
     if (blocks < 1) blocks = 1;
-    {
-      kamd::ProfScope prof_(kamd::K_SOFT_FILL, st);
-      hipLaunchKernelGGL(fill_regions_kernel, dim3(blocks), dim3(256), 0, st, pa.body, pa.n16, 0u, pb.body, pb.n16,
+    kamd::ProfScope prof_(kamd::K_SOFT_FILL, st);
+    hipLaunchKernelGGL(fill_regions_kernel, dim3(blocks), dim3(256), 0, st, pa.body, pa.n16, 0u, pb.body, pb.n16,
                        0xFFFFFFFFu, pc.body, pc.n16, 0u);
-    }
-    KAMD_CHECK(hipGetLastError());
   }
+  KAMD_CHECK(hipGetLastError());
   // 2. bin the enlarged boxes, 3. search
   T* rec = (T*)workspace;
   unsigned int* masks = (unsigned int*)((char*)workspace + align256((size_t)total_faces * REC_STRIDE * sizeof(T)));
   unsigned int* flags = total_faces > 0 ? masks + mask_words(g.ntiles, B, total_faces) : nullptr;
   if (total_faces > 0) {
     KAMD_CHECK(hipMemsetAsync(masks, 0, (mask_words(g.ntiles, B, total_faces) + flag_words(g.ntiles, B)) * 4, st));
-    {
-      kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
-      hipLaunchKernelGGL(bin_faces_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, F, total_faces,
+    kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
+    hipLaunchKernelGGL(bin_faces_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, F, total_faces,
                        (const int64_t*)nullptr, large_bbox, img, (const T*)nullptr, g, multiplier, rec, masks, flags);
-    }
-    KAMD_CHECK(hipGetLastError());
   }
+  KAMD_CHECK(hipGetLastError());
   {
     kamd::ProfScope prof_(kamd::K_SOFT_TILE, st);
-    hipLaunchKernelGGL(soft_mask_wave_kernel<T>, dim3(g.ntiles * B * 16), dim3(64), 0, st, B, F, g, K, sigmainv, multiplier,
-                       rec, masks, flags, sel_idx, soft_mask, prob, idx, type, hit_count);
+    const dim3 grid((unsigned)(g.ntiles * B * 16));
+    if (lean)
+      hipLaunchKernelGGL((soft_mask_search_kernel<T, true>), grid, dim3(64), 0, st, B, F, g, K, sigmainv, multiplier, rec,
+                         masks, flags, sel_idx, soft_mask, (T*)nullptr, (int64_t*)nullptr, (uint8_t*)nullptr,
+                         (uint8_t*)nullptr, *lean);
+    else
+      hipLaunchKernelGGL((soft_mask_search_kernel<T, false>), grid, dim3(64), 0, st, B, F, g, K, sigmainv, multiplier,
+                         rec, masks, flags, sel_idx, soft_mask, prob, idx, type, hit_count, HitList<T>{});
+  }
+  KAMD_RETURN_LAST_ERROR();
+}
+
+template <typename T>
+int soft_mask_backward_list_launch(hipStream_t st, int B, int H, int W, int F, const T* grad, const T* soft_mask,
+                                   const HitList<T>& list, const T* img, float sigmainv, float multiplier, T* g_img) {
+  if ((long long)B * H * W <= 0 || F <= 0) return 0;
+  {
+    kamd::ProfScope prof_(kamd::K_SOFT_BACKWARD, st);
+    hipLaunchKernelGGL(soft_mask_backward_list_kernel<T>, dim3(SL_BLOCKS), dim3(SL_THREADS), 0, st, H, W, F, grad,
+                       soft_mask, list, img, sigmainv, multiplier, g_img);
   }
   KAMD_RETURN_LAST_ERROR();
 }
@@ -463,14 +636,14 @@ int kamd_dibr_soft_mask_forward_f32(void* stream, int B, int H, int W, int F, in
                                     float* soft_mask, float* prob, int64_t* idx, uint8_t* type, void* workspace,
                                     uint8_t* hit_count) {
   return soft_mask_forward_launch<float>((hipStream_t)stream, B, H, W, F, K, img, large_bbox, sel_idx, sigmainv,
-                                         multiplier, soft_mask, prob, idx, type, workspace, hit_count);
+                                         multiplier, soft_mask, prob, idx, type, workspace, hit_count, nullptr);
 }
 int kamd_dibr_soft_mask_forward_f64(void* stream, int B, int H, int W, int F, int K, const double* img,
                                     const double* large_bbox, const int64_t* sel_idx, float sigmainv, float multiplier,
                                     double* soft_mask, double* prob, int64_t* idx, uint8_t* type, void* workspace,
                                     uint8_t* hit_count) {
   return soft_mask_forward_launch<double>((hipStream_t)stream, B, H, W, F, K, img, large_bbox, sel_idx, sigmainv,
-                                          multiplier, soft_mask, prob, idx, type, workspace, hit_count);
+                                          multiplier, soft_mask, prob, idx, type, workspace, hit_count, nullptr);
 }
 int kamd_dibr_soft_mask_backward_f32(void* stream, int B, int H, int W, int F, int K, const float* grad,
                                      const float* soft_mask, const int64_t* sel_idx, const float* prob,
@@ -486,5 +659,27 @@ int kamd_dibr_soft_mask_backward_f64(void* stream, int B, int H, int W, int F, i
   return soft_mask_backward_launch<double>((hipStream_t)stream, B, H, W, F, K, grad, soft_mask, sel_idx, prob, idx,
                                            type, img, sigmainv, multiplier, g_img, hit_count);
 }
+
+
+#define KAMD_LEAN_ENTRY(SFX, T)                                                                                       \
+  int kamd_dibr_soft_mask_forward_lean_##SFX(void* stream, int B, int H, int W, int F, int K, const T* img,          \
+                                             const T* large_bbox, const int64_t* sel_idx, float sigmainv,            \
+                                             float multiplier, T* soft_mask, int32_t* hit_pix, int32_t* hit_face,    \
+                                             T* hit_prob, uint8_t* hit_type, uint64_t* counter, void* workspace) {   \
+    HitList<T> l{hit_pix, hit_face, hit_prob, hit_type, (unsigned long long*)counter};                               \
+    return soft_mask_forward_launch<T>((hipStream_t)stream, B, H, W, F, K, img, large_bbox, sel_idx, sigmainv,       \
+                                       multiplier, soft_mask, nullptr, nullptr, nullptr, workspace, nullptr, &l);    \
+  }                                                                                                                   \
+  int kamd_dibr_soft_mask_backward_lean_##SFX(void* stream, int B, int H, int W, int F, const T* grad,               \
+                                              const T* soft_mask, const int32_t* hit_pix, const int32_t* hit_face,   \
+                                              const T* hit_prob, const uint8_t* hit_type, const uint64_t* counter,   \
+                                              const T* img, float sigmainv, float multiplier, T* g_img) {            \
+    HitList<T> l{(int*)hit_pix, (int*)hit_face, (T*)hit_prob, (uint8_t*)hit_type, (unsigned long long*)counter};     \
+    return soft_mask_backward_list_launch<T>((hipStream_t)stream, B, H, W, F, grad, soft_mask, l, img, sigmainv,     \
+                                             multiplier, g_img);                                                      \
+  }
+KAMD_LEAN_ENTRY(f32, float)
+KAMD_LEAN_ENTRY(f64, double)
+#undef KAMD_LEAN_ENTRY
 
 }  // extern "C"

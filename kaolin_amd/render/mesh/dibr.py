@@ -9,9 +9,11 @@ __all__ = ['dibr_soft_mask', 'dibr_rasterization']
 
 class DibrSoftMaskCuda(torch.autograd.Function):
     """Same contract as the reference's DibrSoftMaskCuda (dibr.py:27-73): the vertices are scaled by
-    ``multiplier`` (and saved scaled), the boxes enlarged by ``boxlen * multiplier``, the K-buffers are
-    kept for backward, whose result is the gradient w.r.t. the unscaled vertices.  Additionally a per-pixel
-    hit count (uint8) is kept so that backward only touches the K-buffers of pixels that have hits."""
+    ``multiplier`` (and saved scaled), the boxes enlarged by ``boxlen * multiplier``, backward returns the
+    gradient w.r.t. the unscaled vertices.  What is kept for backward differs: the reference materialises three
+    (B,H,W,knum) K-buffers (390 B/pixel at knum=30); only silhouette-band pixels ever use them, so this Function
+    keeps a compact list of the actual hits instead (``_C.render.mesh.dibr_soft_mask_forward_lean``).  The
+    K-buffer operators remain available as ``_C.render.mesh.dibr_soft_mask_{forward,backward}_cuda``."""
 
     @staticmethod
     def forward(ctx, face_vertices_image, selected_face_idx, sigmainv, boxlen, knum, multiplier):
@@ -20,18 +22,17 @@ class DibrSoftMaskCuda(torch.autograd.Function):
         lo = torch.min(scaled, dim=-2)[0] - boxlen * multiplier
         hi = torch.max(scaled, dim=-2)[0] + boxlen * multiplier
         large_bboxes = torch.cat([lo, hi], dim=-1)
-        soft_mask, prob, idx, dist_type, hits = _C.render.mesh.dibr_soft_mask_forward_cuda(
-            scaled, large_bboxes.contiguous(), selected_face_idx, sigmainv, knum, multiplier, _with_hit_count=True)
+        soft_mask, hits = _C.render.mesh.dibr_soft_mask_forward_lean(
+            scaled, large_bboxes.contiguous(), selected_face_idx, sigmainv, knum, multiplier)
         ctx.multiplier, ctx.sigmainv = multiplier, sigmainv
-        ctx.save_for_backward(soft_mask, scaled, selected_face_idx, prob, idx, dist_type, hits)
+        ctx.save_for_backward(soft_mask, scaled, *hits)
         return soft_mask
 
     @staticmethod
     def backward(ctx, grad_soft_mask):
-        soft_mask, scaled, selected_face_idx, prob, idx, dist_type, hits = ctx.saved_tensors
-        grad = _C.render.mesh.dibr_soft_mask_backward_cuda(
-            grad_soft_mask.contiguous(), soft_mask, selected_face_idx, prob, idx, dist_type, scaled,
-            ctx.sigmainv, ctx.multiplier, _hit_count=hits)
+        soft_mask, scaled = ctx.saved_tensors[:2]
+        grad = _C.render.mesh.dibr_soft_mask_backward_lean(
+            grad_soft_mask.contiguous(), soft_mask, ctx.saved_tensors[2:], scaled, ctx.sigmainv, ctx.multiplier)
         return grad, None, None, None, None, None
 
 

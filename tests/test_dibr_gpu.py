@@ -299,3 +299,34 @@ def test_backward_with_and_without_hit_count():
     a = m.dibr_soft_mask_backward_cuda(g, soft, face_idx, prob, idx, typ, scaled, 7000., 1000.)
     b = m.dibr_soft_mask_backward_cuda(g, soft, face_idx, prob, idx, typ, scaled, 7000., 1000., _hit_count=hits)
     assert rel_close(a, b, 1e-6)
+
+
+@pytest.mark.parametrize('dtype', [torch.float, torch.double])
+def test_kbuffer_operators_match_lean_autograd_path(dtype):
+    """The reference-contract operators (K-buffers) and the compact-list path used by autograd give the same
+    soft_mask (bit-identical) and the same gradient (atomic order aside); the list holds exactly the K-buffer hits."""
+    fz, fimg, feats, nz = _scene(10, 2, dtype)
+    m = kal()._C.render.mesh
+    H, W = 80, 112
+    _, face_idx = kal().render.mesh.rasterize(H, W, fz.cuda(), fimg.cuda(), torch.cat(feats, -1).cuda(), (nz >= 0).cuda())
+    scaled = fimg.cuda() * 1000.
+    lo, hi = scaled.min(dim=-2)[0] - 20., scaled.max(dim=-2)[0] + 20.
+    bbox = torch.cat([lo, hi], -1)
+    soft, prob, idx, typ = m.dibr_soft_mask_forward_cuda(scaled, bbox, face_idx, 7000., 30, 1000.)
+    soft2, hits = m.dibr_soft_mask_forward_lean(scaled, bbox, face_idx, 7000., 30, 1000.)
+    assert torch.equal(soft, soft2)
+    n = int(hits[4].item())
+    assert n == int((idx >= 0).sum())
+    # same multiset of (pixel, face, type, prob)
+    pix = torch.nonzero(idx >= 0)
+    flat_pix = (pix[:, 0] * H + pix[:, 1]) * W + pix[:, 2]
+    a = torch.stack([flat_pix, idx[idx >= 0], typ[idx >= 0].long()], 1)
+    b_ = torch.stack([hits[0][:n].long(), hits[1][:n].long(), hits[3][:n].long()], 1)
+    ka = (a[:, 0] * 100000 + a[:, 1]) * 8 + a[:, 2]
+    kb = (b_[:, 0] * 100000 + b_[:, 1]) * 8 + b_[:, 2]
+    oa, ob = torch.argsort(ka), torch.argsort(kb)
+    assert torch.equal(ka[oa], kb[ob]) and torch.equal(prob[idx >= 0][oa], hits[2][:n][ob])
+    g = torch.rand(soft.shape, device='cuda', dtype=dtype)
+    ga = m.dibr_soft_mask_backward_cuda(g, soft, face_idx, prob, idx, typ, scaled, 7000., 1000.)
+    gb = m.dibr_soft_mask_backward_lean(g, soft2, hits, scaled, 7000., 1000.)
+    assert rel_close(ga, gb, 1e-6 if dtype == torch.float else 1e-12)
