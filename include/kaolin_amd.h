@@ -175,13 +175,44 @@ int kamd_dibr_soft_mask_backward_lean_f32(void* stream, int B, int H, int W, int
                                           const int32_t* hit_pix, const int32_t* hit_face,
                                           const float* hit_prob, const uint8_t* hit_type,
                                           const uint64_t* counter, const float* img,
-                                          float sigmainv, float multiplier, float* g_img);
+                                          double img_scale, float sigmainv, float multiplier,
+                                          float* g_img);
 int kamd_dibr_soft_mask_backward_lean_f64(void* stream, int B, int H, int W, int F,
                                           const double* grad, const double* soft_mask,
                                           const int32_t* hit_pix, const int32_t* hit_face,
                                           const double* hit_prob, const uint8_t* hit_type,
                                           const uint64_t* counter, const double* img,
-                                          float sigmainv, float multiplier, double* g_img);
+                                          double img_scale, float sigmainv, float multiplier,
+                                          double* g_img);
+/* Fused front doors (ours): take the RAW operator inputs of the Python layer and */
+/* fold its torch glue into the bin kernel -- rasterization.py:292-327 (packing   */
+/* of valid faces with torch.where = a host sync, x multiplier, per-face min/max) */
+/* and dibr.py:31-39 (x multiplier, boxes enlarged by margin = boxlen*multiplier).*/
+/* valid: (B,F) bytes, NULL = all faces.  face_idx comes out mesh-relative.       */
+/* In the lean backward, img_scale multiplies img on the fly (pass the multiplier */
+/* with the unscaled vertices, or 1 with already scaled ones).                    */
+int kamd_rasterize_forward_fused_f32(void* stream, int B, int H, int W, int F, int D,
+                                     const float* z, const float* img, const float* feat,
+                                     const uint8_t* valid, double multiplier, float eps,
+                                     float* interp, int64_t* face_idx, float* weights,
+                                     void* workspace);
+int kamd_rasterize_forward_fused_f64(void* stream, int B, int H, int W, int F, int D,
+                                     const double* z, const double* img, const double* feat,
+                                     const uint8_t* valid, double multiplier, float eps,
+                                     double* interp, int64_t* face_idx, double* weights,
+                                     void* workspace);
+int kamd_dibr_soft_mask_forward_fused_f32(void* stream, int B, int H, int W, int F, int K,
+                                          const float* img, double multiplier, double margin,
+                                          const int64_t* sel_idx, float sigmainv,
+                                          float* soft_mask, int32_t* hit_pix, int32_t* hit_face,
+                                          float* hit_prob, uint8_t* hit_type, uint64_t* counter,
+                                          void* workspace);
+int kamd_dibr_soft_mask_forward_fused_f64(void* stream, int B, int H, int W, int F, int K,
+                                          const double* img, double multiplier, double margin,
+                                          const int64_t* sel_idx, float sigmainv,
+                                          double* soft_mask, int32_t* hit_pix, int32_t* hit_face,
+                                          double* hit_prob, uint8_t* hit_type, uint64_t* counter,
+                                          void* workspace);
 
 /* ------------------------------------------------------------------------- */
 /* metrics.unbatched_triangle_distance_forward_cuda(points, faces, dist,      */

@@ -193,8 +193,10 @@ def dibr_soft_mask_forward_lean(face_vertices_image, face_large_bboxes, selected
     return soft_mask, (hit_pix, hit_face, hit_prob, hit_type, counter)
 
 
-def dibr_soft_mask_backward_lean(grad_soft_mask, soft_mask, hits, face_vertices_image, sigmainv, multiplier):
-    """Backward of :func:`dibr_soft_mask_forward_lean` -> grad_face_vertices_image (B,F,3,2), w.r.t. the unscaled input."""
+def dibr_soft_mask_backward_lean(grad_soft_mask, soft_mask, hits, face_vertices_image, sigmainv, multiplier,
+                                 img_scale=1.0):
+    """Backward of :func:`dibr_soft_mask_forward_lean` / ``_fused`` -> grad_face_vertices_image (B,F,3,2), w.r.t. the
+    unscaled input.  ``face_vertices_image * img_scale`` must be the scaled vertices the forward searched with."""
     fn = 'dibr_soft_mask_backward_lean'
     hit_pix, hit_face, hit_prob, hit_type, counter = hits
     args = [Arg(grad_soft_mask, 'grad_soft_mask', 1), Arg(soft_mask, 'soft_mask', 2),
@@ -212,7 +214,84 @@ def dibr_soft_mask_backward_lean(grad_soft_mask, soft_mask, hits, face_vertices_
         st = getattr(lib, f'kamd_dibr_soft_mask_backward_lean_{sfx}')(
             _lib.stream_ptr(device), batch_size, height, width, num_faces,
             _lib.ptr(grad_soft_mask), _lib.ptr(soft_mask), _lib.ptr(hit_pix), _lib.ptr(hit_face), _lib.ptr(hit_prob),
-            _lib.ptr(hit_type), _lib.ptr(counter), _lib.ptr(face_vertices_image), float(sigmainv), float(multiplier),
-            _lib.ptr(g_img))
+            _lib.ptr(hit_type), _lib.ptr(counter), _lib.ptr(face_vertices_image), float(img_scale), float(sigmainv),
+            float(multiplier), _lib.ptr(g_img))
     _lib.check(st, fn)
     return g_img
+
+
+def _hit_list(batch_size, height, width, knum, dtype, device):
+    cap = max(batch_size * height * width * int(knum), 1)   # capacity only: just the used prefix is ever touched
+    return (torch.empty(cap, dtype=torch.int32, device=device), torch.empty(cap, dtype=torch.int32, device=device),
+            torch.empty(cap, dtype=dtype, device=device), torch.empty(cap, dtype=torch.uint8, device=device),
+            torch.zeros(1, dtype=torch.int64, device=device))
+
+
+def dibr_soft_mask_forward_fused(face_vertices_image, selected_face_idx, sigmainv, boxlen, knum, multiplier):
+    """``dibr_soft_mask_forward_lean`` taking the Python layer's RAW inputs: the scaling by ``multiplier`` and the
+    boxes enlarged by ``boxlen * multiplier`` (dibr.py:31-39) are computed inside the bin kernel.
+    -> (soft_mask, hits)"""
+    fn = 'dibr_soft_mask_forward_fused'
+    args = [Arg(face_vertices_image, 'face_vertices_image', 1), Arg(selected_face_idx, 'selected_face_idx', 2)]
+    check_all_same_gpu(fn, args)
+    check_all_contiguous(fn, args)
+    batch_size, num_faces = face_vertices_image.size(0), face_vertices_image.size(1)
+    height, width = selected_face_idx.size(1), selected_face_idx.size(2)
+    check_size(fn, args[0], [batch_size, num_faces, 3, 2])
+    check_size(fn, args[1], [batch_size, height, width])
+    dtype, device = face_vertices_image.dtype, face_vertices_image.device
+    sfx = _lib.dtype_suffix(dtype, fn)
+    lib = _lib.load()
+    with torch.cuda.device(device):
+        soft_mask = torch.empty((batch_size, height, width), dtype=dtype, device=device)
+        hits = _hit_list(batch_size, height, width, knum, dtype, device)
+        ws = _lib.workspace(lib.kamd_dibr_soft_mask_forward_workspace(batch_size, height, width, num_faces,
+                                                                      face_vertices_image.element_size()), device)
+        st = getattr(lib, f'kamd_dibr_soft_mask_forward_fused_{sfx}')(
+            _lib.stream_ptr(device), batch_size, height, width, num_faces, int(knum), _lib.ptr(face_vertices_image),
+            float(multiplier), float(boxlen * multiplier), _lib.ptr(selected_face_idx), float(sigmainv),
+            _lib.ptr(soft_mask), _lib.ptr(hits[0]), _lib.ptr(hits[1]), _lib.ptr(hits[2]), _lib.ptr(hits[3]),
+            _lib.ptr(hits[4]), _lib.ptr(ws))
+    _lib.check(st, fn)
+    return soft_mask, hits
+
+
+def rasterize_forward_fused(height, width, face_vertices_z, face_vertices_image, face_features, valid_faces,
+                            multiplier, eps):
+    """``packed_rasterize_forward_cuda`` taking the Python layer's RAW (B,F,...) inputs and the optional valid-face
+    mask: packing (torch.where = a host sync + three gathers), scaling and per-face bounding boxes
+    (rasterization.py:292-327) happen inside the bin kernel.
+    -> [interpolated_features (B,H,W,D), face_idx (B,H,W) int64 mesh-relative, output_weights (B,H,W,3)]"""
+    fn = 'rasterize_forward_fused'
+    args = [Arg(face_vertices_z, 'face_vertices_z', 3), Arg(face_vertices_image, 'face_vertices_image', 4),
+            Arg(face_features, 'face_features', 5)]
+    if valid_faces is not None:
+        args.append(Arg(valid_faces, 'valid_faces', 6))
+    check_all_same_gpu(fn, args)
+    check_all_contiguous(fn, args)
+    batch_size, num_faces, feat_dim = face_vertices_z.size(0), face_vertices_z.size(1), face_features.size(3)
+    check_size(fn, args[0], [batch_size, num_faces, 3])
+    check_size(fn, args[1], [batch_size, num_faces, 3, 2])
+    check_size(fn, args[2], [batch_size, num_faces, 3, feat_dim])
+    if valid_faces is not None:
+        check_size(fn, args[3], [batch_size, num_faces])
+        if valid_faces.dtype not in (torch.bool, torch.uint8):
+            raise RuntimeError('valid_faces must be a bool tensor')
+    dtype, device = face_vertices_z.dtype, face_vertices_z.device
+    sfx = _lib.dtype_suffix(dtype, fn)
+    for a in args[1:3]:
+        if a.t.dtype != dtype:
+            raise RuntimeError(f'expected scalar type {_lib._PRETTY[dtype]} but found {_lib._PRETTY.get(a.t.dtype, a.t.dtype)}')
+    lib = _lib.load()
+    with torch.cuda.device(device):
+        face_idx = torch.empty((batch_size, height, width), dtype=torch.long, device=device)
+        wts = torch.empty((batch_size, height, width, 3), dtype=dtype, device=device)
+        interp = torch.empty((batch_size, height, width, feat_dim), dtype=dtype, device=device)
+        ws = _lib.workspace(lib.kamd_rasterize_forward_workspace(batch_size, height, width, batch_size * num_faces,
+                                                                 face_vertices_z.element_size()), device)
+        st = getattr(lib, f'kamd_rasterize_forward_fused_{sfx}')(
+            _lib.stream_ptr(device), batch_size, height, width, num_faces, feat_dim, _lib.ptr(face_vertices_z),
+            _lib.ptr(face_vertices_image), _lib.ptr(face_features), _lib.ptr(valid_faces), float(multiplier), float(eps),
+            _lib.ptr(interp), _lib.ptr(face_idx), _lib.ptr(wts), _lib.ptr(ws))
+    _lib.check(st, fn)
+    return [interp, face_idx, wts]

@@ -19,6 +19,7 @@ _i = ctypes.c_int
 _i64 = ctypes.c_int64
 _f = ctypes.c_float
 _sz = ctypes.c_size_t
+_dbl = ctypes.c_double
 
 # name -> (restype, argtypes).  Lists every symbol include/kaolin_amd.h declares;
 # tests/test_abi.py cross-checks this table against the header and the built library.
@@ -49,7 +50,11 @@ for _t in ('f32', 'f64'):
     SIGNATURES[f'kamd_dibr_soft_mask_forward_lean_{_t}'] = (
         _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_dibr_soft_mask_backward_lean_{_t}'] = (
-        _i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp])
+        _i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _f, _f, _vp])
+    SIGNATURES[f'kamd_rasterize_forward_fused_{_t}'] = (
+        _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _dbl, _f, _vp, _vp, _vp, _vp])
+    SIGNATURES[f'kamd_dibr_soft_mask_forward_fused_{_t}'] = (
+        _i, [_vp, _i, _i, _i, _i, _i, _vp, _dbl, _dbl, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_triangle_distance_forward_{_t}'] = (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_triangle_distance_backward_{_t}'] = (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_trianglemeshes_to_voxelgrids_{_t}'] = (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp])

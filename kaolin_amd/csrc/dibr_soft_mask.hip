@@ -481,7 +481,7 @@ constexpr int SL_CHUNK = 1024;  // hits per workgroup round
 template <typename T>
 __global__ __launch_bounds__(SL_THREADS) void soft_mask_backward_list_kernel(
     int H, int W, int F, const T* __restrict__ grad, const T* __restrict__ soft_mask, HitList<T> list,
-    const T* __restrict__ img, float sigmainv, float multiplier, T* __restrict__ g_img) {
+    const T* __restrict__ img, T img_scale, float sigmainv, float multiplier, T* __restrict__ g_img) {
   __shared__ int s_key[SB_HT];
   __shared__ T s_acc[SB_HT * 6];
   const unsigned long long n = *list.counter;
@@ -512,14 +512,15 @@ __global__ __launch_bounds__(SL_THREADS) void soft_mask_backward_list_kernel(
     const T dLdz = (T)(-1.0 * sigmainv * dLdp * (1.0 - all) / (1.0 - pr + DIBR_EPS) * pr);
     if (e >= 3) {
       const int o = (e - 3) * 2;
-      const T x1 = img[s6 + o], y1 = img[s6 + o + 1];
+      const T x1 = img[s6 + o] * img_scale, y1 = img[s6 + o + 1] * img_scale;
       const T dLdx1 = dLdz * 2 * (x1 - x0);
       const T dLdy1 = dLdz * 2 * (y1 - y0);
       sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o, (T)(dLdx1 / multiplier));
       sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o + 1, (T)(dLdy1 / multiplier));
     } else {
       const int o = e * 2, o2 = ((e + 1) % 3) * 2;
-      const T x1 = img[s6 + o], y1 = img[s6 + o + 1], x2 = img[s6 + o2], y2 = img[s6 + o2 + 1];
+      const T x1 = img[s6 + o] * img_scale, y1 = img[s6 + o + 1] * img_scale;
+      const T x2 = img[s6 + o2] * img_scale, y2 = img[s6 + o2 + 1] * img_scale;
       const T A = y2 - y1, Bc = x1 - x2, C = x2 * y1 - x1 * y2;
       const T up = A * x0 + Bc * y0 + C;
       const T down = A * A + Bc * Bc;
@@ -549,7 +550,10 @@ __global__ __launch_bounds__(SL_THREADS) void soft_mask_backward_list_kernel(
 template <typename T>
 int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, const T* img, const T* large_bbox,
                              const int64_t* sel_idx, float sigmainv, float multiplier, T* soft_mask, T* prob,
-                             int64_t* idx, uint8_t* type, void* workspace, uint8_t* hit_count, const HitList<T>* lean) {
+                             int64_t* idx, uint8_t* type, void* workspace, uint8_t* hit_count, const HitList<T>* lean,
+                             bool raw = false, double raw_multiplier = 1.0, double raw_margin = 0.0) {
+  // raw: `img` is the UNSCALED (B,F,3,2) operator input and `large_bbox` is unused; scaling by raw_multiplier and the
+  // boxes enlarged by raw_margin (= boxlen * multiplier) are produced inside the bin kernel
   if (B <= 0 || H <= 0 || W <= 0) return 0;
   const TileGeom g = tile_geom(H, W);
   const long long total_faces = (long long)B * F;
@@ -577,8 +581,13 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
   if (total_faces > 0) {
     KAMD_CHECK(hipMemsetAsync(masks, 0, (mask_words(g.ntiles, B, total_faces) + flag_words(g.ntiles, B)) * 4, st));
     kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
-    hipLaunchKernelGGL(bin_faces_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, F, total_faces,
-                       (const int64_t*)nullptr, large_bbox, img, (const T*)nullptr, g, multiplier, rec, masks, flags);
+    if (raw)
+      hipLaunchKernelGGL(bin_faces_raw_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, F, img,
+                         (const T*)nullptr, (const uint8_t*)nullptr, (T)raw_multiplier, (T)raw_margin, g, multiplier, rec,
+                         masks, flags);
+    else
+      hipLaunchKernelGGL(bin_faces_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, F, total_faces,
+                         (const int64_t*)nullptr, large_bbox, img, (const T*)nullptr, g, multiplier, rec, masks, flags);
   }
   KAMD_CHECK(hipGetLastError());
   {
@@ -597,12 +606,13 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
 
 template <typename T>
 int soft_mask_backward_list_launch(hipStream_t st, int B, int H, int W, int F, const T* grad, const T* soft_mask,
-                                   const HitList<T>& list, const T* img, float sigmainv, float multiplier, T* g_img) {
+                                   const HitList<T>& list, const T* img, double img_scale, float sigmainv,
+                                   float multiplier, T* g_img) {
   if ((long long)B * H * W <= 0 || F <= 0) return 0;
   {
     kamd::ProfScope prof_(kamd::K_SOFT_BACKWARD, st);
     hipLaunchKernelGGL(soft_mask_backward_list_kernel<T>, dim3(SL_BLOCKS), dim3(SL_THREADS), 0, st, H, W, F, grad,
-                       soft_mask, list, img, sigmainv, multiplier, g_img);
+                       soft_mask, list, img, (T)img_scale, sigmainv, multiplier, g_img);
   }
   KAMD_RETURN_LAST_ERROR();
 }
@@ -673,10 +683,20 @@ int kamd_dibr_soft_mask_backward_f64(void* stream, int B, int H, int W, int F, i
   int kamd_dibr_soft_mask_backward_lean_##SFX(void* stream, int B, int H, int W, int F, const T* grad,               \
                                               const T* soft_mask, const int32_t* hit_pix, const int32_t* hit_face,   \
                                               const T* hit_prob, const uint8_t* hit_type, const uint64_t* counter,   \
-                                              const T* img, float sigmainv, float multiplier, T* g_img) {            \
+                                              const T* img, double img_scale, float sigmainv, float multiplier,      \
+                                              T* g_img) {                                                             \
     HitList<T> l{(int*)hit_pix, (int*)hit_face, (T*)hit_prob, (uint8_t*)hit_type, (unsigned long long*)counter};     \
-    return soft_mask_backward_list_launch<T>((hipStream_t)stream, B, H, W, F, grad, soft_mask, l, img, sigmainv,     \
-                                             multiplier, g_img);                                                      \
+    return soft_mask_backward_list_launch<T>((hipStream_t)stream, B, H, W, F, grad, soft_mask, l, img, img_scale,    \
+                                             sigmainv, multiplier, g_img);                                            \
+  }                                                                                                                   \
+  int kamd_dibr_soft_mask_forward_fused_##SFX(void* stream, int B, int H, int W, int F, int K, const T* img,         \
+                                              double multiplier, double margin, const int64_t* sel_idx,              \
+                                              float sigmainv, T* soft_mask, int32_t* hit_pix, int32_t* hit_face,     \
+                                              T* hit_prob, uint8_t* hit_type, uint64_t* counter, void* workspace) {  \
+    HitList<T> l{hit_pix, hit_face, hit_prob, hit_type, (unsigned long long*)counter};                               \
+    return soft_mask_forward_launch<T>((hipStream_t)stream, B, H, W, F, K, img, nullptr, sel_idx, sigmainv,          \
+                                       (float)multiplier, soft_mask, nullptr, nullptr, nullptr, workspace, nullptr,  \
+                                       &l, true, multiplier, margin);                                                 \
   }
 KAMD_LEAN_ENTRY(f32, float)
 KAMD_LEAN_ENTRY(f64, double)

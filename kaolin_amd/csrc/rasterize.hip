@@ -299,6 +299,35 @@ int rasterize_forward_launch(hipStream_t st, int B, int H, int W, int D, int64_t
   KAMD_RETURN_LAST_ERROR();
 }
 
+// fused front door: raw (B,F,...) inputs + optional valid mask; scaling, bounding boxes and packing happen in
+// bin_faces_raw_kernel; sel_idx comes out as the mesh-relative face index (what the Python layer returns)
+template <typename T>
+int rasterize_forward_fused_launch(hipStream_t st, int B, int H, int W, int F, int D, const T* z, const T* img,
+                                   const T* feat, const uint8_t* valid, double multiplier, float eps, T* interp,
+                                   int64_t* face_idx, T* weights, void* workspace) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  const TileGeom g = tile_geom(H, W);
+  const long long total_faces = (long long)B * F;
+  if (total_faces > 0 && workspace == nullptr) return (int)hipErrorInvalidValue;
+  T* rec = (T*)workspace;
+  unsigned int* masks = (unsigned int*)((char*)workspace + align256((size_t)total_faces * REC_STRIDE * sizeof(T)));
+  unsigned int* flags = total_faces > 0 ? masks + mask_words(g.ntiles, B, total_faces) : nullptr;
+  if (total_faces > 0) {
+    KAMD_CHECK(hipMemsetAsync(masks, 0, (mask_words(g.ntiles, B, total_faces) + flag_words(g.ntiles, B)) * 4, st));
+    kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
+    hipLaunchKernelGGL(bin_faces_raw_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, F, img, z, valid,
+                       (T)multiplier, (T)0, g, (float)multiplier, rec, masks, flags);
+  }
+  KAMD_CHECK(hipGetLastError());
+  {
+    kamd::ProfScope prof_(kamd::K_RASTER_TILE, st);
+    hipLaunchKernelGGL(raster_tile_kernel<T>, dim3(g.ntiles * B), dim3(TILE_THREADS), 0, st, B, F,
+                       (const int64_t*)nullptr, g, D, (float)multiplier, eps, rec, masks, flags, feat, interp, face_idx,
+                       weights);
+  }
+  KAMD_RETURN_LAST_ERROR();
+}
+
 template <typename T>
 int rasterize_backward_launch(hipStream_t st, int B, int H, int W, int F, int D, const T* grad, const int64_t* face_idx,
                               const T* weights, const T* img, const T* feat, float eps, T* g_img, T* g_feat) {
@@ -342,6 +371,18 @@ int kamd_packed_rasterize_forward_f64(void* stream, int B, int H, int W, int D, 
                                       int64_t* sel_idx, double* weights, void* workspace) {
   return rasterize_forward_launch<double>((hipStream_t)stream, B, H, W, D, total_faces, z, img, bbox, feat, first_idx,
                                           multiplier, eps, interp, sel_idx, weights, workspace);
+}
+int kamd_rasterize_forward_fused_f32(void* stream, int B, int H, int W, int F, int D, const float* z, const float* img,
+                                     const float* feat, const uint8_t* valid, double multiplier, float eps,
+                                     float* interp, int64_t* face_idx, float* weights, void* workspace) {
+  return rasterize_forward_fused_launch<float>((hipStream_t)stream, B, H, W, F, D, z, img, feat, valid, multiplier, eps,
+                                               interp, face_idx, weights, workspace);
+}
+int kamd_rasterize_forward_fused_f64(void* stream, int B, int H, int W, int F, int D, const double* z, const double* img,
+                                     const double* feat, const uint8_t* valid, double multiplier, float eps,
+                                     double* interp, int64_t* face_idx, double* weights, void* workspace) {
+  return rasterize_forward_fused_launch<double>((hipStream_t)stream, B, H, W, F, D, z, img, feat, valid, multiplier, eps,
+                                                interp, face_idx, weights, workspace);
 }
 int kamd_rasterize_backward_f32(void* stream, int B, int H, int W, int F, int D, const float* grad,
                                 const int64_t* face_idx, const float* weights, const float* img, const float* feat,

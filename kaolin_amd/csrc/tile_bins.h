@@ -128,6 +128,71 @@ __global__ __launch_bounds__(256) void bin_faces_kernel(
     }
 }
 
+// ---- bin kernel, fused form ------------------------------------------------------------------------------
+// Same as bin_faces_kernel for a dense batch (mesh b owns faces [b*F, (b+1)*F)), but starting from the operator's
+// RAW inputs, i.e. fusing the torch glue of the reference's Python layer (rasterization.py:292-327, dibr.py:31-39):
+//   scaled = face_vertices_image * multiplier          (one rounding, as torch's tensor * scalar)
+//   bbox   = [min over the 3 vertices - margin, max + margin]   (margin = boxlen*multiplier, 0 for rasterize)
+//   faces with valid[b,f] == 0 are skipped (they are what the reference's packing removes)
+// No torch.where (a host sync), no gathers, no packed copies.
+template <typename T>
+__global__ __launch_bounds__(256) void bin_faces_raw_kernel(
+    int B, int F, const T* __restrict__ img, const T* __restrict__ z, const uint8_t* __restrict__ valid,
+    T mult, T margin, TileGeom g, float multiplier, T* __restrict__ rec, unsigned int* __restrict__ masks,
+    unsigned int* __restrict__ tile_flags) {
+  const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (f >= (long long)B * F) return;
+  if (valid != nullptr && valid[f] == 0) return;
+  const int b = (int)(f / F);
+  const long long first_b = (long long)b * F;
+  T v[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) v[i] = img[f * 6 + i] * mult;
+  T xmin = fmin(fmin(v[0], v[2]), v[4]), xmax = fmax(fmax(v[0], v[2]), v[4]);
+  T ymin = fmin(fmin(v[1], v[3]), v[5]), ymax = fmax(fmax(v[1], v[3]), v[5]);
+  if (margin != (T)0) {
+    xmin = xmin - margin;
+    ymin = ymin - margin;
+    xmax = xmax + margin;
+    ymax = ymax + margin;
+  }
+  T* r = rec + (size_t)f * REC_STRIDE;
+  r[0] = xmin;
+  r[1] = ymin;
+  r[2] = xmax;
+  r[3] = ymax;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r[4 + i] = v[i];
+  if (z != nullptr) {
+    r[10] = z[f * 3 + 0];
+    r[11] = z[f * 3 + 1];
+    r[12] = z[f * 3 + 2];
+  }
+  int c_lo = 0, c_hi = g.W - 1, r_lo = 0, r_hi = g.H - 1;
+  const double dxmin = (double)xmin, dxmax = (double)xmax, dymin = (double)ymin, dymax = (double)ymax;
+  const bool has_nan = !(multiplier > 0.f) || !(dxmin == dxmin) || !(dxmax == dxmax) || !(dymin == dymin) || !(dymax == dymax);
+  if (!has_nan) {
+    const double sx = (double)g.W / (double)multiplier, sy = (double)g.H / (double)multiplier;
+    const double cl = floor((dxmin * sx + g.W - 1) * 0.5) - 1.0, ch = ceil((dxmax * sx + g.W - 1) * 0.5) + 1.0;
+    const double rl = floor((g.H - 1 - dymax * sy) * 0.5) - 1.0, rh = ceil((g.H - 1 - dymin * sy) * 0.5) + 1.0;
+    if (ch < 0.0 || cl > (double)(g.W - 1) || rh < 0.0 || rl > (double)(g.H - 1)) return;
+    c_lo = (int)fmax(cl, 0.0);
+    c_hi = (int)fmin(ch, (double)(g.W - 1));
+    r_lo = (int)fmax(rl, 0.0);
+    r_hi = (int)fmin(rh, (double)(g.H - 1));
+  }
+  const int tx0 = c_lo / TILE_W, tx1 = c_hi / TILE_W, ty0 = r_lo / TILE_H, ty1 = r_hi / TILE_H;
+  const long long j = f - first_b;
+  const int stride_b = (F + 31) / 32;
+  const unsigned int bit = 1u << (unsigned)(j & 31);
+  for (int ty = ty0; ty <= ty1; ++ty)
+    for (int tx = tx0; tx <= tx1; ++tx) {
+      const int t = ty * g.tiles_x + tx;
+      atomicOr(masks + mask_base(g.ntiles, first_b, b, t, stride_b) + (size_t)(j >> 5), bit);
+      if (tile_flags[(size_t)b * g.ntiles + t] == 0u) tile_flags[(size_t)b * g.ntiles + t] = 1u;
+    }
+}
+
 // ---- block-wide exclusive scan over 1024 threads (16 wavefronts) -------------------------------------
 __device__ __forceinline__ int wave_inclusive_scan(int v) {
   const int lane = threadIdx.x & 63;

@@ -9,30 +9,27 @@ __all__ = ['dibr_soft_mask', 'dibr_rasterization']
 
 class DibrSoftMaskCuda(torch.autograd.Function):
     """Same contract as the reference's DibrSoftMaskCuda (dibr.py:27-73): the vertices are scaled by
-    ``multiplier`` (and saved scaled), the boxes enlarged by ``boxlen * multiplier``, backward returns the
-    gradient w.r.t. the unscaled vertices.  What is kept for backward differs: the reference materialises three
+    ``multiplier``, the boxes enlarged by ``boxlen * multiplier`` (both inside the bin kernel here, not with torch
+    ops), backward returns the gradient w.r.t. the unscaled vertices.  What is kept for backward differs: the reference materialises three
     (B,H,W,knum) K-buffers (390 B/pixel at knum=30); only silhouette-band pixels ever use them, so this Function
     keeps a compact list of the actual hits instead (``_C.render.mesh.dibr_soft_mask_forward_lean``).  The
     K-buffer operators remain available as ``_C.render.mesh.dibr_soft_mask_{forward,backward}_cuda``."""
 
     @staticmethod
     def forward(ctx, face_vertices_image, selected_face_idx, sigmainv, boxlen, knum, multiplier):
-        scaled = face_vertices_image.contiguous() * multiplier
-        selected_face_idx = selected_face_idx.contiguous()
-        lo = torch.min(scaled, dim=-2)[0] - boxlen * multiplier
-        hi = torch.max(scaled, dim=-2)[0] + boxlen * multiplier
-        large_bboxes = torch.cat([lo, hi], dim=-1)
-        soft_mask, hits = _C.render.mesh.dibr_soft_mask_forward_lean(
-            scaled, large_bboxes.contiguous(), selected_face_idx, sigmainv, knum, multiplier)
+        face_vertices_image = face_vertices_image.contiguous()
+        soft_mask, hits = _C.render.mesh.dibr_soft_mask_forward_fused(
+            face_vertices_image, selected_face_idx.contiguous(), sigmainv, boxlen, knum, multiplier)
         ctx.multiplier, ctx.sigmainv = multiplier, sigmainv
-        ctx.save_for_backward(soft_mask, scaled, *hits)
+        ctx.save_for_backward(soft_mask, face_vertices_image, *hits)
         return soft_mask
 
     @staticmethod
     def backward(ctx, grad_soft_mask):
-        soft_mask, scaled = ctx.saved_tensors[:2]
+        soft_mask, face_vertices_image = ctx.saved_tensors[:2]
         grad = _C.render.mesh.dibr_soft_mask_backward_lean(
-            grad_soft_mask.contiguous(), soft_mask, ctx.saved_tensors[2:], scaled, ctx.sigmainv, ctx.multiplier)
+            grad_soft_mask.contiguous(), soft_mask, ctx.saved_tensors[2:], face_vertices_image, ctx.sigmainv,
+            ctx.multiplier, img_scale=ctx.multiplier)
         return grad, None, None, None, None, None
 
 

@@ -9,46 +9,22 @@ __all__ = ['rasterize']
 
 
 class RasterizeCuda(torch.autograd.Function):
-    """autograd shim with the contract of the reference's RasterizeCuda (rasterization.py:226-371):
-    packs the valid faces, scales by ``multiplier``, builds per-face bounding boxes, calls
-    ``_C.render.mesh.packed_rasterize_forward_cuda``, maps packed indices back to mesh indices; backward
-    returns gradients for face_vertices_image and face_features only (none for face_vertices_z)."""
+    """autograd shim with the contract of the reference's RasterizeCuda (rasterization.py:226-371): only valid
+    faces are rasterized, coordinates are scaled by ``multiplier``, the returned face index is mesh-relative with -1
+    for empty pixels; backward returns gradients for face_vertices_image and face_features only (none for
+    face_vertices_z).  The reference does the packing / scaling / bounding boxes with ~15 torch kernels and a host
+    sync (torch.where); here they are folded into the bin kernel (``_C.render.mesh.rasterize_forward_fused``).  The
+    reference-contract operator ``_C.render.mesh.packed_rasterize_forward_cuda`` is kept and gives the same result
+    (``_packed_forward`` below spells the reference's glue around it; tests compare the two)."""
 
     @staticmethod
     def forward(ctx, height, width, face_vertices_z, face_vertices_image, face_features, valid_faces,
                 multiplier, eps):
-        batch_size, num_faces = face_vertices_z.shape[0], face_vertices_z.shape[1]
-        feat_dim = face_features.shape[-1]
-        device = face_vertices_z.device
         face_features = face_features.contiguous()
         face_vertices_image = face_vertices_image.contiguous()
-        if valid_faces is None:
-            faces_of = None
-            packed_img = face_vertices_image.reshape(batch_size * num_faces, 3, 2)
-            packed_z = face_vertices_z.reshape(batch_size * num_faces, 3)
-            packed_feat = face_features.reshape(batch_size * num_faces, 3, feat_dim)
-            first_idx = torch.arange(batch_size + 1, dtype=torch.long, device=device) * num_faces
-        else:
-            mesh_of, faces_of = torch.where(valid_faces)
-            packed_img = face_vertices_image[mesh_of, faces_of]
-            packed_z = face_vertices_z[mesh_of, faces_of]
-            packed_feat = face_features[mesh_of, faces_of]
-            first_idx = torch.zeros(batch_size + 1, dtype=torch.long, device=device)
-            torch.cumsum(valid_faces.reshape(batch_size, -1).sum(dim=1), dim=0, out=first_idx[1:])
-        packed_img = packed_img * multiplier
-        bboxes = torch.cat((packed_img.min(dim=1)[0], packed_img.max(dim=1)[0]), dim=1)
-        interpolated_features, selected, output_weights = _C.render.mesh.packed_rasterize_forward_cuda(
-            height, width, packed_z.contiguous(), packed_img.contiguous(), bboxes.contiguous(),
-            packed_feat.contiguous(), first_idx.contiguous(), multiplier, eps)
-        if faces_of is None:
-            face_idx = selected  # already mesh-relative, -1 where nothing was hit
-        else:
-            lookup = (selected + first_idx[:-1].reshape(-1, 1, 1)).reshape(-1)
-            if faces_of.numel() > 0:
-                face_idx = faces_of[lookup.clamp_(min=0, max=faces_of.numel() - 1)].reshape(selected.shape).contiguous()
-            else:
-                face_idx = torch.full_like(selected, -1)
-            face_idx[selected == -1] = -1
+        valid = None if valid_faces is None else valid_faces.contiguous()
+        interpolated_features, face_idx, output_weights = _C.render.mesh.rasterize_forward_fused(
+            height, width, face_vertices_z.contiguous(), face_vertices_image, face_features, valid, multiplier, eps)
         ctx.save_for_backward(interpolated_features, face_idx, output_weights, face_vertices_image, face_features)
         ctx.mark_non_differentiable(face_idx)
         ctx.eps = eps
@@ -61,6 +37,46 @@ class RasterizeCuda(torch.autograd.Function):
             grad_interpolated_features.contiguous(), interpolated_features, face_idx, output_weights,
             face_vertices_image, face_features, ctx.eps)
         return None, None, None, grad_img, grad_feat, None, None, None
+
+
+def _packed_forward(height, width, face_vertices_z, face_vertices_image, face_features, valid_faces, multiplier, eps):
+    """The reference's own glue (rasterization.py:282-346) around the reference-contract operator
+    ``packed_rasterize_forward_cuda``: pack valid faces, scale, per-face boxes, map packed indices back.
+    Returns (features, face_idx, weights).  Not used by ``rasterize`` (see RasterizeCuda); kept as the
+    contract-level path and exercised by the parity tests."""
+    batch_size, num_faces = face_vertices_z.shape[0], face_vertices_z.shape[1]
+    feat_dim = face_features.shape[-1]
+    device = face_vertices_z.device
+    face_features = face_features.contiguous()
+    face_vertices_image = face_vertices_image.contiguous()
+    if valid_faces is None:
+        faces_of = None
+        packed_img = face_vertices_image.reshape(batch_size * num_faces, 3, 2)
+        packed_z = face_vertices_z.reshape(batch_size * num_faces, 3)
+        packed_feat = face_features.reshape(batch_size * num_faces, 3, feat_dim)
+        first_idx = torch.arange(batch_size + 1, dtype=torch.long, device=device) * num_faces
+    else:
+        mesh_of, faces_of = torch.where(valid_faces)
+        packed_img = face_vertices_image[mesh_of, faces_of]
+        packed_z = face_vertices_z[mesh_of, faces_of]
+        packed_feat = face_features[mesh_of, faces_of]
+        first_idx = torch.zeros(batch_size + 1, dtype=torch.long, device=device)
+        torch.cumsum(valid_faces.reshape(batch_size, -1).sum(dim=1), dim=0, out=first_idx[1:])
+    packed_img = packed_img * multiplier
+    bboxes = torch.cat((packed_img.min(dim=1)[0], packed_img.max(dim=1)[0]), dim=1)
+    interpolated_features, selected, output_weights = _C.render.mesh.packed_rasterize_forward_cuda(
+        height, width, packed_z.contiguous(), packed_img.contiguous(), bboxes.contiguous(),
+        packed_feat.contiguous(), first_idx.contiguous(), multiplier, eps)
+    if faces_of is None:
+        face_idx = selected
+    else:
+        lookup = (selected + first_idx[:-1].reshape(-1, 1, 1)).reshape(-1)
+        if faces_of.numel() > 0:
+            face_idx = faces_of[lookup.clamp_(min=0, max=faces_of.numel() - 1)].reshape(selected.shape).contiguous()
+        else:
+            face_idx = torch.full_like(selected, -1)
+        face_idx[selected == -1] = -1
+    return interpolated_features, face_idx, output_weights
 
 
 def rasterize(height, width, face_vertices_z, face_vertices_image, face_features, valid_faces=None,

@@ -330,3 +330,28 @@ def test_kbuffer_operators_match_lean_autograd_path(dtype):
     ga = m.dibr_soft_mask_backward_cuda(g, soft, face_idx, prob, idx, typ, scaled, 7000., 1000.)
     gb = m.dibr_soft_mask_backward_lean(g, soft2, hits, scaled, 7000., 1000.)
     assert rel_close(ga, gb, 1e-6 if dtype == torch.float else 1e-12)
+
+
+@pytest.mark.parametrize('dtype', [torch.float, torch.double])
+@pytest.mark.parametrize('with_valid', [False, True])
+def test_fused_front_door_equals_reference_glue_plus_contract_operator(dtype, with_valid):
+    """rasterize() (fused: packing / scaling / boxes inside the bin kernel) is bit-identical to the reference's
+    torch glue around packed_rasterize_forward_cuda; same for the soft mask fused vs lean-with-torch-glue."""
+    from kaolin_amd.render.mesh.rasterization import _packed_forward
+    fz, fimg, feats, nz = _scene(12, 3, dtype)
+    feat = torch.cat(feats, -1).cuda()
+    valid = (nz >= 0).cuda() if with_valid else None
+    H, W = 70, 130
+    a, b_, c = _packed_forward(H, W, fz.cuda(), fimg.cuda(), feat, valid, 1000, 1e-8)
+    x, y, w = kal()._C.render.mesh.rasterize_forward_fused(H, W, fz.cuda(), fimg.cuda(), feat, valid, 1000, 1e-8)
+    assert torch.equal(b_, y) and torch.equal(a, x) and torch.equal(c, w)
+    m = kal()._C.render.mesh
+    scaled = fimg.cuda() * 1000.
+    bbox = torch.cat([scaled.min(dim=-2)[0] - 0.02 * 1000., scaled.max(dim=-2)[0] + 0.02 * 1000.], -1)
+    s1, h1 = m.dibr_soft_mask_forward_lean(scaled, bbox, y, 7000, 30, 1000.)
+    s2, h2 = m.dibr_soft_mask_forward_fused(fimg.cuda(), y, 7000, 0.02, 30, 1000.)
+    assert torch.equal(s1, s2) and int(h1[4]) == int(h2[4])
+    g = torch.rand(s1.shape, device='cuda', dtype=dtype)
+    g1 = m.dibr_soft_mask_backward_lean(g, s1, h1, scaled, 7000, 1000.)
+    g2 = m.dibr_soft_mask_backward_lean(g, s2, h2, fimg.cuda(), 7000, 1000., img_scale=1000.)
+    assert rel_close(g1, g2, 1e-6 if dtype == torch.float else 1e-12)
