@@ -57,7 +57,8 @@ def algorithmic_bytes(kernel, B, P, F, Fv, D, K, esz=4):
         'raster_tile_kernel': P * (8 + 3 * esz + D * esz) + Fv * (13 * esz + 3 * D * esz),
         'raster_backward_kernel': P * (8 + 3 * esz + D * esz) + F * (6 * esz * 2 + 3 * D * esz * 2),
         'fill_regions_kernel': P * K * (esz + 8 + 1),
-        'soft_mask_tile_kernel': P * (8 + esz) + F * 10 * esz,
+        'soft_search_kernel': P * (8 + esz) + F * 10 * esz,
+        'soft_classify_kernel': P * (8 + esz),
         'soft_mask_backward_kernel': P * (8 + 2 * esz) + F * 6 * esz * 2,
         'bin_faces_kernel': F * (13 * esz + 16 * esz),
     }

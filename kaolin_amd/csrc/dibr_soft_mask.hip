@@ -128,22 +128,28 @@ inline int fill_edges(hipStream_t st, void* p, size_t bytes, int v, FillPlan* pl
   return 0;
 }
 
-// ---- K3 search kernel ------------------------------------------------------------------------------------
-// One 64-lane workgroup (a single wavefront: barriers are free) per 16x4-pixel sub-tile; wavefronts without an
-// uncovered pixel leave after reading sel_idx.  The reference's loop "for each pixel: for each face" spends its
-// time on the few silhouette-band pixels, so inside a wavefront the roles are swapped:
-//   1. the 32x32 tile's bitmask is expanded into an ascending id list (popcount + wave scan, 64 words a step);
-//   2. 64 ids at a time, each lane culls one face against the extent of the wavefront's uncovered pixels and the
-//      survivors are compacted, in order, into a candidate queue;
-//   3. per 64 candidates: LANE = FACE.  Each lane loads its face and derives the per-edge invariants in
-//      registers once; then a scalar loop walks the still-active pixels: the pixel centre is broadcast, every
-//      lane evaluates its own face against it (full lane utilisation, no LDS traffic), a ballot gives the hits in
-//      ascending face order, the first (knum - hits so far) are accepted and written at consecutive K-buffer
-//      positions (or appended to the compact hit list), and prod(1 - prob) is continued in that same order.
+// ---- K3 search --------------------------------------------------------------------------------------------
+// The reference's loop "for each pixel: for each face" spends its time on the few silhouette-band pixels
+// (C4: 187k of 8.4M pixels carry all 5.1M hits).  Two kernels:
+//   soft_classify_kernel : one wavefront per 16x4-pixel sub-tile reads sel_idx, settles covered pixels (mask = 1)
+//       and uncovered pixels of tiles no face touches (mask = 0), and queues every other sub-tile in a worklist;
+//   soft_search_kernel   : a persistent grid of single-wavefront workgroups pulls sub-tiles from the worklist
+//       (the band work is spread over all SIMDs instead of sitting in the few workgroups that happen to own it):
+//       1. the 32x32 tile's bitmask is expanded into an ascending id list (popcount + wave scan, 64 words a step);
+//       2. 64 ids at a time, each lane culls one face against the extent of the wavefront's uncovered pixels; the
+//          survivors are compacted, in order, into a candidate queue;
+//       3. per 64 candidates: each lane derives the per-edge invariants of ITS face once and parks them in LDS
+//          (structure of arrays); a scalar loop over the still-active pixels ballots the faces whose box holds the
+//          pixel centre and appends the first (knum - hits so far) of them, in face order, to a PAIR list;
+//       4. the pair list is evaluated with one (pixel, face) pair per lane -- every evaluated pair is an accepted
+//          hit, lanes are fully used -- and written to consecutive K-buffer slots (or the compact hit list);
+//       5. each pixel's owner lane continues prod(1 - prob) over its pairs in order.
 // Results are identical to the reference's pixel-major loop: same expressions per (pixel, face), same order of
 // hits per pixel, same product order.
-constexpr int SM_IDCAP = 2048;   // ids produced by one 64-word step (64 * 32)
-constexpr int SM_LISTBUF = 512;  // compact-list entries buffered per wavefront between flushes
+constexpr int SM_IDCAP = 2048;    // ids produced by one 64-word step (64 * 32)
+constexpr int SM_PAIRCAP = 1024;  // (pixel, face) pairs per evaluation round
+constexpr int SM_NF = 34;         // per-face scalars parked in LDS: bbox 4, vertices 6, 3 edges x 8 invariants
+constexpr int SM_SUBS = (TILE_W / SUB_W) * (TILE_H / SUB_H);  // 16 sub-tiles per tile
 
 template <typename T>
 struct HitList {      // compact output (our own autograd path): one record per (pixel, hit), order irrelevant
@@ -154,211 +160,281 @@ struct HitList {      // compact output (our own autograd path): one record per 
   unsigned long long* counter;  // zeroed by the caller
 };
 
-template <typename T, bool LEAN>
-__global__ __launch_bounds__(64) void soft_mask_search_kernel(
-    int B, int F, TileGeom g, int K, float sigmainv, float multiplier, const T* __restrict__ rec,
-    const unsigned int* __restrict__ masks, const unsigned int* __restrict__ tile_flags,
-    const int64_t* __restrict__ sel_idx, T* __restrict__ soft_mask, T* __restrict__ prob_out,
-    int64_t* __restrict__ idx_out, uint8_t* __restrict__ type_out, uint8_t* __restrict__ hit_count, HitList<T> list) {
-  __shared__ int s_tmp[SM_IDCAP];
-  __shared__ int s_cand[128];
-  __shared__ int l_pix[LEAN ? SM_LISTBUF : 1], l_face[LEAN ? SM_LISTBUF : 1];
-  __shared__ T l_prob[LEAN ? SM_LISTBUF : 1];
-  __shared__ uint8_t l_type[LEAN ? SM_LISTBUF : 1];
-
-  constexpr int SUBS = (TILE_W / SUB_W) * (TILE_H / SUB_H);  // 16 sub-tiles per tile
-  const int sub = blockIdx.x % SUBS;
-  const int b = (blockIdx.x / SUBS) % B;
-  const int tile = blockIdx.x / (SUBS * B);
-  const int lane = threadIdx.x;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+template <typename T>
+__global__ __launch_bounds__(TILE_THREADS) void soft_classify_kernel(
+    int B, TileGeom g, const uint8_t* __restrict__ sub_flags, const int64_t* __restrict__ sel_idx,
+    T* __restrict__ soft_mask, uint8_t* __restrict__ hit_count, int* __restrict__ worklist,
+    unsigned int* __restrict__ work_count) {
+  // workgroup = one (tile, mesh): 16 wavefronts = its 16 sub-tiles; ONE worklist atomic per workgroup
+  __shared__ int s_need[SM_SUBS];
+  const int b = blockIdx.x % B, tile = blockIdx.x / B;
+  const int sub = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int sub_x = (tile % g.tiles_x) * TILE_W + (sub & 1) * SUB_W;
   const int sub_y = (tile / g.tiles_x) * TILE_H + (sub >> 1) * SUB_H;
-  if (sub_x >= g.W || sub_y >= g.H) return;
   const int col = sub_x + (lane & 15), row = sub_y + (lane >> 4);
   const bool in_image = col < g.W && row < g.H;
   const size_t p1 = ((size_t)b * g.H + row) * g.W + col;
   const bool uncovered = in_image && (int)sel_idx[in_image ? p1 : 0] < 0;
-  if (in_image && !uncovered) {
-    soft_mask[p1] = (T)1.0;
-    if (!LEAN && hit_count) hit_count[p1] = 0;
+  const int item = (tile * B + b) * SM_SUBS + sub;
+  const bool touched = sub_flags != nullptr && sub_flags[item] != 0;  // some enlarged box reaches this sub-tile
+  if (in_image && (!uncovered || !touched)) {
+    soft_mask[p1] = uncovered ? (T)(1.0 - 1.0) : (T)1.0;
+    if (hit_count) hit_count[p1] = 0;
   }
-  if (!__any(uncovered)) return;
-
-  const int64_t first_b = (int64_t)b * F;
-  const int stride_b = (F + 31) / 32;
-  const int nwords = (tile_flags != nullptr && tile_flags[(size_t)b * g.ntiles + tile]) ? stride_b : 0;
-  const unsigned int* tmask = masks + mask_base(g.ntiles, first_b, b, tile, stride_b);
-
-  const T x0 = pixel_x(multiplier, g.W, col);
-  const T y0 = pixel_y(multiplier, g.H, row);
-  T ux_min = uncovered ? x0 : (T)INFINITY, ux_max = uncovered ? x0 : (T)-INFINITY;
-  T uy_min = uncovered ? y0 : (T)INFINITY, uy_max = uncovered ? y0 : (T)-INFINITY;
+  const bool need = touched && __any(uncovered);
+  if (lane == 0) s_need[sub] = need ? 1 : 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int n = 0;
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    ux_min = fmin(ux_min, __shfl_xor(ux_min, d, 64));
-    ux_max = fmax(ux_max, __shfl_xor(ux_max, d, 64));
-    uy_min = fmin(uy_min, __shfl_xor(uy_min, d, 64));
-    uy_max = fmax(uy_max, __shfl_xor(uy_max, d, 64));
+    for (int i = 0; i < SM_SUBS; ++i) n += s_need[i];
+    if (n > 0) {
+      unsigned int base = atomicAdd(work_count, (unsigned int)n);
+#pragma unroll
+      for (int i = 0; i < SM_SUBS; ++i)
+        if (s_need[i]) worklist[base++] = (tile * B + b) * SM_SUBS + i;
+    }
   }
+}
 
-  // per-PIXEL state lives in the lane that owns the pixel
-  int kid = 0;
-  T all = 1.0;
-  bool active = uncovered && K > 0;
-  int nbuf = 0;  // entries waiting in the LDS list buffer (LEAN)
+template <typename T, bool LEAN>
+__global__ __launch_bounds__(64) void soft_search_kernel(
+    int B, int F, TileGeom g, int K, float sigmainv, float multiplier, const T* __restrict__ rec,
+    const unsigned int* __restrict__ masks, const int* __restrict__ worklist, const unsigned int* __restrict__ work_count,
+    unsigned int* __restrict__ work_next, const int64_t* __restrict__ sel_idx, T* __restrict__ soft_mask,
+    T* __restrict__ prob_out, int64_t* __restrict__ idx_out, uint8_t* __restrict__ type_out,
+    uint8_t* __restrict__ hit_count, HitList<T> list) {
+  __shared__ int s_tmp[SM_IDCAP];
+  __shared__ int s_cand[128];
+  __shared__ T s_ff[SM_NF][64];
+  __shared__ double s_fd[6][64];
+  __shared__ int s_fid[64];
+  __shared__ unsigned short s_pair[SM_PAIRCAP];
+  __shared__ T s_pr[SM_PAIRCAP];
+  __shared__ int s_off[64];
 
-  auto flush_list = [&]() {
-    if (!LEAN || nbuf == 0) return;
-    __syncthreads();
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(list.counter, (unsigned long long)nbuf);
-    base = __shfl(base, 0, 64);
-    for (int i = lane; i < nbuf; i += 64) {
-      list.pix[base + i] = l_pix[i];
-      list.face[base + i] = l_face[i];
-      list.prob[base + i] = l_prob[i];
-      list.type[base + i] = l_type[i];
-    }
-    nbuf = 0;
-    __syncthreads();
-  };
+  const int lane = threadIdx.x;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const unsigned int n_items = *work_count;
 
-  // evaluates the first n (<= 64) candidates of s_cand against every active pixel
-  auto process_chunk = [&](int n) {
-    const bool face_valid = lane < n;
-    int id = 0;
-    T bb0 = 0, bb1 = 0, bb2 = 0, bb3 = 0, v[6];
-    EdgeInv<T> e[3];
-    double den[3], rcp[3];
+  for (;;) {
+    unsigned int wi_ = 0;
+    if (lane == 0) wi_ = atomicAdd(work_next, 1u);
+    wi_ = __shfl(wi_, 0, 64);
+    if (wi_ >= n_items) break;
+    const int item = worklist[wi_];
+    const int sub = item % SM_SUBS;
+    const int b = (item / SM_SUBS) % B;
+    const int tile = item / (SM_SUBS * B);
+    const int sub_x = (tile % g.tiles_x) * TILE_W + (sub & 1) * SUB_W;
+    const int sub_y = (tile / g.tiles_x) * TILE_H + (sub >> 1) * SUB_H;
+    const int col = sub_x + (lane & 15), row = sub_y + (lane >> 4);
+    const bool in_image = col < g.W && row < g.H;
+    const size_t p1 = ((size_t)b * g.H + row) * g.W + col;
+    const bool uncovered = in_image && (int)sel_idx[in_image ? p1 : 0] < 0;
+
+    const int64_t first_b = (int64_t)b * F;
+    const int nwords = (F + 31) / 32;
+    const unsigned int* tmask = masks + mask_base(g.ntiles, first_b, b, tile, nwords);
+
+    const T x0 = pixel_x(multiplier, g.W, col);
+    const T y0 = pixel_y(multiplier, g.H, row);
+    T ux_min = uncovered ? x0 : (T)INFINITY, ux_max = uncovered ? x0 : (T)-INFINITY;
+    T uy_min = uncovered ? y0 : (T)INFINITY, uy_max = uncovered ? y0 : (T)-INFINITY;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) v[i] = 0;
-    if (face_valid) {
-      id = s_cand[lane];
-      const T* r = rec + ((size_t)first_b + id) * REC_STRIDE;
-      bb0 = r[0];
-      bb1 = r[1];
-      bb2 = r[2];
-      bb3 = r[3];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) v[i] = r[4 + i];
+    for (int d = 32; d >= 1; d >>= 1) {
+      ux_min = fmin(ux_min, __shfl_xor(ux_min, d, 64));
+      ux_max = fmax(ux_max, __shfl_xor(ux_max, d, 64));
+      uy_min = fmin(uy_min, __shfl_xor(uy_min, d, 64));
+      uy_max = fmax(uy_max, __shfl_xor(uy_max, d, 64));
     }
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-      edge_invariants<T>(v[k * 2], v[k * 2 + 1], v[((k + 1) % 3) * 2], v[((k + 1) % 3) * 2 + 1], &e[k], &den[k], &rcp[k]);
-    unsigned long long am = __ballot(active);
-    while (am) {
-      const int u = __ffsll((long long)am) - 1;
-      am &= am - 1;
-      const T xu = __shfl(x0, u, 64), yu = __shfl(y0, u, 64);
-      const bool pass = face_valid && !(xu < bb0 || xu >= bb2 || yu < bb1 || yu >= bb3);
-      const unsigned long long m = __ballot(pass);
-      if (m == 0) continue;
-      const int kid_u = __shfl(kid, u, 64);
-      const int room = K - kid_u;
-      T pr = 0;
-      int which = 0;
-      if (pass) {
-        const T d2 = closest_of_six<T>(v, e, den, rcp, xu, yu, multiplier, &which);
-        const T zz = sigmainv * d2 / multiplier / multiplier;
-        pr = dibr_exp<T>(-zz);
-      }
-      const int rank = __popcll(m & lt_mask);
-      const bool accept = pass && rank < room;
-      const int ucol = sub_x + (u & 15), urow = sub_y + (u >> 4);
-      const size_t p1u = ((size_t)b * g.H + urow) * g.W + ucol;
-      const int nacc = min(__popcll(m), room);
-      if (LEAN) {
-        if (nbuf + nacc > SM_LISTBUF) flush_list();
-        if (accept) {
-          l_pix[nbuf + rank] = (int)p1u;
-          l_face[nbuf + rank] = id;
-          l_prob[nbuf + rank] = pr;
-          l_type[nbuf + rank] = (uint8_t)(which + 1);
-        }
-        nbuf += nacc;
-      } else if (accept) {
-        const size_t o = p1u * K + kid_u + rank;
-        prob_out[o] = pr;
-        idx_out[o] = id;
-        type_out[o] = (uint8_t)(which + 1);
-      }
-      // continue prod(1 - prob) in hit order (dibr_soft_mask_cuda.cu:174-179)
-      T all_u = __shfl(all, u, 64);
-      unsigned long long ma = __ballot(accept);
-      while (ma) {
-        const int l = __ffsll((long long)ma) - 1;
-        ma &= ma - 1;
-        const T p = __shfl(pr, l, 64);
-        all_u = (T)((double)all_u * (1.0 - (double)p));
-      }
-      if (lane == u) {
-        kid = kid_u + nacc;
-        all = all_u;
-        if (kid >= K) active = false;
-      }
-    }
-  };
 
-  int ncand = 0;
-  bool done = false;
-  for (int w0 = 0; w0 < nwords && !done; w0 += 64) {
-    const int wi = w0 + lane;
-    unsigned int word = wi < nwords ? tmask[wi] : 0u;
-    const int c = __popc(word);
-    const int incl = wave_inclusive_scan(c);
-    const int total = __shfl(incl, 63, 64);
-    if (total == 0) continue;
-    __syncthreads();
-    {
-      int pos = incl - c;
-      while (word) {
-        const int bit = __ffs(word) - 1;
-        word &= word - 1;
-        s_tmp[pos++] = wi * 32 + bit;
-      }
-    }
-    __syncthreads();
-    for (int t0 = 0; t0 < total; t0 += 64) {
-      const int k = t0 + lane;
-      bool keep = false;
-      int id = 0;
-      if (k < total) {
-        id = s_tmp[k];
-        const T* r = rec + ((size_t)first_b + id) * REC_STRIDE;
-        const T b0 = r[0], b1 = r[1], b2 = r[2], b3 = r[3];
-        keep = !(ux_max < b0 || ux_min >= b2 || uy_max < b1 || uy_min >= b3);
-      }
-      const unsigned long long m = __ballot(keep);
-      if (m == 0) continue;
-      if (keep) s_cand[ncand + __popcll(m & lt_mask)] = id;
-      ncand += __popcll(m);
+    // per-PIXEL state lives in the lane that owns the pixel
+    int kid = 0;
+    T all = 1.0;
+    bool active = uncovered && K > 0;
+    int my_start = 0, my_cnt = 0;  // this pixel's slice of the current pair list
+    int np = 0;
+
+    // evaluates the np queued pairs, then lets every pixel fold its new hits into prod(1 - prob)
+    auto eval_pairs = [&]() {
       __syncthreads();
-      if (ncand >= 64) {
-        process_chunk(64);
+      unsigned long long base = 0;
+      if (LEAN) {
+        if (lane == 0) base = atomicAdd(list.counter, (unsigned long long)np);
+        base = __shfl(base, 0, 64);
+      }
+      for (int t0 = 0; t0 < np; t0 += 64) {
+        const int t = t0 + lane;
+        if (t < np) {
+          const int pair = s_pair[t];
+          const int u = pair >> 6, fs = pair & 63;
+          const int ucol = sub_x + (u & 15), urow = sub_y + (u >> 4);
+          const T xu = pixel_x(multiplier, g.W, ucol), yu = pixel_y(multiplier, g.H, urow);
+          T v[6];
+          EdgeInv<T> e[3];
+          double den[3], rcp[3];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) v[i] = s_ff[4 + i][fs];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            e[k].A = s_ff[10 + k * 8 + 0][fs];
+            e[k].B = s_ff[10 + k * 8 + 1][fs];
+            e[k].C = s_ff[10 + k * 8 + 2][fs];
+            e[k].AA = s_ff[10 + k * 8 + 3][fs];
+            e[k].BB = s_ff[10 + k * 8 + 4][fs];
+            e[k].AB = s_ff[10 + k * 8 + 5][fs];
+            e[k].AC = s_ff[10 + k * 8 + 6][fs];
+            e[k].BC = s_ff[10 + k * 8 + 7][fs];
+            den[k] = s_fd[k][fs];
+            rcp[k] = s_fd[3 + k][fs];
+          }
+          int which;
+          const T d2 = closest_of_six<T>(v, e, den, rcp, xu, yu, multiplier, &which);
+          const T zz = sigmainv * d2 / multiplier / multiplier;
+          const T pr = dibr_exp<T>(-zz);
+          s_pr[t] = pr;
+          const size_t p1u = ((size_t)b * g.H + urow) * g.W + ucol;
+          if (LEAN) {
+            list.pix[base + t] = (int)p1u;
+            list.face[base + t] = s_fid[fs];
+            list.prob[base + t] = pr;
+            list.type[base + t] = (uint8_t)(which + 1);
+          } else {
+            const size_t o = p1u * K + (size_t)(t + s_off[u]);
+            prob_out[o] = pr;
+            idx_out[o] = s_fid[fs];
+            type_out[o] = (uint8_t)(which + 1);
+          }
+        }
+      }
+      __syncthreads();
+      // continue prod(1 - prob) in hit order (dibr_soft_mask_cuda.cu:174-179)
+      for (int i = 0; i < my_cnt; ++i) all = (T)((double)all * (1.0 - (double)s_pr[my_start + i]));
+      kid += my_cnt;
+      my_cnt = 0;
+      if (kid >= K) active = false;
+      np = 0;
+      __syncthreads();
+    };
+
+    // takes the first n (<= 64) candidates of s_cand: parks their data in LDS, queues and evaluates their pairs
+    auto process_chunk = [&](int n) {
+      const bool face_valid = lane < n;
+      T bb0 = 0, bb1 = 0, bb2 = 0, bb3 = 0, v[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) v[i] = 0;
+      if (face_valid) {
+        const int id = s_cand[lane];
+        const T* r = rec + ((size_t)first_b + id) * REC_STRIDE;
+        bb0 = r[0];
+        bb1 = r[1];
+        bb2 = r[2];
+        bb3 = r[3];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[i] = r[4 + i];
+        s_fid[lane] = id;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s_ff[4 + i][lane] = v[i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          EdgeInv<T> e;
+          double den, rcp;
+          edge_invariants<T>(v[k * 2], v[k * 2 + 1], v[((k + 1) % 3) * 2], v[((k + 1) % 3) * 2 + 1], &e, &den, &rcp);
+          s_ff[10 + k * 8 + 0][lane] = e.A;
+          s_ff[10 + k * 8 + 1][lane] = e.B;
+          s_ff[10 + k * 8 + 2][lane] = e.C;
+          s_ff[10 + k * 8 + 3][lane] = e.AA;
+          s_ff[10 + k * 8 + 4][lane] = e.BB;
+          s_ff[10 + k * 8 + 5][lane] = e.AB;
+          s_ff[10 + k * 8 + 6][lane] = e.AC;
+          s_ff[10 + k * 8 + 7][lane] = e.BC;
+          s_fd[k][lane] = den;
+          s_fd[3 + k][lane] = rcp;
+        }
+      }
+      unsigned long long am = __ballot(active);
+      while (am) {
+        const int u = __ffsll((long long)am) - 1;
+        am &= am - 1;
+        const T xu = __shfl(x0, u, 64), yu = __shfl(y0, u, 64);
+        const bool pass = face_valid && !(xu < bb0 || xu >= bb2 || yu < bb1 || yu >= bb3);
+        const unsigned long long m = __ballot(pass);
+        if (m == 0) continue;
+        const int kid_u = __shfl(kid, u, 64);
+        const int cnt = min(__popcll(m), K - kid_u);
+        if (np + cnt > SM_PAIRCAP) eval_pairs();  // (pixels queued so far are folded; u itself is not among them)
+        const int rank = __popcll(m & lt_mask);
+        if (pass && rank < cnt) s_pair[np + rank] = (unsigned short)((u << 6) | lane);
+        if (lane == u) {
+          my_start = np;
+          my_cnt = cnt;
+          s_off[u] = kid_u - np;
+        }
+        np += cnt;
+      }
+      if (np > 0) eval_pairs();
+    };
+
+    int ncand = 0;
+    bool done = false;
+    for (int w0 = 0; w0 < nwords && !done; w0 += 64) {
+      const int wi = w0 + lane;
+      unsigned int word = wi < nwords ? tmask[wi] : 0u;
+      const int c = __popc(word);
+      const int incl = wave_inclusive_scan(c);
+      const int total = __shfl(incl, 63, 64);
+      if (total == 0) continue;
+      __syncthreads();
+      {
+        int pos = incl - c;
+        while (word) {
+          const int bit = __ffs(word) - 1;
+          word &= word - 1;
+          s_tmp[pos++] = wi * 32 + bit;
+        }
+      }
+      __syncthreads();
+      for (int t0 = 0; t0 < total; t0 += 64) {
+        const int k = t0 + lane;
+        bool keep = false;
+        int id = 0;
+        if (k < total) {
+          id = s_tmp[k];
+          const T* r = rec + ((size_t)first_b + id) * REC_STRIDE;
+          const T b0 = r[0], b1 = r[1], b2 = r[2], b3 = r[3];
+          keep = !(ux_max < b0 || ux_min >= b2 || uy_max < b1 || uy_min >= b3);
+        }
+        const unsigned long long m = __ballot(keep);
+        if (m == 0) continue;
+        if (keep) s_cand[ncand + __popcll(m & lt_mask)] = id;
+        ncand += __popcll(m);
         __syncthreads();
-        const int rest = ncand - 64;
-        const int moved = lane < rest ? s_cand[64 + lane] : 0;
-        __syncthreads();
-        if (lane < rest) s_cand[lane] = moved;
-        ncand = rest;
-        __syncthreads();
-        if (!__any(active)) {
-          done = true;
-          break;
+        if (ncand >= 64) {
+          process_chunk(64);
+          __syncthreads();
+          const int rest = ncand - 64;
+          const int moved = lane < rest ? s_cand[64 + lane] : 0;
+          __syncthreads();
+          if (lane < rest) s_cand[lane] = moved;
+          ncand = rest;
+          __syncthreads();
+          if (!__any(active)) {
+            done = true;
+            break;
+          }
         }
       }
     }
-  }
-  if (!done && ncand > 0) {
+    if (!done && ncand > 0) {
+      __syncthreads();
+      process_chunk(ncand);
+    }
+    if (uncovered) {
+      soft_mask[p1] = (T)(1.0 - (double)all);
+      if (!LEAN && hit_count) hit_count[p1] = (uint8_t)(kid > 255 ? 255 : kid);
+    }
     __syncthreads();
-    process_chunk(ncand);
-  }
-  flush_list();
-
-  if (uncovered) {
-    soft_mask[p1] = (T)(1.0 - (double)all);
-    if (!LEAN && hit_count) hit_count[p1] = (uint8_t)(kid > 255 ? 255 : kid);
   }
 }
 
@@ -578,28 +654,43 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
   T* rec = (T*)workspace;
   unsigned int* masks = (unsigned int*)((char*)workspace + align256((size_t)total_faces * REC_STRIDE * sizeof(T)));
   unsigned int* flags = total_faces > 0 ? masks + mask_words(g.ntiles, B, total_faces) : nullptr;
+  // after the tile flags: sub-tile flags (1 byte each), the worklist header {count, next}, the worklist items
+  const int n_sub = g.ntiles * B * SM_SUBS;
+  uint8_t* sub_flags = total_faces > 0 ? (uint8_t*)(flags + flag_words(g.ntiles, B)) : nullptr;
+  unsigned int* work = total_faces > 0 ? (unsigned int*)(sub_flags + align256((size_t)n_sub)) : nullptr;
   if (total_faces > 0) {
-    KAMD_CHECK(hipMemsetAsync(masks, 0, (mask_words(g.ntiles, B, total_faces) + flag_words(g.ntiles, B)) * 4, st));
+    KAMD_CHECK(hipMemsetAsync(masks, 0, (mask_words(g.ntiles, B, total_faces) + flag_words(g.ntiles, B) + 2) * 4 +
+                                         align256((size_t)n_sub), st));
     kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
     if (raw)
       hipLaunchKernelGGL(bin_faces_raw_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, F, img,
                          (const T*)nullptr, (const uint8_t*)nullptr, (T)raw_multiplier, (T)raw_margin, g, multiplier, rec,
-                         masks, flags);
+                         masks, flags, sub_flags);
     else
       hipLaunchKernelGGL(bin_faces_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, F, total_faces,
-                         (const int64_t*)nullptr, large_bbox, img, (const T*)nullptr, g, multiplier, rec, masks, flags);
+                         (const int64_t*)nullptr, large_bbox, img, (const T*)nullptr, g, multiplier, rec, masks, flags,
+                         sub_flags);
   }
   KAMD_CHECK(hipGetLastError());
+  // worklist area follows the flag words: [count, next, items...]
+  int* worklist = (int*)(work + 2);
   {
+    kamd::ProfScope prof_(kamd::K_SOFT_CLASSIFY, st);
+    hipLaunchKernelGGL(soft_classify_kernel<T>, dim3(g.ntiles * B), dim3(TILE_THREADS), 0, st, B, g, sub_flags, sel_idx,
+                       soft_mask, lean ? (uint8_t*)nullptr : hit_count, worklist, work);
+  }
+  KAMD_CHECK(hipGetLastError());
+  if (total_faces > 0) {
     kamd::ProfScope prof_(kamd::K_SOFT_TILE, st);
-    const dim3 grid((unsigned)(g.ntiles * B * 16));
+    const dim3 grid((unsigned)(n_sub < KAMD_NUM_CU * 6 ? n_sub : KAMD_NUM_CU * 6));
     if (lean)
-      hipLaunchKernelGGL((soft_mask_search_kernel<T, true>), grid, dim3(64), 0, st, B, F, g, K, sigmainv, multiplier, rec,
-                         masks, flags, sel_idx, soft_mask, (T*)nullptr, (int64_t*)nullptr, (uint8_t*)nullptr,
-                         (uint8_t*)nullptr, *lean);
+      hipLaunchKernelGGL((soft_search_kernel<T, true>), grid, dim3(64), 0, st, B, F, g, K, sigmainv, multiplier, rec,
+                         masks, worklist, work, work + 1, sel_idx, soft_mask, (T*)nullptr, (int64_t*)nullptr,
+                         (uint8_t*)nullptr, (uint8_t*)nullptr, *lean);
     else
-      hipLaunchKernelGGL((soft_mask_search_kernel<T, false>), grid, dim3(64), 0, st, B, F, g, K, sigmainv, multiplier,
-                         rec, masks, flags, sel_idx, soft_mask, prob, idx, type, hit_count, HitList<T>{});
+      hipLaunchKernelGGL((soft_search_kernel<T, false>), grid, dim3(64), 0, st, B, F, g, K, sigmainv, multiplier,
+                         rec, masks, worklist, work, work + 1, sel_idx, soft_mask, prob, idx, type, hit_count,
+                         HitList<T>{});
   }
   KAMD_RETURN_LAST_ERROR();
 }
@@ -638,7 +729,10 @@ extern "C" {
 
 size_t kamd_dibr_soft_mask_forward_workspace(int B, int H, int W, int F, int elem_size) {
   if (B <= 0 || H <= 0 || W <= 0 || F <= 0) return 0;
-  return kamd::bins_workspace_bytes(B, H, W, (long long)B * F, elem_size);
+  // bins + the sub-tile worklist {count, next, items[B * ntiles * 16]}
+  const kamd::TileGeom g = kamd::tile_geom(H, W);
+  return kamd::bins_workspace_bytes(B, H, W, (long long)B * F, elem_size) + kamd::align256((size_t)g.ntiles * B * 16) +
+         kamd::align256(((size_t)g.ntiles * B * 16 + 2) * 4);
 }
 
 int kamd_dibr_soft_mask_forward_f32(void* stream, int B, int H, int W, int F, int K, const float* img,

@@ -287,7 +287,7 @@ int rasterize_forward_launch(hipStream_t st, int B, int H, int W, int D, int64_t
     {
       kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
       hipLaunchKernelGGL(bin_faces_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, 0,
-                       (long long)total_faces, first_idx, bbox, img, z, g, multiplier, rec, masks, flags);
+                       (long long)total_faces, first_idx, bbox, img, z, g, multiplier, rec, masks, flags, (uint8_t*)nullptr);
     }
     KAMD_CHECK(hipGetLastError());
   }
@@ -316,7 +316,7 @@ int rasterize_forward_fused_launch(hipStream_t st, int B, int H, int W, int F, i
     KAMD_CHECK(hipMemsetAsync(masks, 0, (mask_words(g.ntiles, B, total_faces) + flag_words(g.ntiles, B)) * 4, st));
     kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
     hipLaunchKernelGGL(bin_faces_raw_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, F, img, z, valid,
-                       (T)multiplier, (T)0, g, (float)multiplier, rec, masks, flags);
+                       (T)multiplier, (T)0, g, (float)multiplier, rec, masks, flags, (uint8_t*)nullptr);
   }
   KAMD_CHECK(hipGetLastError());
   {

@@ -63,6 +63,19 @@ __device__ __forceinline__ size_t mask_base(int ntiles, long long first_b, int b
   return (size_t)ntiles * (size_t)(first_b / 32 + b) + (size_t)t * stride_b;
 }
 
+// marks every 16x4-pixel sub-tile the pixel range [c_lo,c_hi] x [r_lo,r_hi] touches (one byte per
+// (mesh, tile, sub-tile), layout = workgroup item order of the soft-mask kernels; all writers store 1)
+__device__ __forceinline__ void mark_sub_tiles(uint8_t* __restrict__ sub_flags, const TileGeom& g, int B, int b, int c_lo,
+                                               int c_hi, int r_lo, int r_hi) {
+  constexpr int SUBS_X = TILE_W / SUB_W, SUBS = SUBS_X * (TILE_H / SUB_H);
+  for (int sy = r_lo / SUB_H; sy <= r_hi / SUB_H; ++sy)
+    for (int sx = c_lo / SUB_W; sx <= c_hi / SUB_W; ++sx) {
+      const int tile = (sy * SUB_H / TILE_H) * g.tiles_x + (sx * SUB_W / TILE_W);
+      const int sub = (sy % (TILE_H / SUB_H)) * SUBS_X + (sx % SUBS_X);
+      sub_flags[((size_t)tile * B + b) * SUBS + sub] = 1;
+    }
+}
+
 // ---- bin kernel -----------------------------------------------------------------------------------
 // One thread per face of the (packed) face list.  `first` (B+1, device) gives each mesh's face range;
 // first == nullptr means a dense batch: mesh b owns faces [b*F, (b+1)*F).  Copies bbox / vertices / z
@@ -72,7 +85,7 @@ __global__ __launch_bounds__(256) void bin_faces_kernel(
     int B, int F_dense, long long total_faces, const int64_t* __restrict__ first,
     const T* __restrict__ bbox, const T* __restrict__ img, const T* __restrict__ z,
     TileGeom g, float multiplier, T* __restrict__ rec, unsigned int* __restrict__ masks,
-    unsigned int* __restrict__ tile_flags) {
+    unsigned int* __restrict__ tile_flags, uint8_t* __restrict__ sub_flags) {
   const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
   if (f >= total_faces) return;
   int b;
@@ -126,6 +139,7 @@ __global__ __launch_bounds__(256) void bin_faces_kernel(
       atomicOr(masks + mask_base(g.ntiles, first_b, b, t, stride_b) + (size_t)(j >> 5), bit);
       if (tile_flags[(size_t)b * g.ntiles + t] == 0u) tile_flags[(size_t)b * g.ntiles + t] = 1u;  // benign race: all writers store 1
     }
+  if (sub_flags != nullptr) mark_sub_tiles(sub_flags, g, B, b, c_lo, c_hi, r_lo, r_hi);
 }
 
 // ---- bin kernel, fused form ------------------------------------------------------------------------------
@@ -139,7 +153,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bin_faces_raw_kernel(
     int B, int F, const T* __restrict__ img, const T* __restrict__ z, const uint8_t* __restrict__ valid,
     T mult, T margin, TileGeom g, float multiplier, T* __restrict__ rec, unsigned int* __restrict__ masks,
-    unsigned int* __restrict__ tile_flags) {
+    unsigned int* __restrict__ tile_flags, uint8_t* __restrict__ sub_flags) {
   const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
   if (f >= (long long)B * F) return;
   if (valid != nullptr && valid[f] == 0) return;
@@ -191,6 +205,7 @@ __global__ __launch_bounds__(256) void bin_faces_raw_kernel(
       atomicOr(masks + mask_base(g.ntiles, first_b, b, t, stride_b) + (size_t)(j >> 5), bit);
       if (tile_flags[(size_t)b * g.ntiles + t] == 0u) tile_flags[(size_t)b * g.ntiles + t] = 1u;
     }
+  if (sub_flags != nullptr) mark_sub_tiles(sub_flags, g, B, b, c_lo, c_hi, r_lo, r_hi);
 }
 
 // ---- block-wide exclusive scan over 1024 threads (16 wavefronts) -------------------------------------
