@@ -155,33 +155,39 @@ int kamd_dibr_soft_mask_backward_f64(void* stream, int B, int H, int W, int F, i
 /* Compact-list variant used by this package's own autograd Function (not part  */
 /* of the reference's interface): same search, same soft_mask, but instead of   */
 /* the (B,H,W,K) K-buffers every accepted (pixel, face) hit is appended to four */
-/* parallel arrays (capacity B*H*W*K entries, only the used prefix is touched;  */
-/* order irrelevant) and *counter (zeroed by the caller) ends up holding the    */
-/* number of hits.  Requires B*H*W < 2^31.  The backward consumes the list.     */
+/* parallel arrays (capacity B*H*W*K entries).  The list is SEGMENTED: work item */
+/* i (a 16x4-pixel sub-tile that has hits to search) owns the records            */
+/* [i*64*K, i*64*K + item_count[i]); *n_items receives the number of work items. */
+/* item_count holds ceil(W/32)*ceil(H/32)*16*B ints.  No shared append counter:  */
+/* ~20k same-address atomics per step would serialise.  Requires B*H*W < 2^31.   */
+/* Records each of the four hit arrays must hold (64*K per 16x4-pixel sub-tile). */
+size_t kamd_dibr_soft_mask_lean_capacity(int B, int H, int W, int K);
 int kamd_dibr_soft_mask_forward_lean_f32(void* stream, int B, int H, int W, int F, int K,
                                          const float* img, const float* large_bbox,
                                          const int64_t* sel_idx, float sigmainv, float multiplier,
                                          float* soft_mask, int32_t* hit_pix, int32_t* hit_face,
-                                         float* hit_prob, uint8_t* hit_type, uint64_t* counter,
-                                         void* workspace);
+                                         float* hit_prob, uint8_t* hit_type, int32_t* item_count,
+                                         uint32_t* n_items, void* workspace);
 int kamd_dibr_soft_mask_forward_lean_f64(void* stream, int B, int H, int W, int F, int K,
                                          const double* img, const double* large_bbox,
                                          const int64_t* sel_idx, float sigmainv, float multiplier,
                                          double* soft_mask, int32_t* hit_pix, int32_t* hit_face,
-                                         double* hit_prob, uint8_t* hit_type, uint64_t* counter,
-                                         void* workspace);
-int kamd_dibr_soft_mask_backward_lean_f32(void* stream, int B, int H, int W, int F,
+                                         double* hit_prob, uint8_t* hit_type, int32_t* item_count,
+                                         uint32_t* n_items, void* workspace);
+int kamd_dibr_soft_mask_backward_lean_f32(void* stream, int B, int H, int W, int F, int K,
                                           const float* grad, const float* soft_mask,
                                           const int32_t* hit_pix, const int32_t* hit_face,
                                           const float* hit_prob, const uint8_t* hit_type,
-                                          const uint64_t* counter, const float* img,
+                                          const int32_t* item_count, const uint32_t* n_items,
+                                          const float* img,
                                           double img_scale, float sigmainv, float multiplier,
                                           float* g_img);
-int kamd_dibr_soft_mask_backward_lean_f64(void* stream, int B, int H, int W, int F,
+int kamd_dibr_soft_mask_backward_lean_f64(void* stream, int B, int H, int W, int F, int K,
                                           const double* grad, const double* soft_mask,
                                           const int32_t* hit_pix, const int32_t* hit_face,
                                           const double* hit_prob, const uint8_t* hit_type,
-                                          const uint64_t* counter, const double* img,
+                                          const int32_t* item_count, const uint32_t* n_items,
+                                          const double* img,
                                           double img_scale, float sigmainv, float multiplier,
                                           double* g_img);
 /* Fused front doors (ours): take the RAW operator inputs of the Python layer and */
@@ -205,14 +211,14 @@ int kamd_dibr_soft_mask_forward_fused_f32(void* stream, int B, int H, int W, int
                                           const float* img, double multiplier, double margin,
                                           const int64_t* sel_idx, float sigmainv,
                                           float* soft_mask, int32_t* hit_pix, int32_t* hit_face,
-                                          float* hit_prob, uint8_t* hit_type, uint64_t* counter,
-                                          void* workspace);
+                                          float* hit_prob, uint8_t* hit_type, int32_t* item_count,
+                                          uint32_t* n_items, void* workspace);
 int kamd_dibr_soft_mask_forward_fused_f64(void* stream, int B, int H, int W, int F, int K,
                                           const double* img, double multiplier, double margin,
                                           const int64_t* sel_idx, float sigmainv,
                                           double* soft_mask, int32_t* hit_pix, int32_t* hit_face,
-                                          double* hit_prob, uint8_t* hit_type, uint64_t* counter,
-                                          void* workspace);
+                                          double* hit_prob, uint8_t* hit_type, int32_t* item_count,
+                                          uint32_t* n_items, void* workspace);
 
 /* ------------------------------------------------------------------------- */
 /* metrics.unbatched_triangle_distance_forward_cuda(points, faces, dist,      */

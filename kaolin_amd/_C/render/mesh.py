@@ -158,8 +158,8 @@ def dibr_soft_mask_backward_cuda(grad_soft_mask, soft_mask, selected_face_idx, c
 def dibr_soft_mask_forward_lean(face_vertices_image, face_large_bboxes, selected_face_idx, sigmainv, knum, multiplier):
     """Our autograd path's variant of ``dibr_soft_mask_forward_cuda`` (no counterpart in the reference): the same
     search and the same ``soft_mask``, but the per-pixel K-buffers (13*knum bytes per pixel, initialised for every
-    pixel) are replaced by a compact list of the actual (pixel, face, prob, type) hits.
-    -> (soft_mask, (hit_pix, hit_face, hit_prob, hit_type, counter))"""
+    pixel) are replaced by a compact, segmented list of the actual (pixel, face, prob, type) hits.
+    -> (soft_mask, hits); ``hit_list_entries(hits, knum)`` flattens the list."""
     fn = 'dibr_soft_mask_forward_lean'
     args = [Arg(face_vertices_image, 'face_vertices_image', 1), Arg(face_large_bboxes, 'face_bboxes', 2),
             Arg(selected_face_idx, 'selected_face_idx', 3)]
@@ -172,33 +172,28 @@ def dibr_soft_mask_forward_lean(face_vertices_image, face_large_bboxes, selected
     check_size(fn, args[2], [batch_size, height, width])
     dtype, device = face_vertices_image.dtype, face_vertices_image.device
     sfx = _lib.dtype_suffix(dtype, fn)
-    knum = int(knum)
-    cap = max(batch_size * height * width * knum, 1)
     lib = _lib.load()
     with torch.cuda.device(device):
         soft_mask = torch.empty((batch_size, height, width), dtype=dtype, device=device)
-        hit_pix = torch.empty(cap, dtype=torch.int32, device=device)     # capacity only: just the used prefix is touched
-        hit_face = torch.empty(cap, dtype=torch.int32, device=device)
-        hit_prob = torch.empty(cap, dtype=dtype, device=device)
-        hit_type = torch.empty(cap, dtype=torch.uint8, device=device)
-        counter = torch.zeros(1, dtype=torch.int64, device=device)
+        hits = _hit_list(batch_size, height, width, knum, dtype, device)
         ws = _lib.workspace(lib.kamd_dibr_soft_mask_forward_workspace(batch_size, height, width, num_faces,
                                                                       face_vertices_image.element_size()), device)
         st = getattr(lib, f'kamd_dibr_soft_mask_forward_lean_{sfx}')(
-            _lib.stream_ptr(device), batch_size, height, width, num_faces, knum,
+            _lib.stream_ptr(device), batch_size, height, width, num_faces, int(knum),
             _lib.ptr(face_vertices_image), _lib.ptr(face_large_bboxes), _lib.ptr(selected_face_idx),
-            float(sigmainv), float(multiplier), _lib.ptr(soft_mask), _lib.ptr(hit_pix), _lib.ptr(hit_face),
-            _lib.ptr(hit_prob), _lib.ptr(hit_type), _lib.ptr(counter), _lib.ptr(ws))
+            float(sigmainv), float(multiplier), _lib.ptr(soft_mask), _lib.ptr(hits[0]), _lib.ptr(hits[1]),
+            _lib.ptr(hits[2]), _lib.ptr(hits[3]), _lib.ptr(hits[4]), _lib.ptr(hits[5]), _lib.ptr(ws))
     _lib.check(st, fn)
-    return soft_mask, (hit_pix, hit_face, hit_prob, hit_type, counter)
+    return soft_mask, hits
 
 
-def dibr_soft_mask_backward_lean(grad_soft_mask, soft_mask, hits, face_vertices_image, sigmainv, multiplier,
+def dibr_soft_mask_backward_lean(grad_soft_mask, soft_mask, hits, face_vertices_image, sigmainv, knum, multiplier,
                                  img_scale=1.0):
     """Backward of :func:`dibr_soft_mask_forward_lean` / ``_fused`` -> grad_face_vertices_image (B,F,3,2), w.r.t. the
     unscaled input.  ``face_vertices_image * img_scale`` must be the scaled vertices the forward searched with."""
     fn = 'dibr_soft_mask_backward_lean'
-    hit_pix, hit_face, hit_prob, hit_type, counter = hits
+    hit_pix, hit_face, hit_prob, hit_type, item_count, n_items = hits
+    knum = int(knum)
     args = [Arg(grad_soft_mask, 'grad_soft_mask', 1), Arg(soft_mask, 'soft_mask', 2),
             Arg(face_vertices_image, 'face_vertices_image', 4)]
     check_all_same_gpu(fn, args)
@@ -212,19 +207,36 @@ def dibr_soft_mask_backward_lean(grad_soft_mask, soft_mask, hits, face_vertices_
     with torch.cuda.device(device):
         g_img = torch.zeros_like(face_vertices_image)
         st = getattr(lib, f'kamd_dibr_soft_mask_backward_lean_{sfx}')(
-            _lib.stream_ptr(device), batch_size, height, width, num_faces,
+            _lib.stream_ptr(device), batch_size, height, width, num_faces, knum,
             _lib.ptr(grad_soft_mask), _lib.ptr(soft_mask), _lib.ptr(hit_pix), _lib.ptr(hit_face), _lib.ptr(hit_prob),
-            _lib.ptr(hit_type), _lib.ptr(counter), _lib.ptr(face_vertices_image), float(img_scale), float(sigmainv),
+            _lib.ptr(hit_type), _lib.ptr(item_count), _lib.ptr(n_items), _lib.ptr(face_vertices_image), float(img_scale), float(sigmainv),
             float(multiplier), _lib.ptr(g_img))
     _lib.check(st, fn)
     return g_img
 
 
 def _hit_list(batch_size, height, width, knum, dtype, device):
-    cap = max(batch_size * height * width * int(knum), 1)   # capacity only: just the used prefix is ever touched
+    """Storage of the segmented hit list: capacity B*H*W*K records (just the used parts are ever touched), one count
+    per potential work item (16x4-pixel sub-tile), and the number of work items."""
+    cap = max(int(_lib.load().kamd_dibr_soft_mask_lean_capacity(batch_size, height, width, int(knum))), 1)
+    n_sub = ((width + 31) // 32) * ((height + 31) // 32) * 16 * batch_size
     return (torch.empty(cap, dtype=torch.int32, device=device), torch.empty(cap, dtype=torch.int32, device=device),
             torch.empty(cap, dtype=dtype, device=device), torch.empty(cap, dtype=torch.uint8, device=device),
-            torch.zeros(1, dtype=torch.int64, device=device))
+            torch.empty(max(n_sub, 1), dtype=torch.int32, device=device), torch.zeros(1, dtype=torch.int32, device=device))
+
+
+def hit_list_entries(hits, knum):
+    """Flattens a segmented hit list -> (pix, face, prob, type) 1-D tensors of the recorded hits (tests / debugging)."""
+    hit_pix, hit_face, hit_prob, hit_type, item_count, n_items = hits
+    n = int(n_items.item())
+    counts = item_count[:n].long()
+    stride = 64 * int(knum)
+    starts = torch.arange(n, device=counts.device) * stride
+    total = int(counts.sum())
+    seg = torch.repeat_interleave(torch.arange(n, device=counts.device), counts)
+    within = torch.arange(total, device=counts.device) - torch.repeat_interleave(torch.cumsum(counts, 0) - counts, counts)
+    pos = starts[seg] + within
+    return hit_pix[pos], hit_face[pos], hit_prob[pos], hit_type[pos]
 
 
 def dibr_soft_mask_forward_fused(face_vertices_image, selected_face_idx, sigmainv, boxlen, knum, multiplier):
@@ -251,7 +263,7 @@ def dibr_soft_mask_forward_fused(face_vertices_image, selected_face_idx, sigmain
             _lib.stream_ptr(device), batch_size, height, width, num_faces, int(knum), _lib.ptr(face_vertices_image),
             float(multiplier), float(boxlen * multiplier), _lib.ptr(selected_face_idx), float(sigmainv),
             _lib.ptr(soft_mask), _lib.ptr(hits[0]), _lib.ptr(hits[1]), _lib.ptr(hits[2]), _lib.ptr(hits[3]),
-            _lib.ptr(hits[4]), _lib.ptr(ws))
+            _lib.ptr(hits[4]), _lib.ptr(hits[5]), _lib.ptr(ws))
     _lib.check(st, fn)
     return soft_mask, hits
 

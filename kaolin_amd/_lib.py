@@ -29,6 +29,7 @@ SIGNATURES = {
     'kamd_rasterize_forward_workspace': (_sz, [_i, _i, _i, _i64, _i]),
     'kamd_dibr_soft_mask_forward_workspace': (_sz, [_i, _i, _i, _i, _i]),
     'kamd_triangle_distance_forward_workspace': (_sz, [_i, _i, _i]),
+    'kamd_dibr_soft_mask_lean_capacity': (_sz, [_i, _i, _i, _i]),
     'kamd_profile_enable': (_i, [_i]),
     'kamd_profile_reset': (_i, []),
     'kamd_profile_num_kernels': (_i, []),
@@ -48,13 +49,13 @@ for _t in ('f32', 'f64'):
     SIGNATURES[f'kamd_dibr_soft_mask_backward_{_t}'] = (
         _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp])
     SIGNATURES[f'kamd_dibr_soft_mask_forward_lean_{_t}'] = (
-        _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+        _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_dibr_soft_mask_backward_lean_{_t}'] = (
-        _i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _f, _f, _vp])
+        _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _f, _f, _vp])
     SIGNATURES[f'kamd_rasterize_forward_fused_{_t}'] = (
         _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _dbl, _f, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_dibr_soft_mask_forward_fused_{_t}'] = (
-        _i, [_vp, _i, _i, _i, _i, _i, _vp, _dbl, _dbl, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+        _i, [_vp, _i, _i, _i, _i, _i, _vp, _dbl, _dbl, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_triangle_distance_forward_{_t}'] = (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_triangle_distance_backward_{_t}'] = (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_trianglemeshes_to_voxelgrids_{_t}'] = (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp])

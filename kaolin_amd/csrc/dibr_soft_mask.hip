@@ -138,17 +138,17 @@ inline int fill_edges(hipStream_t st, void* p, size_t bytes, int v, FillPlan* pl
 //       1. the 32x32 tile's bitmask is expanded into an ascending id list (popcount + wave scan, 64 words a step);
 //       2. 64 ids at a time, each lane culls one face against the extent of the wavefront's uncovered pixels; the
 //          survivors are compacted, in order, into a candidate queue;
-//       3. per 64 candidates: each lane derives the per-edge invariants of ITS face once and parks them in LDS
-//          (structure of arrays); a scalar loop over the still-active pixels ballots the faces whose box holds the
-//          pixel centre and appends the first (knum - hits so far) of them, in face order, to a PAIR list;
+//       3. per 64 candidates: each lane parks ITS face in LDS; then, lane = pixel, every lane walks the 64 boxes
+//          and keeps the faces holding its pixel centre as a 64-bit mask; the first (knum - hits so far) set bits
+//          of every pixel, in face order, form a PAIR list (slices assigned by a wave scan);
 //       4. the pair list is evaluated with one (pixel, face) pair per lane -- every evaluated pair is an accepted
 //          hit, lanes are fully used -- and written to consecutive K-buffer slots (or the compact hit list);
 //       5. each pixel's owner lane continues prod(1 - prob) over its pairs in order.
 // Results are identical to the reference's pixel-major loop: same expressions per (pixel, face), same order of
 // hits per pixel, same product order.
-constexpr int SM_IDCAP = 2048;    // ids produced by one 64-word step (64 * 32)
-constexpr int SM_PAIRCAP = 1024;  // (pixel, face) pairs per evaluation round
-constexpr int SM_NF = 34;         // per-face scalars parked in LDS: bbox 4, vertices 6, 3 edges x 8 invariants
+constexpr int SM_WORDS = 64;      // bitmask words expanded per step
+constexpr int SM_IDCAP = SM_WORDS * 32;  // ids one step can produce
+constexpr int SM_PAIRCAP = 1024;  // (pixel, face) pairs per evaluation window
 constexpr int SM_SUBS = (TILE_W / SUB_W) * (TILE_H / SUB_H);  // 16 sub-tiles per tile
 
 template <typename T>
@@ -157,7 +157,10 @@ struct HitList {      // compact output (our own autograd path): one record per 
   int* face;
   T* prob;
   uint8_t* type;
-  unsigned long long* counter;  // zeroed by the caller
+  // Segmented: worklist entry i (a 16x4-pixel sub-tile) owns records [i*64*K, i*64*K + item_count[i]).  A shared
+  // append counter would serialise ~20k same-address atomics per step (measured: ~8 ns each = the whole kernel).
+  int* item_count;          // one per worklist entry
+  unsigned int* n_items;    // number of worklist entries (written by the search kernel)
 };
 
 template <typename T>
@@ -201,13 +204,13 @@ template <typename T, bool LEAN>
 __global__ __launch_bounds__(64) void soft_search_kernel(
     int B, int F, TileGeom g, int K, float sigmainv, float multiplier, const T* __restrict__ rec,
     const unsigned int* __restrict__ masks, const int* __restrict__ worklist, const unsigned int* __restrict__ work_count,
-    unsigned int* __restrict__ work_next, const int64_t* __restrict__ sel_idx, T* __restrict__ soft_mask,
+    const int64_t* __restrict__ sel_idx, T* __restrict__ soft_mask,
     T* __restrict__ prob_out, int64_t* __restrict__ idx_out, uint8_t* __restrict__ type_out,
     uint8_t* __restrict__ hit_count, HitList<T> list) {
   __shared__ int s_tmp[SM_IDCAP];
   __shared__ int s_cand[128];
-  __shared__ T s_ff[SM_NF][64];
-  __shared__ double s_fd[6][64];
+  __shared__ __attribute__((aligned(16))) T s_bb[64 * 4];  // the chunk's boxes
+  __shared__ T s_fv[6][64];  // the chunk's face vertices (structure of arrays: conflict-free gathers)
   __shared__ int s_fid[64];
   __shared__ unsigned short s_pair[SM_PAIRCAP];
   __shared__ T s_pr[SM_PAIRCAP];
@@ -217,12 +220,13 @@ __global__ __launch_bounds__(64) void soft_search_kernel(
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const unsigned int n_items = *work_count;
 
-  for (;;) {
-    unsigned int wi_ = 0;
-    if (lane == 0) wi_ = atomicAdd(work_next, 1u);
-    wi_ = __shfl(wi_, 0, 64);
-    if (wi_ >= n_items) break;
+  // static round-robin over the COMPACTED worklist (every entry is real work, so this balances well; a shared
+  // "next item" counter costs more in same-address atomic latency than the imbalance it removes: measured 117 us)
+  if (LEAN && blockIdx.x == 0 && lane == 0) *list.n_items = n_items;
+  for (unsigned int wi_ = blockIdx.x; wi_ < n_items; wi_ += gridDim.x) {
     const int item = worklist[wi_];
+    const size_t list_base = (size_t)wi_ * 64 * (size_t)K;
+    int item_pairs = 0;
     const int sub = item % SM_SUBS;
     const int b = (item / SM_SUBS) % B;
     const int tile = item / (SM_SUBS * B);
@@ -253,134 +257,109 @@ __global__ __launch_bounds__(64) void soft_search_kernel(
     int kid = 0;
     T all = 1.0;
     bool active = uncovered && K > 0;
-    int my_start = 0, my_cnt = 0;  // this pixel's slice of the current pair list
-    int np = 0;
 
-    // evaluates the np queued pairs, then lets every pixel fold its new hits into prod(1 - prob)
-    auto eval_pairs = [&]() {
-      __syncthreads();
-      unsigned long long base = 0;
-      if (LEAN) {
-        if (lane == 0) base = atomicAdd(list.counter, (unsigned long long)np);
-        base = __shfl(base, 0, 64);
-      }
-      for (int t0 = 0; t0 < np; t0 += 64) {
-        const int t = t0 + lane;
-        if (t < np) {
-          const int pair = s_pair[t];
-          const int u = pair >> 6, fs = pair & 63;
-          const int ucol = sub_x + (u & 15), urow = sub_y + (u >> 4);
-          const T xu = pixel_x(multiplier, g.W, ucol), yu = pixel_y(multiplier, g.H, urow);
-          T v[6];
-          EdgeInv<T> e[3];
-          double den[3], rcp[3];
-#pragma unroll
-          for (int i = 0; i < 6; ++i) v[i] = s_ff[4 + i][fs];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            e[k].A = s_ff[10 + k * 8 + 0][fs];
-            e[k].B = s_ff[10 + k * 8 + 1][fs];
-            e[k].C = s_ff[10 + k * 8 + 2][fs];
-            e[k].AA = s_ff[10 + k * 8 + 3][fs];
-            e[k].BB = s_ff[10 + k * 8 + 4][fs];
-            e[k].AB = s_ff[10 + k * 8 + 5][fs];
-            e[k].AC = s_ff[10 + k * 8 + 6][fs];
-            e[k].BC = s_ff[10 + k * 8 + 7][fs];
-            den[k] = s_fd[k][fs];
-            rcp[k] = s_fd[3 + k][fs];
-          }
-          int which;
-          const T d2 = closest_of_six<T>(v, e, den, rcp, xu, yu, multiplier, &which);
-          const T zz = sigmainv * d2 / multiplier / multiplier;
-          const T pr = dibr_exp<T>(-zz);
-          s_pr[t] = pr;
-          const size_t p1u = ((size_t)b * g.H + urow) * g.W + ucol;
-          if (LEAN) {
-            list.pix[base + t] = (int)p1u;
-            list.face[base + t] = s_fid[fs];
-            list.prob[base + t] = pr;
-            list.type[base + t] = (uint8_t)(which + 1);
-          } else {
-            const size_t o = p1u * K + (size_t)(t + s_off[u]);
-            prob_out[o] = pr;
-            idx_out[o] = s_fid[fs];
-            type_out[o] = (uint8_t)(which + 1);
-          }
-        }
-      }
-      __syncthreads();
-      // continue prod(1 - prob) in hit order (dibr_soft_mask_cuda.cu:174-179)
-      for (int i = 0; i < my_cnt; ++i) all = (T)((double)all * (1.0 - (double)s_pr[my_start + i]));
-      kid += my_cnt;
-      my_cnt = 0;
-      if (kid >= K) active = false;
-      np = 0;
-      __syncthreads();
-    };
-
-    // takes the first n (<= 64) candidates of s_cand: parks their data in LDS, queues and evaluates their pairs
+    // takes the first n (<= 64) candidates of s_cand.
+    //   a. lane = FACE: park bbox, vertices and id of the lane's face in LDS;
+    //   b. lane = PIXEL: walk the n boxes (uniform LDS reads) and collect the faces holding the pixel centre in a
+    //      64-bit mask -- ascending face order for free; the first (knum - kid) set bits are this pixel's new hits;
+    //   c. a wave scan of the hit counts gives every pixel a slice of the PAIR list; pairs are evaluated one per
+    //      lane (every evaluated pair is an accepted hit) in windows of SM_PAIRCAP;
+    //   d. each pixel folds the probabilities of its slice, in order, into prod(1 - prob).
     auto process_chunk = [&](int n) {
-      const bool face_valid = lane < n;
-      T bb0 = 0, bb1 = 0, bb2 = 0, bb3 = 0, v[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) v[i] = 0;
-      if (face_valid) {
+      if (lane < n) {
         const int id = s_cand[lane];
         const T* r = rec + ((size_t)first_b + id) * REC_STRIDE;
-        bb0 = r[0];
-        bb1 = r[1];
-        bb2 = r[2];
-        bb3 = r[3];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) v[i] = r[4 + i];
+        for (int i = 0; i < 4; ++i) s_bb[lane * 4 + i] = r[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s_fv[i][lane] = r[4 + i];
         s_fid[lane] = id;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) s_ff[4 + i][lane] = v[i];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          EdgeInv<T> e;
-          double den, rcp;
-          edge_invariants<T>(v[k * 2], v[k * 2 + 1], v[((k + 1) % 3) * 2], v[((k + 1) % 3) * 2 + 1], &e, &den, &rcp);
-          s_ff[10 + k * 8 + 0][lane] = e.A;
-          s_ff[10 + k * 8 + 1][lane] = e.B;
-          s_ff[10 + k * 8 + 2][lane] = e.C;
-          s_ff[10 + k * 8 + 3][lane] = e.AA;
-          s_ff[10 + k * 8 + 4][lane] = e.BB;
-          s_ff[10 + k * 8 + 5][lane] = e.AB;
-          s_ff[10 + k * 8 + 6][lane] = e.AC;
-          s_ff[10 + k * 8 + 7][lane] = e.BC;
-          s_fd[k][lane] = den;
-          s_fd[3 + k][lane] = rcp;
-        }
       }
-      unsigned long long am = __ballot(active);
-      while (am) {
-        const int u = __ffsll((long long)am) - 1;
-        am &= am - 1;
-        const T xu = __shfl(x0, u, 64), yu = __shfl(y0, u, 64);
-        const bool pass = face_valid && !(xu < bb0 || xu >= bb2 || yu < bb1 || yu >= bb3);
-        const unsigned long long m = __ballot(pass);
-        if (m == 0) continue;
-        const int kid_u = __shfl(kid, u, 64);
-        const int cnt = min(__popcll(m), K - kid_u);
-        if (np + cnt > SM_PAIRCAP) eval_pairs();  // (pixels queued so far are folded; u itself is not among them)
-        const int rank = __popcll(m & lt_mask);
-        if (pass && rank < cnt) s_pair[np + rank] = (unsigned short)((u << 6) | lane);
-        if (lane == u) {
-          my_start = np;
-          my_cnt = cnt;
-          s_off[u] = kid_u - np;
-        }
-        np += cnt;
+      __syncthreads();
+      unsigned long long hm = 0;
+      for (int k = 0; k < n; ++k) {
+        const T xmin = s_bb[k * 4 + 0], ymin = s_bb[k * 4 + 1], xmax = s_bb[k * 4 + 2], ymax = s_bb[k * 4 + 3];
+        const bool pass = !(x0 < xmin || x0 >= xmax || y0 < ymin || y0 >= ymax);
+        hm |= pass ? (1ull << k) : 0ull;
       }
-      if (np > 0) eval_pairs();
+      const int cnt = active ? min(__popcll(hm), K - kid) : 0;
+      const int incl = wave_inclusive_scan(cnt);
+      const int start = incl - cnt;
+      const int total = __shfl(incl, 63, 64);
+      if (total == 0) {
+        __syncthreads();
+        return;
+      }
+      s_off[lane] = kid - start;
+      for (int lo = 0; lo < total; lo += SM_PAIRCAP) {
+        const int np = min(SM_PAIRCAP, total - lo);
+        {  // this pixel's pairs that fall into the window [lo, lo + np)
+          unsigned long long m = hm;
+          for (int i = 0; i < cnt; ++i) {
+            const int k = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int pos = start + i - lo;
+            if (pos >= 0 && pos < np) s_pair[pos] = (unsigned short)((lane << 6) | k);
+          }
+        }
+        __syncthreads();
+        const size_t base = list_base + (size_t)item_pairs;
+        item_pairs += np;
+        for (int t0 = 0; t0 < np; t0 += 64) {
+          const int t = t0 + lane;
+          if (t < np) {
+            const int pair = s_pair[t];
+            const int u = pair >> 6, fs = pair & 63;
+            const int ucol = sub_x + (u & 15), urow = sub_y + (u >> 4);
+            const T xu = pixel_x(multiplier, g.W, ucol), yu = pixel_y(multiplier, g.H, urow);
+            T v[6];
+            EdgeInv<T> e[3];
+            double den[3], rcp[3];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v[i] = s_fv[i][fs];
+            // the per-edge invariants are re-derived per pair (3 reciprocals) rather than parked in LDS: the kernel is
+            // latency-bound and 12 KiB less LDS per wavefront lets a SIMD interleave more wavefronts
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              edge_invariants<T>(v[k * 2], v[k * 2 + 1], v[((k + 1) % 3) * 2], v[((k + 1) % 3) * 2 + 1], &e[k], &den[k], &rcp[k]);
+            int which;
+            const T d2 = closest_of_six<T>(v, e, den, rcp, xu, yu, multiplier, &which);
+            const T zz = sigmainv * d2 / multiplier / multiplier;
+            const T pr = dibr_exp<T>(-zz);
+            s_pr[t] = pr;
+            const size_t p1u = ((size_t)b * g.H + urow) * g.W + ucol;
+            if (LEAN) {
+              list.pix[base + t] = (int)p1u;
+              list.face[base + t] = s_fid[fs];
+              list.prob[base + t] = pr;
+              list.type[base + t] = (uint8_t)(which + 1);
+            } else {
+              const size_t o = p1u * K + (size_t)(lo + t + s_off[u]);
+              prob_out[o] = pr;
+              idx_out[o] = s_fid[fs];
+              type_out[o] = (uint8_t)(which + 1);
+            }
+          }
+        }
+        __syncthreads();
+        // continue prod(1 - prob) in hit order (dibr_soft_mask_cuda.cu:174-179)
+        for (int i = 0; i < cnt; ++i) {
+          const int pos = start + i - lo;
+          if (pos >= 0 && pos < np) all = (T)((double)all * (1.0 - (double)s_pr[pos]));
+        }
+        __syncthreads();
+      }
+      kid += cnt;
+      if (kid >= K) active = false;
     };
 
     int ncand = 0;
     bool done = false;
-    for (int w0 = 0; w0 < nwords && !done; w0 += 64) {
+    unsigned int next_word = lane < nwords ? tmask[lane] : 0u;
+    for (int w0 = 0; w0 < nwords && !done; w0 += SM_WORDS) {
       const int wi = w0 + lane;
-      unsigned int word = wi < nwords ? tmask[wi] : 0u;
+      unsigned int word = next_word;
+      next_word = (wi + SM_WORDS < nwords) ? tmask[wi + SM_WORDS] : 0u;  // in flight while this step is processed
       const int c = __popc(word);
       const int incl = wave_inclusive_scan(c);
       const int total = __shfl(incl, 63, 64);
@@ -434,6 +413,7 @@ __global__ __launch_bounds__(64) void soft_search_kernel(
       soft_mask[p1] = (T)(1.0 - (double)all);
       if (!LEAN && hit_count) hit_count[p1] = (uint8_t)(kid > 255 ? 255 : kid);
     }
+    if (LEAN && lane == 0) list.item_count[wi_] = item_pairs;
     __syncthreads();
   }
 }
@@ -548,78 +528,76 @@ __global__ __launch_bounds__(64) void soft_mask_backward_kernel(
 }
 
 // ---- K4, compact-list form (our own autograd path) ---------------------------------------------------------
-// One lane per recorded (pixel, hit); the list is written wavefront by wavefront, so a workgroup's contiguous
-// slice of it touches few faces: contributions are summed per face in an LDS hash table and flushed once.
+// One workgroup per worklist entry (round-robin), one lane per recorded (pixel, hit).  An entry is one 16x4-pixel
+// sub-tile, so its records touch few faces: contributions are summed per face in an LDS hash table and flushed
+// with one global atomic per touched (face, coordinate).
 constexpr int SL_THREADS = 256;
-constexpr int SL_BLOCKS = 4096;
-constexpr int SL_CHUNK = 1024;  // hits per workgroup round
 
 template <typename T>
 __global__ __launch_bounds__(SL_THREADS) void soft_mask_backward_list_kernel(
-    int H, int W, int F, const T* __restrict__ grad, const T* __restrict__ soft_mask, HitList<T> list,
+    int H, int W, int F, int K, const T* __restrict__ grad, const T* __restrict__ soft_mask, HitList<T> list,
     const T* __restrict__ img, T img_scale, float sigmainv, float multiplier, T* __restrict__ g_img) {
   __shared__ int s_key[SB_HT];
   __shared__ T s_acc[SB_HT * 6];
-  const unsigned long long n = *list.counter;
+  const unsigned int n_items = *list.n_items;
   const long long P = (long long)H * W;
-  // contiguous chunks of SL_CHUNK hits (the list is written wavefront by wavefront: a chunk touches few faces)
-  for (unsigned long long begin = (unsigned long long)blockIdx.x * SL_CHUNK; begin < n;
-       begin += (unsigned long long)gridDim.x * SL_CHUNK) {
-  const unsigned long long end = begin + SL_CHUNK < n ? begin + SL_CHUNK : n;
-  __syncthreads();
-  for (int i = threadIdx.x; i < SB_HT; i += SL_THREADS) s_key[i] = -1;
-  for (int i = threadIdx.x; i < SB_HT * 6; i += SL_THREADS) s_acc[i] = 0;
-  __syncthreads();
-  for (unsigned long long t = begin + threadIdx.x; t < end; t += SL_THREADS) {
-    const int pix = list.pix[t];
-    const int f = list.face[t];
-    const T pr = list.prob[t];
-    const int e = (int)list.type[t] - 1;
-    const int b = (int)(pix / P);
-    const int rem = (int)(pix - (long long)b * P);
-    const int col = rem % W, row = rem / W;
-    const T x0 = pixel_x(multiplier, W, col);
-    const T y0 = pixel_y(multiplier, H, row);
-    const T dLdp = grad[pix];
-    const T all = soft_mask[pix];
-    const size_t s6 = ((size_t)b * F + f) * 6;
-    // faces of different images never share a slice in practice, but the key must still be unique: b*F + f
-    const int key = (int)(((long long)b * F + f) & 0x7fffffff);
-    const T dLdz = (T)(-1.0 * sigmainv * dLdp * (1.0 - all) / (1.0 - pr + DIBR_EPS) * pr);
-    if (e >= 3) {
-      const int o = (e - 3) * 2;
-      const T x1 = img[s6 + o] * img_scale, y1 = img[s6 + o + 1] * img_scale;
-      const T dLdx1 = dLdz * 2 * (x1 - x0);
-      const T dLdy1 = dLdz * 2 * (y1 - y0);
-      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o, (T)(dLdx1 / multiplier));
-      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o + 1, (T)(dLdy1 / multiplier));
-    } else {
-      const int o = e * 2, o2 = ((e + 1) % 3) * 2;
-      const T x1 = img[s6 + o] * img_scale, y1 = img[s6 + o + 1] * img_scale;
-      const T x2 = img[s6 + o2] * img_scale, y2 = img[s6 + o2 + 1] * img_scale;
-      const T A = y2 - y1, Bc = x1 - x2, C = x2 * y1 - x1 * y2;
-      const T up = A * x0 + Bc * y0 + C;
-      const T down = A * A + Bc * Bc;
-      const T d2 = up * up / (down + DIBR_EPS);
-      const T dzdA = 2 * (x0 * up - d2 * A) / (down + DIBR_EPS);
-      const T dzdB = 2 * (y0 * up - d2 * Bc) / (down + DIBR_EPS);
-      const T dzdC = 2 * up / (down + DIBR_EPS);
-      const T dLdx1 = dLdz * (dzdB - y2 * dzdC);
-      const T dLdy1 = dLdz * (x2 * dzdC - dzdA);
-      const T dLdx2 = dLdz * (y1 * dzdC - dzdB);
-      const T dLdy2 = dLdz * (dzdA - x1 * dzdC);
-      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o, (T)(dLdx1 / multiplier));
-      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o + 1, (T)(dLdy1 / multiplier));
-      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o2, (T)(dLdx2 / multiplier));
-      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o2 + 1, (T)(dLdy2 / multiplier));
+  for (unsigned int it = blockIdx.x; it < n_items; it += gridDim.x) {
+    const int n = list.item_count[it];
+    if (n <= 0) continue;
+    const size_t base = (size_t)it * 64 * (size_t)K;
+    __syncthreads();
+    for (int i = threadIdx.x; i < SB_HT; i += SL_THREADS) s_key[i] = -1;
+    for (int i = threadIdx.x; i < SB_HT * 6; i += SL_THREADS) s_acc[i] = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < n; t += SL_THREADS) {
+      const int pix = list.pix[base + t];
+      const int f = list.face[base + t];
+      const T pr = list.prob[base + t];
+      const int e = (int)list.type[base + t] - 1;
+      const int b = (int)(pix / P);
+      const int rem = (int)(pix - (long long)b * P);
+      const int col = rem % W, row = rem / W;
+      const T x0 = pixel_x(multiplier, W, col);
+      const T y0 = pixel_y(multiplier, H, row);
+      const T dLdp = grad[pix];
+      const T all = soft_mask[pix];
+      const size_t s6 = ((size_t)b * F + f) * 6;
+      const int key = (int)(((long long)b * F + f) & 0x7fffffff);
+      const T dLdz = (T)(-1.0 * sigmainv * dLdp * (1.0 - all) / (1.0 - pr + DIBR_EPS) * pr);
+      if (e >= 3) {
+        const int o = (e - 3) * 2;
+        const T x1 = img[s6 + o] * img_scale, y1 = img[s6 + o + 1] * img_scale;
+        const T dLdx1 = dLdz * 2 * (x1 - x0);
+        const T dLdy1 = dLdz * 2 * (y1 - y0);
+        sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o, (T)(dLdx1 / multiplier));
+        sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o + 1, (T)(dLdy1 / multiplier));
+      } else {
+        const int o = e * 2, o2 = ((e + 1) % 3) * 2;
+        const T x1 = img[s6 + o] * img_scale, y1 = img[s6 + o + 1] * img_scale;
+        const T x2 = img[s6 + o2] * img_scale, y2 = img[s6 + o2 + 1] * img_scale;
+        const T A = y2 - y1, Bc = x1 - x2, C = x2 * y1 - x1 * y2;
+        const T up = A * x0 + Bc * y0 + C;
+        const T down = A * A + Bc * Bc;
+        const T d2 = up * up / (down + DIBR_EPS);
+        const T dzdA = 2 * (x0 * up - d2 * A) / (down + DIBR_EPS);
+        const T dzdB = 2 * (y0 * up - d2 * Bc) / (down + DIBR_EPS);
+        const T dzdC = 2 * up / (down + DIBR_EPS);
+        const T dLdx1 = dLdz * (dzdB - y2 * dzdC);
+        const T dLdy1 = dLdz * (x2 * dzdC - dzdA);
+        const T dLdx2 = dLdz * (y1 * dzdC - dzdB);
+        const T dLdy2 = dLdz * (dzdA - x1 * dzdC);
+        sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o, (T)(dLdx1 / multiplier));
+        sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o + 1, (T)(dLdy1 / multiplier));
+        sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o2, (T)(dLdx2 / multiplier));
+        sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o2 + 1, (T)(dLdy2 / multiplier));
+      }
     }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < SB_HT * 6; i += SL_THREADS) {
-    const int k = s_key[i / 6];
-    const T v = s_acc[i];
-    if (k >= 0 && v != (T)0) kamd_atomic_add(g_img + (size_t)k * 6 + (i % 6), v);
-  }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SB_HT * 6; i += SL_THREADS) {
+      const int k = s_key[i / 6];
+      const T v = s_acc[i];
+      if (k >= 0 && v != (T)0) kamd_atomic_add(g_img + (size_t)k * 6 + (i % 6), v);
+    }
   }
 }
 
@@ -682,27 +660,27 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
   KAMD_CHECK(hipGetLastError());
   if (total_faces > 0) {
     kamd::ProfScope prof_(kamd::K_SOFT_TILE, st);
-    const dim3 grid((unsigned)(n_sub < KAMD_NUM_CU * 6 ? n_sub : KAMD_NUM_CU * 6));
+    const dim3 grid((unsigned)(n_sub < KAMD_NUM_CU * 8 ? n_sub : KAMD_NUM_CU * 8));
     if (lean)
       hipLaunchKernelGGL((soft_search_kernel<T, true>), grid, dim3(64), 0, st, B, F, g, K, sigmainv, multiplier, rec,
-                         masks, worklist, work, work + 1, sel_idx, soft_mask, (T*)nullptr, (int64_t*)nullptr,
+                         masks, worklist, work, sel_idx, soft_mask, (T*)nullptr, (int64_t*)nullptr,
                          (uint8_t*)nullptr, (uint8_t*)nullptr, *lean);
     else
       hipLaunchKernelGGL((soft_search_kernel<T, false>), grid, dim3(64), 0, st, B, F, g, K, sigmainv, multiplier,
-                         rec, masks, worklist, work, work + 1, sel_idx, soft_mask, prob, idx, type, hit_count,
+                         rec, masks, worklist, work, sel_idx, soft_mask, prob, idx, type, hit_count,
                          HitList<T>{});
   }
   KAMD_RETURN_LAST_ERROR();
 }
 
 template <typename T>
-int soft_mask_backward_list_launch(hipStream_t st, int B, int H, int W, int F, const T* grad, const T* soft_mask,
+int soft_mask_backward_list_launch(hipStream_t st, int B, int H, int W, int F, int K, const T* grad, const T* soft_mask,
                                    const HitList<T>& list, const T* img, double img_scale, float sigmainv,
                                    float multiplier, T* g_img) {
   if ((long long)B * H * W <= 0 || F <= 0) return 0;
   {
     kamd::ProfScope prof_(kamd::K_SOFT_BACKWARD, st);
-    hipLaunchKernelGGL(soft_mask_backward_list_kernel<T>, dim3(SL_BLOCKS), dim3(SL_THREADS), 0, st, H, W, F, grad,
+    hipLaunchKernelGGL(soft_mask_backward_list_kernel<T>, dim3(KAMD_NUM_CU * 8), dim3(SL_THREADS), 0, st, H, W, F, K, grad,
                        soft_mask, list, img, (T)img_scale, sigmainv, multiplier, g_img);
   }
   KAMD_RETURN_LAST_ERROR();
@@ -726,6 +704,12 @@ int soft_mask_backward_launch(hipStream_t st, int B, int H, int W, int F, int K,
 }  // namespace
 
 extern "C" {
+
+size_t kamd_dibr_soft_mask_lean_capacity(int B, int H, int W, int K) {
+  // records the segmented hit list must be able to hold: every 16x4-pixel sub-tile of every image owns 64*K slots
+  if (B <= 0 || H <= 0 || W <= 0 || K <= 0) return 0;
+  return (size_t)B * ((W + kamd::SUB_W - 1) / kamd::SUB_W) * ((H + kamd::SUB_H - 1) / kamd::SUB_H) * 64 * (size_t)K;
+}
 
 size_t kamd_dibr_soft_mask_forward_workspace(int B, int H, int W, int F, int elem_size) {
   if (B <= 0 || H <= 0 || W <= 0 || F <= 0) return 0;
@@ -769,25 +753,28 @@ int kamd_dibr_soft_mask_backward_f64(void* stream, int B, int H, int W, int F, i
   int kamd_dibr_soft_mask_forward_lean_##SFX(void* stream, int B, int H, int W, int F, int K, const T* img,          \
                                              const T* large_bbox, const int64_t* sel_idx, float sigmainv,            \
                                              float multiplier, T* soft_mask, int32_t* hit_pix, int32_t* hit_face,    \
-                                             T* hit_prob, uint8_t* hit_type, uint64_t* counter, void* workspace) {   \
-    HitList<T> l{hit_pix, hit_face, hit_prob, hit_type, (unsigned long long*)counter};                               \
+                                             T* hit_prob, uint8_t* hit_type, int32_t* item_count,                    \
+                                             uint32_t* n_items, void* workspace) {                                   \
+    HitList<T> l{hit_pix, hit_face, hit_prob, hit_type, item_count, n_items};                                        \
     return soft_mask_forward_launch<T>((hipStream_t)stream, B, H, W, F, K, img, large_bbox, sel_idx, sigmainv,       \
                                        multiplier, soft_mask, nullptr, nullptr, nullptr, workspace, nullptr, &l);    \
   }                                                                                                                   \
-  int kamd_dibr_soft_mask_backward_lean_##SFX(void* stream, int B, int H, int W, int F, const T* grad,               \
+  int kamd_dibr_soft_mask_backward_lean_##SFX(void* stream, int B, int H, int W, int F, int K, const T* grad,        \
                                               const T* soft_mask, const int32_t* hit_pix, const int32_t* hit_face,   \
-                                              const T* hit_prob, const uint8_t* hit_type, const uint64_t* counter,   \
-                                              const T* img, double img_scale, float sigmainv, float multiplier,      \
-                                              T* g_img) {                                                             \
-    HitList<T> l{(int*)hit_pix, (int*)hit_face, (T*)hit_prob, (uint8_t*)hit_type, (unsigned long long*)counter};     \
-    return soft_mask_backward_list_launch<T>((hipStream_t)stream, B, H, W, F, grad, soft_mask, l, img, img_scale,    \
-                                             sigmainv, multiplier, g_img);                                            \
+                                              const T* hit_prob, const uint8_t* hit_type, const int32_t* item_count,  \
+                                              const uint32_t* n_items, const T* img, double img_scale,               \
+                                              float sigmainv, float multiplier, T* g_img) {                           \
+    HitList<T> l{(int*)hit_pix, (int*)hit_face, (T*)hit_prob, (uint8_t*)hit_type, (int*)item_count,                  \
+                 (unsigned int*)n_items};                                                                             \
+    return soft_mask_backward_list_launch<T>((hipStream_t)stream, B, H, W, F, K, grad, soft_mask, l, img,            \
+                                             img_scale, sigmainv, multiplier, g_img);                                 \
   }                                                                                                                   \
   int kamd_dibr_soft_mask_forward_fused_##SFX(void* stream, int B, int H, int W, int F, int K, const T* img,         \
                                               double multiplier, double margin, const int64_t* sel_idx,              \
                                               float sigmainv, T* soft_mask, int32_t* hit_pix, int32_t* hit_face,     \
-                                              T* hit_prob, uint8_t* hit_type, uint64_t* counter, void* workspace) {  \
-    HitList<T> l{hit_pix, hit_face, hit_prob, hit_type, (unsigned long long*)counter};                               \
+                                              T* hit_prob, uint8_t* hit_type, int32_t* item_count,                   \
+                                              uint32_t* n_items, void* workspace) {                                  \
+    HitList<T> l{hit_pix, hit_face, hit_prob, hit_type, item_count, n_items};                                        \
     return soft_mask_forward_launch<T>((hipStream_t)stream, B, H, W, F, K, img, nullptr, sel_idx, sigmainv,          \
                                        (float)multiplier, soft_mask, nullptr, nullptr, nullptr, workspace, nullptr,  \
                                        &l, true, multiplier, margin);                                                 \

@@ -20,7 +20,7 @@ class DibrSoftMaskCuda(torch.autograd.Function):
         face_vertices_image = face_vertices_image.contiguous()
         soft_mask, hits = _C.render.mesh.dibr_soft_mask_forward_fused(
             face_vertices_image, selected_face_idx.contiguous(), sigmainv, boxlen, knum, multiplier)
-        ctx.multiplier, ctx.sigmainv = multiplier, sigmainv
+        ctx.multiplier, ctx.sigmainv, ctx.knum = multiplier, sigmainv, knum
         ctx.save_for_backward(soft_mask, face_vertices_image, *hits)
         return soft_mask
 
@@ -29,7 +29,7 @@ class DibrSoftMaskCuda(torch.autograd.Function):
         soft_mask, face_vertices_image = ctx.saved_tensors[:2]
         grad = _C.render.mesh.dibr_soft_mask_backward_lean(
             grad_soft_mask.contiguous(), soft_mask, ctx.saved_tensors[2:], face_vertices_image, ctx.sigmainv,
-            ctx.multiplier, img_scale=ctx.multiplier)
+            ctx.knum, ctx.multiplier, img_scale=ctx.multiplier)
         return grad, None, None, None, None, None
 
 

@@ -12,10 +12,10 @@ bbox = torch.cat([lo, hi], -1).contiguous()
 for _ in range(3):
     soft, hits = m.dibr_soft_mask_forward_lean(scaled, bbox, face_idx, 7000., 30, 1000.)
     g = torch.rand_like(soft)
-    m.dibr_soft_mask_backward_lean(g, soft, hits, scaled, 7000., 1000.)
+    m.dibr_soft_mask_backward_lean(g, soft, hits, scaled, 7000., 30, 1000.)
 torch.cuda.synchronize()
-n = int(hits[4].item())
-pix = hits[0][:n].long()
+pix = m.hit_list_entries(hits, 30)[0].long()
+n = pix.numel()
 upix = torch.unique(pix)
 print('hits', n, 'pixels with hits', upix.numel(), 'hits/pixel', n / upix.numel())
 sub = ((upix // (H * W)) * 100000000 + ((upix % (H * W)) // W // 4) * 10000 + ((upix % W) // 16))
