@@ -146,9 +146,9 @@ inline int fill_edges(hipStream_t st, void* p, size_t bytes, int v, FillPlan* pl
 //       5. each pixel's owner lane continues prod(1 - prob) over its pairs in order.
 // Results are identical to the reference's pixel-major loop: same expressions per (pixel, face), same order of
 // hits per pixel, same product order.
-constexpr int SM_WORDS = 64;      // bitmask words expanded per step
+constexpr int SM_WORDS = 32;      // bitmask words expanded per step
 constexpr int SM_IDCAP = SM_WORDS * 32;  // ids one step can produce
-constexpr int SM_PAIRCAP = 1024;  // (pixel, face) pairs per evaluation window
+constexpr int SM_PAIRCAP = 512;   // (pixel, face) pairs per evaluation window
 constexpr int SM_SUBS = (TILE_W / SUB_W) * (TILE_H / SUB_H);  // 16 sub-tiles per tile
 
 template <typename T>
@@ -277,6 +277,7 @@ __global__ __launch_bounds__(64) void soft_search_kernel(
       }
       __syncthreads();
       unsigned long long hm = 0;
+#pragma unroll 8
       for (int k = 0; k < n; ++k) {
         const T xmin = s_bb[k * 4 + 0], ymin = s_bb[k * 4 + 1], xmax = s_bb[k * 4 + 2], ymax = s_bb[k * 4 + 3];
         const bool pass = !(x0 < xmin || x0 >= xmax || y0 < ymin || y0 >= ymax);
@@ -355,11 +356,11 @@ __global__ __launch_bounds__(64) void soft_search_kernel(
 
     int ncand = 0;
     bool done = false;
-    unsigned int next_word = lane < nwords ? tmask[lane] : 0u;
+    unsigned int next_word = (lane < SM_WORDS && lane < nwords) ? tmask[lane] : 0u;
     for (int w0 = 0; w0 < nwords && !done; w0 += SM_WORDS) {
       const int wi = w0 + lane;
       unsigned int word = next_word;
-      next_word = (wi + SM_WORDS < nwords) ? tmask[wi + SM_WORDS] : 0u;  // in flight while this step is processed
+      next_word = (lane < SM_WORDS && wi + SM_WORDS < nwords) ? tmask[wi + SM_WORDS] : 0u;  // in flight while this step is processed
       const int c = __popc(word);
       const int incl = wave_inclusive_scan(c);
       const int total = __shfl(incl, 63, 64);
@@ -660,7 +661,7 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
   KAMD_CHECK(hipGetLastError());
   if (total_faces > 0) {
     kamd::ProfScope prof_(kamd::K_SOFT_TILE, st);
-    const dim3 grid((unsigned)(n_sub < KAMD_NUM_CU * 8 ? n_sub : KAMD_NUM_CU * 8));
+    const dim3 grid((unsigned)(n_sub < KAMD_NUM_CU * 16 ? n_sub : KAMD_NUM_CU * 16));
     if (lean)
       hipLaunchKernelGGL((soft_search_kernel<T, true>), grid, dim3(64), 0, st, B, F, g, K, sigmainv, multiplier, rec,
                          masks, worklist, work, sel_idx, soft_mask, (T*)nullptr, (int64_t*)nullptr,

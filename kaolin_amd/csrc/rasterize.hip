@@ -146,19 +146,11 @@ __global__ __launch_bounds__(TILE_THREADS) void raster_tile_kernel(
 
 // ---- K2 -------------------------------------------------------------------------------------------------
 // Per covered pixel the reference issues 3*D + 6*D float atomics on addresses shared by every pixel of the same
-// face (rasterization_cuda.cu:283,391-398): the run time is atomic contention.  Here a wavefront owns a 16x4
-// pixel block, finds the distinct faces among its 64 pixels (ballot on the leader's face), sums each face's
-// 6 + 3*D values across its lanes with a butterfly, and one lane issues the atomics: ~64/faces-per-wave fewer
-// atomics and no same-address pile-up.  After RB_MAX_ROUNDS distinct faces (tiny faces: nothing to merge) the
-// remaining lanes fall back to their own atomics.
-constexpr int RB_MAX_ROUNDS = 12;
-
-template <typename T>
-__device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
-}
+// face (rasterization_cuda.cu:283,391-398): the run time is atomic contention (measured 2.4 ms for C4).  Here a
+// workgroup owns a 16x16-pixel block: every lane computes its pixel's 6 + 3*D contributions, finds / creates its
+// face's slot in an LDS hash table (one compare-and-swap) and adds them there with non-returning LDS atomics
+// (ds_add_f32: nothing to wait for); at the end one global atomic per touched (face, value) is issued.
+constexpr int RB_HT = 512;  // hash slots: a 256-pixel block holds at most 256 distinct faces
 
 // numerators of d(w1)/d(.) and d(w2)/d(.) for the six vertex coordinates (ax, ay, bx, by, cx, cy), and k3
 // (rasterization_cuda.cu:287-371); the common 1/k3^2 is applied by the caller
@@ -195,12 +187,17 @@ __device__ __forceinline__ T barycentric_jacobian(const T* v, T aw, T bw, T cw, 
   return k3;
 }
 
-// DT > 0: feature count known at compile time (values live in registers, wave-merged); DT == 0: any D, per-lane atomics
+// DT > 0: feature count known at compile time (block-merged through LDS); DT == 0: any D, per-lane global atomics
 template <typename T, int DT>
 __global__ __launch_bounds__(256) void raster_backward_kernel(
     int B, int H, int W, int F, int D, const T* __restrict__ grad, const int64_t* __restrict__ face_idx,
     const T* __restrict__ weights, const T* __restrict__ img, const T* __restrict__ feat, float eps,
     T* __restrict__ g_img, T* __restrict__ g_feat) {
+  constexpr int NV = DT > 0 ? 6 + 3 * DT : 6;
+  __shared__ int s_key[DT > 0 ? RB_HT : 1];
+  __shared__ T s_acc[DT > 0 ? RB_HT * NV : 1];
+  __shared__ int s_used[DT > 0 ? 256 : 1];
+  __shared__ int s_nused;
   // workgroup = 16x16 pixels of one image; wavefront = 16x4
   const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
   const int tile = blockIdx.x % (tiles_x * tiles_y), b = blockIdx.x / (tiles_x * tiles_y);
@@ -209,15 +206,18 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(
   const bool in_image = col < W && row < H;
   const size_t tp = ((size_t)b * H + row) * W + col;
   const int f = in_image ? (int)face_idx[tp] : -1;
-  unsigned long long todo = __ballot(f >= 0);
-  if (todo == 0) return;
-  const size_t tf = (size_t)b * F + (size_t)(f >= 0 ? f : 0);
-
-  constexpr int NV = DT > 0 ? 6 + 3 * DT : 6;
-  T vals[NV];
-#pragma unroll
-  for (int i = 0; i < NV; ++i) vals[i] = 0;
+  if (DT > 0) {
+    if (!__syncthreads_or(f >= 0)) return;  // nothing covered in this block
+    for (int i = threadIdx.x; i < RB_HT; i += 256) s_key[i] = -1;
+    for (int i = threadIdx.x; i < RB_HT * NV; i += 256) s_acc[i] = 0;
+    if (threadIdx.x == 0) s_nused = 0;
+    __syncthreads();
+  }
   if (f >= 0) {
+    const size_t tf = (size_t)b * F + (size_t)f;
+    T vals[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) vals[i] = 0;
     const T aw = weights[tp * 3 + 0], bw = weights[tp * 3 + 1], cw = weights[tp * 3 + 2];
     T dw1[6], dw2[6];
     const T k3 = barycentric_jacobian<T>(img + tf * 6, aw, bw, cw, eps, dw1, dw2);
@@ -240,35 +240,33 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(
         kamd_atomic_add(g_feat + (tf * 3 + 2) * D + d, (T)(gd * cw));
       }
     }
-  }
-
-  int rounds = 0;
-  while (todo) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const int lf = __shfl(f, leader, 64);
-    const bool mine = (f == lf);
-    const unsigned long long m = __ballot(mine);
-    todo &= ~m;
-    if (__popcll(m) == 1 || rounds >= RB_MAX_ROUNDS) {
-      if (mine) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) kamd_atomic_add(g_img + tf * 6 + j, vals[j]);
-#pragma unroll
-        for (int i = 6; i < NV; ++i) kamd_atomic_add(g_feat + tf * 3 * D + (i - 6), vals[i]);
+    if constexpr (DT > 0) {
+      int slot = (int)(((unsigned)f * 2654435761u) >> 23) & (RB_HT - 1);
+      for (;;) {  // the table is twice the number of pixels: an empty slot always exists
+        const int k = atomicCAS(&s_key[slot], -1, f);
+        if (k == -1) s_used[atomicAdd(&s_nused, 1)] = slot;
+        if (k == -1 || k == f) break;
+        slot = (slot + 1) & (RB_HT - 1);
       }
+#pragma unroll
+      for (int i = 0; i < NV; ++i) atomicAdd(&s_acc[slot * NV + i], vals[i]);
     } else {
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const T s = wave_sum<T>(mine ? vals[i] : (T)0);
-        if (lane == leader) {
-          if (i < 6)
-            kamd_atomic_add(g_img + tf * 6 + i, s);
-          else
-            kamd_atomic_add(g_feat + tf * 3 * D + (i - 6), s);
-        }
-      }
+      for (int j = 0; j < 6; ++j) kamd_atomic_add(g_img + tf * 6 + j, vals[j]);
     }
-    ++rounds;
+  }
+  if constexpr (DT > 0) {
+    __syncthreads();
+    const int nused = s_nused;
+    for (int i = threadIdx.x; i < nused * NV; i += 256) {
+      const int slot = s_used[i / NV], v = i % NV;
+      const size_t tf = (size_t)b * F + (size_t)s_key[slot];
+      const T val = s_acc[slot * NV + v];
+      if (v < 6)
+        kamd_atomic_add(g_img + tf * 6 + v, val);
+      else
+        kamd_atomic_add(g_feat + tf * 3 * D + (v - 6), val);
+    }
   }
 }
 
