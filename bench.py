@@ -89,16 +89,19 @@ def main():
     g = torch.Generator().manual_seed(0)
     uv = torch.rand((1, F, 3, 2), generator=g).to(dev).expand(V, -1, -1, -1).contiguous()
     ones = torch.ones((V, F, 3, 1), device=dev)
+    feats3 = torch.cat([uv, ones], dim=-1).contiguous()   # D = 3 (uv + mask channel, as in the tutorial), static input
     G1 = torch.rand((V, H, W, 3), generator=g).to(dev)
     G2 = torch.rand((V, H, W), generator=g).to(dev)
+    G1f, G2f = G1.reshape(-1), G2.reshape(-1)
 
     def dibr_step():
         verts.grad = None
         fv_cam, fv_img, normals = kal.render.mesh.prepare_vertices(
             verts.unsqueeze(0).expand(V, -1, -1), faces, proj, camera_rot=rot, camera_trans=trans)
-        (f_uv, f_one), soft, face_idx = kal.render.mesh.dibr_rasterization(
-            H, W, fv_cam[..., 2], fv_img, [uv, ones], normals[..., 2])
-        loss = (f_uv * G1[..., :2]).sum() + (f_one * G1[..., 2:]).sum() + (soft * G2).sum()
+        feat, soft, face_idx = kal.render.mesh.dibr_rasterization(
+            H, W, fv_cam[..., 2], fv_img, feats3, normals[..., 2])
+        # (features * G1).sum() + (soft_mask * G2).sum(), written as two dot products (one pass each way)
+        loss = torch.dot(feat.reshape(-1), G1f) + torch.dot(soft.reshape(-1), G2f)
         loss.backward()
         D.all_reduce_gradients([verts])
         return face_idx
@@ -198,7 +201,7 @@ def main():
                 verts.detach().unsqueeze(0), faces, proj, camera_rot=rot[:1], camera_trans=trans[:1])
         sH = sW = 256
         fz, fimg, nz = fv_cam[..., 2].cpu(), fv_img.cpu(), normals[..., 2].cpu()
-        feat = torch.cat([uv[:1], ones[:1]], -1).cpu()
+        feat = feats3[:1].cpu()
         t0 = time.perf_counter()
         ref = oracle.dibr_rasterization(sH, sW, fz, fimg, feat, nz, omp=True)
         oracle.rasterize_backward(torch.ones_like(ref['features']), ref['face_idx'], ref['weights'], fimg, feat, 1e-8)

@@ -424,7 +424,7 @@ __global__ __launch_bounds__(64) void soft_search_kernel(
 // face's vertices with global atomics (dibr_soft_mask_cuda.cu:299-302,339-347); a silhouette face receives
 // hundreds of them.  Here the wavefront first sums per face in an LDS hash table (ds_add_f32), then flushes one
 // global atomic per touched (face, coordinate).
-constexpr int SB_HT = 1024;  // hash slots (a wavefront rarely sees more than ~200 distinct faces)
+constexpr int SB_HT = 512;  // hash slots (a sub-tile rarely sees more than ~300 distinct faces; overflow -> global atomics)
 
 template <typename T>
 __device__ __forceinline__ void sb_accumulate(int* s_key, T* s_acc, T* __restrict__ g_face, int f, int off, T v) {
@@ -681,7 +681,7 @@ int soft_mask_backward_list_launch(hipStream_t st, int B, int H, int W, int F, i
   if ((long long)B * H * W <= 0 || F <= 0) return 0;
   {
     kamd::ProfScope prof_(kamd::K_SOFT_BACKWARD, st);
-    hipLaunchKernelGGL(soft_mask_backward_list_kernel<T>, dim3(KAMD_NUM_CU * 8), dim3(SL_THREADS), 0, st, H, W, F, K, grad,
+    hipLaunchKernelGGL(soft_mask_backward_list_kernel<T>, dim3(KAMD_NUM_CU * 10), dim3(SL_THREADS), 0, st, H, W, F, K, grad,
                        soft_mask, list, img, (T)img_scale, sigmainv, multiplier, g_img);
   }
   KAMD_RETURN_LAST_ERROR();

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(TILE_THREADS) void raster_tile_kernel(
 // workgroup owns a 16x16-pixel block: every lane computes its pixel's 6 + 3*D contributions, finds / creates its
 // face's slot in an LDS hash table (one compare-and-swap) and adds them there with non-returning LDS atomics
 // (ds_add_f32: nothing to wait for); at the end one global atomic per touched (face, value) is issued.
-constexpr int RB_HT = 512;  // hash slots: a 256-pixel block holds at most 256 distinct faces
+constexpr int RB_HT = 256;  // hash slots = pixels per block: every face finds a slot (linear probing terminates)
 
 // numerators of d(w1)/d(.) and d(w2)/d(.) for the six vertex coordinates (ax, ay, bx, by, cx, cy), and k3
 // (rasterization_cuda.cu:287-371); the common 1/k3^2 is applied by the caller
