@@ -60,6 +60,7 @@ def algorithmic_bytes(kernel, B, P, F, Fv, D, K, esz=4):
         'soft_search_kernel': P * (8 + esz) + F * 10 * esz,
         'soft_classify_kernel': P * (8 + esz),
         'soft_mask_backward_kernel': P * (8 + 2 * esz) + F * 6 * esz * 2,
+        'soft_mask_backward_list_kernel': P * (2 * esz) + F * 6 * esz * 2,
         'bin_faces_kernel': F * (13 * esz + 16 * esz),
     }
     return B * per[kernel] if kernel in per else None
@@ -148,7 +149,9 @@ def main():
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
     if dom and os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get(dom)
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, calibrated on launches of
+        # known size: tools/pmc_traffic.py, tools/parse_traffic.py, raw tables in profiles/r01b_pmc_*.txt)
+        traffic = (json.load(open(tpath)).get(dom) or {}).get('hbm_bytes')
     roofline = None
     if dom:
         roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': kernels[dom]['algorithmic_GBps'], 'peak': HBM_PEAK_GBS,
@@ -199,20 +202,32 @@ def main():
         with torch.no_grad():
             fv_cam, fv_img, normals = kal.render.mesh.prepare_vertices(
                 verts.detach().unsqueeze(0), faces, proj, camera_rot=rot[:1], camera_trans=trans[:1])
-        sH = sW = 256
         fz, fimg, nz = fv_cam[..., 2].cpu(), fv_img.cpu(), normals[..., 2].cpu()
         feat = feats3[:1].cpu()
-        t0 = time.perf_counter()
-        ref = oracle.dibr_rasterization(sH, sW, fz, fimg, feat, nz, omp=True)
-        oracle.rasterize_backward(torch.ones_like(ref['features']), ref['face_idx'], ref['weights'], fimg, feat, 1e-8)
-        oracle.dibr_soft_mask_backward(torch.ones_like(ref['soft_mask']), ref['soft_mask'], ref['face_idx'],
-                                       ref['close_face_prob'], ref['close_face_idx'], ref['close_face_dist_type'],
-                                       ref['scaled_vertices'], 7000, 1000.)
-        cdt = time.perf_counter() - t0
-        cpu = {'value': round(sH * sW / cdt / 1e6, 4), 'unit': 'Mpixels/s', 'cores': oracle.num_threads(True),
+
+        def cpu_pass(res):
+            t0 = time.perf_counter()
+            ref = oracle.dibr_rasterization(res, res, fz, fimg, feat, nz, omp=True)
+            oracle.rasterize_backward(torch.ones_like(ref['features']), ref['face_idx'], ref['weights'], fimg, feat, 1e-8)
+            oracle.dibr_soft_mask_backward(torch.ones_like(ref['soft_mask']), ref['soft_mask'], ref['face_idx'],
+                                           ref['close_face_prob'], ref['close_face_idx'], ref['close_face_dist_type'],
+                                           ref['scaled_vertices'], 7000, 1000.)
+            return time.perf_counter() - t0
+
+        probe = cpu_pass(128)                                  # sizes the sample for ~15 s of CPU work
+        sres = int(min(1024, max(128, 128 * math.sqrt(15.0 / max(probe, 1e-3)))) // 32 * 32)
+        cdt = cpu_pass(sres)
+        reps = 1
+        if sres == 1024 and cdt < 10.0:                        # many host cores: repeat the view until ~12 s are spent
+            more = min(int(math.ceil(12.0 / cdt)) - 1, 15)
+            for _ in range(more):
+                cdt += cpu_pass(sres)
+            reps += more
+        cpu = {'value': round(reps * sres * sres / cdt / 1e6, 4), 'unit': 'Mpixels/s', 'cores': oracle.num_threads(True),
                'kind': 'port',
-               'sample': f'1 view of the same {F}-triangle mesh at {sH}x{sW} (the brute-force reference algorithm costs '
-                         f'O(faces) per pixel at any resolution), oracle forward (OpenMP) + both backwards, {cdt:.1f} s'}
+               'sample': f'{reps} pass(es) over 1 view of the same {F}-triangle mesh at {sres}x{sres} (the brute-force reference algorithm costs '
+                         f'O(faces) per pixel at any resolution), oracle forward (OpenMP over pixels) + both backward passes '
+                         f'(single thread), {cdt:.1f} s'}
 
     if rank == 0:
         out = {
