@@ -186,13 +186,23 @@ def main():
         lib.kamd_profile_enable(0)
         cprof = _lib.kernel_profile(reset=True)
         pairs = 2.0 * world * n * n * args.steps
-        main_ms, main_n = cprof.get('sd_main_f32', (0.0, 1))
-        chamfer = {'metric': 'Mpoint-pairs/s chamfer fwd+bwd', 'value': round(pairs / cdt / 1e6, 1),
-                   'ms_per_step': round(cdt / args.steps * 1e3, 4), 'points': n,
-                   'sd_main_avg_us': round(main_ms / max(main_n, 1) * 1e3, 2),
-                   # 6.7 VALU lane-ops per pair in sd_main_f32 (kaolin_amd/csrc/sided_distance.hip header)
-                   'valu_Tlaneops_per_s': round(6.7 * n * n / (main_ms / max(main_n, 1) * 1e-3) / 1e12, 2) if main_ms else None,
+        chamfer = {'metric': 'Mpoint-pairs/s chamfer fwd+bwd (effective pairs = 2*N*M per item; the exact grid search '
+                             'evaluates far fewer and returns the brute-force-identical result)',
+                   'value': round(pairs / cdt / 1e6, 1), 'ms_per_step': round(cdt / args.steps * 1e3, 4), 'points': n,
+                   'kernels_avg_us': {k: round(v[0] / v[1] * 1e3, 2) for k, v in cprof.items()},
                    'hbm_frac_of_8TBps': round(192.0 * n / (cdt / args.steps) / 1e9 / HBM_PEAK_GBS, 6)}
+        # the all-pairs kernels for comparison (VALU-bound: 6.7 lane-ops per pair, sided_distance.hip header)
+        os.environ['KAMD_SIDED_DISTANCE'] = 'brute'
+        lib.kamd_profile_reset()
+        lib.kamd_profile_enable(1)
+        bdt = timed(chamfer_step, max(args.steps // 4, 2), 2)
+        lib.kamd_profile_enable(0)
+        bprof = _lib.kernel_profile(reset=True)
+        del os.environ['KAMD_SIDED_DISTANCE']
+        main_ms, main_n = bprof.get('sd_main_f32', (0.0, 1))
+        chamfer['brute_force'] = {'value': round(2.0 * world * n * n * max(args.steps // 4, 2) / bdt / 1e6, 1),
+                                  'sd_main_avg_us': round(main_ms / max(main_n, 1) * 1e3, 2),
+                                  'valu_Tlaneops_per_s': round(6.7 * n * n / (main_ms / max(main_n, 1) * 1e-3) / 1e12, 2) if main_ms else None}
 
     # ---------------- CPU baseline: the oracle (OpenMP) on a bounded sample, rank 0 at N = 1 only
     cpu = None

@@ -25,7 +25,9 @@
 //     chunk with the identical arithmetic (kernel sd_final_f32).
 // That is 6.7 VALU/pair instead of 9 for the compare+2xselect formulation.
 #include "common.h"
+#include <stdlib.h>
 #include "profile.h"
+#include "sided_distance_grid.h"
 #include "../../include/kaolin_amd.h"
 
 namespace {
@@ -308,12 +310,19 @@ int sd_backward_launch(hipStream_t st, int B, int N, int M, const T* grad, const
   KAMD_RETURN_LAST_ERROR();
 }
 
+// KAMD_SIDED_DISTANCE=brute keeps the all-pairs kernels for every size (A/B timing, tests of both paths)
+inline bool sd_force_brute() {
+  const char* e = getenv("KAMD_SIDED_DISTANCE");
+  return e != nullptr && e[0] == 'b';
+}
+
 }  // namespace
 
 extern "C" {
 
 size_t kamd_sided_distance_forward_workspace(int B, int N, int M, int elem_size) {
   if (elem_size != 4 || B <= 0 || N <= 0 || M <= 0) return 0;
+  if (kamd::sdgrid_applicable(B, N, M) && !sd_force_brute()) return kamd::sdgrid_workspace_bytes(B, N, M);
   SdPlan p = sd_plan(B, N, M);
   if (!p.fast) return 0;
   return (size_t)p.S * B * N * (sizeof(float) + sizeof(int));
@@ -323,6 +332,8 @@ int kamd_sided_distance_forward_f32(void* stream, int B, int N, int M, const flo
                                     float* dist, int64_t* idx, void* workspace) {
   hipStream_t st = (hipStream_t)stream;
   if (B <= 0 || N <= 0 || M <= 0) return 0;
+  if (workspace != nullptr && kamd::sdgrid_applicable(B, N, M) && !sd_force_brute())
+    return kamd::sdgrid_forward_f32(st, B, N, M, p1, p2, dist, idx, workspace);
   SdPlan p = sd_plan(B, N, M);
   if (!p.fast || workspace == nullptr) return sd_forward_generic_launch<float>(st, B, N, M, p1, p2, dist, idx);
   float* part_d = (float*)workspace;

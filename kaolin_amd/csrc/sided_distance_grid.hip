@@ -1,0 +1,338 @@
+// sided_distance forward, exact uniform-grid search (fp32) for MI355X (gfx950).
+//
+// The reference (kaolin/csrc/metrics/sided_distance_cuda.cu:52-201) is an all-pairs search: N*M distance
+// evaluations against 24*(N+M) bytes of input, 8 300 FLOP/B at 100k x 100k -- VALU-bound by construction
+// (sd_main_f32 already issues at 97 % of the measured FMA peak).  The only way to go faster is to evaluate fewer
+// pairs while returning the SAME answer: dist = min_j d(p1_i, p2_j) with the identical fp32 expression
+// d = fma(dz,dz, fma(dy,dy, dx*dx)), idx = the lowest j attaining it, and a NaN distance to target 0 sticking
+// (the reference's `k == 0 ||` seed).  A uniform grid over the targets does that:
+//   1. sdg_bbox      bounding box of the finite targets (per batch item), in partials;
+//   2. sdg_cells     cell id of every target and every query; per-cell counts (atomicAdd);
+//   3. sdg_scan      exclusive scan of the counts (one workgroup per batch item and array);
+//   4. sdg_scatter   counting-sort scatter: targets as float4 {x, y, z, original index}; queries as an index list in
+//                    cell order, so that the 64 queries of a wavefront are spatial neighbours (same cells, same lines);
+//   5. sdg_query     per query: seed with target 0 exactly as the reference does, then visit the cube of cells around
+//                    the query ring by ring; after each ring every unvisited target is provably farther than the
+//                    distance from the query to the cube's faces (minus a rounding margin), so the search stops as soon
+//                    as the best distance is below that bound.  Ties are resolved towards the lower original index
+//                    explicitly, so the arbitrary order inside a cell does not matter.
+// Work per query is O(points in a few cells) instead of O(M); the result is bit-identical to the brute-force kernels
+// (tests/test_sided_distance.py compares both with the oracle, incl. duplicates, NaNs, queries outside the box,
+// degenerate boxes).  Non-finite targets are binned at a clamped cell: they yield NaN/inf distances that can never win
+// against a finite one, as in the reference.
+#include "common.h"
+#include "profile.h"
+#include "sided_distance_grid.h"
+
+namespace kamd {
+namespace {
+
+constexpr int SDG_MAXG = 128;      // cells per axis at most
+constexpr int SDG_NB = 64;         // bbox partial blocks per batch item
+
+struct SdgGeom {
+  int G, NC;
+};
+inline SdgGeom sdg_geom(int M) {
+  // ~2 targets per cell on average for a volume-filling cloud; surfaces leave most cells empty, which is fine
+  int G = (int)floor(cbrt((double)M / 2.0) + 0.5);
+  if (G < 1) G = 1;
+  if (G > SDG_MAXG) G = SDG_MAXG;
+  return SdgGeom{G, G * G * G};
+}
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct SdgWs {
+  float* bbox_part;   // B * SDG_NB * 6
+  int* t_count;       // B * (NC + 1)   counts -> starts (after the scan)
+  int* q_count;       // B * (NC + 1)
+  int* t_fill;        // B * NC
+  int* q_fill;        // B * NC
+  int* t_cell;        // B * M
+  int* q_cell;        // B * N
+  float4* t_sorted;   // B * M
+  int* q_sorted;      // B * N
+  size_t zero_bytes;  // prefix of the workspace that must be zeroed (counts + fills)
+  size_t total;
+};
+inline SdgWs sdg_layout(void* base, int B, int N, int M) {
+  const SdgGeom g = sdg_geom(M);
+  SdgWs w;
+  char* p = (char*)base;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* r = p + off;
+    off += al(bytes);
+    return r;
+  };
+  w.t_count = (int*)take((size_t)B * (g.NC + 1) * 4);
+  w.q_count = (int*)take((size_t)B * (g.NC + 1) * 4);
+  w.t_fill = (int*)take((size_t)B * g.NC * 4);
+  w.q_fill = (int*)take((size_t)B * g.NC * 4);
+  w.zero_bytes = off;
+  w.bbox_part = (float*)take((size_t)B * SDG_NB * 6 * 4);
+  w.t_cell = (int*)take((size_t)B * M * 4);
+  w.q_cell = (int*)take((size_t)B * N * 4);
+  w.t_sorted = (float4*)take((size_t)B * M * 16);
+  w.q_sorted = (int*)take((size_t)B * N * 4);
+  w.total = off;
+  return w;
+}
+
+// ---- 1. bounding box partials ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sdg_bbox(int M, const float* __restrict__ p2, float* __restrict__ part) {
+  __shared__ float s[6][256];
+  const int b = blockIdx.y;
+  const float* P = p2 + (size_t)b * M * 3;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < M; i += gridDim.x * 256) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float v = P[(size_t)i * 3 + a];
+      if (isfinite(v)) {
+        lo[a] = fminf(lo[a], v);
+        hi[a] = fmaxf(hi[a], v);
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    s[a][threadIdx.x] = lo[a];
+    s[3 + a][threadIdx.x] = hi[a];
+  }
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if (threadIdx.x < d) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        s[a][threadIdx.x] = fminf(s[a][threadIdx.x], s[a][threadIdx.x + d]);
+        s[3 + a][threadIdx.x] = fmaxf(s[3 + a][threadIdx.x], s[3 + a][threadIdx.x + d]);
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 6) part[((size_t)b * SDG_NB + blockIdx.x) * 6 + threadIdx.x] = s[threadIdx.x][0];
+}
+
+struct Box {
+  float lo[3], size[3], inv[3];  // origin, cell size, 1 / cell size per axis
+};
+// every consumer re-reduces the <= 64 partials (a few hundred bytes from L2) into the grid geometry
+__device__ __forceinline__ Box sdg_box(const float* __restrict__ part, int b, int nb, int G) {
+  Box bx;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float lo = INFINITY, hi = -INFINITY;
+    for (int k = 0; k < nb; ++k) {
+      lo = fminf(lo, part[((size_t)b * SDG_NB + k) * 6 + a]);
+      hi = fmaxf(hi, part[((size_t)b * SDG_NB + k) * 6 + 3 + a]);
+    }
+    if (!(lo <= hi)) {  // no finite target on this axis
+      lo = 0.f;
+      hi = 0.f;
+    }
+    float size = (hi - lo) / (float)G;
+    if (!(size > 0.f) || !isfinite(size)) size = 1.f;  // degenerate extent: a single slab holds everything
+    bx.lo[a] = lo;
+    bx.size[a] = size;
+    bx.inv[a] = 1.f / size;
+  }
+  return bx;
+}
+__device__ __forceinline__ int sdg_axis_cell(float v, float lo, float inv, int G) {
+  const float t = (v - lo) * inv;
+  int c = (t >= 0.f) ? (t < (float)G ? (int)t : G - 1) : 0;  // NaN -> 0, +-inf -> clamped
+  return c;
+}
+
+// ---- 2. cell ids + counts ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sdg_cells(int n, int nb, int G, const float* __restrict__ pts,
+                                                 const float* __restrict__ part, int* __restrict__ cell,
+                                                 int* __restrict__ count) {
+  __shared__ Box s_box;
+  const int b = blockIdx.y;
+  if (threadIdx.x == 0) s_box = sdg_box(part, b, nb, G);
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* P = pts + ((size_t)b * n + i) * 3;
+  const int cx = sdg_axis_cell(P[0], s_box.lo[0], s_box.inv[0], G);
+  const int cy = sdg_axis_cell(P[1], s_box.lo[1], s_box.inv[1], G);
+  const int cz = sdg_axis_cell(P[2], s_box.lo[2], s_box.inv[2], G);
+  const int c = (cz * G + cy) * G + cx;
+  cell[(size_t)b * n + i] = c;
+  atomicAdd(count + (size_t)b * (G * G * G + 1) + c, 1);
+}
+
+// ---- 3. exclusive scan of NC counts (in place; entry NC receives the total) ------------------------------------
+__global__ __launch_bounds__(1024) void sdg_scan(int NC, int* __restrict__ t_count, int* __restrict__ q_count) {
+  __shared__ int s_wave[16];
+  __shared__ int s_carry;
+  int* cnt = (blockIdx.y == 0 ? t_count : q_count) + (size_t)blockIdx.x * (NC + 1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < NC; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < NC ? cnt[i] : 0;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_wave[w];
+    const int carry = s_carry;
+    if (i < NC) cnt[i] = carry + woff + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = carry + woff + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cnt[NC] = s_carry;
+}
+
+// ---- 4. counting-sort scatter ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sdg_scatter_targets(int M, int NC, const float* __restrict__ p2,
+                                                           const int* __restrict__ cell, const int* __restrict__ start,
+                                                           int* __restrict__ fill, float4* __restrict__ sorted) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  const int c = cell[(size_t)b * M + i];
+  const int pos = start[(size_t)b * (NC + 1) + c] + atomicAdd(fill + (size_t)b * NC + c, 1);
+  const float* P = p2 + ((size_t)b * M + i) * 3;
+  sorted[(size_t)b * M + pos] = make_float4(P[0], P[1], P[2], __int_as_float(i));
+}
+__global__ __launch_bounds__(256) void sdg_scatter_queries(int N, int NC, const int* __restrict__ cell,
+                                                           const int* __restrict__ start, int* __restrict__ fill,
+                                                           int* __restrict__ sorted) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const int c = cell[(size_t)b * N + i];
+  const int pos = start[(size_t)b * (NC + 1) + c] + atomicAdd(fill + (size_t)b * NC + c, 1);
+  sorted[(size_t)b * N + pos] = i;
+}
+
+// ---- 5. query ----------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sdg_dist(float tx, float ty, float tz, float qx, float qy, float qz) {
+  const float dx = tx - qx, dy = ty - qy, dz = tz - qz;
+  return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+
+__global__ __launch_bounds__(256) void sdg_query(int N, int M, int nb, int G, const float* __restrict__ p1,
+                                                 const float* __restrict__ p2, const float* __restrict__ part,
+                                                 const int* __restrict__ q_sorted, const int* __restrict__ q_cell,
+                                                 const int* __restrict__ t_start, const float4* __restrict__ t_sorted,
+                                                 float* __restrict__ dist, int64_t* __restrict__ idx) {
+  __shared__ Box s_box;
+  const int b = blockIdx.y;
+  if (threadIdx.x == 0) s_box = sdg_box(part, b, nb, G);
+  __syncthreads();
+  const int slot = blockIdx.x * 256 + threadIdx.x;
+  if (slot >= N) return;
+  const int NC = G * G * G;
+  const int qi = q_sorted[(size_t)b * N + slot];
+  const float* Q = p1 + ((size_t)b * N + qi) * 3;
+  const float qx = Q[0], qy = Q[1], qz = Q[2];
+  const float* T0 = p2 + (size_t)b * M * 3;
+  // the reference's seed: target 0 unconditionally (a NaN distance sticks)
+  float best = sdg_dist(T0[0], T0[1], T0[2], qx, qy, qz);
+  int best_i = 0;
+  if (best == best) {
+    const int c = q_cell[(size_t)b * N + qi];
+    const int cx = c % G, cy = (c / G) % G, cz = c / (G * G);
+    const int* start = t_start + (size_t)b * (NC + 1);
+    const float4* TS = t_sorted + (size_t)b * M;
+    // rounding head-room of the geometric bound: cell membership is decided by a rounded (v - lo) * inv
+    const float q[3] = {qx, qy, qz};
+    float slack[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) slack[a] = 4e-6f * (fabsf(q[a]) + fabsf(s_box.lo[a]) + s_box.size[a] * (float)G);
+    const int cq[3] = {cx, cy, cz};
+    for (int r = 0; r < G; ++r) {
+      const int z0 = max(cz - r, 0), z1 = min(cz + r, G - 1);
+      const int y0 = max(cy - r, 0), y1 = min(cy + r, G - 1);
+      const int x0 = max(cx - r, 0), x1 = min(cx + r, G - 1);
+      for (int z = z0; z <= z1; ++z)
+        for (int y = y0; y <= y1; ++y) {
+          const bool shell_row = (abs(z - cz) == r) || (abs(y - cy) == r);
+          // on a shell row every x is new; otherwise only the two end cells are
+          const int step = shell_row ? 1 : max(x1 - x0, 1);
+          for (int x = x0; x <= x1; x += step) {
+            if (!shell_row && abs(x - cx) != r) continue;
+            const int cc = (z * G + y) * G + x;
+            const int e = start[cc + 1];
+            for (int k = start[cc]; k < e; ++k) {
+              const float4 t = TS[k];
+              const float d = sdg_dist(t.x, t.y, t.z, qx, qy, qz);
+              const int ti = __float_as_int(t.w);
+              if (d < best || (d == best && ti < best_i)) {
+                best = d;
+                best_i = ti;
+              }
+            }
+          }
+        }
+      // every target outside the cube of cells [c - r, c + r] is at least `bound` away from the query
+      float bound = INFINITY;
+      bool whole_grid = true;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        if (cq[a] - r > 0) {
+          whole_grid = false;
+          bound = fminf(bound, q[a] - (s_box.lo[a] + (float)(cq[a] - r) * s_box.size[a]) - slack[a]);
+        }
+        if (cq[a] + r < G - 1) {
+          whole_grid = false;
+          bound = fminf(bound, (s_box.lo[a] + (float)(cq[a] + r + 1) * s_box.size[a]) - q[a] - slack[a]);
+        }
+      }
+      if (whole_grid) break;
+      if (bound > 0.f && best < bound * bound * 0.99999f) break;
+    }
+  }
+  dist[(size_t)b * N + qi] = best;
+  idx[(size_t)b * N + qi] = best_i;
+}
+
+}  // namespace
+
+bool sdgrid_applicable(int B, int N, int M) {
+  // below this the brute-force kernels are as fast as the seven launches of the grid pipeline
+  return B >= 1 && M >= 8192 && N >= 2048 && (long long)B * (long long)(M > N ? M : N) < (1ll << 30);
+}
+size_t sdgrid_workspace_bytes(int B, int N, int M) { return sdg_layout(nullptr, B, N, M).total; }
+
+int sdgrid_forward_f32(hipStream_t st, int B, int N, int M, const float* p1, const float* p2, float* dist, int64_t* idx,
+                       void* workspace) {
+  const SdgGeom g = sdg_geom(M);
+  const SdgWs w = sdg_layout(workspace, B, N, M);
+  const int nb = kamd_cdiv(M, 4096) < SDG_NB ? kamd_cdiv(M, 4096) : SDG_NB;
+  KAMD_CHECK(hipMemsetAsync(workspace, 0, w.zero_bytes, st));
+  {
+    ProfScope p(K_SDG_BUILD, st);
+    hipLaunchKernelGGL(sdg_bbox, dim3(nb, B), dim3(256), 0, st, M, p2, w.bbox_part);
+    hipLaunchKernelGGL(sdg_cells, dim3(kamd_cdiv(M, 256), B), dim3(256), 0, st, M, nb, g.G, p2, w.bbox_part, w.t_cell,
+                       w.t_count);
+    hipLaunchKernelGGL(sdg_cells, dim3(kamd_cdiv(N, 256), B), dim3(256), 0, st, N, nb, g.G, p1, w.bbox_part, w.q_cell,
+                       w.q_count);
+    hipLaunchKernelGGL(sdg_scan, dim3(B, 2), dim3(1024), 0, st, g.NC, w.t_count, w.q_count);
+    hipLaunchKernelGGL(sdg_scatter_targets, dim3(kamd_cdiv(M, 256), B), dim3(256), 0, st, M, g.NC, p2, w.t_cell, w.t_count,
+                       w.t_fill, w.t_sorted);
+    hipLaunchKernelGGL(sdg_scatter_queries, dim3(kamd_cdiv(N, 256), B), dim3(256), 0, st, N, g.NC, w.q_cell, w.q_count,
+                       w.q_fill, w.q_sorted);
+  }
+  KAMD_CHECK(hipGetLastError());
+  {
+    ProfScope p(K_SDG_QUERY, st);
+    hipLaunchKernelGGL(sdg_query, dim3(kamd_cdiv(N, 256), B), dim3(256), 0, st, N, M, nb, g.G, p1, p2, w.bbox_part, w.q_sorted,
+                       w.q_cell, w.t_count, w.t_sorted, dist, idx);
+  }
+  KAMD_RETURN_LAST_ERROR();
+}
+
+}  // namespace kamd

@@ -234,3 +234,65 @@ def test_full_size_properties_100k():
     perm = torch.randperm(100000, device='cuda')
     dp, ip = pc.sided_distance(p1[:, perm], p2)
     assert torch.equal(dp, d[:, perm]) and torch.equal(ip, i[:, perm])
+
+
+def _clouds(kind, B, N, M, seed):
+    g = torch.Generator().manual_seed(seed)
+    if kind == 'uniform':
+        return torch.rand(B, N, 3, generator=g), torch.rand(B, M, 3, generator=g)
+    if kind == 'clustered':   # 20 tight gaussian clusters + far outliers, queries partly far outside the target box
+        c = torch.rand(20, 3, generator=g) * 10
+        p2 = c[torch.randint(0, 20, (B, M), generator=g)] + torch.randn(B, M, 3, generator=g) * 0.01
+        p1 = c[torch.randint(0, 20, (B, N), generator=g)] + torch.randn(B, N, 3, generator=g) * 0.5
+        p1[:, ::7] += 100.
+        return p1, p2
+    if kind == 'surface':     # points on a sphere (most grid cells empty), queries inside and outside
+        d = torch.randn(B, M, 3, generator=g)
+        p2 = d / d.norm(dim=-1, keepdim=True)
+        p1 = torch.randn(B, N, 3, generator=g)
+        return p1, p2
+    if kind == 'flat':        # degenerate box: all targets share z; duplicated targets (ties)
+        p2 = torch.rand(B, M // 2, 3, generator=g)
+        p2[..., 2] = 0.25
+        p2 = torch.cat([p2, p2], dim=1)
+        p1 = torch.rand(B, N, 3, generator=g)
+        return p1, p2
+    raise ValueError(kind)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['uniform', 'clustered', 'surface', 'flat'])
+@pytest.mark.parametrize('shape', [(1, 20000, 30011), (3, 2048, 8192), (2, 5000, 100000)])
+def test_grid_search_bit_exact_vs_oracle(kind, shape):
+    """fp32, M >= 8192 and N >= 2048 take the exact uniform-grid search (sided_distance_grid.hip): dist and idx must
+    be bit-identical to the all-pairs oracle whatever the point distribution."""
+    pc = _pc()
+    B, N, M = shape
+    p1, p2 = _clouds(kind, B, N, M, seed=N + M)
+    d_ref, i_ref = oracle.sided_distance_forward(p1, p2, omp=True)
+    d, i = pc.sided_distance(p1.cuda(), p2.cuda())
+    assert torch.equal(i.cpu(), i_ref)
+    assert torch.equal(d.cpu(), d_ref)
+
+
+@pytest.mark.gpu
+def test_grid_search_nonfinite_and_brute_force_switch():
+    """NaN / inf handling of the grid path equals the reference's seed semantics; KAMD_SIDED_DISTANCE=brute keeps the
+    all-pairs kernels, and both paths agree bit for bit."""
+    pc = _pc()
+    torch.manual_seed(5)
+    p1, p2 = torch.rand(2, 4000, 3), torch.rand(2, 9000, 3)
+    p2[0, 0, 1] = float('nan')          # NaN distance to target 0 sticks for the whole batch item 0
+    p2[1, 17, 0] = float('nan')         # a NaN target elsewhere never wins
+    p2[1, 23, 2] = float('inf')
+    p1[1, 5, 0] = float('nan')          # a NaN query: NaN distance to target 0 -> (NaN, 0)
+    d_ref, i_ref = oracle.sided_distance_forward(p1, p2, omp=True)
+    d, i = pc.sided_distance(p1.cuda(), p2.cuda())
+    assert torch.equal(i.cpu(), i_ref)
+    assert torch.equal(torch.isnan(d.cpu()), torch.isnan(d_ref)) and torch.equal(torch.nan_to_num(d.cpu()), torch.nan_to_num(d_ref))
+    os.environ['KAMD_SIDED_DISTANCE'] = 'brute'
+    try:
+        d2, i2 = pc.sided_distance(p1.cuda(), p2.cuda())
+    finally:
+        del os.environ['KAMD_SIDED_DISTANCE']
+    assert torch.equal(i2, i) and torch.equal(torch.nan_to_num(d2), torch.nan_to_num(d))
