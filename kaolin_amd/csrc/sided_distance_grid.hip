@@ -7,7 +7,7 @@
 // d = fma(dz,dz, fma(dy,dy, dx*dx)), idx = the lowest j attaining it, and a NaN distance to target 0 sticking
 // (the reference's `k == 0 ||` seed).  A uniform grid over the targets does that:
 //   1. sdg_bbox      bounding box of the finite targets (per batch item), in partials;
-//   2. sdg_cells     cell id of every target and every query; per-cell counts (atomicAdd);
+//   2. sdg_cells     cell id of every target and every query; per-cell counts (atomicAdd); one launch for both;
 //   3. sdg_scan      exclusive scan of the counts (one workgroup per batch item and array);
 //   4. sdg_scatter   counting-sort scatter: targets as float4 {x, y, z, original index}; queries as an index list in
 //                    cell order, so that the 64 queries of a wavefront are spatial neighbours (same cells, same lines);
@@ -52,6 +52,7 @@ struct SdgWs {
   int* q_cell;        // B * N
   float4* t_sorted;   // B * M
   int* q_sorted;      // B * N
+  int* scan_sums;     // 2 * B * ceil(NC / 1024)
   size_t zero_bytes;  // prefix of the workspace that must be zeroed (counts + fills)
   size_t total;
 };
@@ -75,6 +76,7 @@ inline SdgWs sdg_layout(void* base, int B, int N, int M) {
   w.q_cell = (int*)take((size_t)B * N * 4);
   w.t_sorted = (float4*)take((size_t)B * M * 16);
   w.q_sorted = (int*)take((size_t)B * N * 4);
+  w.scan_sums = (int*)take((size_t)2 * B * ((g.NC + 1023) / 1024) * 4);
   w.total = off;
   return w;
 }
@@ -145,76 +147,95 @@ __device__ __forceinline__ int sdg_axis_cell(float v, float lo, float inv, int G
   return c;
 }
 
-// ---- 2. cell ids + counts ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sdg_cells(int n, int nb, int G, const float* __restrict__ pts,
-                                                 const float* __restrict__ part, int* __restrict__ cell,
-                                                 int* __restrict__ count) {
+// ---- 2. cell ids + counts (targets and queries in one launch) ------------------------------------------------
+__global__ __launch_bounds__(256) void sdg_cells(int M, int N, int nb, int G, const float* __restrict__ p2,
+                                                 const float* __restrict__ p1, const float* __restrict__ part,
+                                                 int* __restrict__ t_cell, int* __restrict__ q_cell,
+                                                 int* __restrict__ t_count, int* __restrict__ q_count) {
   __shared__ Box s_box;
   const int b = blockIdx.y;
   if (threadIdx.x == 0) s_box = sdg_box(part, b, nb, G);
   __syncthreads();
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int mb = (M + 255) / 256;
+  const bool is_t = (int)blockIdx.x < mb;
+  const int n = is_t ? M : N;
+  const int i = (is_t ? blockIdx.x : blockIdx.x - mb) * 256 + threadIdx.x;
   if (i >= n) return;
-  const float* P = pts + ((size_t)b * n + i) * 3;
+  const float* P = (is_t ? p2 : p1) + ((size_t)b * n + i) * 3;
   const int cx = sdg_axis_cell(P[0], s_box.lo[0], s_box.inv[0], G);
   const int cy = sdg_axis_cell(P[1], s_box.lo[1], s_box.inv[1], G);
   const int cz = sdg_axis_cell(P[2], s_box.lo[2], s_box.inv[2], G);
   const int c = (cz * G + cy) * G + cx;
-  cell[(size_t)b * n + i] = c;
-  atomicAdd(count + (size_t)b * (G * G * G + 1) + c, 1);
+  (is_t ? t_cell : q_cell)[(size_t)b * n + i] = c;
+  atomicAdd((is_t ? t_count : q_count) + (size_t)b * (G * G * G + 1) + c, 1);
 }
 
 // ---- 3. exclusive scan of NC counts (in place; entry NC receives the total) ------------------------------------
-__global__ __launch_bounds__(1024) void sdg_scan(int NC, int* __restrict__ t_count, int* __restrict__ q_count) {
-  __shared__ int s_wave[16];
-  __shared__ int s_carry;
-  int* cnt = (blockIdx.y == 0 ? t_count : q_count) + (size_t)blockIdx.x * (NC + 1);
+// two small launches: (a) sums of 1024-entry blocks, (b) every block adds up the sums before it and scans itself
+__device__ __forceinline__ int sdg_block_inclusive(int v, int* s_wave) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) s_carry = 0;
-  __syncthreads();
-  for (int base = 0; base < NC; base += 1024) {
-    const int i = base + threadIdx.x;
-    const int v = i < NC ? cnt[i] : 0;
-    int inc = v;
+  int inc = v;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(inc, d, 64);
-      if (lane >= d) inc += o;
-    }
-    if (lane == 63) s_wave[wave] = inc;
-    __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < wave; ++w) woff += s_wave[w];
-    const int carry = s_carry;
-    if (i < NC) cnt[i] = carry + woff + inc - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) s_carry = carry + woff + inc;
-    __syncthreads();
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
   }
-  if (threadIdx.x == 0) cnt[NC] = s_carry;
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  int woff = 0;
+  for (int w = 0; w < wave; ++w) woff += s_wave[w];
+  return woff + inc;
+}
+__global__ __launch_bounds__(1024) void sdg_scan_sums(int NC, int nblk, const int* __restrict__ t_count,
+                                                      const int* __restrict__ q_count, int* __restrict__ sums) {
+  __shared__ int s_wave[16];
+  const int* cnt = (blockIdx.z == 0 ? t_count : q_count) + (size_t)blockIdx.y * (NC + 1);
+  const int i = blockIdx.x * 1024 + threadIdx.x;
+  const int tot = sdg_block_inclusive(i < NC ? cnt[i] : 0, s_wave);
+  if (threadIdx.x == 1023) sums[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * nblk + blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(1024) void sdg_scan_apply(int NC, int nblk, int* __restrict__ t_count, int* __restrict__ q_count,
+                                                       const int* __restrict__ sums) {
+  __shared__ int s_wave[16];
+  __shared__ int s_off;
+  int* cnt = (blockIdx.z == 0 ? t_count : q_count) + (size_t)blockIdx.y * (NC + 1);
+  const int* my = sums + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * nblk;
+  int part = 0;
+  for (int k = threadIdx.x; k < (int)blockIdx.x; k += 1024) part += my[k];
+  const int before = sdg_block_inclusive(part, s_wave);
+  if (threadIdx.x == 1023) s_off = before;
+  __syncthreads();
+  const int off = s_off;
+  __syncthreads();
+  const int i = blockIdx.x * 1024 + threadIdx.x;
+  const int v = i < NC ? cnt[i] : 0;
+  const int inc = sdg_block_inclusive(v, s_wave);
+  if (i < NC) cnt[i] = off + inc - v;
+  if (i == NC - 1) cnt[NC] = off + inc;
 }
 
-// ---- 4. counting-sort scatter ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sdg_scatter_targets(int M, int NC, const float* __restrict__ p2,
-                                                           const int* __restrict__ cell, const int* __restrict__ start,
-                                                           int* __restrict__ fill, float4* __restrict__ sorted) {
+// ---- 4. counting-sort scatter (targets and queries in one launch) --------------------------------------------------
+__global__ __launch_bounds__(256) void sdg_scatter(int M, int N, int NC, const float* __restrict__ p2,
+                                                   const int* __restrict__ t_cell, const int* __restrict__ q_cell,
+                                                   const int* __restrict__ t_start, const int* __restrict__ q_start,
+                                                   int* __restrict__ t_fill, int* __restrict__ q_fill,
+                                                   float4* __restrict__ t_sorted, int* __restrict__ q_sorted) {
   const int b = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= M) return;
-  const int c = cell[(size_t)b * M + i];
-  const int pos = start[(size_t)b * (NC + 1) + c] + atomicAdd(fill + (size_t)b * NC + c, 1);
-  const float* P = p2 + ((size_t)b * M + i) * 3;
-  sorted[(size_t)b * M + pos] = make_float4(P[0], P[1], P[2], __int_as_float(i));
-}
-__global__ __launch_bounds__(256) void sdg_scatter_queries(int N, int NC, const int* __restrict__ cell,
-                                                           const int* __restrict__ start, int* __restrict__ fill,
-                                                           int* __restrict__ sorted) {
-  const int b = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
-  const int c = cell[(size_t)b * N + i];
-  const int pos = start[(size_t)b * (NC + 1) + c] + atomicAdd(fill + (size_t)b * NC + c, 1);
-  sorted[(size_t)b * N + pos] = i;
+  const int mb = (M + 255) / 256;
+  if ((int)blockIdx.x < mb) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const int c = t_cell[(size_t)b * M + i];
+    const int pos = t_start[(size_t)b * (NC + 1) + c] + atomicAdd(t_fill + (size_t)b * NC + c, 1);
+    const float* P = p2 + ((size_t)b * M + i) * 3;
+    t_sorted[(size_t)b * M + pos] = make_float4(P[0], P[1], P[2], __int_as_float(i));
+  } else {
+    const int i = (blockIdx.x - mb) * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int c = q_cell[(size_t)b * N + i];
+    const int pos = q_start[(size_t)b * (NC + 1) + c] + atomicAdd(q_fill + (size_t)b * NC + c, 1);
+    q_sorted[(size_t)b * N + pos] = i;
+  }
 }
 
 // ---- 5. query ----------------------------------------------------------------------------------------------------------
@@ -222,6 +243,8 @@ __device__ __forceinline__ float sdg_dist(float tx, float ty, float tz, float qx
   const float dx = tx - qx, dy = ty - qy, dz = tz - qz;
   return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
+
+constexpr int SDG_GROUP = 8;  // lanes cooperating on one query (rows of the cell cube are dealt round-robin)
 
 __global__ __launch_bounds__(256) void sdg_query(int N, int M, int nb, int G, const float* __restrict__ p1,
                                                  const float* __restrict__ p2, const float* __restrict__ part,
@@ -232,17 +255,21 @@ __global__ __launch_bounds__(256) void sdg_query(int N, int M, int nb, int G, co
   const int b = blockIdx.y;
   if (threadIdx.x == 0) s_box = sdg_box(part, b, nb, G);
   __syncthreads();
-  const int slot = blockIdx.x * 256 + threadIdx.x;
-  if (slot >= N) return;
+  // 100k queries are only ~1.5 wavefronts per SIMD and every query is a chain of dependent loads (cell range ->
+  // targets): 8 lanes share a query so that 8x more loads are in flight; the lanes' (dist, idx) are merged with a
+  // 3-step butterfly after every ring
+  const int sub = threadIdx.x % SDG_GROUP;
+  const int slot = (blockIdx.x * 256 + threadIdx.x) / SDG_GROUP;
+  const bool live = slot < N;
   const int NC = G * G * G;
-  const int qi = q_sorted[(size_t)b * N + slot];
+  const int qi = live ? q_sorted[(size_t)b * N + slot] : 0;
   const float* Q = p1 + ((size_t)b * N + qi) * 3;
   const float qx = Q[0], qy = Q[1], qz = Q[2];
   const float* T0 = p2 + (size_t)b * M * 3;
   // the reference's seed: target 0 unconditionally (a NaN distance sticks)
   float best = sdg_dist(T0[0], T0[1], T0[2], qx, qy, qz);
   int best_i = 0;
-  if (best == best) {
+  if (best == best) {  // uniform within the group (same query)
     const int c = q_cell[(size_t)b * N + qi];
     const int cx = c % G, cy = (c / G) % G, cz = c / (G * G);
     const int* start = t_start + (size_t)b * (NC + 1);
@@ -257,26 +284,51 @@ __global__ __launch_bounds__(256) void sdg_query(int N, int M, int nb, int G, co
       const int z0 = max(cz - r, 0), z1 = min(cz + r, G - 1);
       const int y0 = max(cy - r, 0), y1 = min(cy + r, G - 1);
       const int x0 = max(cx - r, 0), x1 = min(cx + r, G - 1);
-      for (int z = z0; z <= z1; ++z)
-        for (int y = y0; y <= y1; ++y) {
-          const bool shell_row = (abs(z - cz) == r) || (abs(y - cy) == r);
-          // on a shell row every x is new; otherwise only the two end cells are
-          const int step = shell_row ? 1 : max(x1 - x0, 1);
-          for (int x = x0; x <= x1; x += step) {
-            if (!shell_row && abs(x - cx) != r) continue;
-            const int cc = (z * G + y) * G + x;
-            const int e = start[cc + 1];
-            for (int k = start[cc]; k < e; ++k) {
-              const float4 t = TS[k];
-              const float d = sdg_dist(t.x, t.y, t.z, qx, qy, qz);
-              const int ti = __float_as_int(t.w);
-              if (d < best || (d == best && ti < best_i)) {
-                best = d;
-                best_i = ti;
-              }
-            }
+      const int ny = y1 - y0 + 1, nrows = (z1 - z0 + 1) * ny;
+      for (int j = sub; j < nrows; j += SDG_GROUP) {
+        const int z = z0 + j / ny, y = y0 + j % ny;
+        const int row = (z * G + y) * G;
+        const bool shell_row = (abs(z - cz) == r) || (abs(y - cy) == r);
+        // cells are numbered x-fastest and targets are sorted by cell: the cells x0..x1 of a row own ONE contiguous
+        // slice of the sorted targets.  On a shell row every x is new; elsewhere only the two end cells are.
+        int k0[2], k1[2], nseg;
+        if (shell_row) {
+          k0[0] = start[row + x0];
+          k1[0] = start[row + x1 + 1];
+          nseg = 1;
+        } else {
+          nseg = 0;
+          if (cx - r >= 0) {
+            k0[nseg] = start[row + cx - r];
+            k1[nseg] = start[row + cx - r + 1];
+            ++nseg;
+          }
+          if (cx + r <= G - 1) {
+            k0[nseg] = start[row + cx + r];
+            k1[nseg] = start[row + cx + r + 1];
+            ++nseg;
           }
         }
+        for (int sgm = 0; sgm < nseg; ++sgm)
+          for (int k = k0[sgm]; k < k1[sgm]; ++k) {
+            const float4 t = TS[k];
+            const float d = sdg_dist(t.x, t.y, t.z, qx, qy, qz);
+            const int ti = __float_as_int(t.w);
+            if (d < best || (d == best && ti < best_i)) {
+              best = d;
+              best_i = ti;
+            }
+          }
+      }
+#pragma unroll
+      for (int m = 1; m < SDG_GROUP; m <<= 1) {  // lexicographic (dist, idx) minimum over the group
+        const float od = __shfl_xor(best, m, 64);
+        const int oi = __shfl_xor(best_i, m, 64);
+        if (od < best || (od == best && oi < best_i)) {
+          best = od;
+          best_i = oi;
+        }
+      }
       // every target outside the cube of cells [c - r, c + r] is at least `bound` away from the query
       float bound = INFINITY;
       bool whole_grid = true;
@@ -295,8 +347,10 @@ __global__ __launch_bounds__(256) void sdg_query(int N, int M, int nb, int G, co
       if (bound > 0.f && best < bound * bound * 0.99999f) break;
     }
   }
-  dist[(size_t)b * N + qi] = best;
-  idx[(size_t)b * N + qi] = best_i;
+  if (live && sub == 0) {
+    dist[(size_t)b * N + qi] = best;
+    idx[(size_t)b * N + qi] = best_i;
+  }
 }
 
 }  // namespace
@@ -316,20 +370,18 @@ int sdgrid_forward_f32(hipStream_t st, int B, int N, int M, const float* p1, con
   {
     ProfScope p(K_SDG_BUILD, st);
     hipLaunchKernelGGL(sdg_bbox, dim3(nb, B), dim3(256), 0, st, M, p2, w.bbox_part);
-    hipLaunchKernelGGL(sdg_cells, dim3(kamd_cdiv(M, 256), B), dim3(256), 0, st, M, nb, g.G, p2, w.bbox_part, w.t_cell,
-                       w.t_count);
-    hipLaunchKernelGGL(sdg_cells, dim3(kamd_cdiv(N, 256), B), dim3(256), 0, st, N, nb, g.G, p1, w.bbox_part, w.q_cell,
-                       w.q_count);
-    hipLaunchKernelGGL(sdg_scan, dim3(B, 2), dim3(1024), 0, st, g.NC, w.t_count, w.q_count);
-    hipLaunchKernelGGL(sdg_scatter_targets, dim3(kamd_cdiv(M, 256), B), dim3(256), 0, st, M, g.NC, p2, w.t_cell, w.t_count,
-                       w.t_fill, w.t_sorted);
-    hipLaunchKernelGGL(sdg_scatter_queries, dim3(kamd_cdiv(N, 256), B), dim3(256), 0, st, N, g.NC, w.q_cell, w.q_count,
-                       w.q_fill, w.q_sorted);
+    hipLaunchKernelGGL(sdg_cells, dim3(kamd_cdiv(M, 256) + kamd_cdiv(N, 256), B), dim3(256), 0, st, M, N, nb, g.G, p2, p1,
+                       w.bbox_part, w.t_cell, w.q_cell, w.t_count, w.q_count);
+    const int nblk = kamd_cdiv(g.NC, 1024);
+    hipLaunchKernelGGL(sdg_scan_sums, dim3(nblk, B, 2), dim3(1024), 0, st, g.NC, nblk, w.t_count, w.q_count, w.scan_sums);
+    hipLaunchKernelGGL(sdg_scan_apply, dim3(nblk, B, 2), dim3(1024), 0, st, g.NC, nblk, w.t_count, w.q_count, w.scan_sums);
+    hipLaunchKernelGGL(sdg_scatter, dim3(kamd_cdiv(M, 256) + kamd_cdiv(N, 256), B), dim3(256), 0, st, M, N, g.NC, p2,
+                       w.t_cell, w.q_cell, w.t_count, w.q_count, w.t_fill, w.q_fill, w.t_sorted, w.q_sorted);
   }
   KAMD_CHECK(hipGetLastError());
   {
     ProfScope p(K_SDG_QUERY, st);
-    hipLaunchKernelGGL(sdg_query, dim3(kamd_cdiv(N, 256), B), dim3(256), 0, st, N, M, nb, g.G, p1, p2, w.bbox_part, w.q_sorted,
+    hipLaunchKernelGGL(sdg_query, dim3(kamd_cdiv((long long)N * SDG_GROUP, 256), B), dim3(256), 0, st, N, M, nb, g.G, p1, p2, w.bbox_part, w.q_sorted,
                        w.q_cell, w.t_count, w.t_sorted, dist, idx);
   }
   KAMD_RETURN_LAST_ERROR();
