@@ -48,6 +48,7 @@ def parse():
     ap.add_argument('--chamfer-points', type=int, default=100000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-chamfer', action='store_true')
+    ap.add_argument('--no-c5', action='store_true', help='skip the voxelgrid / point-to-mesh extras (config C5)')
     return ap.parse_args()
 
 
@@ -204,6 +205,27 @@ def main():
                                   'sd_main_avg_us': round(main_ms / max(main_n, 1) * 1e3, 2),
                                   'valu_Tlaneops_per_s': round(6.7 * n * n / (main_ms / max(main_n, 1) * 1e-3) / 1e12, 2) if main_ms else None}
 
+    # ---------------- config C5 extras (rank 0 only, replicas-only ops): voxelgrid 256^3 + point_to_mesh 1M x 50k
+    c5 = None
+    if rank == 0 and not args.no_c5:
+        def per_call_ms(fn, n=5):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+        v1 = verts.detach().unsqueeze(0)
+        vox_ms = per_call_ms(lambda: kal.ops.conversions.trianglemeshes_to_voxelgrids(v1, faces, 256), 10)
+        fv = v1[0][faces].unsqueeze(0).contiguous()
+        q = (torch.rand((1, 1000000, 3), generator=torch.Generator().manual_seed(0)) * 1.2 - 0.6).to(dev)
+        p2m_ms = per_call_ms(lambda: kal.metrics.trianglemesh.point_to_mesh_distance(q, fv), 3)
+        c5 = {'voxelgrid_256_us': round(vox_ms * 1e3, 1), 'voxelgrid_write_GBps': round(256 ** 3 * 4 / (vox_ms * 1e-3) / 1e9, 1),
+              'point_to_mesh_1Mx50k_ms': round(p2m_ms, 3),
+              'point_to_mesh_Gpairs_per_s': round(1e6 * F / (p2m_ms * 1e-3) / 1e9, 1)}
+
     # ---------------- CPU baseline: the oracle (OpenMP) on a bounded sample, rank 0 at N = 1 only
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
@@ -250,7 +272,7 @@ def main():
                        'views_per_gpu': V, 'global_views': V * world, 'height': H, 'width': W, 'faces': F,
                        'covered_pixel_fraction': round(covered, 4), 'parallelism': f'views sharded {world}-way'},
             'roofline': roofline, 'step_roofline': step_roofline, 'kernels': kernels,
-            'cpu_baseline': cpu, 'chamfer': chamfer,
+            'cpu_baseline': cpu, 'chamfer': chamfer, 'c5': c5,
         }
         print(json.dumps(out))
     if D.is_distributed():

@@ -25,7 +25,7 @@ def init_from_env(backend=None):
         return world > 1
     use_cuda = torch.cuda.is_available()
     if use_cuda:
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1))
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     dist.init_process_group(backend or ('nccl' if use_cuda else 'gloo'), init_method='env://')
     return True
