@@ -177,3 +177,41 @@ def test_gpu_full_size_properties():
     assert float((dist[0] - approx).abs().max()) < 2e-3
     d2, i2, t2 = _tm().point_to_mesh_distance(pts[None, 500000:], fv[None])
     assert torch.equal(d2[0], dist[0, 500000:]) and torch.equal(i2[0], idx[0, 500000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float, torch.double])
+@pytest.mark.parametrize('kind', ['sphere', 'sphere_plus_large', 'soup', 'two_blobs'])
+def test_gpu_grid_search_vs_oracle_and_brute(dtype, kind):
+    """F >= 2048 and N >= 4096 take the exact uniform-grid search: dist / face_idx / dist_type must equal the oracle
+    and the all-pairs kernels (KAMD_TRIANGLE_DISTANCE=brute) bit for bit -- small faces, faces larger than a grid
+    cell (the "large" list), a random triangle soup (every face large), and a mesh far from part of the queries."""
+    from kaolin_amd.utils.testing import geodesic_sphere
+    torch.manual_seed(11)
+    v, f = geodesic_sphere(16)                      # 5120 faces
+    fv = v.to(dtype)[f]
+    if kind == 'sphere':
+        pts = torch.rand(6000, 3, dtype=dtype) * 1.4 - 0.7
+    elif kind == 'sphere_plus_large':
+        big = torch.randn(40, 3, 3, dtype=dtype)
+        fv = torch.cat([fv[:2000], big, fv[2000:]])
+        pts = torch.rand(6000, 3, dtype=dtype) * 1.4 - 0.7
+    elif kind == 'soup':
+        fv = torch.randn(2500, 3, 3, dtype=dtype)
+        pts = torch.randn(4500, 3, dtype=dtype)
+    else:
+        fv = torch.cat([fv * 0.2 + 3.0, fv * 0.1 - 2.0])
+        pts = torch.cat([torch.rand(3000, 3, dtype=dtype) * 8 - 4, torch.randn(3000, 3, dtype=dtype) * 0.3 + 3.0])
+    d_ref, i_ref, t_ref = oracle.triangle_distance_forward(pts, fv, omp=True)
+    os.environ['KAMD_TRIANGLE_DISTANCE'] = 'grid'     # (by default the grid is reserved for >= 400k queries)
+    try:
+        dist, idx, typ = _gpu_fwd(pts, fv)
+    finally:
+        del os.environ['KAMD_TRIANGLE_DISTANCE']
+    assert torch.equal(idx.cpu(), i_ref) and torch.equal(typ.cpu(), t_ref) and torch.equal(dist.cpu(), d_ref)
+    os.environ['KAMD_TRIANGLE_DISTANCE'] = 'brute'
+    try:
+        d2, i2, t2 = _gpu_fwd(pts, fv)
+    finally:
+        del os.environ['KAMD_TRIANGLE_DISTANCE']
+    assert torch.equal(i2, idx) and torch.equal(t2, typ) and torch.equal(d2, dist)
