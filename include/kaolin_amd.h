@@ -221,6 +221,50 @@ int kamd_dibr_soft_mask_forward_fused_f64(void* stream, int B, int H, int W, int
                                           uint32_t* n_items, void* workspace);
 
 /* ------------------------------------------------------------------------- */
+/* dibr_rasterization in one call (ours; kaolin/render/mesh/dibr.py:119-209   */
+/* = rasterize with valid faces + dibr_soft_mask over all faces).  Same       */
+/* kernels as the separate entry points; kernels that do not depend on each   */
+/* other (soft-mask binning vs. rasterizer; the two backward kernels) are     */
+/* enqueued on an internal side stream forked from / joined to `stream` with  */
+/* events, so the call is still stream-ordered for the caller.  g_img         */
+/* (zeroed by the caller) receives BOTH gradient contributions.               */
+/* ------------------------------------------------------------------------- */
+int kamd_dibr_rasterization_forward_f32(void* stream, int B, int H, int W, int F, int D, int K,
+                                        const float* z, const float* img, const float* feat,
+                                        const uint8_t* valid, double multiplier, float eps,
+                                        float sigmainv, double margin, float* interp,
+                                        int64_t* face_idx, float* weights, float* soft_mask,
+                                        int32_t* hit_pix, int32_t* hit_face, float* hit_prob,
+                                        uint8_t* hit_type, int32_t* item_count, uint32_t* n_items,
+                                        void* ws_raster, void* ws_soft);
+int kamd_dibr_rasterization_forward_f64(void* stream, int B, int H, int W, int F, int D, int K,
+                                        const double* z, const double* img, const double* feat,
+                                        const uint8_t* valid, double multiplier, float eps,
+                                        float sigmainv, double margin, double* interp,
+                                        int64_t* face_idx, double* weights, double* soft_mask,
+                                        int32_t* hit_pix, int32_t* hit_face, double* hit_prob,
+                                        uint8_t* hit_type, int32_t* item_count, uint32_t* n_items,
+                                        void* ws_raster, void* ws_soft);
+int kamd_dibr_rasterization_backward_f32(void* stream, int B, int H, int W, int F, int D, int K,
+                                         const float* grad_feat, const float* grad_soft,
+                                         const int64_t* face_idx, const float* weights,
+                                         const float* soft_mask, const int32_t* hit_pix,
+                                         const int32_t* hit_face, const float* hit_prob,
+                                         const uint8_t* hit_type, const int32_t* item_count,
+                                         const uint32_t* n_items, const float* img, const float* feat,
+                                         double multiplier, float eps, float sigmainv,
+                                         float* g_img, float* g_feat);
+int kamd_dibr_rasterization_backward_f64(void* stream, int B, int H, int W, int F, int D, int K,
+                                         const double* grad_feat, const double* grad_soft,
+                                         const int64_t* face_idx, const double* weights,
+                                         const double* soft_mask, const int32_t* hit_pix,
+                                         const int32_t* hit_face, const double* hit_prob,
+                                         const uint8_t* hit_type, const int32_t* item_count,
+                                         const uint32_t* n_items, const double* img, const double* feat,
+                                         double multiplier, float eps, float sigmainv,
+                                         double* g_img, double* g_feat);
+
+/* ------------------------------------------------------------------------- */
 /* metrics.unbatched_triangle_distance_forward_cuda(points, faces, dist,      */
 /*     face_idx, dist_type) -> void                                           */
 /* reference: kaolin/csrc/metrics/unbatched_triangle_distance.cpp:43-72,      */

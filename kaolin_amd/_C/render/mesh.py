@@ -307,3 +307,84 @@ def rasterize_forward_fused(height, width, face_vertices_z, face_vertices_image,
             _lib.ptr(interp), _lib.ptr(face_idx), _lib.ptr(wts), _lib.ptr(ws))
     _lib.check(st, fn)
     return [interp, face_idx, wts]
+
+
+def dibr_rasterization_forward_fused(height, width, face_vertices_z, face_vertices_image, face_features, valid_faces,
+                                     sigmainv, boxlen, knum, multiplier, eps):
+    """``rasterize_forward_fused`` + ``dibr_soft_mask_forward_fused`` in one library call (ours): the same kernels,
+    with the soft mask's binning enqueued on an internal side stream next to the rasterizer.
+    -> (interpolated_features, face_idx, output_weights, soft_mask, hits)"""
+    fn = 'dibr_rasterization_forward_fused'
+    args = [Arg(face_vertices_z, 'face_vertices_z', 3), Arg(face_vertices_image, 'face_vertices_image', 4),
+            Arg(face_features, 'face_features', 5)]
+    if valid_faces is not None:
+        args.append(Arg(valid_faces, 'valid_faces', 6))
+    check_all_same_gpu(fn, args)
+    check_all_contiguous(fn, args)
+    batch_size, num_faces, feat_dim = face_vertices_z.size(0), face_vertices_z.size(1), face_features.size(3)
+    check_size(fn, args[0], [batch_size, num_faces, 3])
+    check_size(fn, args[1], [batch_size, num_faces, 3, 2])
+    check_size(fn, args[2], [batch_size, num_faces, 3, feat_dim])
+    if valid_faces is not None:
+        check_size(fn, args[3], [batch_size, num_faces])
+    dtype, device = face_vertices_z.dtype, face_vertices_z.device
+    sfx = _lib.dtype_suffix(dtype, fn)
+    for a in args[1:3]:
+        if a.t.dtype != dtype:
+            raise RuntimeError(f'expected scalar type {_lib._PRETTY[dtype]} but found {_lib._PRETTY.get(a.t.dtype, a.t.dtype)}')
+    lib = _lib.load()
+    esz = face_vertices_z.element_size()
+    with torch.cuda.device(device):
+        face_idx = torch.empty((batch_size, height, width), dtype=torch.long, device=device)
+        wts = torch.empty((batch_size, height, width, 3), dtype=dtype, device=device)
+        interp = torch.empty((batch_size, height, width, feat_dim), dtype=dtype, device=device)
+        soft_mask = torch.empty((batch_size, height, width), dtype=dtype, device=device)
+        hits = _hit_list(batch_size, height, width, knum, dtype, device)
+        ws_r = _lib.workspace(lib.kamd_rasterize_forward_workspace(batch_size, height, width, batch_size * num_faces, esz), device)
+        ws_s = _lib.workspace(lib.kamd_dibr_soft_mask_forward_workspace(batch_size, height, width, num_faces, esz), device)
+        st = getattr(lib, f'kamd_dibr_rasterization_forward_{sfx}')(
+            _lib.stream_ptr(device), batch_size, height, width, num_faces, feat_dim, int(knum),
+            _lib.ptr(face_vertices_z), _lib.ptr(face_vertices_image), _lib.ptr(face_features), _lib.ptr(valid_faces),
+            float(multiplier), float(eps), float(sigmainv), float(boxlen * multiplier),
+            _lib.ptr(interp), _lib.ptr(face_idx), _lib.ptr(wts), _lib.ptr(soft_mask),
+            _lib.ptr(hits[0]), _lib.ptr(hits[1]), _lib.ptr(hits[2]), _lib.ptr(hits[3]), _lib.ptr(hits[4]), _lib.ptr(hits[5]),
+            _lib.ptr(ws_r), _lib.ptr(ws_s))
+        # the side stream reads / writes these buffers: keep torch's allocator from recycling them under it
+        for t in (ws_s, face_vertices_image) + tuple(hits):
+            if t is not None:
+                t.record_stream(torch.cuda.current_stream(device))
+    _lib.check(st, fn)
+    return interp, face_idx, wts, soft_mask, hits
+
+
+def dibr_rasterization_backward_fused(grad_features, grad_soft_mask, face_idx, output_weights, soft_mask, hits,
+                                      face_vertices_image, face_features, sigmainv, knum, multiplier, eps):
+    """Backward of :func:`dibr_rasterization_forward_fused`: the rasterizer's and the soft mask's backward kernels run
+    concurrently and accumulate into ONE grad_face_vertices_image. -> (grad_face_vertices_image, grad_face_features)"""
+    fn = 'dibr_rasterization_backward_fused'
+    args = [Arg(grad_features, 'grad_features', 1), Arg(grad_soft_mask, 'grad_soft_mask', 2), Arg(face_idx, 'face_idx', 3),
+            Arg(output_weights, 'output_weights', 4), Arg(soft_mask, 'soft_mask', 5),
+            Arg(face_vertices_image, 'face_vertices_image', 7), Arg(face_features, 'face_features', 8)]
+    check_all_same_gpu(fn, args)
+    check_all_contiguous(fn, args)
+    batch_size, height, width, feat_dim = grad_features.shape
+    num_faces = face_vertices_image.size(1)
+    check_size(fn, args[1], [batch_size, height, width])
+    check_size(fn, args[2], [batch_size, height, width])
+    check_size(fn, args[3], [batch_size, height, width, 3])
+    check_size(fn, args[5], [batch_size, num_faces, 3, 2])
+    check_size(fn, args[6], [batch_size, num_faces, 3, feat_dim])
+    dtype, device = face_vertices_image.dtype, face_vertices_image.device
+    sfx = _lib.dtype_suffix(dtype, fn)
+    lib = _lib.load()
+    with torch.cuda.device(device):
+        g_img = torch.zeros_like(face_vertices_image)
+        g_feat = torch.zeros_like(face_features)
+        st = getattr(lib, f'kamd_dibr_rasterization_backward_{sfx}')(
+            _lib.stream_ptr(device), batch_size, height, width, num_faces, feat_dim, int(knum),
+            _lib.ptr(grad_features), _lib.ptr(grad_soft_mask), _lib.ptr(face_idx), _lib.ptr(output_weights),
+            _lib.ptr(soft_mask), _lib.ptr(hits[0]), _lib.ptr(hits[1]), _lib.ptr(hits[2]), _lib.ptr(hits[3]),
+            _lib.ptr(hits[4]), _lib.ptr(hits[5]), _lib.ptr(face_vertices_image), _lib.ptr(face_features),
+            float(multiplier), float(eps), float(sigmainv), _lib.ptr(g_img), _lib.ptr(g_feat))
+    _lib.check(st, fn)
+    return g_img, g_feat

@@ -56,6 +56,10 @@ for _t in ('f32', 'f64'):
         _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _dbl, _f, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_dibr_soft_mask_forward_fused_{_t}'] = (
         _i, [_vp, _i, _i, _i, _i, _i, _vp, _dbl, _dbl, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+    SIGNATURES[f'kamd_dibr_rasterization_forward_{_t}'] = (
+        _i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _dbl, _f, _f, _dbl] + [_vp] * 12)
+    SIGNATURES[f'kamd_dibr_rasterization_backward_{_t}'] = (
+        _i, [_vp, _i, _i, _i, _i, _i, _i] + [_vp] * 13 + [_dbl, _f, _f, _vp, _vp])
     SIGNATURES[f'kamd_triangle_distance_forward_{_t}'] = (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_triangle_distance_backward_{_t}'] = (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_trianglemeshes_to_voxelgrids_{_t}'] = (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp])

@@ -16,6 +16,7 @@
 // pixel, 390 B at knum = 30) dominate HBM traffic: they are initialised by one streaming fill kernel
 // (16-byte stores), after which the tile kernel only touches the entries of actual hits.
 #include "common.h"
+#include <mutex>
 #include "profile.h"
 #include "tile_bins.h"
 #include "../../include/kaolin_amd.h"
@@ -602,11 +603,15 @@ __global__ __launch_bounds__(SL_THREADS) void soft_mask_backward_list_kernel(
   }
 }
 
+// The forward is two phases: BIN (memset + bin kernel: needs only the vertices) and SEARCH (classify + search: needs
+// the rasterizer's face_idx).  `bin_st` lets the fused DIB-R entry point run the BIN phase on a side stream, concurrently
+// with the rasterizer; with bin_st == st everything is stream-ordered as usual.
 template <typename T>
 int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, const T* img, const T* large_bbox,
                              const int64_t* sel_idx, float sigmainv, float multiplier, T* soft_mask, T* prob,
                              int64_t* idx, uint8_t* type, void* workspace, uint8_t* hit_count, const HitList<T>* lean,
-                             bool raw = false, double raw_multiplier = 1.0, double raw_margin = 0.0) {
+                             bool raw = false, double raw_multiplier = 1.0, double raw_margin = 0.0,
+                             int phases = 3 /* bit 0: BIN, bit 1: SEARCH */) {
   // raw: `img` is the UNSCALED (B,F,3,2) operator input and `large_bbox` is unused; scaling by raw_multiplier and the
   // boxes enlarged by raw_margin (= boxlen * multiplier) are produced inside the bin kernel
   if (B <= 0 || H <= 0 || W <= 0) return 0;
@@ -614,62 +619,64 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
   const long long total_faces = (long long)B * F;
   if (total_faces > 0 && workspace == nullptr) return (int)hipErrorInvalidValue;
   if (lean != nullptr && (long long)B * H * W >= (1ll << 31)) return (int)hipErrorInvalidValue;
-  // 1. K-buffer initialisation (one streaming pass) -- reference-contract outputs only
-  const size_t nk = lean ? 0 : (size_t)B * H * W * K;
-  if (nk > 0) {
-    FillPlan pa, pb, pc;
-    KAMD_CHECK(fill_edges(st, prob, nk * sizeof(T), 0x00, &pa));
-    KAMD_CHECK(fill_edges(st, idx, nk * 8, 0xFF, &pb));
-    KAMD_CHECK(fill_edges(st, type, nk, 0x00, &pc));
-    const size_t most = pb.n16 > pa.n16 ? pb.n16 : pa.n16;
-    int blocks = (int)((most + 255) / 256 < (size_t)KAMD_NUM_CU * 16 ? (most + 255) / 256 : (size_t)KAMD_NUM_CU * 16);
-    if (blocks < 1) blocks = 1;
-    kamd::ProfScope prof_(kamd::K_SOFT_FILL, st);
-    hipLaunchKernelGGL(fill_regions_kernel, dim3(blocks), dim3(256), 0, st, pa.body, pa.n16, 0u, pb.body, pb.n16,
-                       0xFFFFFFFFu, pc.body, pc.n16, 0u);
-  }
-  KAMD_CHECK(hipGetLastError());
-  // 2. bin the enlarged boxes, 3. search
   T* rec = (T*)workspace;
   unsigned int* masks = (unsigned int*)((char*)workspace + align256((size_t)total_faces * REC_STRIDE * sizeof(T)));
   unsigned int* flags = total_faces > 0 ? masks + mask_words(g.ntiles, B, total_faces) : nullptr;
-  // after the tile flags: sub-tile flags (1 byte each), the worklist header {count, next}, the worklist items
+  // after the tile flags: sub-tile flags (1 byte each), the worklist header {count, unused}, the worklist items
   const int n_sub = g.ntiles * B * SM_SUBS;
   uint8_t* sub_flags = total_faces > 0 ? (uint8_t*)(flags + flag_words(g.ntiles, B)) : nullptr;
   unsigned int* work = total_faces > 0 ? (unsigned int*)(sub_flags + align256((size_t)n_sub)) : nullptr;
-  if (total_faces > 0) {
-    KAMD_CHECK(hipMemsetAsync(masks, 0, (mask_words(g.ntiles, B, total_faces) + flag_words(g.ntiles, B) + 2) * 4 +
-                                         align256((size_t)n_sub), st));
-    kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
-    if (raw)
-      hipLaunchKernelGGL(bin_faces_raw_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, F, img,
-                         (const T*)nullptr, (const uint8_t*)nullptr, (T)raw_multiplier, (T)raw_margin, g, multiplier, rec,
-                         masks, flags, sub_flags);
-    else
-      hipLaunchKernelGGL(bin_faces_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, F, total_faces,
-                         (const int64_t*)nullptr, large_bbox, img, (const T*)nullptr, g, multiplier, rec, masks, flags,
-                         sub_flags);
+  if (phases & 1) {
+    // K-buffer initialisation (one streaming pass) -- reference-contract outputs only
+    const size_t nk = lean ? 0 : (size_t)B * H * W * K;
+    if (nk > 0) {
+      FillPlan pa, pb, pc;
+      KAMD_CHECK(fill_edges(st, prob, nk * sizeof(T), 0x00, &pa));
+      KAMD_CHECK(fill_edges(st, idx, nk * 8, 0xFF, &pb));
+      KAMD_CHECK(fill_edges(st, type, nk, 0x00, &pc));
+      const size_t most = pb.n16 > pa.n16 ? pb.n16 : pa.n16;
+      int blocks = (int)((most + 255) / 256 < (size_t)KAMD_NUM_CU * 16 ? (most + 255) / 256 : (size_t)KAMD_NUM_CU * 16);
+      if (blocks < 1) blocks = 1;
+      kamd::ProfScope prof_(kamd::K_SOFT_FILL, st);
+      hipLaunchKernelGGL(fill_regions_kernel, dim3(blocks), dim3(256), 0, st, pa.body, pa.n16, 0u, pb.body, pb.n16,
+                         0xFFFFFFFFu, pc.body, pc.n16, 0u);
+    }
+    KAMD_CHECK(hipGetLastError());
+    if (total_faces > 0) {
+      KAMD_CHECK(hipMemsetAsync(masks, 0, (mask_words(g.ntiles, B, total_faces) + flag_words(g.ntiles, B) + 2) * 4 +
+                                           align256((size_t)n_sub), st));
+      kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
+      if (raw)
+        hipLaunchKernelGGL(bin_faces_raw_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, F, img,
+                           (const T*)nullptr, (const uint8_t*)nullptr, (T)raw_multiplier, (T)raw_margin, g, multiplier, rec,
+                           masks, flags, sub_flags);
+      else
+        hipLaunchKernelGGL(bin_faces_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, F, total_faces,
+                           (const int64_t*)nullptr, large_bbox, img, (const T*)nullptr, g, multiplier, rec, masks, flags,
+                           sub_flags);
+    }
+    KAMD_CHECK(hipGetLastError());
   }
-  KAMD_CHECK(hipGetLastError());
-  // worklist area follows the flag words: [count, next, items...]
-  int* worklist = (int*)(work + 2);
-  {
-    kamd::ProfScope prof_(kamd::K_SOFT_CLASSIFY, st);
-    hipLaunchKernelGGL(soft_classify_kernel<T>, dim3(g.ntiles * B), dim3(TILE_THREADS), 0, st, B, g, sub_flags, sel_idx,
-                       soft_mask, lean ? (uint8_t*)nullptr : hit_count, worklist, work);
-  }
-  KAMD_CHECK(hipGetLastError());
-  if (total_faces > 0) {
-    kamd::ProfScope prof_(kamd::K_SOFT_TILE, st);
-    const dim3 grid((unsigned)(n_sub < KAMD_NUM_CU * 16 ? n_sub : KAMD_NUM_CU * 16));
-    if (lean)
-      hipLaunchKernelGGL((soft_search_kernel<T, true>), grid, dim3(64), 0, st, B, F, g, K, sigmainv, multiplier, rec,
-                         masks, worklist, work, sel_idx, soft_mask, (T*)nullptr, (int64_t*)nullptr,
-                         (uint8_t*)nullptr, (uint8_t*)nullptr, *lean);
-    else
-      hipLaunchKernelGGL((soft_search_kernel<T, false>), grid, dim3(64), 0, st, B, F, g, K, sigmainv, multiplier,
-                         rec, masks, worklist, work, sel_idx, soft_mask, prob, idx, type, hit_count,
-                         HitList<T>{});
+  if (phases & 2) {
+    int* worklist = (int*)(work + 2);
+    {
+      kamd::ProfScope prof_(kamd::K_SOFT_CLASSIFY, st);
+      hipLaunchKernelGGL(soft_classify_kernel<T>, dim3(g.ntiles * B), dim3(TILE_THREADS), 0, st, B, g, sub_flags, sel_idx,
+                         soft_mask, lean ? (uint8_t*)nullptr : hit_count, worklist, work);
+    }
+    KAMD_CHECK(hipGetLastError());
+    if (total_faces > 0) {
+      kamd::ProfScope prof_(kamd::K_SOFT_TILE, st);
+      const dim3 grid((unsigned)(n_sub < KAMD_NUM_CU * 16 ? n_sub : KAMD_NUM_CU * 16));
+      if (lean)
+        hipLaunchKernelGGL((soft_search_kernel<T, true>), grid, dim3(64), 0, st, B, F, g, K, sigmainv, multiplier, rec,
+                           masks, worklist, work, sel_idx, soft_mask, (T*)nullptr, (int64_t*)nullptr,
+                           (uint8_t*)nullptr, (uint8_t*)nullptr, *lean);
+      else
+        hipLaunchKernelGGL((soft_search_kernel<T, false>), grid, dim3(64), 0, st, B, F, g, K, sigmainv, multiplier,
+                           rec, masks, worklist, work, sel_idx, soft_mask, prob, idx, type, hit_count,
+                           HitList<T>{});
+    }
   }
   KAMD_RETURN_LAST_ERROR();
 }
@@ -785,3 +792,104 @@ KAMD_LEAN_ENTRY(f64, double)
 #undef KAMD_LEAN_ENTRY
 
 }  // extern "C"
+
+// ---- fused DIB-R front door: rasterize + soft mask in one call, independent kernels on two streams ---------------
+namespace {
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+std::mutex g_side_mu;
+SideStream g_side[16];
+// the side stream / events of the current device (created on first use); the caller holds g_side_mu while enqueuing
+int side_stream(SideStream** out) {
+  int dev = 0;
+  KAMD_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return (int)hipErrorInvalidDevice;
+  SideStream& ss = g_side[dev];
+  if (ss.s == nullptr) {
+    KAMD_CHECK(hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking));
+    KAMD_CHECK(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
+    KAMD_CHECK(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));
+  }
+  *out = &ss;
+  return 0;
+}
+
+template <typename T>
+int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K, const T* z, const T* img, const T* feat,
+                       const uint8_t* valid, double multiplier, float eps, float sigmainv, double margin, T* interp,
+                       int64_t* face_idx, T* weights, T* soft_mask, const HitList<T>& list, void* ws_raster, void* ws_soft) {
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  SideStream* ss;
+  KAMD_CHECK(side_stream(&ss));
+  // the soft mask's BIN phase needs only the vertices: side stream, concurrently with the rasterizer
+  KAMD_CHECK(hipEventRecord(ss->fork, st));
+  KAMD_CHECK(hipStreamWaitEvent(ss->s, ss->fork, 0));
+  KAMD_CHECK(soft_mask_forward_launch<T>(ss->s, B, H, W, F, K, img, nullptr, nullptr, sigmainv, (float)multiplier, soft_mask,
+                                         nullptr, nullptr, nullptr, ws_soft, nullptr, &list, true, multiplier, margin, 1));
+  KAMD_CHECK(hipEventRecord(ss->join, ss->s));
+  int rc;
+  if (sizeof(T) == 4)
+    rc = kamd_rasterize_forward_fused_f32(st, B, H, W, F, D, (const float*)z, (const float*)img, (const float*)feat, valid,
+                                          multiplier, eps, (float*)interp, face_idx, (float*)weights, ws_raster);
+  else
+    rc = kamd_rasterize_forward_fused_f64(st, B, H, W, F, D, (const double*)z, (const double*)img, (const double*)feat,
+                                          valid, multiplier, eps, (double*)interp, face_idx, (double*)weights, ws_raster);
+  KAMD_CHECK(rc);
+  KAMD_CHECK(hipStreamWaitEvent(st, ss->join, 0));
+  return soft_mask_forward_launch<T>(st, B, H, W, F, K, img, nullptr, face_idx, sigmainv, (float)multiplier, soft_mask,
+                                     nullptr, nullptr, nullptr, ws_soft, nullptr, &list, true, multiplier, margin, 2);
+}
+
+template <typename T>
+int dibr_backward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K, const T* grad_feat, const T* grad_soft,
+                        const int64_t* face_idx, const T* weights, const T* soft_mask, const HitList<T>& list, const T* img,
+                        const T* feat, double multiplier, float eps, float sigmainv, T* g_img, T* g_feat) {
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  SideStream* ss;
+  KAMD_CHECK(side_stream(&ss));
+  // the two backward kernels are independent and both accumulate atomically into the same zero-initialised g_img
+  KAMD_CHECK(hipEventRecord(ss->fork, st));
+  KAMD_CHECK(hipStreamWaitEvent(ss->s, ss->fork, 0));
+  KAMD_CHECK(soft_mask_backward_list_launch<T>(ss->s, B, H, W, F, K, grad_soft, soft_mask, list, img, multiplier, sigmainv,
+                                               (float)multiplier, g_img));
+  KAMD_CHECK(hipEventRecord(ss->join, ss->s));
+  int rc;
+  if (sizeof(T) == 4)
+    rc = kamd_rasterize_backward_f32(st, B, H, W, F, D, (const float*)grad_feat, face_idx, (const float*)weights,
+                                     (const float*)img, (const float*)feat, eps, (float*)g_img, (float*)g_feat);
+  else
+    rc = kamd_rasterize_backward_f64(st, B, H, W, F, D, (const double*)grad_feat, face_idx, (const double*)weights,
+                                     (const double*)img, (const double*)feat, eps, (double*)g_img, (double*)g_feat);
+  KAMD_CHECK(rc);
+  return (int)hipStreamWaitEvent(st, ss->join, 0);
+}
+}  // namespace
+
+extern "C" {
+#define KAMD_DIBR_ENTRY(SFX, T)                                                                                       \
+  int kamd_dibr_rasterization_forward_##SFX(                                                                          \
+      void* stream, int B, int H, int W, int F, int D, int K, const T* z, const T* img, const T* feat,                \
+      const uint8_t* valid, double multiplier, float eps, float sigmainv, double margin, T* interp, int64_t* face_idx, \
+      T* weights, T* soft_mask, int32_t* hit_pix, int32_t* hit_face, T* hit_prob, uint8_t* hit_type,                  \
+      int32_t* item_count, uint32_t* n_items, void* ws_raster, void* ws_soft) {                                       \
+    HitList<T> l{hit_pix, hit_face, hit_prob, hit_type, item_count, n_items};                                         \
+    return dibr_forward_fused<T>((hipStream_t)stream, B, H, W, F, D, K, z, img, feat, valid, multiplier, eps, sigmainv, \
+                                 margin, interp, face_idx, weights, soft_mask, l, ws_raster, ws_soft);                \
+  }                                                                                                                   \
+  int kamd_dibr_rasterization_backward_##SFX(                                                                         \
+      void* stream, int B, int H, int W, int F, int D, int K, const T* grad_feat, const T* grad_soft,                 \
+      const int64_t* face_idx, const T* weights, const T* soft_mask, const int32_t* hit_pix, const int32_t* hit_face,  \
+      const T* hit_prob, const uint8_t* hit_type, const int32_t* item_count, const uint32_t* n_items, const T* img,   \
+      const T* feat, double multiplier, float eps, float sigmainv, T* g_img, T* g_feat) {                             \
+    HitList<T> l{(int*)hit_pix, (int*)hit_face, (T*)hit_prob, (uint8_t*)hit_type, (int*)item_count,                   \
+                 (unsigned int*)n_items};                                                                             \
+    return dibr_backward_fused<T>((hipStream_t)stream, B, H, W, F, D, K, grad_feat, grad_soft, face_idx, weights,     \
+                                  soft_mask, l, img, feat, multiplier, eps, sigmainv, g_img, g_feat);                 \
+  }
+KAMD_DIBR_ENTRY(f32, float)
+KAMD_DIBR_ENTRY(f64, double)
+#undef KAMD_DIBR_ENTRY
+}  // extern "C"
+

@@ -51,6 +51,39 @@ def dibr_soft_mask(face_vertices_image, selected_face_idx, sigmainv=7000, boxlen
     return DibrSoftMaskCuda.apply(face_vertices_image, selected_face_idx, sigmainv, boxlen, knum, multiplier)
 
 
+class DibrRasterizationCuda(torch.autograd.Function):
+    """``rasterize`` (front faces only) + ``dibr_soft_mask`` (all faces) as ONE autograd node: one library call each way
+    (``_C.render.mesh.dibr_rasterization_{forward,backward}_fused``), kernels that do not depend on each other run
+    concurrently, and both gradient contributions to ``face_vertices_image`` land in one buffer.  Outputs are bit-identical
+    to calling the two functions separately (the same kernels)."""
+
+    @staticmethod
+    def forward(ctx, height, width, face_vertices_z, face_vertices_image, face_features, valid_faces,
+                sigmainv, boxlen, knum, multiplier, eps):
+        face_vertices_image = face_vertices_image.contiguous()
+        face_features = face_features.contiguous()
+        feats, face_idx, weights, soft_mask, hits = _C.render.mesh.dibr_rasterization_forward_fused(
+            height, width, face_vertices_z.contiguous(), face_vertices_image, face_features, valid_faces.contiguous(),
+            sigmainv, boxlen, knum, multiplier, eps)
+        ctx.save_for_backward(face_idx, weights, soft_mask, face_vertices_image, face_features, *hits)
+        ctx.mark_non_differentiable(face_idx)
+        ctx.cfg = (sigmainv, knum, multiplier, eps)
+        return feats, soft_mask, face_idx
+
+    @staticmethod
+    def backward(ctx, grad_feats, grad_soft_mask, grad_face_idx):
+        face_idx, weights, soft_mask, face_vertices_image, face_features = ctx.saved_tensors[:5]
+        sigmainv, knum, multiplier, eps = ctx.cfg
+        if grad_feats is None:
+            grad_feats = torch.zeros(soft_mask.shape + (face_features.shape[-1],), dtype=soft_mask.dtype, device=soft_mask.device)
+        if grad_soft_mask is None:
+            grad_soft_mask = torch.zeros_like(soft_mask)
+        g_img, g_feat = _C.render.mesh.dibr_rasterization_backward_fused(
+            grad_feats.contiguous(), grad_soft_mask.contiguous(), face_idx, weights, soft_mask, ctx.saved_tensors[5:],
+            face_vertices_image, face_features, sigmainv, knum, multiplier, eps)
+        return None, None, None, g_img, g_feat, None, None, None, None, None, None
+
+
 def dibr_rasterization(height, width, face_vertices_z, face_vertices_image, face_features, face_normals_z,
                        sigmainv=7000, boxlen=0.02, knum=30, multiplier=None, eps=None, rast_backend='cuda'):
     r"""DIB-R rasterization: :func:`rasterize` restricted to front faces (``face_normals_z >= 0``) followed
@@ -60,8 +93,22 @@ def dibr_rasterization(height, width, face_vertices_z, face_vertices_image, face
         (torch.Tensor or tuple, torch.Tensor, torch.LongTensor): features (B, H, W, D), soft mask (B, H, W),
         face index (B, H, W).
     """
-    interpolated_features, face_idx = rasterize(height, width, face_vertices_z, face_vertices_image,
-                                                face_features, face_normals_z >= 0., multiplier, eps, rast_backend)
     _multiplier = 1000. if multiplier is None else multiplier
-    soft_mask = dibr_soft_mask(face_vertices_image, face_idx, sigmainv, boxlen, knum, _multiplier)
-    return interpolated_features, soft_mask, face_idx
+    if rast_backend != 'cuda' or not face_vertices_image.is_cuda:
+        interpolated_features, face_idx = rasterize(height, width, face_vertices_z, face_vertices_image,
+                                                    face_features, face_normals_z >= 0., multiplier, eps, rast_backend)
+        soft_mask = dibr_soft_mask(face_vertices_image, face_idx, sigmainv, boxlen, knum, _multiplier)
+        return interpolated_features, soft_mask, face_idx
+    is_list = isinstance(face_features, (list, tuple))
+    _features = torch.cat(face_features, dim=-1) if is_list else face_features
+    # rasterize()'s defaults (multiplier 1000, eps 1e-8) and dibr_soft_mask's multiplier (1000.) coincide numerically
+    image_features, soft_mask, face_idx = DibrRasterizationCuda.apply(
+        height, width, face_vertices_z, face_vertices_image, _features, face_normals_z >= 0., sigmainv, boxlen, knum,
+        _multiplier, 1e-8 if eps is None else eps)
+    if is_list:
+        out, cur = [], 0
+        for f in face_features:
+            out.append(image_features[..., cur:cur + f.shape[-1]])
+            cur += f.shape[-1]
+        image_features = tuple(out)
+    return image_features, soft_mask, face_idx
