@@ -687,7 +687,7 @@ int soft_mask_backward_list_launch(hipStream_t st, int B, int H, int W, int F, i
                                    float multiplier, T* g_img) {
   if ((long long)B * H * W <= 0 || F <= 0) return 0;
   {
-    kamd::ProfScope prof_(kamd::K_SOFT_BACKWARD, st);
+    kamd::ProfScope prof_(kamd::K_SOFT_BACKWARD_LIST, st);
     hipLaunchKernelGGL(soft_mask_backward_list_kernel<T>, dim3(KAMD_NUM_CU * 10), dim3(SL_THREADS), 0, st, H, W, F, K, grad,
                        soft_mask, list, img, (T)img_scale, sigmainv, multiplier, g_img);
   }
@@ -823,12 +823,14 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
   std::lock_guard<std::mutex> lk(g_side_mu);
   SideStream* ss;
   KAMD_CHECK(side_stream(&ss));
-  // the soft mask's BIN phase needs only the vertices: side stream, concurrently with the rasterizer
+  // the soft mask's BIN phase needs only the vertices: side stream, concurrently with the rasterizer.  (While the
+  // per-kernel profiler is on everything stays on `st`, so that each kernel's event pair times that kernel alone.)
+  const hipStream_t side = kamd::prof_enabled() ? st : ss->s;
   KAMD_CHECK(hipEventRecord(ss->fork, st));
-  KAMD_CHECK(hipStreamWaitEvent(ss->s, ss->fork, 0));
-  KAMD_CHECK(soft_mask_forward_launch<T>(ss->s, B, H, W, F, K, img, nullptr, nullptr, sigmainv, (float)multiplier, soft_mask,
+  KAMD_CHECK(hipStreamWaitEvent(side, ss->fork, 0));
+  KAMD_CHECK(soft_mask_forward_launch<T>(side, B, H, W, F, K, img, nullptr, nullptr, sigmainv, (float)multiplier, soft_mask,
                                          nullptr, nullptr, nullptr, ws_soft, nullptr, &list, true, multiplier, margin, 1));
-  KAMD_CHECK(hipEventRecord(ss->join, ss->s));
+  KAMD_CHECK(hipEventRecord(ss->join, side));
   int rc;
   if (sizeof(T) == 4)
     rc = kamd_rasterize_forward_fused_f32(st, B, H, W, F, D, (const float*)z, (const float*)img, (const float*)feat, valid,
@@ -850,11 +852,12 @@ int dibr_backward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K
   SideStream* ss;
   KAMD_CHECK(side_stream(&ss));
   // the two backward kernels are independent and both accumulate atomically into the same zero-initialised g_img
+  const hipStream_t side = kamd::prof_enabled() ? st : ss->s;
   KAMD_CHECK(hipEventRecord(ss->fork, st));
-  KAMD_CHECK(hipStreamWaitEvent(ss->s, ss->fork, 0));
-  KAMD_CHECK(soft_mask_backward_list_launch<T>(ss->s, B, H, W, F, K, grad_soft, soft_mask, list, img, multiplier, sigmainv,
+  KAMD_CHECK(hipStreamWaitEvent(side, ss->fork, 0));
+  KAMD_CHECK(soft_mask_backward_list_launch<T>(side, B, H, W, F, K, grad_soft, soft_mask, list, img, multiplier, sigmainv,
                                                (float)multiplier, g_img));
-  KAMD_CHECK(hipEventRecord(ss->join, ss->s));
+  KAMD_CHECK(hipEventRecord(ss->join, side));
   int rc;
   if (sizeof(T) == 4)
     rc = kamd_rasterize_backward_f32(st, B, H, W, F, D, (const float*)grad_feat, face_idx, (const float*)weights,

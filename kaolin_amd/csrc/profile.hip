@@ -10,7 +10,7 @@ namespace {
 const char* const kNames[K_NUM] = {
     "sd_main_f32", "sd_final_f32", "sd_forward_generic", "sd_backward", "sdg_build(5 kernels)", "sdg_query",
     "bin_faces_kernel", "raster_tile_kernel", "raster_backward_kernel",
-    "fill_regions_kernel", "soft_classify_kernel", "soft_search_kernel", "soft_mask_backward_kernel",
+    "fill_regions_kernel", "soft_classify_kernel", "soft_search_kernel", "soft_mask_backward_kernel", "soft_mask_backward_list_kernel",
     "td_prep_kernel", "td_main_kernel", "td_final_kernel", "td_backward_kernel",
     "vox_vertices_kernel", "vox_faces_kernel", "hipMemsetAsync"};
 struct Pending {
