@@ -213,11 +213,11 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(
     if (threadIdx.x == 0) s_nused = 0;
     __syncthreads();
   }
+  T vals[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) vals[i] = 0;
   if (f >= 0) {
     const size_t tf = (size_t)b * F + (size_t)f;
-    T vals[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) vals[i] = 0;
     const T aw = weights[tp * 3 + 0], bw = weights[tp * 3 + 1], cw = weights[tp * 3 + 2];
     T dw1[6], dw2[6];
     const T k3 = barycentric_jacobian<T>(img + tf * 6, aw, bw, cw, eps, dw1, dw2);
@@ -240,9 +240,38 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(
         kamd_atomic_add(g_feat + (tf * 3 + 2) * D + d, (T)(gd * cw));
       }
     }
-    if constexpr (DT > 0) {
-      int slot = (int)(((unsigned)f * 2654435761u) >> 23) & (RB_HT - 1);
-      for (;;) {  // the table is twice the number of pixels: an empty slot always exists
+    if constexpr (DT == 0) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) kamd_atomic_add(g_img + tf * 6 + j, vals[j]);
+    }
+  }
+  if constexpr (DT > 0) {
+    // Pixels of one face are neighbours: in lane order (16 per row) they form runs.  A segmented inclusive scan sums
+    // every run (6 shuffle steps per value), and only the LAST lane of a run touches the LDS table: same-address LDS
+    // atomics were 56 % of this kernel's wave time (SQ_WAIT_INST_LDS) when every lane added on its own.
+    if (__ballot(f >= 0) != 0ull) {
+    const int prev_f = __shfl_up(f, 1, 64);
+    const int next_f = __shfl_down(f, 1, 64);
+    const bool run_start = lane == 0 || prev_f != f;
+    int start_lane = run_start ? lane : 0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(start_lane, d, 64);
+      if (lane >= d) start_lane = max(start_lane, o);
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const bool take = lane >= d && start_lane <= lane - d;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const T o = __shfl_up(vals[i], d, 64);
+        if (take) vals[i] += o;
+      }
+    }
+    const bool run_end = lane == 63 || next_f != f;
+    if (f >= 0 && run_end) {
+      int slot = (int)(((unsigned)f * 2654435761u) >> 24) & (RB_HT - 1);
+      for (;;) {  // at most 256 distinct faces for 256 slots: an empty slot always exists
         const int k = atomicCAS(&s_key[slot], -1, f);
         if (k == -1) s_used[atomicAdd(&s_nused, 1)] = slot;
         if (k == -1 || k == f) break;
@@ -250,9 +279,7 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(
       }
 #pragma unroll
       for (int i = 0; i < NV; ++i) atomicAdd(&s_acc[slot * NV + i], vals[i]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 6; ++j) kamd_atomic_add(g_img + tf * 6 + j, vals[j]);
+    }
     }
   }
   if constexpr (DT > 0) {
