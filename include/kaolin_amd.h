@@ -265,6 +265,38 @@ int kamd_dibr_rasterization_backward_f64(void* stream, int B, int H, int W, int 
                                          double* g_img, double* g_feat);
 
 /* ------------------------------------------------------------------------- */
+/* render.mesh.prepare_vertices, fused (the reference is     */
+/* pure torch: kaolin/render/mesh/utils.py:128-175).  vertices (Bv,V,3) with    */
+/* batch stride `vstride` elements (0 = one mesh shared by all B views),        */
+/* faces (F,3) int64, proj (3); camera either rot (B,3,3) + trans (B,3) or      */
+/* transform (B,4,3) (the other pointers NULL).  Outputs fv_cam (B,F,3,3),      */
+/* fv_img (B,F,3,2), unit normals (B,F,3).  Backward: gradient w.r.t. the       */
+/* vertices only, g_vertices (B,V,3) fully written; any of g_cam / g_img /      */
+/* g_nrm may be NULL; adj_offsets (V+1) / adj_entries (3F, values face*3+k)     */
+/* list each vertex's incident face corners.                                    */
+/* ------------------------------------------------------------------------- */
+int kamd_prepare_vertices_forward_f32(void* stream, int B, int V, int F, const float* vertices,
+                                      int64_t vstride, const int64_t* faces, const float* proj,
+                                      const float* rot, const float* trans, const float* transform,
+                                      float* fv_cam, float* fv_img, float* normals);
+int kamd_prepare_vertices_forward_f64(void* stream, int B, int V, int F, const double* vertices,
+                                      int64_t vstride, const int64_t* faces, const double* proj,
+                                      const double* rot, const double* trans, const double* transform,
+                                      double* fv_cam, double* fv_img, double* normals);
+int kamd_prepare_vertices_backward_f32(void* stream, int B, int V, int F, const float* vertices,
+                                       int64_t vstride, const int64_t* faces, const float* proj,
+                                       const float* rot, const float* trans, const float* transform,
+                                       const int32_t* adj_offsets, const int32_t* adj_entries,
+                                       const float* g_cam, const float* g_img, const float* g_nrm,
+                                       float* g_vertices);
+int kamd_prepare_vertices_backward_f64(void* stream, int B, int V, int F, const double* vertices,
+                                       int64_t vstride, const int64_t* faces, const double* proj,
+                                       const double* rot, const double* trans, const double* transform,
+                                       const int32_t* adj_offsets, const int32_t* adj_entries,
+                                       const double* g_cam, const double* g_img, const double* g_nrm,
+                                       double* g_vertices);
+
+/* ------------------------------------------------------------------------- */
 /* metrics.unbatched_triangle_distance_forward_cuda(points, faces, dist,      */
 /*     face_idx, dist_type) -> void                                           */
 /* reference: kaolin/csrc/metrics/unbatched_triangle_distance.cpp:43-72,      */

@@ -388,3 +388,80 @@ def dibr_rasterization_backward_fused(grad_features, grad_soft_mask, face_idx, o
             float(multiplier), float(eps), float(sigmainv), _lib.ptr(g_img), _lib.ptr(g_feat))
     _lib.check(st, fn)
     return g_img, g_feat
+
+
+_ADJ_CACHE = {}
+
+
+def vertex_face_adjacency(faces, num_vertices):
+    """CSR list of the (face, corner) incidences of every vertex: (offsets (V+1) int32, entries (3F) int32 = face*3+k).
+    Built with three torch ops the first time a `faces` tensor is seen and cached (mesh topology is static in training)."""
+    key = (faces.data_ptr(), tuple(faces.shape), faces._version, int(num_vertices), str(faces.device))
+    hit = _ADJ_CACHE.get(key)
+    if hit is not None:
+        return hit
+    flat = faces.reshape(-1)
+    entries = torch.argsort(flat, stable=True).to(torch.int32)
+    counts = torch.bincount(flat, minlength=num_vertices)
+    offsets = torch.zeros(num_vertices + 1, dtype=torch.int32, device=faces.device)
+    offsets[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    if len(_ADJ_CACHE) > 8:
+        _ADJ_CACHE.clear()
+    _ADJ_CACHE[key] = (offsets, entries, faces)   # keep `faces` alive so that its data_ptr stays unique
+    return _ADJ_CACHE[key]
+
+
+def _pv_common(vertices, faces, camera_proj, camera_rot, camera_trans, camera_transform):
+    fn = 'prepare_vertices'
+    batch_size = (camera_transform if camera_transform is not None else camera_rot).size(0)
+    if vertices.size(0) not in (1, batch_size):
+        raise RuntimeError(f'{fn}: vertices batch {vertices.size(0)} does not match the cameras ({batch_size})')
+    # a (1, V, 3) tensor or an expanded view (batch stride 0) is one mesh shared by all views
+    vstride = 0 if (vertices.size(0) == 1 or vertices.stride(0) == 0) else vertices.size(1) * 3
+    v = vertices[:1].contiguous() if vstride == 0 else vertices.contiguous()
+    return fn, batch_size, vstride, v
+
+
+def prepare_vertices_forward_fused(vertices, faces, camera_proj, camera_rot, camera_trans, camera_transform):
+    """``kaolin.render.mesh.prepare_vertices`` (utils.py:128-175) in one kernel
+    -> (face_vertices_camera (B,F,3,3), face_vertices_image (B,F,3,2), face_normals (B,F,3))."""
+    fn, B, vstride, v = _pv_common(vertices, faces, camera_proj, camera_rot, camera_trans, camera_transform)
+    dtype, device = v.dtype, v.device
+    sfx = _lib.dtype_suffix(dtype, fn)
+    V, F = v.size(1), faces.size(0)
+    lib = _lib.load()
+    c = lambda t: None if t is None else t.to(dtype).contiguous()  # noqa: E731
+    proj, rot, trans, tf = c(camera_proj.reshape(-1)), c(camera_rot), c(camera_trans), c(camera_transform)
+    faces = faces.contiguous()
+    with torch.cuda.device(device):
+        fv_cam = torch.empty((B, F, 3, 3), dtype=dtype, device=device)
+        fv_img = torch.empty((B, F, 3, 2), dtype=dtype, device=device)
+        nrm = torch.empty((B, F, 3), dtype=dtype, device=device)
+        st = getattr(lib, f'kamd_prepare_vertices_forward_{sfx}')(
+            _lib.stream_ptr(device), B, V, F, _lib.ptr(v), vstride, _lib.ptr(faces), _lib.ptr(proj), _lib.ptr(rot),
+            _lib.ptr(trans), _lib.ptr(tf), _lib.ptr(fv_cam), _lib.ptr(fv_img), _lib.ptr(nrm))
+    _lib.check(st, fn)
+    return fv_cam, fv_img, nrm
+
+
+def prepare_vertices_backward_fused(vertices, faces, camera_proj, camera_rot, camera_trans, camera_transform,
+                                    grad_cam, grad_img, grad_nrm):
+    """Gradient of :func:`prepare_vertices_forward_fused` w.r.t. the vertices -> (B, V, 3)."""
+    fn, B, vstride, v = _pv_common(vertices, faces, camera_proj, camera_rot, camera_trans, camera_transform)
+    dtype, device = v.dtype, v.device
+    sfx = _lib.dtype_suffix(dtype, fn)
+    V, F = v.size(1), faces.size(0)
+    lib = _lib.load()
+    c = lambda t: None if t is None else t.to(dtype).contiguous()  # noqa: E731
+    proj, rot, trans, tf = c(camera_proj.reshape(-1)), c(camera_rot), c(camera_trans), c(camera_transform)
+    faces = faces.contiguous()
+    offsets, entries, _ = vertex_face_adjacency(faces, V)
+    g = [None if t is None else t.contiguous() for t in (grad_cam, grad_img, grad_nrm)]
+    with torch.cuda.device(device):
+        g_vertices = torch.empty((B, V, 3), dtype=dtype, device=device)
+        st = getattr(lib, f'kamd_prepare_vertices_backward_{sfx}')(
+            _lib.stream_ptr(device), B, V, F, _lib.ptr(v), vstride, _lib.ptr(faces), _lib.ptr(proj), _lib.ptr(rot),
+            _lib.ptr(trans), _lib.ptr(tf), _lib.ptr(offsets), _lib.ptr(entries), _lib.ptr(g[0]), _lib.ptr(g[1]),
+            _lib.ptr(g[2]), _lib.ptr(g_vertices))
+    _lib.check(st, fn)
+    return g_vertices

@@ -3,14 +3,60 @@
 import torch
 
 from .. import camera
+from ... import _C
 from ...ops import mesh as _mesh
 
 __all__ = ['prepare_vertices', 'texture_mapping']
 
 
+class _PrepareVerticesCuda(torch.autograd.Function):
+    """One kernel each way for the torch op chain of ``prepare_vertices`` (fused path, gradients w.r.t. vertices only)."""
+
+    @staticmethod
+    def forward(ctx, vertices, faces, camera_proj, camera_rot, camera_trans, camera_transform):
+        out = _C.render.mesh.prepare_vertices_forward_fused(vertices, faces, camera_proj, camera_rot, camera_trans,
+                                                            camera_transform)
+        ctx.save_for_backward(vertices, faces, camera_proj,
+                              *(t for t in (camera_rot, camera_trans, camera_transform) if t is not None))
+        ctx.has_transform = camera_transform is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_cam, grad_img, grad_nrm):
+        vertices, faces, camera_proj = ctx.saved_tensors[:3]
+        rest = ctx.saved_tensors[3:]
+        rot, trans, tf = (None, None, rest[0]) if ctx.has_transform else (rest[0], rest[1], None)
+        g = _C.render.mesh.prepare_vertices_backward_fused(vertices, faces, camera_proj, rot, trans, tf,
+                                                           grad_cam, grad_img, grad_nrm)
+        if g.shape[0] != vertices.shape[0]:      # one shared (1, V, 3) mesh: sum the per-view gradients
+            g = g.sum(dim=0, keepdim=True)
+        return g, None, None, None, None, None
+
+
+def _fusable(vertices, faces, camera_proj, camera_rot, camera_trans, camera_transform):
+    cams = [t for t in (camera_proj, camera_rot, camera_trans, camera_transform) if t is not None]
+    return (vertices.is_cuda and vertices.dtype in (torch.float32, torch.float64) and vertices.dim() == 3 and
+            faces.is_cuda and faces.dtype == torch.long and faces.dim() == 2 and faces.shape[1] == 3 and
+            all(t.is_cuda for t in cams) and not any(t.requires_grad for t in cams))
+
+
 def prepare_vertices(vertices, faces, camera_proj, camera_rot=None, camera_trans=None, camera_transform=None):
     """World-space vertices (B, V, 3) -> (face_vertices_camera (B,F,3,3), face_vertices_image (B,F,3,2),
-    unit face_normals (B,F,3)).  Either (camera_rot, camera_trans) or a (B, 4, 3) camera_transform."""
+    unit face_normals (B,F,3)).  Either (camera_rot, camera_trans) or a (B, 4, 3) camera_transform.
+    On the GPU (float/double, no gradient required for the camera tensors) this is one fused HIP kernel each way;
+    otherwise the torch op chain below, which is also the definition the fused path is tested against."""
+    if camera_transform is None:
+        if camera_rot is None or camera_trans is None:
+            raise AssertionError('camera_transform or camera_trans and camera_rot must be defined')
+    elif camera_rot is not None or camera_trans is not None:
+        raise AssertionError('camera_trans and camera_rot must be None when camera_transform is defined')
+    if _fusable(vertices, faces, camera_proj, camera_rot, camera_trans, camera_transform):
+        return _PrepareVerticesCuda.apply(vertices, faces, camera_proj, camera_rot, camera_trans, camera_transform)
+    return _prepare_vertices_torch(vertices, faces, camera_proj, camera_rot, camera_trans, camera_transform)
+
+
+def _prepare_vertices_torch(vertices, faces, camera_proj, camera_rot=None, camera_trans=None, camera_transform=None):
+    """The reference's op chain (kaolin/render/mesh/utils.py:156-175)."""
     if camera_transform is None:
         if camera_rot is None or camera_trans is None:
             raise AssertionError('camera_transform or camera_trans and camera_rot must be defined')
