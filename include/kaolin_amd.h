@@ -297,6 +297,18 @@ int kamd_prepare_vertices_backward_f64(void* stream, int B, int V, int F, const 
                                        double* g_vertices);
 
 /* ------------------------------------------------------------------------- */
+/* ops.mesh.unbatched_mesh_intersection_cuda(points, v1, v2, v3) -> result     */
+/* (reference: kaolin/csrc/ops/mesh/mesh_intersection.cpp,  */
+/* mesh_intersection_cuda.cu:101-253).  points (N,3); v1,v2,v3 (F,3) = the      */
+/* faces' three vertices; result (N) fully written = number of faces the +x ray */
+/* from each point crosses (check_sign takes its parity).                       */
+/* ------------------------------------------------------------------------- */
+int kamd_mesh_intersection_f32(void* stream, int N, int F, const float* points, const float* v1,
+                               const float* v2, const float* v3, float* result);
+int kamd_mesh_intersection_f64(void* stream, int N, int F, const double* points, const double* v1,
+                               const double* v2, const double* v3, double* result);
+
+/* ------------------------------------------------------------------------- */
 /* metrics.unbatched_triangle_distance_forward_cuda(points, faces, dist,      */
 /*     face_idx, dist_type) -> void                                           */
 /* reference: kaolin/csrc/metrics/unbatched_triangle_distance.cpp:43-72,      */

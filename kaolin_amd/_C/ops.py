@@ -25,3 +25,27 @@ def trianglemeshes_to_voxelgrids_cuda(normalized_vertices, faces, resolution):
             _lib.stream_ptr(v.device), B, V, F, R, _lib.ptr(v), _lib.ptr(f), _lib.ptr(grid))
     _lib.check(st, fn)
     return grid
+
+
+def unbatched_mesh_intersection_cuda(points, verts_1, verts_2, verts_3):
+    """reference: kaolin/csrc/ops/mesh/mesh_intersection.cpp (bindings.cpp, ``_C.ops.mesh.unbatched_mesh_intersection_cuda``):
+    points (N,3), verts_k (F,3) -> (N) tensor, the number of faces the +x ray from every point crosses."""
+    fn = 'unbatched_mesh_intersection_cuda'
+    for name, t in (('points', points), ('verts_1', verts_1), ('verts_2', verts_2), ('verts_3', verts_3)):
+        torch_check(t.is_cuda, f'{name} must be a CUDA tensor')
+    for name, t in (('points', points), ('verts_1', verts_1), ('verts_2', verts_2), ('verts_3', verts_3)):
+        torch_check(t.is_contiguous(), f'{name} must be contiguous')
+    n, m = points.size(0), verts_1.size(0)
+    torch_check(list(points.shape) == [n, 3], 'points must of size {num_points, 3}')
+    for name, t in (('verts_1', verts_1), ('verts_2', verts_2), ('verts_3', verts_3)):
+        torch_check(list(t.shape) == [m, 3], f'{name} must of size {{num_faces, 3}}')
+        torch_check(t.dtype == points.dtype, 'expected points and vertices to have the same scalar type')
+    sfx = _lib.dtype_suffix(points.dtype, fn)
+    lib = _lib.load()
+    with torch.cuda.device(points.device):
+        result = torch.empty(n, dtype=points.dtype, device=points.device)
+        st = getattr(lib, f'kamd_mesh_intersection_{sfx}')(
+            _lib.stream_ptr(points.device), n, m, _lib.ptr(points), _lib.ptr(verts_1), _lib.ptr(verts_2),
+            _lib.ptr(verts_3), _lib.ptr(result))
+    _lib.check(st, fn)
+    return result

@@ -11,7 +11,7 @@ enum KernelId {
   K_BIN_FACES, K_RASTER_TILE, K_RASTER_BACKWARD,
   K_SOFT_FILL, K_SOFT_CLASSIFY, K_SOFT_TILE, K_SOFT_BACKWARD, K_SOFT_BACKWARD_LIST,
   K_TD_PREP, K_TD_MAIN, K_TD_FINAL, K_TD_BACKWARD,
-  K_VOX_VERTICES, K_VOX_FACES, K_MEMSET, K_PV_FORWARD, K_PV_BACKWARD,
+  K_VOX_VERTICES, K_VOX_FACES, K_MEMSET, K_PV_FORWARD, K_PV_BACKWARD, K_MESH_INTERSECTION,
   K_NUM
 };
 

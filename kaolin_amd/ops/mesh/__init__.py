@@ -2,7 +2,7 @@
 subdivision the voxelizer's definition rests on."""
 import torch
 
-__all__ = ['index_vertices_by_faces', 'face_normals']
+__all__ = ['index_vertices_by_faces', 'face_normals', 'check_sign']
 
 
 def index_vertices_by_faces(vertices_features, faces):
@@ -29,3 +29,59 @@ def face_normals(face_vertices, unit=False):
     if unit:
         n = n / (n.norm(dim=2, keepdim=True) + 1e-10)
     return n
+
+
+def _unbatched_check_sign_cuda(verts, faces, points):
+    """kaolin/ops/mesh/check_sign.py:45-54."""
+    from ... import _C
+    points = points.contiguous()
+    v1 = torch.index_select(verts, 0, faces[:, 0]).view(-1, 3).contiguous()
+    v2 = torch.index_select(verts, 0, faces[:, 1]).view(-1, 3).contiguous()
+    v3 = torch.index_select(verts, 0, faces[:, 2]).view(-1, 3).contiguous()
+    ints = _C.ops.unbatched_mesh_intersection_cuda(points, v1, v2, v3)
+    return ints % 2 == 1.
+
+
+def check_sign(verts, faces, points, hash_resolution=512):
+    r"""Checks if a set of points is contained inside a watertight triangle mesh: shoots a ray from each point along +x
+    and uses the parity of the number of crossed faces (reference: kaolin/ops/mesh/check_sign.py:56-155).
+
+    Args:
+        verts (torch.Tensor): (B, V, 3).  faces (torch.LongTensor): (F, 3).  points (torch.Tensor): (B, N, 3).
+        hash_resolution (int): only used by the reference's CPU path; kept for signature compatibility.
+
+    Returns:
+        (torch.BoolTensor): (B, N), True for points inside the mesh.
+    """
+    assert verts.device == points.device
+    assert faces.device == points.device
+    if not faces.dtype == torch.int64:
+        raise TypeError(f"Expected faces entries to be torch.int64 "
+                        f"but got {faces.dtype}.")
+    if not isinstance(hash_resolution, int):
+        raise TypeError(f"Expected hash_resolution to be int "
+                        f"but got {type(hash_resolution)}.")
+    for name, t, what, n in (('verts', verts, 'dimensions', 3), ('faces', faces, 'dimensions', 2),
+                             ('points', points, 'dimensions', 3)):
+        if t.ndim != n:
+            raise ValueError(f"Expected {name} to have {n} dimensions "
+                             f"but got {t.ndim} dimensions.")
+    if verts.shape[2] != 3:
+        raise ValueError(f"Expected verts to have 3 coordinates "
+                         f"but got {verts.shape[2]} coordinates.")
+    if faces.shape[1] != 3:
+        raise ValueError(f"Expected faces to have 3 vertices "
+                         f"but got {faces.shape[1]} vertices.")
+    if points.shape[2] != 3:
+        raise ValueError(f"Expected points to have 3 coordinates "
+                         f"but got {points.shape[2]} coordinates.")
+    if points.device.type != 'cuda':
+        raise RuntimeError('check_sign: only the GPU path is implemented (the reference CPU path is a C++ TriangleHash, '
+                           'out of scope: SURVEY.md section 2)')
+    xlen = verts[..., 0].max(-1)[0] - verts[..., 0].min(-1)[0]
+    ylen = verts[..., 1].max(-1)[0] - verts[..., 1].min(-1)[0]
+    zlen = verts[..., 2].max(-1)[0] - verts[..., 2].min(-1)[0]
+    maxlen = torch.max(torch.stack([xlen, ylen, zlen]), 0)[0]
+    verts = verts / maxlen.view(-1, 1, 1)
+    points = points / maxlen.view(-1, 1, 1)
+    return torch.stack([_unbatched_check_sign_cuda(verts[i], faces, points[i]) for i in range(verts.shape[0])])

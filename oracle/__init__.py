@@ -228,3 +228,31 @@ def point_to_mesh_distance(pointclouds, face_vertices, omp=False):
     """kaolin/metrics/trianglemesh.py:20-99: per-batch loop, stacked results."""
     out = [triangle_distance_forward(pointclouds[i], face_vertices[i], omp=omp) for i in range(pointclouds.shape[0])]
     return tuple(torch.stack([o[k] for o in out], dim=0) for k in range(3))
+
+
+# ---- check_sign (ray-parity inside test; reference `_C.ops.mesh.unbatched_mesh_intersection_cuda`) ---------------
+def mesh_intersection(points, verts_1, verts_2, verts_3, omp=False):
+    """kaolin/csrc/ops/mesh/mesh_intersection.cpp: number of faces the +x ray of every point crosses -> (N) float."""
+    pts, a, b, c = _cpu(points), _cpu(verts_1), _cpu(verts_2), _cpu(verts_3)
+    N, F = pts.shape[0], a.shape[0]
+    out = torch.zeros(N, dtype=pts.dtype)
+    f = getattr(lib(omp), f'oracle_mesh_intersection_{_SFX[pts.dtype]}')
+    f(_ci(N), _ci(F), _p(pts), _p(a), _p(b), _p(c), _p(out))
+    return out
+
+
+def check_sign(verts, faces, points, omp=False):
+    """kaolin/ops/mesh/check_sign.py:45-155 (GPU branch): normalise by the largest extent, count, parity."""
+    verts, faces, points = _cpu(verts), _cpu(faces, torch.long), _cpu(points)
+    xlen = verts[..., 0].max(-1)[0] - verts[..., 0].min(-1)[0]
+    ylen = verts[..., 1].max(-1)[0] - verts[..., 1].min(-1)[0]
+    zlen = verts[..., 2].max(-1)[0] - verts[..., 2].min(-1)[0]
+    maxlen = torch.max(torch.stack([xlen, ylen, zlen]), 0)[0]
+    verts = verts / maxlen.view(-1, 1, 1)
+    points = points / maxlen.view(-1, 1, 1)
+    res = []
+    for i in range(verts.shape[0]):
+        v = verts[i]
+        ints = mesh_intersection(points[i], v[faces[:, 0]], v[faces[:, 1]], v[faces[:, 2]], omp=omp)
+        res.append(ints % 2 == 1.)
+    return torch.stack(res)

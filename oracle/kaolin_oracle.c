@@ -249,3 +249,15 @@ DEFINE_SIDED_BWD(oracle_sided_distance_backward_f64, double)
 #undef FN
 #undef SQRTFN
 #undef REF_TILE
+
+/* ---- mesh intersection (check_sign), instantiated for float and double ----------------- */
+#define T float
+#define FN(n) n##_f32
+#include "meshint_oracle.inc"
+#undef T
+#undef FN
+#define T double
+#define FN(n) n##_f64
+#include "meshint_oracle.inc"
+#undef T
+#undef FN
