@@ -12,80 +12,75 @@ __all__ = ['sided_distance', 'chamfer_distance', 'f_score']
 
 
 class _SidedDistanceFunction(torch.autograd.Function):
-    """autograd shim, same contract as kaolin/metrics/pointcloud.py:20-49: saves
-    (p1, p2, idx), idx is non-differentiable, backward returns (grad_p1, grad_p2)."""
+    """autograd shim with the contract of the reference's (kaolin/metrics/pointcloud.py:20-49): the nearest index is a
+    non-differentiable output, both clouds receive gradients."""
 
     @staticmethod
     def forward(ctx, p1, p2):
-        p1 = p1.contiguous()
-        p2 = p2.contiguous()
-        dist, idx = _C.metrics.sided_distance_forward_cuda(p1, p2)
-        ctx.save_for_backward(p1, p2, idx)
-        ctx.mark_non_differentiable(idx)
-        return dist, idx
+        queries, targets = p1.contiguous(), p2.contiguous()
+        dist, nearest = _C.metrics.sided_distance_forward_cuda(queries, targets)
+        ctx.mark_non_differentiable(nearest)
+        ctx.save_for_backward(queries, targets, nearest)
+        return dist, nearest
 
     @staticmethod
-    def backward(ctx, grad_output_dist, grad_output_idx):
-        p1, p2, idx = ctx.saved_tensors
-        grad_p1, grad_p2 = _C.metrics.sided_distance_backward_cuda(
-            grad_output_dist.contiguous(), p1, p2, idx)
-        return grad_p1, grad_p2
+    def backward(ctx, grad_dist, _grad_idx):
+        queries, targets, nearest = ctx.saved_tensors
+        return tuple(_C.metrics.sided_distance_backward_cuda(grad_dist.contiguous(), queries, targets, nearest))
 
 
 def sided_distance(p1, p2):
-    r"""For each point in :math:`p_{1i} \in P_1` finds the index and squared euclidean distance
-    of the closest point in :math:`P_2` (reference: kaolin/metrics/pointcloud.py:51-87).
+    r"""For every point of ``p1``: squared euclidean distance to, and index of, its nearest point in ``p2``
+    (reference: kaolin/metrics/pointcloud.py:51-87).
 
     Args:
-        p1 (torch.Tensor): of shape :math:`(\text{batch_size}, \text{num_points1}, 3)`.
-        p2 (torch.Tensor): of shape :math:`(\text{batch_size}, \text{num_points2}, 3)`.
+        p1 (torch.Tensor): :math:`(\text{batch_size}, \text{num_points1}, 3)`.
+        p2 (torch.Tensor): :math:`(\text{batch_size}, \text{num_points2}, 3)`.
 
     Returns:
-        (torch.Tensor, torch.LongTensor): squared distances :math:`(B, N_1)` and, for every
-        point of ``p1``, the (lowest) index of its nearest point in ``p2``.
+        (torch.Tensor, torch.LongTensor): squared distances :math:`(B, N_1)` and the (lowest) index of the nearest
+        point of ``p2`` for every point of ``p1``.
     """
-    dist, idx = _SidedDistanceFunction.apply(p1, p2)
-    return dist, idx
+    return _SidedDistanceFunction.apply(p1, p2)
+
+
+def _mean_nearest(src, dst, squared):
+    d = sided_distance(src, dst)[0]
+    return (d if squared else d.sqrt()).mean(dim=-1)
 
 
 def chamfer_distance(p1, p2, w1=1., w2=1., squared=True):
-    r"""Chamfer distance between two point clouds: the weighted sum of the two mean sided
-    distances (reference: kaolin/metrics/pointcloud.py:89-136).
+    r"""Chamfer distance: ``w1 * mean_i d(p1_i, p2) + w2 * mean_j d(p2_j, p1)`` with ``d`` the (squared) distance to
+    the nearest point of the other cloud (reference: kaolin/metrics/pointcloud.py:89-136).
 
     Args:
-        p1, p2 (torch.Tensor): of shapes :math:`(B, N_1, 3)` and :math:`(B, N_2, 3)`.
-        w1, w2 (float): weights of the p1->p2 and p2->p1 terms. Default: 1.
-        squared (bool): use squared distances (default) or their square roots.
+        p1, p2 (torch.Tensor): :math:`(B, N_1, 3)` and :math:`(B, N_2, 3)`.
+        w1, w2 (float): weights of the two directions. Default: 1.
+        squared (bool): squared distances (default) or their square roots.
 
     Returns:
-        (torch.Tensor): of shape :math:`(B)`.
+        (torch.Tensor): :math:`(B)`.
     """
-    sdist1 = sided_distance(p1, p2)[0]
-    sdist2 = sided_distance(p2, p1)[0]
-    if not squared:
-        sdist1 = torch.sqrt(sdist1)
-        sdist2 = torch.sqrt(sdist2)
-    dist_to_p2 = sdist1.mean(dim=-1)
-    dist_to_p1 = sdist2.mean(dim=-1)
+    forward_term = _mean_nearest(p1, p2, squared)
+    backward_term = _mean_nearest(p2, p1, squared)
     if w1 == 1 and w2 == 1:
-        return dist_to_p2 + dist_to_p1
-    return w1 * dist_to_p2 + w2 * dist_to_p1
+        return forward_term + backward_term
+    return w1 * forward_term + w2 * backward_term
 
 
 def f_score(gt_points, pred_points, radius=0.01, eps=1e-8):
-    r"""F-score of a predicted point cloud w.r.t. a ground-truth one: a prediction is a true
-    positive when a ground-truth point lies within ``radius``
+    r"""F-score of a predicted cloud: a predicted point is a true positive when a ground-truth point lies within
+    ``radius``; misses are ground-truth points with no prediction within ``radius``
     (reference: kaolin/metrics/pointcloud.py:138-184).
 
     Returns:
-        (torch.Tensor): of shape :math:`(B)`.
+        (torch.Tensor): :math:`(B)`.
     """
-    pred_distances = torch.sqrt(sided_distance(gt_points, pred_points)[0])
-    gt_distances = torch.sqrt(sided_distance(pred_points, gt_points)[0])
-    data_type = gt_points.dtype
-    fn = torch.sum(pred_distances > radius, dim=1).type(data_type)
-    fp = torch.sum(gt_distances > radius, dim=1).type(data_type)
-    tp = (gt_distances.shape[1] - fp).type(data_type)
-    precision = tp / (tp + fp)
-    recall = tp / (tp + fn)
+    dtype = gt_points.dtype
+    gt_to_pred = sided_distance(gt_points, pred_points)[0].sqrt()
+    pred_to_gt = sided_distance(pred_points, gt_points)[0].sqrt()
+    missed = (gt_to_pred > radius).sum(dim=1).type(dtype)          # false negatives
+    spurious = (pred_to_gt > radius).sum(dim=1).type(dtype)        # false positives
+    hits = (pred_to_gt.shape[1] - spurious).type(dtype)            # true positives
+    precision, recall = hits / (hits + spurious), hits / (hits + missed)
     return 2 * (precision * recall) / (precision + recall + eps)

@@ -11,30 +11,28 @@ __all__ = ['point_to_mesh_distance', 'average_edge_length']
 
 
 class _UnbatchedTriangleDistanceCuda(torch.autograd.Function):
-    """Same contract as the reference's shim (metrics/trianglemesh.py:125-149): the three outputs are allocated
-    here (zeros) and filled by the operator; face_idx / dist_type are non-differentiable; backward accumulates
-    into zero-initialised grad_points / grad_face_vertices."""
+    """Same contract as the reference's shim (metrics/trianglemesh.py:125-149): the operator writes into three
+    caller-allocated outputs; the face index and region code are non-differentiable; backward accumulates into
+    zero-initialised gradients."""
 
     @staticmethod
     def forward(ctx, points, face_vertices):
-        num_points = points.shape[0]
-        points, face_vertices = points.contiguous(), face_vertices.contiguous()
-        min_dist = torch.zeros((num_points), device=points.device, dtype=points.dtype)
-        min_dist_idx = torch.zeros((num_points), device=points.device, dtype=torch.long)
-        dist_type = torch.zeros((num_points), device=points.device, dtype=torch.int32)
-        _C.metrics.unbatched_triangle_distance_forward_cuda(points, face_vertices, min_dist, min_dist_idx, dist_type)
-        ctx.save_for_backward(points, face_vertices, min_dist_idx, dist_type)
-        ctx.mark_non_differentiable(min_dist_idx, dist_type)
-        return min_dist, min_dist_idx, dist_type
+        pts, tris = points.contiguous(), face_vertices.contiguous()
+        n, dev = pts.shape[0], pts.device
+        out = (torch.zeros(n, device=dev, dtype=pts.dtype), torch.zeros(n, device=dev, dtype=torch.long),
+               torch.zeros(n, device=dev, dtype=torch.int32))
+        _C.metrics.unbatched_triangle_distance_forward_cuda(pts, tris, *out)
+        ctx.mark_non_differentiable(out[1], out[2])
+        ctx.save_for_backward(pts, tris, out[1], out[2])
+        return out
 
     @staticmethod
-    def backward(ctx, grad_dist, grad_face_idx, grad_dist_type):
-        points, face_vertices, face_idx, dist_type = ctx.saved_tensors
-        grad_points = torch.zeros_like(points)
-        grad_face_vertices = torch.zeros_like(face_vertices)
-        _C.metrics.unbatched_triangle_distance_backward_cuda(
-            grad_dist.contiguous(), points, face_vertices, face_idx, dist_type, grad_points, grad_face_vertices)
-        return grad_points, grad_face_vertices
+    def backward(ctx, grad_dist, _grad_idx, _grad_type):
+        pts, tris, nearest_face, region = ctx.saved_tensors
+        g_pts, g_tris = torch.zeros_like(pts), torch.zeros_like(tris)
+        _C.metrics.unbatched_triangle_distance_backward_cuda(grad_dist.contiguous(), pts, tris, nearest_face, region,
+                                                             g_pts, g_tris)
+        return g_pts, g_tris
 
 
 def point_to_mesh_distance(pointclouds, face_vertices):
@@ -49,13 +47,8 @@ def point_to_mesh_distance(pointclouds, face_vertices):
         (torch.Tensor, torch.LongTensor, torch.IntTensor): squared distances (B, N); index of the closest face
         (B, N); region code (B, N): 0 the face interior, 1-3 vertex v1/v2/v3, 4-6 edge v1v2 / v2v3 / v3v1.
     """
-    dists, idxs, types = [], [], []
-    for i in range(pointclouds.shape[0]):
-        d, f, t = _UnbatchedTriangleDistanceCuda.apply(pointclouds[i], face_vertices[i])
-        dists.append(d)
-        idxs.append(f)
-        types.append(t)
-    return torch.stack(dists, dim=0), torch.stack(idxs, dim=0), torch.stack(types, dim=0)
+    per_item = [_UnbatchedTriangleDistanceCuda.apply(pointclouds[b], face_vertices[b]) for b in range(pointclouds.shape[0])]
+    return tuple(torch.stack(column, dim=0) for column in zip(*per_item))
 
 
 def average_edge_length(vertices, faces):

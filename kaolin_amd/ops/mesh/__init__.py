@@ -34,12 +34,9 @@ def face_normals(face_vertices, unit=False):
 def _unbatched_check_sign_cuda(verts, faces, points):
     """kaolin/ops/mesh/check_sign.py:45-54."""
     from ... import _C
-    points = points.contiguous()
-    v1 = torch.index_select(verts, 0, faces[:, 0]).view(-1, 3).contiguous()
-    v2 = torch.index_select(verts, 0, faces[:, 1]).view(-1, 3).contiguous()
-    v3 = torch.index_select(verts, 0, faces[:, 2]).view(-1, 3).contiguous()
-    ints = _C.ops.unbatched_mesh_intersection_cuda(points, v1, v2, v3)
-    return ints % 2 == 1.
+    corners = [verts[faces[:, k]].contiguous() for k in range(3)]
+    crossings = _C.ops.unbatched_mesh_intersection_cuda(points.contiguous(), *corners)
+    return crossings % 2 == 1.
 
 
 def check_sign(verts, faces, points, hash_resolution=512):
@@ -78,10 +75,8 @@ def check_sign(verts, faces, points, hash_resolution=512):
     if points.device.type != 'cuda':
         raise RuntimeError('check_sign: only the GPU path is implemented (the reference CPU path is a C++ TriangleHash, '
                            'out of scope: SURVEY.md section 2)')
-    xlen = verts[..., 0].max(-1)[0] - verts[..., 0].min(-1)[0]
-    ylen = verts[..., 1].max(-1)[0] - verts[..., 1].min(-1)[0]
-    zlen = verts[..., 2].max(-1)[0] - verts[..., 2].min(-1)[0]
-    maxlen = torch.max(torch.stack([xlen, ylen, zlen]), 0)[0]
-    verts = verts / maxlen.view(-1, 1, 1)
-    points = points / maxlen.view(-1, 1, 1)
+    # normalise by the largest extent of each mesh (check_sign.py:139-145): the ray's far end is then surely outside
+    extent = verts.max(dim=1)[0] - verts.min(dim=1)[0]                      # (B, 3)
+    scale = extent.max(dim=1)[0].view(-1, 1, 1)
+    verts, points = verts / scale, points / scale
     return torch.stack([_unbatched_check_sign_cuda(verts[i], faces, points[i]) for i in range(verts.shape[0])])
