@@ -164,15 +164,25 @@ struct HitList {      // compact output (our own autograd path): one record per 
   unsigned int* n_items;    // number of worklist entries (written by the search kernel)
 };
 
+constexpr int CL_IDCAP = 2048;   // tile ids the classify workgroup can expand in LDS
+constexpr int SM_CANDCAP = 512;  // candidate faces per work item handed to the search kernel (more: it expands itself)
+
 template <typename T>
 __global__ __launch_bounds__(TILE_THREADS) void soft_classify_kernel(
-    int B, TileGeom g, const uint8_t* __restrict__ sub_flags, const int64_t* __restrict__ sel_idx,
-    T* __restrict__ soft_mask, uint8_t* __restrict__ hit_count, int* __restrict__ worklist,
-    unsigned int* __restrict__ work_count) {
-  // workgroup = one (tile, mesh): 16 wavefronts = its 16 sub-tiles; ONE worklist atomic per workgroup
-  __shared__ int s_need[SM_SUBS];
+    int B, int F, TileGeom g, float multiplier, const T* __restrict__ rec, const unsigned int* __restrict__ masks,
+    const uint8_t* __restrict__ sub_flags, const int64_t* __restrict__ sel_idx, T* __restrict__ soft_mask,
+    uint8_t* __restrict__ hit_count, int* __restrict__ worklist, unsigned int* __restrict__ work_count,
+    int* __restrict__ cand, int* __restrict__ cand_count) {
+  // workgroup = one (tile, mesh): 16 wavefronts = its 16 sub-tiles.  Settles the trivial pixels, queues the sub-tiles
+  // that need a search (ONE worklist atomic per workgroup) and -- because the 16 sub-tiles share the tile's bitmask --
+  // expands that bitmask once and lets every queued wavefront cull it against its own uncovered pixels: the search
+  // kernel then starts from a short candidate list instead of scanning F/32 mask words per sub-tile.
+  __shared__ int s_slot[SM_SUBS];
+  __shared__ int s_nneed;
+  __shared__ int s_ids[CL_IDCAP];
+  __shared__ int s_scan[TILE_THREADS / 64 + 1];
   const int b = blockIdx.x % B, tile = blockIdx.x / B;
-  const int sub = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tid = threadIdx.x, sub = tid >> 6, lane = tid & 63;
   const int sub_x = (tile % g.tiles_x) * TILE_W + (sub & 1) * SUB_W;
   const int sub_y = (tile / g.tiles_x) * TILE_H + (sub >> 1) * SUB_H;
   const int col = sub_x + (lane & 15), row = sub_y + (lane >> 4);
@@ -186,25 +196,95 @@ __global__ __launch_bounds__(TILE_THREADS) void soft_classify_kernel(
     if (hit_count) hit_count[p1] = 0;
   }
   const bool need = touched && __any(uncovered);
-  if (lane == 0) s_need[sub] = need ? 1 : 0;
+  if (lane == 0) s_slot[sub] = need ? 1 : 0;
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
     int n = 0;
 #pragma unroll
-    for (int i = 0; i < SM_SUBS; ++i) n += s_need[i];
-    if (n > 0) {
-      unsigned int base = atomicAdd(work_count, (unsigned int)n);
+    for (int i = 0; i < SM_SUBS; ++i) n += s_slot[i];
+    unsigned int base = n > 0 ? atomicAdd(work_count, (unsigned int)n) : 0u;
 #pragma unroll
-      for (int i = 0; i < SM_SUBS; ++i)
-        if (s_need[i]) worklist[base++] = (tile * B + b) * SM_SUBS + i;
+    for (int i = 0; i < SM_SUBS; ++i) {
+      if (s_slot[i]) {
+        worklist[base] = (tile * B + b) * SM_SUBS + i;
+        s_slot[i] = (int)base++;
+      } else {
+        s_slot[i] = -1;
+      }
+    }
+    s_nneed = n;
+  }
+  __syncthreads();
+  if (s_nneed == 0) return;
+  const int slot = s_slot[sub];
+
+  // expand the tile's bitmask (ascending ids) -- two words per thread
+  const int64_t first_b = (int64_t)b * F;
+  const int nwords = (F + 31) / 32;
+  const unsigned int* tmask = masks + mask_base(g.ntiles, first_b, b, tile, nwords);
+  bool overflow = nwords > 2 * TILE_THREADS;
+  int total = 0;
+  if (!overflow) {
+    const int wi = 2 * tid;
+    const unsigned int w0 = wi < nwords ? tmask[wi] : 0u, w1 = wi + 1 < nwords ? tmask[wi + 1] : 0u;
+    const int excl = block_exclusive_scan(__popc(w0) + __popc(w1), s_scan, &total);
+    overflow = total > CL_IDCAP;
+    if (!overflow) {
+      int pos = excl;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        unsigned int wv = h == 0 ? w0 : w1;
+        while (wv) {
+          const int bit = __ffs(wv) - 1;
+          wv &= wv - 1;
+          s_ids[pos++] = (wi + h) * 32 + bit;
+        }
+      }
     }
   }
+  __syncthreads();
+  if (slot < 0) return;  // (whole wavefront)
+  if (overflow) {
+    if (lane == 0) cand_count[slot] = -1;  // the search kernel expands the bitmask itself
+    return;
+  }
+  // cull against the extent of this wavefront's uncovered pixels
+  const T x0 = pixel_x(multiplier, g.W, col);
+  const T y0 = pixel_y(multiplier, g.H, row);
+  T ux_min = uncovered ? x0 : (T)INFINITY, ux_max = uncovered ? x0 : (T)-INFINITY;
+  T uy_min = uncovered ? y0 : (T)INFINITY, uy_max = uncovered ? y0 : (T)-INFINITY;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    ux_min = fmin(ux_min, __shfl_xor(ux_min, d, 64));
+    ux_max = fmax(ux_max, __shfl_xor(ux_max, d, 64));
+    uy_min = fmin(uy_min, __shfl_xor(uy_min, d, 64));
+    uy_max = fmax(uy_max, __shfl_xor(uy_max, d, 64));
+  }
+  int* mine = cand + (size_t)slot * SM_CANDCAP;
+  int ncand = 0;
+  for (int t0 = 0; t0 < total; t0 += 64) {
+    const int k = t0 + lane;
+    bool keep = false;
+    int id = 0;
+    if (k < total) {
+      id = s_ids[k];
+      const T* r = rec + ((size_t)first_b + id) * REC_STRIDE;
+      const T b0 = r[0], b1 = r[1], b2 = r[2], b3 = r[3];
+      keep = !(ux_max < b0 || ux_min >= b2 || uy_max < b1 || uy_min >= b3);
+    }
+    const unsigned long long m = __ballot(keep);
+    const int pos = ncand + __popcll(m & ((1ull << lane) - 1ull));
+    if (keep && pos < SM_CANDCAP) mine[pos] = id;
+    ncand += __popcll(m);
+  }
+  if (lane == 0) cand_count[slot] = ncand <= SM_CANDCAP ? ncand : -1;
 }
 
 template <typename T, bool LEAN>
 __global__ __launch_bounds__(64) void soft_search_kernel(
     int B, int F, TileGeom g, int K, float sigmainv, float multiplier, const T* __restrict__ rec,
     const unsigned int* __restrict__ masks, const int* __restrict__ worklist, const unsigned int* __restrict__ work_count,
+    const int* __restrict__ cand, const int* __restrict__ cand_count,
     const int64_t* __restrict__ sel_idx, T* __restrict__ soft_mask,
     T* __restrict__ prob_out, int64_t* __restrict__ idx_out, uint8_t* __restrict__ type_out,
     uint8_t* __restrict__ hit_count, HitList<T> list) {
@@ -355,61 +435,75 @@ __global__ __launch_bounds__(64) void soft_search_kernel(
       if (kid >= K) active = false;
     };
 
-    int ncand = 0;
-    bool done = false;
-    unsigned int next_word = (lane < SM_WORDS && lane < nwords) ? tmask[lane] : 0u;
-    for (int w0 = 0; w0 < nwords && !done; w0 += SM_WORDS) {
-      const int wi = w0 + lane;
-      unsigned int word = next_word;
-      next_word = (lane < SM_WORDS && wi + SM_WORDS < nwords) ? tmask[wi + SM_WORDS] : 0u;  // in flight while this step is processed
-      const int c = __popc(word);
-      const int incl = wave_inclusive_scan(c);
-      const int total = __shfl(incl, 63, 64);
-      if (total == 0) continue;
-      __syncthreads();
-      {
-        int pos = incl - c;
-        while (word) {
-          const int bit = __ffs(word) - 1;
-          word &= word - 1;
-          s_tmp[pos++] = wi * 32 + bit;
-        }
-      }
-      __syncthreads();
-      for (int t0 = 0; t0 < total; t0 += 64) {
-        const int k = t0 + lane;
-        bool keep = false;
-        int id = 0;
-        if (k < total) {
-          id = s_tmp[k];
-          const T* r = rec + ((size_t)first_b + id) * REC_STRIDE;
-          const T b0 = r[0], b1 = r[1], b2 = r[2], b3 = r[3];
-          keep = !(ux_max < b0 || ux_min >= b2 || uy_max < b1 || uy_min >= b3);
-        }
-        const unsigned long long m = __ballot(keep);
-        if (m == 0) continue;
-        if (keep) s_cand[ncand + __popcll(m & lt_mask)] = id;
-        ncand += __popcll(m);
+    const int given = cand_count[wi_];
+    if (given >= 0) {
+      // the classify kernel already expanded and culled the tile's bitmask for this sub-tile
+      const int* mine = cand + (size_t)wi_ * SM_CANDCAP;
+      for (int c0 = 0; c0 < given; c0 += 64) {
+        const int n = min(64, given - c0);
         __syncthreads();
-        if (ncand >= 64) {
-          process_chunk(64);
+        if (lane < n) s_cand[lane] = mine[c0 + lane];
+        __syncthreads();
+        process_chunk(n);
+        if (!__any(active)) break;
+      }
+    } else {
+      int ncand = 0;
+      bool done = false;
+      unsigned int next_word = (lane < SM_WORDS && lane < nwords) ? tmask[lane] : 0u;
+      for (int w0 = 0; w0 < nwords && !done; w0 += SM_WORDS) {
+        const int wi = w0 + lane;
+        unsigned int word = next_word;
+        next_word = (lane < SM_WORDS && wi + SM_WORDS < nwords) ? tmask[wi + SM_WORDS] : 0u;  // in flight while this step is processed
+        const int c = __popc(word);
+        const int incl = wave_inclusive_scan(c);
+        const int total = __shfl(incl, 63, 64);
+        if (total == 0) continue;
+        __syncthreads();
+        {
+          int pos = incl - c;
+          while (word) {
+            const int bit = __ffs(word) - 1;
+            word &= word - 1;
+            s_tmp[pos++] = wi * 32 + bit;
+          }
+        }
+        __syncthreads();
+        for (int t0 = 0; t0 < total; t0 += 64) {
+          const int k = t0 + lane;
+          bool keep = false;
+          int id = 0;
+          if (k < total) {
+            id = s_tmp[k];
+            const T* r = rec + ((size_t)first_b + id) * REC_STRIDE;
+            const T b0 = r[0], b1 = r[1], b2 = r[2], b3 = r[3];
+            keep = !(ux_max < b0 || ux_min >= b2 || uy_max < b1 || uy_min >= b3);
+          }
+          const unsigned long long m = __ballot(keep);
+          if (m == 0) continue;
+          if (keep) s_cand[ncand + __popcll(m & lt_mask)] = id;
+          ncand += __popcll(m);
           __syncthreads();
-          const int rest = ncand - 64;
-          const int moved = lane < rest ? s_cand[64 + lane] : 0;
-          __syncthreads();
-          if (lane < rest) s_cand[lane] = moved;
-          ncand = rest;
-          __syncthreads();
-          if (!__any(active)) {
-            done = true;
-            break;
+          if (ncand >= 64) {
+            process_chunk(64);
+            __syncthreads();
+            const int rest = ncand - 64;
+            const int moved = lane < rest ? s_cand[64 + lane] : 0;
+            __syncthreads();
+            if (lane < rest) s_cand[lane] = moved;
+            ncand = rest;
+            __syncthreads();
+            if (!__any(active)) {
+              done = true;
+              break;
+            }
           }
         }
       }
-    }
-    if (!done && ncand > 0) {
-      __syncthreads();
-      process_chunk(ncand);
+      if (!done && ncand > 0) {
+        __syncthreads();
+        process_chunk(ncand);
+      }
     }
     if (uncovered) {
       soft_mask[p1] = (T)(1.0 - (double)all);
@@ -643,7 +737,7 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
     }
     KAMD_CHECK(hipGetLastError());
     if (total_faces > 0) {
-      KAMD_CHECK(hipMemsetAsync(masks, 0, (mask_words(g.ntiles, B, total_faces) + flag_words(g.ntiles, B) + 2) * 4 +
+      KAMD_CHECK(kamd_zero_async(masks, (mask_words(g.ntiles, B, total_faces) + flag_words(g.ntiles, B) + 2) * 4 +
                                            align256((size_t)n_sub), st));
       kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
       if (raw)
@@ -659,10 +753,14 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
   }
   if (phases & 2) {
     int* worklist = (int*)(work + 2);
+    // after the worklist: per-item candidate counts and candidate lists (filled by the classify kernel)
+    int* cand_count = worklist + n_sub;
+    int* cand = (int*)((char*)cand_count + align256((size_t)n_sub * 4));
     {
       kamd::ProfScope prof_(kamd::K_SOFT_CLASSIFY, st);
-      hipLaunchKernelGGL(soft_classify_kernel<T>, dim3(g.ntiles * B), dim3(TILE_THREADS), 0, st, B, g, sub_flags, sel_idx,
-                         soft_mask, lean ? (uint8_t*)nullptr : hit_count, worklist, work);
+      hipLaunchKernelGGL(soft_classify_kernel<T>, dim3(g.ntiles * B), dim3(TILE_THREADS), 0, st, B, F, g, multiplier, rec, masks,
+                         sub_flags, sel_idx, soft_mask, lean ? (uint8_t*)nullptr : hit_count, worklist, work, cand,
+                         cand_count);
     }
     KAMD_CHECK(hipGetLastError());
     if (total_faces > 0) {
@@ -670,11 +768,11 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
       const dim3 grid((unsigned)(n_sub < KAMD_NUM_CU * 16 ? n_sub : KAMD_NUM_CU * 16));
       if (lean)
         hipLaunchKernelGGL((soft_search_kernel<T, true>), grid, dim3(64), 0, st, B, F, g, K, sigmainv, multiplier, rec,
-                           masks, worklist, work, sel_idx, soft_mask, (T*)nullptr, (int64_t*)nullptr,
+                           masks, worklist, work, cand, cand_count, sel_idx, soft_mask, (T*)nullptr, (int64_t*)nullptr,
                            (uint8_t*)nullptr, (uint8_t*)nullptr, *lean);
       else
         hipLaunchKernelGGL((soft_search_kernel<T, false>), grid, dim3(64), 0, st, B, F, g, K, sigmainv, multiplier,
-                           rec, masks, worklist, work, sel_idx, soft_mask, prob, idx, type, hit_count,
+                           rec, masks, worklist, work, cand, cand_count, sel_idx, soft_mask, prob, idx, type, hit_count,
                            HitList<T>{});
     }
   }
@@ -723,8 +821,9 @@ size_t kamd_dibr_soft_mask_forward_workspace(int B, int H, int W, int F, int ele
   if (B <= 0 || H <= 0 || W <= 0 || F <= 0) return 0;
   // bins + the sub-tile worklist {count, next, items[B * ntiles * 16]}
   const kamd::TileGeom g = kamd::tile_geom(H, W);
-  return kamd::bins_workspace_bytes(B, H, W, (long long)B * F, elem_size) + kamd::align256((size_t)g.ntiles * B * 16) +
-         kamd::align256(((size_t)g.ntiles * B * 16 + 2) * 4);
+  const size_t n_sub = (size_t)g.ntiles * B * 16;
+  return kamd::bins_workspace_bytes(B, H, W, (long long)B * F, elem_size) + kamd::align256(n_sub) +
+         kamd::align256((n_sub + 2) * 4) + kamd::align256(n_sub * 4) + n_sub * 512 * 4 + 256;
 }
 
 int kamd_dibr_soft_mask_forward_f32(void* stream, int B, int H, int W, int F, int K, const float* img,

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void vox_faces_kernel(long long total, int V, 
 template <typename T>
 int vox_launch(hipStream_t st, int B, int V, int F, int R, const T* vertices, const int64_t* faces, T* grid) {
   if (B <= 0 || R <= 1) return 0;
-  KAMD_CHECK(hipMemsetAsync(grid, 0, (size_t)B * R * R * R * sizeof(T), st));
+  KAMD_CHECK(kamd_zero_async(grid, (size_t)B * R * R * R * sizeof(T), st));
   if (V > 0) {
     const long long tv = (long long)B * V;
     {
