@@ -358,11 +358,11 @@ __global__ __launch_bounds__(64) void soft_search_kernel(
       }
       __syncthreads();
       unsigned long long hm = 0;
+      const Box4<T>* boxes = reinterpret_cast<const Box4<T>*>(s_bb);
 #pragma unroll 8
       for (int k = 0; k < n; ++k) {
-        const T xmin = s_bb[k * 4 + 0], ymin = s_bb[k * 4 + 1], xmax = s_bb[k * 4 + 2], ymax = s_bb[k * 4 + 3];
-        const bool pass = !(x0 < xmin || x0 >= xmax || y0 < ymin || y0 >= ymax);
-        hm |= pass ? (1ull << k) : 0ull;
+        const Box4<T> bb = boxes[k];  // one uniform ds_read_b128
+        hm |= box_rejects<T>(bb, x0, y0) ? 0ull : (1ull << k);
       }
       const int cnt = active ? min(__popcll(hm), K - kid) : 0;
       const int incl = wave_inclusive_scan(cnt);

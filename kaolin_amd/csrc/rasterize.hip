@@ -102,8 +102,8 @@ __global__ __launch_bounds__(TILE_THREADS) void raster_tile_kernel(
             const int j = __ffsll((long long)m) - 1;
             m &= m - 1;
             const int kk = k0 + j;
-            const T xmin = s_bbox[kk * 4 + 0], ymin = s_bbox[kk * 4 + 1], xmax = s_bbox[kk * 4 + 2], ymax = s_bbox[kk * 4 + 3];
-            if (x0 < xmin || x0 >= xmax || y0 < ymin || y0 >= ymax) continue;
+            const Box4<T> bb = reinterpret_cast<const Box4<T>*>(s_bbox)[kk];  // one uniform ds_read_b128
+            if (box_rejects<T>(bb, x0, y0)) continue;
             const T* v = s_rest + kk * 12;
             const T aex = v[0] - x0, aey = v[1] - y0;
             const T bex = v[2] - x0, bey = v[3] - y0;

@@ -29,6 +29,18 @@ constexpr int SUB_W = 16, SUB_H = 4;     // pixels per wavefront sub-tile (64 la
 constexpr int TILE_THREADS = 1024;       // 16 wavefronts: 2 x 8 sub-tiles
 constexpr int REC_STRIDE = 16;           // scalars per face record
 
+// four scalars read with ONE wide LDS / global load (a short-circuit chain of compares on four separately indexed
+// scalars compiles to dependent ds_read_b32 + branch pairs: measured ~300 cycles per box in the soft-mask search)
+template <typename T>
+struct alignas(16) Box4 {
+  T x0, y0, x1, y1;  // xmin, ymin, xmax, ymax
+};
+// the reference's reject test `x < xmin || x >= xmax || y < ymin || y >= ymax`, branch-free (NaN limits never reject)
+template <typename T>
+__device__ __forceinline__ bool box_rejects(const Box4<T>& b, T x, T y) {
+  return (x < b.x0) | (x >= b.x1) | (y < b.y0) | (y >= b.y1);
+}
+
 struct TileGeom {
   int H, W, tiles_x, tiles_y, ntiles;
 };
