@@ -1,0 +1,23 @@
+#!/bin/bash
+# One call on the GPU box that regenerates everything kept under profiles/ for a round:
+#   bash tools/round_profile.sh <tag> [pmc]
+# writes gpurun_out/<tag>/{pytest_gpu.log, bench.json, bench_under_rocprof.json, kernel_stats.csv,
+# pmc_fetch.csv, pmc_write.csv}.  PMC passes run on their own (never combined with a trace domain).
+set -u
+tag=${1:-r01x}; pmc=${2:-}
+repo=$(pwd); out=$repo/gpurun_out/$tag; mkdir -p $out
+timeout 900 python -m pytest tests -m gpu -q -x > $out/pytest_gpu.log 2>&1; tail -2 $out/pytest_gpu.log
+timeout 600 python bench.py 2> $out/bench.err | tail -1 > $out/bench.json
+timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python $repo/bench.py --no-cpu-baseline 2> $out/prof.err | tail -1 > $out/bench_under_rocprof.json
+find $out/prof -name '*kernel_stats.csv' -exec cp {} $out/kernel_stats.csv \;
+if [ -n "$pmc" ]; then
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_f -- python $repo/tools/pmc_traffic.py > /dev/null 2>&1
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_w -- python $repo/tools/pmc_traffic.py > /dev/null 2>&1
+  find $out/pmc_f -name '*counter_collection.csv' -exec cp {} $out/pmc_fetch.csv \;
+  find $out/pmc_w -name '*counter_collection.csv' -exec cp {} $out/pmc_write.csv \;
+  rm -rf $out/pmc_f $out/pmc_w
+fi
+rm -rf $out/prof
+cd $repo; ls -la $out; cat $out/bench.json | cut -c1-400
