@@ -297,6 +297,63 @@ int kamd_prepare_vertices_backward_f64(void* stream, int B, int V, int F, const 
                                        double* g_vertices);
 
 /* ------------------------------------------------------------------------- */
+/* render.mesh.deftet_sparse_render_forward_cuda(face_vertices_z,             */
+/*     face_vertices_image, face_bboxes, pixel_coords, pixel_depth_ranges,    */
+/*     knum, eps) -> [face_idx, pixel_depths, w0, w1]                          */
+/* (reference: kaolin/csrc/render/mesh/deftet.cpp:47-108,   */
+/* deftet_cuda.cu:31-232).  face_vertices_z (B,F,3), face_vertices_image      */
+/* (B,F,3,2), face_bboxes (B,F,4) = (xmin,ymin,xmax,ymax), pixel_coords and    */
+/* pixel_depth_ranges (B,P,2).  Outputs (B,P,K), FULLY written here (the       */
+/* reference pre-fills them: -1 / -inf / 0 / 0): per pixel the first K faces   */
+/* in mesh order whose box [min,max) and triangle contain the pixel with       */
+/* min_depth <= depth < max_depth, unsorted.  workspace: the pixel-ordering    */
+/* scratch, kamd_deftet_forward_workspace(B,P) bytes (0 when P <= 256), no     */
+/* initialisation needed.                                                      */
+/*                                                                             */
+/* _forward_fused = the whole of DeftetSparseRenderer.forward                  */
+/* (kaolin/render/mesh/deftet.py:269-315): the operator above, then hits       */
+/* sorted by depth (descending, equal depths keep mesh order),                 */
+/* w2 = 1 - (w0 + w1), corner features weighted and summed.  tmp_* (B,P,K) and */
+/* hit_count (B,P) int32 are uninitialised scratch; sorted_face_idx (B,P,K),   */
+/* weights (B,P,K,3), interpolated_features (B,P,K,D) are fully written.       */
+/*                                                                             */
+/* render.mesh.deftet_sparse_render_backward_cuda(grad, face_idx, weights,    */
+/*     face_vertices_image, face_features, eps) -> [g_image, g_features]       */
+/* (deftet.cpp:110-161, deftet_cuda.cu:240-449): grad (B,P,K,D), face_idx      */
+/* (B,P,K), weights (B,P,K,3); both gradients ACCUMULATE: caller zero-fills    */
+/* (the reference wrapper allocates them with zeros_like).                     */
+/* ------------------------------------------------------------------------- */
+size_t kamd_deftet_forward_workspace(int B, int P);
+int kamd_deftet_sparse_render_forward_f32(void* stream, int B, int F, int P, int K, const float* face_vertices_z,
+        const float* face_vertices_image, const float* face_bboxes, const float* pixel_coords,
+        const float* pixel_depth_ranges, float eps, int64_t* face_idx, float* pixel_depths, float* w0, float* w1,
+        void* workspace, size_t workspace_bytes);
+int kamd_deftet_sparse_render_forward_fused_f32(void* stream, int B, int F, int P, int K, int D,
+        const float* face_vertices_z, const float* face_vertices_image, const float* face_bboxes,
+        const float* pixel_coords, const float* pixel_depth_ranges, const float* face_features, float eps,
+        int64_t* tmp_face_idx, float* tmp_depths, float* tmp_w0, float* tmp_w1, int32_t* hit_count,
+        int64_t* sorted_face_idx, float* weights, float* interpolated_features, void* workspace,
+        size_t workspace_bytes);
+int kamd_deftet_sparse_render_backward_f32(void* stream, int B, int F, int P, int K, int D,
+        const float* grad_interpolated_features, const int64_t* face_idx, const float* weights,
+        const float* face_vertices_image, const float* face_features, float eps,
+        float* grad_face_vertices_image, float* grad_face_features);
+int kamd_deftet_sparse_render_forward_f64(void* stream, int B, int F, int P, int K, const double* face_vertices_z,
+        const double* face_vertices_image, const double* face_bboxes, const double* pixel_coords,
+        const double* pixel_depth_ranges, float eps, int64_t* face_idx, double* pixel_depths, double* w0, double* w1,
+        void* workspace, size_t workspace_bytes);
+int kamd_deftet_sparse_render_forward_fused_f64(void* stream, int B, int F, int P, int K, int D,
+        const double* face_vertices_z, const double* face_vertices_image, const double* face_bboxes,
+        const double* pixel_coords, const double* pixel_depth_ranges, const double* face_features, float eps,
+        int64_t* tmp_face_idx, double* tmp_depths, double* tmp_w0, double* tmp_w1, int32_t* hit_count,
+        int64_t* sorted_face_idx, double* weights, double* interpolated_features, void* workspace,
+        size_t workspace_bytes);
+int kamd_deftet_sparse_render_backward_f64(void* stream, int B, int F, int P, int K, int D,
+        const double* grad_interpolated_features, const int64_t* face_idx, const double* weights,
+        const double* face_vertices_image, const double* face_features, float eps,
+        double* grad_face_vertices_image, double* grad_face_features);
+
+/* ------------------------------------------------------------------------- */
 /* ops.mesh.unbatched_mesh_intersection_cuda(points, v1, v2, v3) -> result     */
 /* (reference: kaolin/csrc/ops/mesh/mesh_intersection.cpp,  */
 /* mesh_intersection_cuda.cu:101-253).  points (N,3); v1,v2,v3 (F,3) = the      */

@@ -465,3 +465,113 @@ def prepare_vertices_backward_fused(vertices, faces, camera_proj, camera_rot, ca
             _lib.ptr(g[2]), _lib.ptr(g_vertices))
     _lib.check(st, fn)
     return g_vertices
+
+
+# ---- deftet sparse render --------------------------------------------------------------------
+def _deftet_forward_args(fn, face_vertices_z, face_vertices_image, face_bboxes, pixel_coords, pixel_depth_ranges):
+    args = [Arg(face_vertices_z, 'face_vertices_z', 1), Arg(face_vertices_image, 'face_vertices_image', 2),
+            Arg(face_bboxes, 'face_bboxes', 3), Arg(pixel_coords, 'pixel_coords', 4),
+            Arg(pixel_depth_ranges, 'pixel_depth_ranges', 5)]
+    check_all_same_gpu(fn, args)
+    check_all_contiguous(fn, args)
+    batch_size, num_faces, num_points = face_vertices_z.size(0), face_vertices_z.size(1), pixel_coords.size(1)
+    check_size(fn, args[0], [batch_size, num_faces, 3])
+    check_size(fn, args[1], [batch_size, num_faces, 3, 2])
+    check_size(fn, args[2], [batch_size, num_faces, 4])
+    check_size(fn, args[3], [batch_size, num_points, 2])
+    check_size(fn, args[4], [batch_size, num_points, 2])
+    return batch_size, num_faces, num_points
+
+
+def _deftet_workspace(lib, batch_size, num_points, device):
+    nbytes = lib.kamd_deftet_forward_workspace(batch_size, num_points)
+    return torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=device), nbytes
+
+
+def deftet_sparse_render_forward_cuda(face_vertices_z, face_vertices_image, face_bboxes, pixel_coords,
+                                      pixel_depth_ranges, knum, eps):
+    """reference: deftet.cpp:47-108 -> [face_idx (B,P,knum) int64, pixel_depths, w0, w1 (B,P,knum)]: per pixel the
+    first knum intersected faces in mesh order (unsorted); unused slots hold -1 / -inf / 0 / 0."""
+    fn = 'deftet_sparse_render_forward_cuda'
+    batch_size, num_faces, num_points = _deftet_forward_args(
+        fn, face_vertices_z, face_vertices_image, face_bboxes, pixel_coords, pixel_depth_ranges)
+    dtype, device = face_vertices_z.dtype, face_vertices_z.device
+    sfx = _lib.dtype_suffix(dtype, fn)
+    lib = _lib.load()
+    knum = int(knum)
+    with torch.cuda.device(device):
+        face_idx = torch.empty((batch_size, num_points, knum), dtype=torch.long, device=device)
+        depths, w0, w1 = (torch.empty((batch_size, num_points, knum), dtype=dtype, device=device) for _ in range(3))
+        ws, nbytes = _deftet_workspace(lib, batch_size, num_points, device)
+        st = getattr(lib, f'kamd_deftet_sparse_render_forward_{sfx}')(
+            _lib.stream_ptr(device), batch_size, num_faces, num_points, knum, _lib.ptr(face_vertices_z),
+            _lib.ptr(face_vertices_image), _lib.ptr(face_bboxes), _lib.ptr(pixel_coords), _lib.ptr(pixel_depth_ranges),
+            float(eps), _lib.ptr(face_idx), _lib.ptr(depths), _lib.ptr(w0), _lib.ptr(w1), _lib.ptr(ws), nbytes)
+    _lib.check(st, fn)
+    return [face_idx, depths, w0, w1]
+
+
+def deftet_sparse_render_forward_fused(face_vertices_z, face_vertices_image, face_bboxes, pixel_coords,
+                                       pixel_depth_ranges, face_features, knum, eps):
+    """The whole of DeftetSparseRenderer.forward (kaolin/render/mesh/deftet.py:269-315) in one call: the forward
+    operator, the depth sort, w2 and the feature interpolation.
+    -> [interpolated_features (B,P,knum,D), sorted_face_idx (B,P,knum) int64, weights (B,P,knum,3)]"""
+    fn = 'deftet_sparse_render_forward_fused'
+    batch_size, num_faces, num_points = _deftet_forward_args(
+        fn, face_vertices_z, face_vertices_image, face_bboxes, pixel_coords, pixel_depth_ranges)
+    feat = Arg(face_features, 'face_features', 6)
+    check_all_same_gpu(fn, [Arg(face_vertices_z, 'face_vertices_z', 1), feat])
+    check_all_contiguous(fn, [feat])
+    feat_dim = face_features.size(-1)
+    check_size(fn, feat, [batch_size, num_faces, 3, feat_dim])
+    dtype, device = face_vertices_z.dtype, face_vertices_z.device
+    sfx = _lib.dtype_suffix(dtype, fn)
+    lib = _lib.load()
+    knum = int(knum)
+    shape = (batch_size, num_points, knum)
+    with torch.cuda.device(device):
+        tmp_idx = torch.empty(shape, dtype=torch.long, device=device)
+        tmp_d, tmp_w0, tmp_w1 = (torch.empty(shape, dtype=dtype, device=device) for _ in range(3))
+        hit_count = torch.empty((batch_size, num_points), dtype=torch.int32, device=device)
+        sorted_idx = torch.empty(shape, dtype=torch.long, device=device)
+        weights = torch.empty(shape + (3,), dtype=dtype, device=device)
+        out = torch.empty(shape + (feat_dim,), dtype=dtype, device=device)
+        ws, nbytes = _deftet_workspace(lib, batch_size, num_points, device)
+        st = getattr(lib, f'kamd_deftet_sparse_render_forward_fused_{sfx}')(
+            _lib.stream_ptr(device), batch_size, num_faces, num_points, knum, feat_dim, _lib.ptr(face_vertices_z),
+            _lib.ptr(face_vertices_image), _lib.ptr(face_bboxes), _lib.ptr(pixel_coords), _lib.ptr(pixel_depth_ranges),
+            _lib.ptr(face_features), float(eps), _lib.ptr(tmp_idx), _lib.ptr(tmp_d), _lib.ptr(tmp_w0), _lib.ptr(tmp_w1),
+            _lib.ptr(hit_count), _lib.ptr(sorted_idx), _lib.ptr(weights), _lib.ptr(out), _lib.ptr(ws), nbytes)
+    _lib.check(st, fn)
+    return [out, sorted_idx, weights]
+
+
+def deftet_sparse_render_backward_cuda(grad_interpolated_features, face_idx, weights, face_vertices_image,
+                                       face_features, eps):
+    """reference: deftet.cpp:110-161 -> [grad_face_vertices_image (B,F,3,2), grad_face_features (B,F,3,D)]"""
+    fn = 'deftet_sparse_render_backward_cuda'
+    args = [Arg(grad_interpolated_features, 'grad_interpolated_features', 1), Arg(face_idx, 'face_idx', 2),
+            Arg(weights, 'weights', 3), Arg(face_vertices_image, 'face_vertices_image', 4),
+            Arg(face_features, 'face_features', 5)]
+    check_all_same_gpu(fn, args)
+    check_all_contiguous(fn, args)
+    batch_size, num_pixels, knum, feat_dim = (grad_interpolated_features.size(0), grad_interpolated_features.size(1),
+                                              grad_interpolated_features.size(2), grad_interpolated_features.size(3))
+    num_faces = face_vertices_image.size(1)
+    check_size(fn, args[0], [batch_size, num_pixels, knum, feat_dim])
+    check_size(fn, args[1], [batch_size, num_pixels, knum])
+    check_size(fn, args[2], [batch_size, num_pixels, knum, 3])
+    check_size(fn, args[3], [batch_size, num_faces, 3, 2])
+    check_size(fn, args[4], [batch_size, num_faces, 3, feat_dim])
+    dtype, device = grad_interpolated_features.dtype, grad_interpolated_features.device
+    sfx = _lib.dtype_suffix(dtype, fn)
+    lib = _lib.load()
+    with torch.cuda.device(device):
+        g_img = torch.zeros_like(face_vertices_image)
+        g_feat = torch.zeros_like(face_features)
+        st = getattr(lib, f'kamd_deftet_sparse_render_backward_{sfx}')(
+            _lib.stream_ptr(device), batch_size, num_faces, num_pixels, knum, feat_dim,
+            _lib.ptr(grad_interpolated_features), _lib.ptr(face_idx), _lib.ptr(weights), _lib.ptr(face_vertices_image),
+            _lib.ptr(face_features), float(eps), _lib.ptr(g_img), _lib.ptr(g_feat))
+    _lib.check(st, fn)
+    return [g_img, g_feat]

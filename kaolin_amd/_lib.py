@@ -30,6 +30,7 @@ SIGNATURES = {
     'kamd_dibr_soft_mask_forward_workspace': (_sz, [_i, _i, _i, _i, _i]),
     'kamd_triangle_distance_forward_workspace': (_sz, [_i, _i, _i]),
     'kamd_dibr_soft_mask_lean_capacity': (_sz, [_i, _i, _i, _i]),
+    'kamd_deftet_forward_workspace': (_sz, [_i, _i]),
     'kamd_profile_enable': (_i, [_i]),
     'kamd_profile_reset': (_i, []),
     'kamd_profile_num_kernels': (_i, []),
@@ -65,6 +66,12 @@ for _t in ('f32', 'f64'):
     SIGNATURES[f'kamd_prepare_vertices_backward_{_t}'] = (
         _i, [_vp, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_mesh_intersection_{_t}'] = (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp])
+    SIGNATURES[f'kamd_deftet_sparse_render_forward_{_t}'] = (
+        _i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _sz])
+    SIGNATURES[f'kamd_deftet_sparse_render_forward_fused_{_t}'] = (
+        _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f] + [_vp] * 9 + [_sz])
+    SIGNATURES[f'kamd_deftet_sparse_render_backward_{_t}'] = (
+        _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp])
     SIGNATURES[f'kamd_triangle_distance_forward_{_t}'] = (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_triangle_distance_backward_{_t}'] = (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_trianglemeshes_to_voxelgrids_{_t}'] = (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp])

@@ -256,3 +256,55 @@ def check_sign(verts, faces, points, omp=False):
         ints = mesh_intersection(points[i], v[faces[:, 0]], v[faces[:, 1]], v[faces[:, 2]], omp=omp)
         res.append(ints % 2 == 1.)
     return torch.stack(res)
+
+
+# ---- deftet sparse render (multi-hit rasterization of free pixel coordinates) ------------------
+def deftet_sparse_render_forward(face_vertices_z, face_vertices_image, face_bboxes, pixel_coords, pixel_depth_ranges,
+                                 knum, eps, omp=False):
+    """deftet.cpp:47-108: -> face_idx (B,P,knum) int64, pixel_depths, w0, w1 (first knum hits in mesh order, unsorted)."""
+    z, img, bb = _cpu(face_vertices_z), _cpu(face_vertices_image), _cpu(face_bboxes)
+    pix, rng = _cpu(pixel_coords), _cpu(pixel_depth_ranges)
+    B, F = z.shape[:2]
+    P = pix.shape[1]
+    face_idx = torch.empty(B, P, knum, dtype=torch.long)
+    depth, w0, w1 = (torch.empty(B, P, knum, dtype=z.dtype) for _ in range(3))
+    f = getattr(lib(omp), f'oracle_deftet_forward_{_SFX[z.dtype]}')
+    f(_ci(B), _ci(F), _ci(P), _ci(knum), _p(z), _p(img), _p(bb), _p(pix), _p(rng), _cf(eps), _p(face_idx), _p(depth),
+      _p(w0), _p(w1))
+    return face_idx, depth, w0, w1
+
+
+def deftet_sparse_render_backward(grad_interpolated_features, face_idx, weights, face_vertices_image, face_features,
+                                  eps):
+    """deftet.cpp:110-161 -> grad_face_vertices_image, grad_face_features."""
+    grad, face_idx, weights = _cpu(grad_interpolated_features), _cpu(face_idx, torch.long), _cpu(weights)
+    img, feat = _cpu(face_vertices_image), _cpu(face_features)
+    B, P, K, D = grad.shape
+    F = img.shape[1]
+    g_img, g_feat = torch.zeros_like(img), torch.zeros_like(feat)
+    f = getattr(lib(False), f'oracle_deftet_backward_{_SFX[grad.dtype]}')
+    f(_ci(B), _ci(F), _ci(P), _ci(K), _ci(D), _p(grad), _p(face_idx), _p(weights), _p(img), _p(feat), _cf(eps),
+      _p(g_img), _p(g_feat))
+    return g_img, g_feat
+
+
+def deftet_sparse_render(pixel_coords, render_ranges, face_vertices_z, face_vertices_image, face_features, knum=300,
+                         eps=1e-8, omp=False):
+    """kaolin/render/mesh/deftet.py:269-315 (DeftetSparseRenderer.forward): boxes, the forward operator, sort by depth
+    (descending; the reference's `torch.argsort` leaves the order of equal depths unspecified -- here, and in the
+    product, equal depths keep mesh order), w2 = [hit] - (w0 + w1), corner features weighted and summed.
+    -> dict(features (B,P,knum,D), face_idx, weights (B,P,knum,3))."""
+    z, img, feat = _cpu(face_vertices_z), _cpu(face_vertices_image), _cpu(face_features)
+    bb = torch.cat([img.min(dim=2)[0], img.max(dim=2)[0]], dim=2)
+    face_idx, depth, w0, w1 = deftet_sparse_render_forward(z, img, bb, pixel_coords, render_ranges, knum, eps, omp=omp)
+    order = torch.argsort(depth, descending=True, dim=-1, stable=True)
+    face_idx = torch.gather(face_idx, -1, order).contiguous()
+    w0, w1 = torch.gather(w0, -1, order), torch.gather(w1, -1, order)
+    w2 = (face_idx != -1).to(z.dtype) - (w0 + w1)
+    weights = torch.stack([w0, w1, w2], dim=-1).contiguous()
+    B, F, _, D = feat.shape
+    padded = torch.cat([torch.zeros(B, 1, 3, D, dtype=feat.dtype), feat], dim=1)
+    sel = padded[torch.arange(B).view(B, 1, 1), face_idx + 1]           # (B,P,knum,3,D)
+    features = (weights[..., 0, None] * sel[..., 0, :] + weights[..., 1, None] * sel[..., 1, :]) + \
+        weights[..., 2, None] * sel[..., 2, :]
+    return dict(features=features.contiguous(), face_idx=face_idx, weights=weights)

@@ -261,3 +261,15 @@ DEFINE_SIDED_BWD(oracle_sided_distance_backward_f64, double)
 #include "meshint_oracle.inc"
 #undef T
 #undef FN
+
+/* ---- deftet sparse render ---- */
+#define T float
+#define FN(n) n##_f32
+#include "deftet_oracle.inc"
+#undef T
+#undef FN
+#define T double
+#define FN(n) n##_f64
+#include "deftet_oracle.inc"
+#undef T
+#undef FN

@@ -246,6 +246,39 @@ def dibr_soft_mask():
     save('dibr_soft_mask', **out)
 
 
+@section
+def deftet():
+    """reference oracle: _naive_deftet_sparse_render (kaolin/render/mesh/deftet.py:101-267) on the fixtures of
+    tests/python/kaolin/render/mesh/test_deftet.py:332-441 (model.obj, 3 cameras, seeded random pixel coordinates in
+    [-1,1]^2, render range [zmin | (zmin+zmax)/2, 0], knum 20): face_idx + features for float / double, and for double the
+    autograd gradients of a seeded grad_out (test_backward, :443-489).  hits per pixel stay below knum, so "first knum
+    in mesh order, then sorted" (the CUDA operator) and "first knum by depth" (this oracle) coincide."""
+    dt = _refload.load_reference()['deftet']
+    P, knum = 257, 20
+    out = {}
+    for dn, dtype in (('f32', torch.float), ('f64', torch.double)):
+        fz, fimg, fuv, valid, rr = _model_obj_scene(dtype, 3, False)
+        torch.manual_seed(11)
+        pix = torch.rand(3, P, 2, dtype=dtype) * 2. - 1.
+        zmin, zmax = fz.reshape(3, -1).min(dim=1)[0], fz.reshape(3, -1).max(dim=1)[0]
+        out[f'{dn}_z'], out[f'{dn}_img'], out[f'{dn}_uv'], out[f'{dn}_pix'] = fz, fimg, fuv, pix
+        for centre in (0, 1):
+            lo = (zmin + zmax) / 2. if centre else zmin
+            ranges = torch.nn.functional.pad(lo.unsqueeze(-1), (0, 1), value=0.).unsqueeze(1).repeat(1, P, 1)
+            tag = f'{dn}_centre{centre}'
+            out[tag + '_ranges'] = ranges
+            a, u = fimg.clone().requires_grad_(), fuv.clone().requires_grad_()
+            feats, idx = dt._naive_deftet_sparse_render(pix, ranges, fz, a, u, knum)
+            assert int((idx != -1).sum(-1).max()) < knum
+            out[tag + '_face_idx'], out[tag + '_feat'] = idx.to(torch.int32), feats.detach()
+            if dtype == torch.double:
+                torch.manual_seed(13 + centre)
+                grad_out = torch.rand_like(feats)
+                feats.backward(grad_out)
+                out[tag + '_grad_out'], out[tag + '_g_img'], out[tag + '_g_uv'] = grad_out, a.grad, u.grad
+    save('deftet', **out)
+
+
 if __name__ == '__main__':
     todo = sys.argv[1:] or list(SECTIONS)
     for s in todo:
