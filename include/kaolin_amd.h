@@ -306,9 +306,10 @@ int kamd_prepare_vertices_backward_f64(void* stream, int B, int V, int F, const 
 /* pixel_depth_ranges (B,P,2).  Outputs (B,P,K), FULLY written here (the       */
 /* reference pre-fills them: -1 / -inf / 0 / 0): per pixel the first K faces   */
 /* in mesh order whose box [min,max) and triangle contain the pixel with       */
-/* min_depth <= depth < max_depth, unsorted.  workspace: the pixel-ordering    */
-/* scratch, kamd_deftet_forward_workspace(B,P) bytes (0 when P <= 256), no     */
-/* initialisation needed.                                                      */
+/* min_depth <= depth < max_depth, unsorted.  workspace: sorted pixels, cell    */
+/* table, per-pixel counters and two work lists,                               */
+/* kamd_deftet_forward_workspace(B,F,P,elem_size) bytes (elem_size = 4 | 8),   */
+/* data-independent, no initialisation needed.                                 */
 /*                                                                             */
 /* _forward_fused = the whole of DeftetSparseRenderer.forward                  */
 /* (kaolin/render/mesh/deftet.py:269-315): the operator above, then hits       */
@@ -323,7 +324,7 @@ int kamd_prepare_vertices_backward_f64(void* stream, int B, int V, int F, const 
 /* (B,P,K), weights (B,P,K,3); both gradients ACCUMULATE: caller zero-fills    */
 /* (the reference wrapper allocates them with zeros_like).                     */
 /* ------------------------------------------------------------------------- */
-size_t kamd_deftet_forward_workspace(int B, int P);
+size_t kamd_deftet_forward_workspace(int B, int F, int P, int elem_size);
 int kamd_deftet_sparse_render_forward_f32(void* stream, int B, int F, int P, int K, const float* face_vertices_z,
         const float* face_vertices_image, const float* face_bboxes, const float* pixel_coords,
         const float* pixel_depth_ranges, float eps, int64_t* face_idx, float* pixel_depths, float* w0, float* w1,

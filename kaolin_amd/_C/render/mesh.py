@@ -483,8 +483,8 @@ def _deftet_forward_args(fn, face_vertices_z, face_vertices_image, face_bboxes, 
     return batch_size, num_faces, num_points
 
 
-def _deftet_workspace(lib, batch_size, num_points, device):
-    nbytes = lib.kamd_deftet_forward_workspace(batch_size, num_points)
+def _deftet_workspace(lib, batch_size, num_faces, num_points, dtype, device):
+    nbytes = lib.kamd_deftet_forward_workspace(batch_size, num_faces, num_points, dtype.itemsize)
     return torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=device), nbytes
 
 
@@ -502,7 +502,7 @@ def deftet_sparse_render_forward_cuda(face_vertices_z, face_vertices_image, face
     with torch.cuda.device(device):
         face_idx = torch.empty((batch_size, num_points, knum), dtype=torch.long, device=device)
         depths, w0, w1 = (torch.empty((batch_size, num_points, knum), dtype=dtype, device=device) for _ in range(3))
-        ws, nbytes = _deftet_workspace(lib, batch_size, num_points, device)
+        ws, nbytes = _deftet_workspace(lib, batch_size, num_faces, num_points, dtype, device)
         st = getattr(lib, f'kamd_deftet_sparse_render_forward_{sfx}')(
             _lib.stream_ptr(device), batch_size, num_faces, num_points, knum, _lib.ptr(face_vertices_z),
             _lib.ptr(face_vertices_image), _lib.ptr(face_bboxes), _lib.ptr(pixel_coords), _lib.ptr(pixel_depth_ranges),
@@ -536,7 +536,7 @@ def deftet_sparse_render_forward_fused(face_vertices_z, face_vertices_image, fac
         sorted_idx = torch.empty(shape, dtype=torch.long, device=device)
         weights = torch.empty(shape + (3,), dtype=dtype, device=device)
         out = torch.empty(shape + (feat_dim,), dtype=dtype, device=device)
-        ws, nbytes = _deftet_workspace(lib, batch_size, num_points, device)
+        ws, nbytes = _deftet_workspace(lib, batch_size, num_faces, num_points, dtype, device)
         st = getattr(lib, f'kamd_deftet_sparse_render_forward_fused_{sfx}')(
             _lib.stream_ptr(device), batch_size, num_faces, num_points, knum, feat_dim, _lib.ptr(face_vertices_z),
             _lib.ptr(face_vertices_image), _lib.ptr(face_bboxes), _lib.ptr(pixel_coords), _lib.ptr(pixel_depth_ranges),

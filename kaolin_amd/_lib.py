@@ -30,7 +30,7 @@ SIGNATURES = {
     'kamd_dibr_soft_mask_forward_workspace': (_sz, [_i, _i, _i, _i, _i]),
     'kamd_triangle_distance_forward_workspace': (_sz, [_i, _i, _i]),
     'kamd_dibr_soft_mask_lean_capacity': (_sz, [_i, _i, _i, _i]),
-    'kamd_deftet_forward_workspace': (_sz, [_i, _i]),
+    'kamd_deftet_forward_workspace': (_sz, [_i, _i, _i, _i]),
     'kamd_profile_enable': (_i, [_i]),
     'kamd_profile_reset': (_i, []),
     'kamd_profile_num_kernels': (_i, []),

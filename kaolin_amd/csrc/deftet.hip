@@ -3,17 +3,19 @@
 // Replaces kaolin/csrc/render/mesh/deftet_cuda.cu (forward :31-186, backward :240-404) and the torch chain that
 // follows the forward operator in kaolin/render/mesh/deftet.py:297-311 (argsort by depth, 3 gathers, pad, stack, sum).
 //
-// The reference visits every face for every pixel (P x F box tests).  Here:
-//   1. pixels are counting-sorted into a 64 x 64 grid over their own extent (two LDS-histogram passes, one global
-//      atomic per (workgroup, non-empty cell)), so a workgroup owns 256 pixels that lie close together;
-//   2. a workgroup streams the face boxes once (16-byte loads, thread = face), keeps the faces whose box can contain
-//      one of ITS pixels, and compacts them IN MESH ORDER (ballot + prefix) into an LDS list together with their
-//      vertices;
-//   3. lane = pixel walks that short list in order: one ds_read_b128 per box, a wave-uniform skip when no lane is
-//      inside, the reference's arithmetic for the survivors, hits appended to the pixel's row while fewer than knum.
-// The order of the pixels never changes a result (every pixel is independent), only which faces share a workgroup.
+// The reference visits every face for every pixel (P x F box tests, a warp per pixel).  Here the work is the number of
+// (pixel, face) pairs that are CLOSE, whichever of P and F is large:
+//   1. pixels are counting-sorted by the Z-order number of their cell in a 64 x 64 grid over their own extent (two
+//      LDS-histogram passes, one global atomic per (workgroup, non-empty cell)); the sorted copy (x, y, range) makes a
+//      cell's pixels contiguous;
+//   2. thread = face walks the pixels of the few cells its box overlaps, runs the reference's arithmetic on the ones
+//      inside the box and appends every hit to that pixel's row through a per-pixel counter (any order);
+//      a face whose cells hold more than 256 pixels goes to a second kernel, workgroup = face, thread = cell;
+//   3. rows are put in mesh order afterwards (they hold a handful of entries).  A pixel that collected MORE than knum
+//      hits needs "the first knum in mesh order": those (rare) pixels are redone the reference's way, one wavefront per
+//      pixel streaming the faces in order with ballot-prefix appends.
 // Arithmetic follows the reference expression by expression (-ffp-contract=off): integer outputs are bit-exact vs
-// oracle/deftet_oracle.inc, floats equal.
+// oracle/deftet_oracle.inc, floats equal; results do not depend on the order in which hits arrive.
 #include "common.h"
 #include "profile.h"
 #include "tile_bins.h"
@@ -23,47 +25,94 @@ namespace {
 using kamd::Box4;
 
 constexpr int DT_THREADS = 256;
-constexpr int DT_WAVES = DT_THREADS / 64;
-constexpr int DT_G = 64;               // pixel-sort cells per axis
-constexpr int DT_NC = DT_G * DT_G;     // 4096 cells
 constexpr int DT_NB = 64;              // extent partials per batch item
-constexpr int DT_PPB = 4096;           // pixels per workgroup in the two histogram passes
-constexpr int DT_CAP = 512;            // LDS face list capacity (flushed before a 256-face chunk could overflow it)
+constexpr int DT_MAX_GSHIFT = 8;       // at most 256 x 256 cells
+constexpr int DT_SMALL_CELLS = 16;     // thread = face handles a box over at most this many cells ...
+constexpr int DT_SMALL_CAND = 256;     // ... holding at most this many pixels
+constexpr int DT_WAVE_CELLS = 1024;    // up to here a wavefront per face, above a workgroup per face
 
-// workspace (4-byte words) per batch item: extent partials | cell starts (NC + 1) | cell cursors (NC) | order (P)
-__host__ __device__ inline size_t dt_ws_words(int P) { return (size_t)DT_NB * 4 + (DT_NC + 1) + DT_NC + (size_t)P; }
+// grid resolution: G = 2^gshift cells per axis so that a cell holds about 8 pixels (16 <= G <= 256)
+__host__ __device__ inline int dt_gshift(int P) {
+  int g = 4;
+  while (g < DT_MAX_GSHIFT && ((size_t)1 << (2 * g)) * 8 < (size_t)P) ++g;
+  return g;
+}
+
+// workspace, 4-byte words (B batch items, P pixels, F faces, NC = G*G cells), ST = sizeof(T) / 4:
+//   [zeroed every call]  counters (4) | cell starts B*(NC+4) | per-pixel hit counters B*P (padded to 4)
+//   [fully written]      extent partials B*NB*4 | cell cursors B*NC | order B*P | wave-face list B*F | workgroup-face
+//                        list B*F | overflow list B*P | sorted pixels B*P*4*ST
 struct DtWs {
-  float* part;
-  int* start;
-  int* cursor;
-  int* order;
+  int* counters;   // [0] = faces for the wave kernel, [1] = faces for the workgroup kernel, [2] = overflowing pixels
+  int* start;      // + b * (NC + 4)
+  int* cnt;        // + b * P
+  float* part;     // + b * NB * 4
+  int* cursor;     // + b * NC
+  int* order;      // + b * P
+  int* wlist;      // (b * F + f) entries
+  int* glist;      // (b * F + f) entries
+  int* over;       // (b * P + p) entries
+  void* spix;      // 4 T per sorted pixel: x, y, min depth, max depth
+  size_t zero_words, total_words;
+  int gshift, nc;
 };
-__host__ __device__ inline DtWs dt_ws(void* base, int P, int b) {
-  int* w = (int*)base + (size_t)b * dt_ws_words(P);
+__host__ __device__ inline size_t dt_pad4(size_t n) { return (n + 3) & ~(size_t)3; }
+__host__ __device__ inline DtWs dt_ws(void* base, int B, int F, int P, int st) {
   DtWs r;
+  r.gshift = dt_gshift(P);
+  r.nc = 1 << (2 * r.gshift);
+  int* w = (int*)base;
+  r.counters = w;
+  w += 4;
+  r.start = w;
+  w += (size_t)B * (r.nc + 4);
+  r.cnt = w;
+  w += dt_pad4((size_t)B * P);
+  r.zero_words = (size_t)(w - (int*)base);
   r.part = (float*)w;
-  r.start = w + DT_NB * 4;
-  r.cursor = r.start + DT_NC + 1;
-  r.order = r.cursor + DT_NC;
+  w += (size_t)B * DT_NB * 4;
+  r.cursor = w;
+  w += (size_t)B * r.nc;
+  r.order = w;
+  w += dt_pad4((size_t)B * P);
+  r.wlist = w;
+  w += dt_pad4((size_t)B * F);
+  r.glist = w;
+  w += dt_pad4((size_t)B * F);
+  r.over = w;
+  w += dt_pad4((size_t)B * P);
+  r.spix = (void*)w;
+  w += (size_t)B * P * 4 * st;
+  r.total_words = (size_t)(w - (int*)base);
   return r;
 }
 
-// ---- 1. extent of the finite pixel coordinates (partials) ------------------------------------------------------
+// ---- 1. extent of the finite pixel coordinates (partials), as floats rounded OUTWARDS ---------------------------
 template <typename T>
-__global__ __launch_bounds__(DT_THREADS) void dt_extent_kernel(int P, const T* __restrict__ pix, void* ws) {
+__device__ __forceinline__ float dt_round_down(T v) {
+  float f = (float)v;
+  if ((T)f > v) f = nextafterf(f, -INFINITY);
+  return f;
+}
+template <typename T>
+__device__ __forceinline__ float dt_round_up(T v) {
+  float f = (float)v;
+  if ((T)f < v) f = nextafterf(f, INFINITY);
+  return f;
+}
+template <typename T>
+__global__ __launch_bounds__(DT_THREADS) void dt_extent_kernel(int P, const T* __restrict__ pix, float* __restrict__ part) {
   __shared__ float s[4][DT_THREADS];
   const int b = blockIdx.y;
   const T* X = pix + (size_t)b * P * 2;
   float lo0 = INFINITY, lo1 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY;
   for (int i = blockIdx.x * DT_THREADS + threadIdx.x; i < P; i += gridDim.x * DT_THREADS) {
-    const float x = (float)X[(size_t)i * 2], y = (float)X[(size_t)i * 2 + 1];
-    if (isfinite(x)) {
-      lo0 = fminf(lo0, x);
-      hi0 = fmaxf(hi0, x);
-    }
-    if (isfinite(y)) {
-      lo1 = fminf(lo1, y);
-      hi1 = fmaxf(hi1, y);
+    const T x = X[(size_t)i * 2], y = X[(size_t)i * 2 + 1];
+    if (isfinite(x) && isfinite(y)) {  // a pixel with a non-finite coordinate is inside no face (see dt_face_kernel)
+      lo0 = fminf(lo0, dt_round_down<T>(x));
+      hi0 = fmaxf(hi0, dt_round_up<T>(x));
+      lo1 = fminf(lo1, dt_round_down<T>(y));
+      hi1 = fmaxf(hi1, dt_round_up<T>(y));
     }
   }
   s[0][threadIdx.x] = lo0;
@@ -80,14 +129,15 @@ __global__ __launch_bounds__(DT_THREADS) void dt_extent_kernel(int P, const T* _
     }
     __syncthreads();
   }
-  if (threadIdx.x < 4) dt_ws(ws, P, b).part[blockIdx.x * 4 + threadIdx.x] = s[threadIdx.x][0];
+  if (threadIdx.x < 4) part[((size_t)b * DT_NB + blockIdx.x) * 4 + threadIdx.x] = s[threadIdx.x][0];
 }
 
 struct DtGrid {
-  float lo[2], inv[2];
+  float lo[2], hi[2], inv[2];
+  int G;
 };
-// every consumer re-reduces the 64 partials (1 KB from L2); called by the first wave, result broadcast through LDS
-__device__ __forceinline__ void dt_grid_setup(const float* __restrict__ part, DtGrid* g) {
+// every consumer re-reduces the 64 partials of its batch item (1 KB from L2); first wave, broadcast through LDS
+__device__ __forceinline__ void dt_grid_setup(const float* __restrict__ part, int gshift, DtGrid* g) {
   if (threadIdx.x < 64) {
     float lo0 = part[threadIdx.x * 4], lo1 = part[threadIdx.x * 4 + 1];
     float hi0 = part[threadIdx.x * 4 + 2], hi1 = part[threadIdx.x * 4 + 3];
@@ -100,56 +150,57 @@ __device__ __forceinline__ void dt_grid_setup(const float* __restrict__ part, Dt
     }
     if (threadIdx.x == 0) {
       const float lo[2] = {lo0, lo1}, hi[2] = {hi0, hi1};
+      g->G = 1 << gshift;
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        float l = lo[a], size = (hi[a] - lo[a]) / (float)DT_G;
-        if (!(lo[a] <= hi[a])) l = 0.f;
+        float size = (hi[a] - lo[a]) / (float)(1 << gshift);
         if (!(size > 0.f) || !isfinite(size)) size = 1.f;  // degenerate extent: one slab holds everything
-        g->lo[a] = l;
+        g->lo[a] = lo[a];  // +inf / -inf when no pixel is finite: every face is then rejected
+        g->hi[a] = hi[a];
         g->inv[a] = 1.f / size;
       }
     }
   }
   __syncthreads();
 }
-__device__ __forceinline__ int dt_axis_cell(float v, float lo, float inv) {
+// monotone non-decreasing in v (float subtract, multiply, truncate, clamp): a <= b  =>  cell(a) <= cell(b)
+__device__ __forceinline__ int dt_axis_cell(float v, float lo, float inv, int G) {
   const float t = (v - lo) * inv;
-  return (t >= 0.f) ? (t < (float)DT_G ? (int)t : DT_G - 1) : 0;  // NaN -> 0, +-inf clamped
+  return (t >= 0.f) ? (t < (float)G ? (int)t : G - 1) : 0;  // NaN -> 0, +-inf clamped
 }
+__device__ __forceinline__ unsigned dt_spread8(unsigned v) {  // abcdefgh -> 0a0b0c0d0e0f0g0h
+  v = (v | (v << 4)) & 0x0F0Fu;
+  v = (v | (v << 2)) & 0x3333u;
+  v = (v | (v << 1)) & 0x5555u;
+  return v;
+}
+// Z-order cell number: neighbouring cells are neighbours in memory, which keeps a face's pixel reads in few lines
+__device__ __forceinline__ int dt_code(int cx, int cy) { return (int)(dt_spread8((unsigned)cx) | (dt_spread8((unsigned)cy) << 1)); }
 template <typename T>
 __device__ __forceinline__ int dt_cell(const DtGrid& g, const T* __restrict__ X, int i) {
-  return dt_axis_cell((float)X[(size_t)i * 2 + 1], g.lo[1], g.inv[1]) * DT_G +
-         dt_axis_cell((float)X[(size_t)i * 2], g.lo[0], g.inv[0]);
+  return dt_code(dt_axis_cell((float)X[(size_t)i * 2], g.lo[0], g.inv[0], g.G),
+                 dt_axis_cell((float)X[(size_t)i * 2 + 1], g.lo[1], g.inv[1], g.G));
 }
 
-// ---- 2. cell histogram: LDS counts per workgroup, one global atomic per (workgroup, non-empty cell) ----------
+// ---- 2. cell histogram.  A cell holds ~8 pixels by construction, so plain global atomics see little contention --------
 template <typename T>
-__global__ __launch_bounds__(DT_THREADS) void dt_count_kernel(int P, const T* __restrict__ pix, void* ws) {
-  __shared__ int s_hist[DT_NC];
+__global__ __launch_bounds__(DT_THREADS) void dt_count_kernel(int P, const T* __restrict__ pix, DtWs w) {
   __shared__ DtGrid s_g;
   const int b = blockIdx.y;
-  const DtWs w = dt_ws(ws, P, b);
-  for (int c = threadIdx.x; c < DT_NC; c += DT_THREADS) s_hist[c] = 0;
-  dt_grid_setup(w.part, &s_g);
-  const T* X = pix + (size_t)b * P * 2;
-  const int i0 = blockIdx.x * DT_PPB, i1 = min(P, i0 + DT_PPB);
-  for (int i = i0 + threadIdx.x; i < i1; i += DT_THREADS) atomicAdd(&s_hist[dt_cell<T>(s_g, X, i)], 1);
-  __syncthreads();
-  for (int c = threadIdx.x; c < DT_NC; c += DT_THREADS)
-    if (s_hist[c]) atomicAdd(&w.start[c], s_hist[c]);
+  dt_grid_setup(w.part + (size_t)b * DT_NB * 4, w.gshift, &s_g);
+  const int i = blockIdx.x * DT_THREADS + threadIdx.x;
+  if (i < P) atomicAdd(&w.start[(size_t)b * (w.nc + 4) + dt_cell<T>(s_g, pix + (size_t)b * P * 2, i)], 1);
 }
 
-// ---- 3. exclusive scan of the 4096 counts (one workgroup per batch item); cursors start at the cell starts --------
-__global__ __launch_bounds__(1024) void dt_scan_kernel(int P, void* ws) {
+// ---- 3. exclusive scan of the NC counts (one workgroup per batch item); cursors start at the cell starts -----------
+__global__ __launch_bounds__(1024) void dt_scan_kernel(DtWs w) {
   __shared__ int s_wave[16];
-  const DtWs w = dt_ws(ws, P, blockIdx.x);
+  int* start = w.start + (size_t)blockIdx.x * (w.nc + 4);
+  int* cursor = w.cursor + (size_t)blockIdx.x * w.nc;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  int v[4], sum = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    v[k] = w.start[t * 4 + k];
-    sum += v[k];
-  }
+  const int per = (w.nc + 1023) / 1024, i0 = t * per, i1 = min(w.nc, i0 + per);
+  int sum = 0;
+  for (int i = i0; i < i1; ++i) sum += start[i];
   int inc = sum;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -160,45 +211,33 @@ __global__ __launch_bounds__(1024) void dt_scan_kernel(int P, void* ws) {
   __syncthreads();
   int off = inc - sum;
   for (int k = 0; k < wave; ++k) off += s_wave[k];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    w.start[t * 4 + k] = off;
-    w.cursor[t * 4 + k] = off;
-    off += v[k];
+  for (int i = i0; i < i1; ++i) {
+    const int v = start[i];
+    start[i] = off;
+    cursor[i] = off;
+    off += v;
   }
-  if (t == 1023) w.start[DT_NC] = off;
+  if (t == 1023) start[w.nc] = off;
 }
 
-// ---- 4. scatter: rank inside the workgroup from the LDS atomic, one global reservation per non-empty cell ------
+// ---- 4. scatter into cell order, with a contiguous copy of (x, y, min depth, max depth) -----------------------------
 template <typename T>
-__global__ __launch_bounds__(DT_THREADS) void dt_scatter_kernel(int P, const T* __restrict__ pix, void* ws) {
-  __shared__ int s_hist[DT_NC];
+__global__ __launch_bounds__(DT_THREADS) void dt_scatter_kernel(int P, const T* __restrict__ pix,
+                                                                const T* __restrict__ range, DtWs w) {
   __shared__ DtGrid s_g;
   const int b = blockIdx.y;
-  const DtWs w = dt_ws(ws, P, b);
-  for (int c = threadIdx.x; c < DT_NC; c += DT_THREADS) s_hist[c] = 0;
-  dt_grid_setup(w.part, &s_g);
+  dt_grid_setup(w.part + (size_t)b * DT_NB * 4, w.gshift, &s_g);
+  const int i = blockIdx.x * DT_THREADS + threadIdx.x;
+  if (i >= P) return;
   const T* X = pix + (size_t)b * P * 2;
-  const int i0 = blockIdx.x * DT_PPB, i1 = min(P, i0 + DT_PPB);
-  int cell[DT_PPB / DT_THREADS], rank[DT_PPB / DT_THREADS];
-#pragma unroll
-  for (int k = 0; k < DT_PPB / DT_THREADS; ++k) {
-    const int i = i0 + k * DT_THREADS + threadIdx.x;
-    cell[k] = -1;
-    if (i < i1) {
-      cell[k] = dt_cell<T>(s_g, X, i);
-      rank[k] = atomicAdd(&s_hist[cell[k]], 1);
-    }
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < DT_NC; c += DT_THREADS) {
-    const int n = s_hist[c];
-    if (n) s_hist[c] = atomicAdd(&w.cursor[c], n);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < DT_PPB / DT_THREADS; ++k)
-    if (cell[k] >= 0) w.order[s_hist[cell[k]] + rank[k]] = i0 + k * DT_THREADS + threadIdx.x;
+  const int pos = atomicAdd(&w.cursor[(size_t)b * w.nc + dt_cell<T>(s_g, X, i)], 1);
+  w.order[(size_t)b * P + pos] = i;
+  Box4<T> v;
+  v.x0 = X[(size_t)i * 2];
+  v.y0 = X[(size_t)i * 2 + 1];
+  v.x1 = range[((size_t)b * P + i) * 2];
+  v.y1 = range[((size_t)b * P + i) * 2 + 1];
+  reinterpret_cast<Box4<T>*>(w.spix)[(size_t)b * P + pos] = v;
 }
 
 // ---- outputs of the reference wrapper start as (-1, -inf, 0, 0) (deftet.cpp:90-96) ---------------------------------
@@ -214,153 +253,261 @@ __global__ __launch_bounds__(256) void dt_fill_kernel(size_t n, int64_t* __restr
   }
 }
 
-// ---- 5. the search ---------------------------------------------------------------------------------------------
+// ---- 5. thread = face -----------------------------------------------------------------------------------------------
 template <typename T>
 struct DtFace {
   T ax, ay, bx, by, cx, cy, az, bz, cz;
 };
-
 template <typename T>
-__global__ __launch_bounds__(DT_THREADS) void dt_forward_kernel(int F, int P, int K, const T* __restrict__ fz,
-                                                                const T* __restrict__ fimg, const T* __restrict__ fbb,
-                                                                const T* __restrict__ pix, const T* __restrict__ range,
-                                                                float eps, const void* ws, int sorted,
-                                                                int64_t* __restrict__ face_idx, T* __restrict__ depth,
-                                                                T* __restrict__ w0a, T* __restrict__ w1a,
-                                                                int* __restrict__ hit_count) {
-  __shared__ Box4<T> s_box[DT_CAP];
-  __shared__ DtFace<T> s_face[DT_CAP];
-  __shared__ int s_id[DT_CAP];
-  __shared__ int s_wcnt[2][DT_WAVES];
-  __shared__ T s_ext[4][DT_WAVES];
-  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int slot = blockIdx.x * DT_THREADS + tid;
-  const bool live = slot < P;
-  int p = 0;
-  if (live) p = sorted ? dt_ws(const_cast<void*>(ws), P, b).order[slot] : slot;
-  const size_t bp = (size_t)b * P + p;
-  T x0 = 0, y0 = 0, dmin = 0, dmax = 0;
-  if (live) {
-    x0 = pix[bp * 2];
-    y0 = pix[bp * 2 + 1];
-    dmin = range[bp * 2];
-    dmax = range[bp * 2 + 1];
+__device__ __forceinline__ DtFace<T> dt_load_face(const T* __restrict__ fimg, const T* __restrict__ fz, size_t g) {
+  DtFace<T> fc;
+  fc.ax = fimg[g * 6 + 0];
+  fc.ay = fimg[g * 6 + 1];
+  fc.bx = fimg[g * 6 + 2];
+  fc.by = fimg[g * 6 + 3];
+  fc.cx = fimg[g * 6 + 4];
+  fc.cy = fimg[g * 6 + 5];
+  fc.az = fz[g * 3 + 0];
+  fc.bz = fz[g * 3 + 1];
+  fc.cz = fz[g * 3 + 2];
+  return fc;
+}
+// deftet_cuda.cu:117-152 for one (pixel, face): box [min,max), normalised edge functions >= 0, depth in [min,max)
+template <typename T>
+__device__ __forceinline__ bool dt_hit(const Box4<T>& bb, const DtFace<T>& fc, T x0, T y0, T dmin, T dmax, T eps_f, T* w0o,
+                                       T* w1o, T* dout) {
+  if (!((x0 >= bb.x0) & (x0 < bb.x1) & (y0 >= bb.y0) & (y0 < bb.y1))) return false;
+  const T aex = fc.ax - x0, aey = fc.ay - y0, bex = fc.bx - x0, bey = fc.by - y0, cex = fc.cx - x0, cey = fc.cy - y0;
+  const T u0 = bex * cey - bey * cex;
+  const T u1 = cex * aey - cey * aex;
+  const T u2 = aex * bey - aey * bex;
+  const T norm = u0 + u1 + u2;
+  const T norm_eps = (T)copysignf((float)eps_f, (float)norm);  // both arguments as FLOAT (:135-136)
+  const T w0 = u0 / (norm + norm_eps), w1 = u1 / (norm + norm_eps), w2 = u2 / (norm + norm_eps);
+  if (!(w0 >= 0. && w1 >= 0. && w2 >= 0.)) return false;
+  const T d = w0 * fc.az + w1 * fc.bz + w2 * fc.cz;
+  if (!(d < dmax && d >= dmin)) return false;
+  *w0o = w0;
+  *w1o = w1;
+  *dout = d;
+  return true;
+}
+template <typename T>
+struct DtOut {
+  int64_t* face_idx;
+  T *depth, *w0, *w1;
+};
+// appends to the pixel's row in arrival order; the counter keeps counting past K so that overflow is detectable
+template <typename T>
+__device__ __forceinline__ void dt_append(const DtOut<T>& o, int* __restrict__ cnt, size_t bp, int K, int f, T d, T w0, T w1) {
+  const int slot = atomicAdd(&cnt[bp], 1);
+  if (slot < K) {
+    const size_t i = bp * K + slot;
+    o.face_idx[i] = f;
+    o.depth[i] = d;
+    o.w0[i] = w0;
+    o.w1[i] = w1;
   }
-  // closed extent of this workgroup's finite pixel coordinates (a non-finite coordinate can never be inside a box)
-  {
-    T lx = INFINITY, ly = INFINITY, hx = -INFINITY, hy = -INFINITY;
-    if (live && isfinite(x0) && isfinite(y0)) {
-      lx = hx = x0;
-      ly = hy = y0;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      lx = fmin(lx, __shfl_xor(lx, d, 64));
-      ly = fmin(ly, __shfl_xor(ly, d, 64));
-      hx = fmax(hx, __shfl_xor(hx, d, 64));
-      hy = fmax(hy, __shfl_xor(hy, d, 64));
-    }
-    if (lane == 0) {
-      s_ext[0][wave] = lx;
-      s_ext[1][wave] = ly;
-      s_ext[2][wave] = hx;
-      s_ext[3][wave] = hy;
-    }
+}
+// the pixels of one cell against one face
+template <typename T>
+__device__ __forceinline__ void dt_face_cell(const Box4<T>& bb, const DtFace<T>& fc, int f, int b, int P, int K, T eps_f,
+                                             const Box4<T>* __restrict__ spix, const int* __restrict__ order,
+                                             int i0, int i1, int step, int first, const DtOut<T>& o, int* __restrict__ cnt) {
+  for (int i = i0 + first; i < i1; i += step) {
+    const Box4<T> px = spix[i];  // x, y, min depth, max depth
+    T w0, w1, d;
+    if (dt_hit<T>(bb, fc, px.x0, px.y0, px.x1, px.y1, eps_f, &w0, &w1, &d))
+      dt_append<T>(o, cnt, (size_t)b * P + order[i], K, f, d, w0, w1);
   }
-  __syncthreads();
-  T ex0 = s_ext[0][0], ey0 = s_ext[1][0], ex1 = s_ext[2][0], ey1 = s_ext[3][0];
-#pragma unroll
-  for (int k = 1; k < DT_WAVES; ++k) {
-    ex0 = fmin(ex0, s_ext[0][k]);
-    ey0 = fmin(ey0, s_ext[1][k]);
-    ex1 = fmax(ex1, s_ext[2][k]);
-    ey1 = fmax(ey1, s_ext[3][k]);
-  }
-  const T norm_sign_eps = (T)(float)(double)eps;  // |copysignf((double)eps, .)|: eps as FLOAT (deftet_cuda.cu:135)
-  const size_t row = bp * K;
-  int n_hit = 0, n_list = 0;
-  const Box4<T>* boxes = reinterpret_cast<const Box4<T>*>(fbb) + (size_t)b * F;
-  // box loads run two chunks ahead of their use: the loop below has no other global access outside a flush
-  Box4<T> fb = {0, 0, 0, 0}, fb_n1 = {0, 0, 0, 0}, fb_n2 = {0, 0, 0, 0};
-  if (tid < F) fb_n1 = boxes[tid];
-  if (tid + DT_THREADS < F) fb_n2 = boxes[tid + DT_THREADS];
-  int it = 0;
-  for (int base = 0; base < F; base += DT_THREADS, it ^= 1) {
-    const int f = base + tid;
-    fb = fb_n1;
-    fb_n1 = fb_n2;
-    if (f + 2 * DT_THREADS < F) fb_n2 = boxes[f + 2 * DT_THREADS];
-    // a pixel is inside when min <= x < max: impossible when max <= (smallest x) or min > (largest x)
-    const bool keep = (f < F) & !((fb.x1 <= ex0) | (fb.x0 > ex1) | (fb.y1 <= ey0) | (fb.y0 > ey1));
-    const unsigned long long m = __ballot(keep);
-    if (lane == 0) s_wcnt[it][wave] = __popcll(m);
-    __syncthreads();  // the only barrier of a chunk that is not flushed (s_wcnt is double-buffered)
-    int woff = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < DT_WAVES; ++k) {
-      if (k < wave) woff += s_wcnt[it][k];
-      total += s_wcnt[it][k];
-    }
-    if (keep) {
-      const int pos = n_list + woff + __popcll(m & ((1ull << lane) - 1ull));
-      s_box[pos] = fb;
-      s_id[pos] = f;
-    }
-    n_list += total;
-    if (n_list > DT_CAP - DT_THREADS || base + DT_THREADS >= F) {
-      __syncthreads();  // list entries visible
-      // vertices of the listed faces: one round of independent loads per flush, thread = entry
-      for (int k = tid; k < n_list; k += DT_THREADS) {
-        const size_t g = (size_t)b * F + s_id[k];
-        DtFace<T> fc;
-        fc.ax = fimg[g * 6 + 0];
-        fc.ay = fimg[g * 6 + 1];
-        fc.bx = fimg[g * 6 + 2];
-        fc.by = fimg[g * 6 + 3];
-        fc.cx = fimg[g * 6 + 4];
-        fc.cy = fimg[g * 6 + 5];
-        fc.az = fz[g * 3 + 0];
-        fc.bz = fz[g * 3 + 1];
-        fc.cz = fz[g * 3 + 2];
-        s_face[k] = fc;
-      }
-      __syncthreads();
-      for (int k = 0; k < n_list; ++k) {
-        const Box4<T> bb = s_box[k];
-        const bool inside = live & (n_hit < K) & (x0 >= bb.x0) & (x0 < bb.x1) & (y0 >= bb.y0) & (y0 < bb.y1);
-        if (!__any(inside)) continue;
-        if (inside) {
-          const DtFace<T> fc = s_face[k];
-          const T aex = fc.ax - x0, aey = fc.ay - y0, bex = fc.bx - x0, bey = fc.by - y0;
-          const T cex = fc.cx - x0, cey = fc.cy - y0;
-          const T u0 = bex * cey - bey * cex;
-          const T u1 = cex * aey - cey * aex;
-          const T u2 = aex * bey - aey * bex;
-          const T norm = u0 + u1 + u2;
-          const T norm_eps = (T)copysignf((float)norm_sign_eps, (float)norm);
-          const T w0 = u0 / (norm + norm_eps), w1 = u1 / (norm + norm_eps), w2 = u2 / (norm + norm_eps);
-          if (w0 >= 0. && w1 >= 0. && w2 >= 0.) {
-            const T d = w0 * fc.az + w1 * fc.bz + w2 * fc.cz;
-            if (d < dmax && d >= dmin) {
-              face_idx[row + n_hit] = s_id[k];
-              depth[row + n_hit] = d;
-              w0a[row + n_hit] = w0;
-              w1a[row + n_hit] = w1;
-              ++n_hit;
-            }
-          }
-        }
-      }
-      n_list = 0;
-      __syncthreads();  // everyone is done reading the list before it is refilled
-    }
-  }
-  if (live && hit_count) hit_count[bp] = n_hit;
 }
 
-// ---- 6. depth sort + weights + interpolation (deftet.py:297-311) ------------------------------------------------
-// thread = (pixel, k): rank of entry k among the pixel's n hits by (depth descending, then position) = its output
-// slot; slots >= n get the defaults.  Equal depths keep mesh order (torch.argsort in the reference leaves it open).
+struct DtCells {
+  int cx0, cx1, cy0, cy1;
+};
+template <typename T>
+__device__ __forceinline__ DtCells dt_cells_of(const DtGrid& g, const Box4<T>& bb) {
+  // xmin <= x < xmax and the cell mapping is monotone: the pixel's cell lies in [cell(xmin), cell(xmax)]
+  DtCells c;
+  c.cx0 = dt_axis_cell((float)bb.x0, g.lo[0], g.inv[0], g.G);
+  c.cx1 = dt_axis_cell((float)bb.x1, g.lo[0], g.inv[0], g.G);
+  c.cy0 = dt_axis_cell((float)bb.y0, g.lo[1], g.inv[1], g.G);
+  c.cy1 = dt_axis_cell((float)bb.y1, g.lo[1], g.inv[1], g.G);
+  return c;
+}
+
+template <typename T>
+__global__ __launch_bounds__(DT_THREADS) void dt_face_kernel(int F, int P, int K, const T* __restrict__ fz,
+                                                             const T* __restrict__ fimg, const T* __restrict__ fbb,
+                                                             float eps, DtWs w, DtOut<T> o) {
+  __shared__ DtGrid s_g;
+  const int b = blockIdx.y;
+  dt_grid_setup(w.part + (size_t)b * DT_NB * 4, w.gshift, &s_g);
+  const int f = blockIdx.x * DT_THREADS + threadIdx.x;
+  if (f >= F) return;
+  const size_t g = (size_t)b * F + f;
+  const Box4<T> bb = reinterpret_cast<const Box4<T>*>(fbb)[g];
+  // an empty box, a NaN limit, or a box that misses the extent of the finite pixels contains no pixel.
+  // (a pixel with a non-finite coordinate is in no face either: inside [min,max) it needs a vertex at -inf on that axis,
+  //  which turns the edge functions and all three weights into NaN)
+  if (!((bb.x0 < bb.x1) & (bb.y0 < bb.y1))) return;
+  if ((bb.x1 <= (T)s_g.lo[0]) | (bb.x0 > (T)s_g.hi[0]) | (bb.y1 <= (T)s_g.lo[1]) | (bb.y0 > (T)s_g.hi[1])) return;
+  const DtCells c = dt_cells_of<T>(s_g, bb);
+  const int* start = w.start + (size_t)b * (w.nc + 4);
+  const int ncell = (c.cx1 - c.cx0 + 1) * (c.cy1 - c.cy0 + 1);
+  int cand = DT_SMALL_CAND + 1;
+  if (ncell <= DT_SMALL_CELLS) {
+    cand = 0;
+    for (int cy = c.cy0; cy <= c.cy1; ++cy)
+      for (int cx = c.cx0; cx <= c.cx1; ++cx) {
+        const int z = dt_code(cx, cy);
+        cand += start[z + 1] - start[z];
+      }
+  }
+  if (cand == 0) return;
+  if (cand > DT_SMALL_CAND) {  // hand over: a wavefront per face, or a workgroup when the box spans very many cells
+    if (ncell <= DT_WAVE_CELLS)
+      w.wlist[atomicAdd(&w.counters[0], 1)] = (int)g;
+    else
+      w.glist[atomicAdd(&w.counters[1], 1)] = (int)g;
+    return;
+  }
+  const DtFace<T> fc = dt_load_face<T>(fimg, fz, g);
+  const T eps_f = (T)(float)(double)eps;
+  const Box4<T>* spix = reinterpret_cast<const Box4<T>*>(w.spix) + (size_t)b * P;
+  const int* order = w.order + (size_t)b * P;
+  for (int cy = c.cy0; cy <= c.cy1; ++cy)
+    for (int cx = c.cx0; cx <= c.cx1; ++cx) {
+      const int z = dt_code(cx, cy);
+      dt_face_cell<T>(bb, fc, f, b, P, K, eps_f, spix, order, start[z], start[z + 1], 1, 0, o, w.cnt);
+    }
+}
+
+// a group of GROUP threads (a wavefront, or the whole workgroup) per handed-over face: 4 lanes per cell
+template <typename T, int GROUP>
+__global__ __launch_bounds__(DT_THREADS) void dt_big_face_kernel(int F, int P, int K, const T* __restrict__ fz,
+                                                                 const T* __restrict__ fimg, const T* __restrict__ fbb,
+                                                                 float eps, DtWs w, DtOut<T> o) {
+  const int n = GROUP == 64 ? w.counters[0] : w.counters[1];
+  const int* list = GROUP == 64 ? w.wlist : w.glist;
+  const T eps_f = (T)(float)(double)eps;
+  const int groups = DT_THREADS / GROUP, gid = threadIdx.x / GROUP, t = threadIdx.x % GROUP;
+  for (int q = blockIdx.x * groups + gid; q < n; q += gridDim.x * groups) {
+    const size_t g = (size_t)list[q];
+    const int b = (int)(g / (size_t)F), f = (int)(g - (size_t)b * F);
+    // grid geometry of batch item b, re-reduced by every group (64 partials)
+    DtGrid gr;
+    {
+      const float* part = w.part + (size_t)b * DT_NB * 4;
+      const int l = threadIdx.x & 63;
+      float lo0 = part[l * 4], lo1 = part[l * 4 + 1], hi0 = part[l * 4 + 2], hi1 = part[l * 4 + 3];
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        lo0 = fminf(lo0, __shfl_xor(lo0, d, 64));
+        lo1 = fminf(lo1, __shfl_xor(lo1, d, 64));
+        hi0 = fmaxf(hi0, __shfl_xor(hi0, d, 64));
+        hi1 = fmaxf(hi1, __shfl_xor(hi1, d, 64));
+      }
+      const float lo[2] = {lo0, lo1}, hi[2] = {hi0, hi1};
+      gr.G = 1 << w.gshift;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        float size = (hi[a] - lo[a]) / (float)gr.G;
+        if (!(size > 0.f) || !isfinite(size)) size = 1.f;
+        gr.lo[a] = lo[a];
+        gr.hi[a] = hi[a];
+        gr.inv[a] = 1.f / size;
+      }
+    }
+    const Box4<T> bb = reinterpret_cast<const Box4<T>*>(fbb)[g];
+    const DtFace<T> fc = dt_load_face<T>(fimg, fz, g);
+    const DtCells c = dt_cells_of<T>(gr, bb);
+    const int nx = c.cx1 - c.cx0 + 1, ncell = nx * (c.cy1 - c.cy0 + 1);
+    const int* start = w.start + (size_t)b * (w.nc + 4);
+    const Box4<T>* spix = reinterpret_cast<const Box4<T>*>(w.spix) + (size_t)b * P;
+    const int* order = w.order + (size_t)b * P;
+    for (int ci = t >> 2; ci < ncell; ci += GROUP / 4) {
+      const int z = dt_code(c.cx0 + ci % nx, c.cy0 + ci / nx);
+      dt_face_cell<T>(bb, fc, f, b, P, K, eps_f, spix, order, start[z], start[z + 1], 4, t & 3, o, w.cnt);
+    }
+  }
+}
+
+// ---- 6. rows in mesh order; overflowing pixels redone exactly ----------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dt_order_rows_kernel(size_t BP, int K, DtOut<T> o, DtWs w, int* __restrict__ hit_count,
+                                                            int sort_rows) {
+  const size_t bp = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (bp >= BP) return;
+  const int n = w.cnt[bp];
+  if (n > K) {
+    w.over[atomicAdd(&w.counters[2], 1)] = (int)bp;  // B * P < 2^31 (checked on the host)
+    return;                                          // dt_overflow_kernel writes the row and its count
+  }
+  if (hit_count) hit_count[bp] = n;
+  if (!sort_rows) return;
+  const size_t row = bp * K;
+  for (int i = 1; i < n; ++i) {  // insertion sort by face number: rows hold a handful of entries
+    const int64_t f = o.face_idx[row + i];
+    const T d = o.depth[row + i], a = o.w0[row + i], c = o.w1[row + i];
+    int j = i - 1;
+    while (j >= 0 && o.face_idx[row + j] > f) {
+      o.face_idx[row + j + 1] = o.face_idx[row + j];
+      o.depth[row + j + 1] = o.depth[row + j];
+      o.w0[row + j + 1] = o.w0[row + j];
+      o.w1[row + j + 1] = o.w1[row + j];
+      --j;
+    }
+    o.face_idx[row + j + 1] = f;
+    o.depth[row + j + 1] = d;
+    o.w0[row + j + 1] = a;
+    o.w1[row + j + 1] = c;
+  }
+}
+
+// one wavefront per overflowing pixel: faces streamed in mesh order, 64 at a time, hits appended by ballot prefix
+template <typename T>
+__global__ __launch_bounds__(DT_THREADS) void dt_overflow_kernel(int F, int P, int K, const T* __restrict__ fz,
+                                                                 const T* __restrict__ fimg, const T* __restrict__ fbb,
+                                                                 const T* __restrict__ pix, const T* __restrict__ range,
+                                                                 float eps, DtWs w, DtOut<T> o, int* __restrict__ hit_count) {
+  const int nover = w.counters[2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const T eps_f = (T)(float)(double)eps;
+  for (int q = blockIdx.x * (DT_THREADS / 64) + wave; q < nover; q += gridDim.x * (DT_THREADS / 64)) {
+    const size_t bp = (size_t)w.over[q];
+    const int b = (int)(bp / (size_t)P);
+    const T x0 = pix[bp * 2], y0 = pix[bp * 2 + 1], dmin = range[bp * 2], dmax = range[bp * 2 + 1];
+    const size_t row = bp * K;
+    int n = 0;
+    for (int base = 0; base < F && n < K; base += 64) {
+      const int f = base + lane;
+      bool hit = false;
+      T w0 = 0, w1 = 0, d = 0;
+      if (f < F) {
+        const size_t g = (size_t)b * F + f;
+        const Box4<T> bb = reinterpret_cast<const Box4<T>*>(fbb)[g];
+        if ((x0 >= bb.x0) & (x0 < bb.x1) & (y0 >= bb.y0) & (y0 < bb.y1))
+          hit = dt_hit<T>(bb, dt_load_face<T>(fimg, fz, g), x0, y0, dmin, dmax, eps_f, &w0, &w1, &d);
+      }
+      const unsigned long long m = __ballot(hit);
+      const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+      if (hit && pos < K) {
+        o.face_idx[row + pos] = f;
+        o.depth[row + pos] = d;
+        o.w0[row + pos] = w0;
+        o.w1[row + pos] = w1;
+      }
+      n += __popcll(m);
+    }
+    if (lane == 0 && hit_count) hit_count[bp] = K;
+  }
+}
+
+// ---- 7. depth sort + weights + interpolation (deftet.py:297-311) ------------------------------------------------
+// thread = (pixel, k): rank of entry k among the pixel's n hits by (depth descending, then face number) = its output
+// slot; slots >= n get the defaults.  Rows arrive in any order; equal depths are ordered by face number = mesh order
+// (torch.argsort in the reference leaves that case open).
 template <typename T>
 __global__ __launch_bounds__(256) void dt_sort_interp_kernel(int B, int F, int P, int K, int D,
                                                              const int64_t* __restrict__ face_idx,
@@ -383,12 +530,12 @@ __global__ __launch_bounds__(256) void dt_sort_interp_kernel(int B, int F, int P
     }
     const size_t row = bp * K;
     const T dk = depth[i];
+    const int64_t f = face_idx[i];
     int r = 0;
     for (int j = 0; j < n; ++j) {
       const T dj = depth[row + j];
-      r += (dj > dk) | ((dj == dk) & (j < k));
+      r += (dj > dk) | ((dj == dk) & (face_idx[row + j] < f));
     }
-    const int64_t f = face_idx[i];
     const T w0 = w0a[i], w1 = w1a[i];
     const T w2 = (T)1 - (w0 + w1);
     const size_t o = row + r;
@@ -402,7 +549,7 @@ __global__ __launch_bounds__(256) void dt_sort_interp_kernel(int B, int F, int P
   }
 }
 
-// ---- 7. backward -----------------------------------------------------------------------------------------------
+// ---- 8. backward -----------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void dt_backward_kernel(int B, int F, int P, int K, int D, const T* __restrict__ grad,
                                                           const int64_t* __restrict__ face_idx,
@@ -458,24 +605,37 @@ __global__ __launch_bounds__(256) void dt_backward_kernel(int B, int F, int P, i
 // ---- host side --------------------------------------------------------------------------------------------------
 template <typename T>
 int dt_search(hipStream_t st, int B, int F, int P, int K, const T* fz, const T* fimg, const T* fbb, const T* pix,
-              const T* range, float eps, int64_t* face_idx, T* depth, T* w0, T* w1, int* hit_count, void* ws,
+              const T* range, float eps, int64_t* face_idx, T* depth, T* w0, T* w1, int* hit_count, int sort_rows, void* ws,
               size_t ws_bytes) {
   if (B <= 0 || P <= 0) return 0;
-  // a single workgroup per batch item gains nothing from sorted pixels
-  const bool sorted = P > DT_THREADS && ws != nullptr && ws_bytes >= (size_t)B * dt_ws_words(P) * 4;
-  if (P > DT_THREADS && !sorted) return (int)hipErrorInvalidValue;
+  if ((size_t)B * P >= (1ull << 31) || (size_t)B * (F > 0 ? F : 0) >= (1ull << 31)) return (int)hipErrorInvalidValue;
+  const DtWs w = dt_ws(ws, B, F > 0 ? F : 0, P, (int)(sizeof(T) / 4));
+  if (ws == nullptr || ws_bytes < w.total_words * 4) return (int)hipErrorInvalidValue;
   kamd::ProfScope prof_(kamd::K_DEFTET_FORWARD, st);
-  if (sorted) {
-    // clear the cell counts (the partials / cursors / order are fully written)
-    for (int b = 0; b < B; ++b) KAMD_CHECK(hipMemsetAsync(dt_ws(ws, P, b).start, 0, (DT_NC + 1) * sizeof(int), st));
-    const int nblk = kamd_cdiv(P, DT_PPB);
-    hipLaunchKernelGGL(dt_extent_kernel<T>, dim3(DT_NB, B), dim3(DT_THREADS), 0, st, P, pix, ws);
-    hipLaunchKernelGGL(dt_count_kernel<T>, dim3(nblk, B), dim3(DT_THREADS), 0, st, P, pix, ws);
-    hipLaunchKernelGGL(dt_scan_kernel, dim3(B), dim3(1024), 0, st, P, ws);
-    hipLaunchKernelGGL(dt_scatter_kernel<T>, dim3(nblk, B), dim3(DT_THREADS), 0, st, P, pix, ws);
+  KAMD_CHECK(kamd_zero_async(ws, w.zero_words * 4, st));
+  DtOut<T> o;
+  o.face_idx = face_idx;
+  o.depth = depth;
+  o.w0 = w0;
+  o.w1 = w1;
+  const int nblk = kamd_cdiv(P, DT_THREADS);
+  hipLaunchKernelGGL(dt_extent_kernel<T>, dim3(DT_NB, B), dim3(DT_THREADS), 0, st, P, pix, w.part);
+  hipLaunchKernelGGL(dt_count_kernel<T>, dim3(nblk, B), dim3(DT_THREADS), 0, st, P, pix, w);
+  hipLaunchKernelGGL(dt_scan_kernel, dim3(B), dim3(1024), 0, st, w);
+  hipLaunchKernelGGL(dt_scatter_kernel<T>, dim3(nblk, B), dim3(DT_THREADS), 0, st, P, pix, range, w);
+  if (F > 0) {
+    hipLaunchKernelGGL(dt_face_kernel<T>, dim3(kamd_cdiv(F, DT_THREADS), B), dim3(DT_THREADS), 0, st, F, P, K, fz, fimg, fbb,
+                       eps, w, o);
+    hipLaunchKernelGGL((dt_big_face_kernel<T, 64>), dim3(KAMD_NUM_CU * 8), dim3(DT_THREADS), 0, st, F, P, K, fz, fimg, fbb,
+                       eps, w, o);
+    hipLaunchKernelGGL((dt_big_face_kernel<T, DT_THREADS>), dim3(KAMD_NUM_CU * 4), dim3(DT_THREADS), 0, st, F, P, K, fz,
+                       fimg, fbb, eps, w, o);
   }
-  hipLaunchKernelGGL(dt_forward_kernel<T>, dim3(kamd_cdiv(P, DT_THREADS), B), dim3(DT_THREADS), 0, st, F, P, K, fz, fimg,
-                     fbb, pix, range, eps, (const void*)ws, sorted ? 1 : 0, face_idx, depth, w0, w1, hit_count);
+  const size_t BP = (size_t)B * P;
+  hipLaunchKernelGGL(dt_order_rows_kernel<T>, dim3(kamd_cdiv(BP, 256)), dim3(256), 0, st, BP, K, o, w, hit_count, sort_rows);
+  if (F > 0)
+    hipLaunchKernelGGL(dt_overflow_kernel<T>, dim3(KAMD_NUM_CU * 2), dim3(DT_THREADS), 0, st, F, P, K, fz, fimg, fbb, pix,
+                       range, eps, w, o, hit_count);
   KAMD_RETURN_LAST_ERROR();
 }
 
@@ -491,7 +651,7 @@ int dt_forward(hipStream_t st, int B, int F, int P, int K, const T* fz, const T*
   const size_t n = (size_t)B * P * K;
   if (n == 0) return 0;
   hipLaunchKernelGGL(dt_fill_kernel<T>, dim3(dt_grid_for(n)), dim3(256), 0, st, n, face_idx, depth, w0, w1);
-  return dt_search<T>(st, B, F, P, K, fz, fimg, fbb, pix, range, eps, face_idx, depth, w0, w1, nullptr, ws, ws_bytes);
+  return dt_search<T>(st, B, F, P, K, fz, fimg, fbb, pix, range, eps, face_idx, depth, w0, w1, nullptr, 1, ws, ws_bytes);
 }
 
 template <typename T>
@@ -500,7 +660,8 @@ int dt_forward_fused(hipStream_t st, int B, int F, int P, int K, int D, const T*
                      T* tmp_w1, int* hit_count, int64_t* out_idx, T* out_w, T* out_feat, void* ws, size_t ws_bytes) {
   const size_t n = (size_t)B * P * K;
   if (n == 0) return 0;
-  KAMD_CHECK(dt_search<T>(st, B, F, P, K, fz, fimg, fbb, pix, range, eps, tmp_idx, tmp_depth, tmp_w0, tmp_w1, hit_count,
+  // rows stay in arrival order: the depth sort below ranks by (depth, face number) and does not need mesh order
+  KAMD_CHECK(dt_search<T>(st, B, F, P, K, fz, fimg, fbb, pix, range, eps, tmp_idx, tmp_depth, tmp_w0, tmp_w1, hit_count, 0,
                           ws, ws_bytes));
   kamd::ProfScope prof_(kamd::K_DEFTET_SORT, st);
   hipLaunchKernelGGL(dt_sort_interp_kernel<T>, dim3(dt_grid_for(n)), dim3(256), 0, st, B, F, P, K, D, tmp_idx, tmp_depth,
@@ -522,9 +683,9 @@ int dt_backward(hipStream_t st, int B, int F, int P, int K, int D, const T* grad
 }  // namespace
 
 extern "C" {
-size_t kamd_deftet_forward_workspace(int B, int P) {
-  if (B <= 0 || P <= DT_THREADS) return 0;
-  return (size_t)B * dt_ws_words(P) * 4;
+size_t kamd_deftet_forward_workspace(int B, int F, int P, int elem_size) {
+  if (B <= 0 || P <= 0) return 0;
+  return dt_ws(nullptr, B, F > 0 ? F : 0, P, elem_size / 4).total_words * 4;
 }
 
 #define KAMD_DEFTET_ENTRY(SFX, T)                                                                                       \
