@@ -225,6 +225,30 @@ def main():
         c5 = {'voxelgrid_256_us': round(vox_ms * 1e3, 1), 'voxelgrid_write_GBps': round(256 ** 3 * 4 / (vox_ms * 1e-3) / 1e9, 1),
               'point_to_mesh_1Mx50k_ms': round(p2m_ms, 3),
               'point_to_mesh_Gpairs_per_s': round(1e6 * F / (p2m_ms * 1e-3) / 1e9, 1)}
+        # deftet_sparse_render fwd+bwd, view 0 of the same mesh, knum 30, free pixel coordinates
+        with torch.no_grad():
+            d_cam, d_img, _ = kal.render.mesh.prepare_vertices(
+                verts.detach().unsqueeze(0), faces, proj, camera_rot=rot[:1], camera_trans=trans[:1])
+        d_z, d_img, d_feat = d_cam[..., 2].contiguous(), d_img.contiguous(), feats3[:1].contiguous()
+        for n_pix in (4096, 1 << 20):
+            gen = torch.Generator().manual_seed(1)
+            pix = (torch.rand((1, n_pix, 2), generator=gen) * 2. - 1.).to(dev)
+            rng = torch.tensor([[[-10., 0.]]], device=dev).repeat(1, n_pix, 1)
+            g_out = torch.rand((1, n_pix, 30, 3), generator=gen).to(dev)
+            a_img, a_feat = d_img.clone().requires_grad_(), d_feat.clone().requires_grad_()
+
+            def deftet_step():
+                a_img.grad = None
+                a_feat.grad = None
+                out, _ = kal.render.mesh.deftet_sparse_render(pix, rng, d_z, a_img, a_feat, 30)
+                out.backward(g_out)
+            lib.kamd_profile_reset()
+            lib.kamd_profile_enable(1)
+            ms = per_call_ms(deftet_step, 5)
+            lib.kamd_profile_enable(0)
+            prof = {k: round(v[0] / v[1] * 1e3, 1) for k, v in _lib.kernel_profile(reset=True).items() if 'deftet' in k}
+            c5[f'deftet_{n_pix}px_x_{F}f_fwd_bwd_ms'] = round(ms, 3)
+            c5[f'deftet_{n_pix}px_kernels_avg_us'] = prof
 
     # ---------------- CPU baseline: the oracle (OpenMP) on a bounded sample, rank 0 at N = 1 only
     cpu = None

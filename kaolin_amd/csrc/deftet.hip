@@ -5,12 +5,13 @@
 //
 // The reference visits every face for every pixel (P x F box tests, a warp per pixel).  Here the work is the number of
 // (pixel, face) pairs that are CLOSE, whichever of P and F is large:
-//   1. pixels are counting-sorted by the Z-order number of their cell in a 64 x 64 grid over their own extent (two
-//      LDS-histogram passes, one global atomic per (workgroup, non-empty cell)); the sorted copy (x, y, range) makes a
-//      cell's pixels contiguous;
+//   1. pixels are counting-sorted by the Z-order number of their cell in a G x G grid over their own extent, G chosen
+//      so that a cell holds ~8 pixels (16 <= G <= 256; one global atomic per pixel, little contention by construction);
+//      the sorted copy (x, y, range) makes a cell's pixels contiguous;
 //   2. thread = face walks the pixels of the few cells its box overlaps, runs the reference's arithmetic on the ones
 //      inside the box and appends every hit to that pixel's row through a per-pixel counter (any order);
-//      a face whose cells hold more than 256 pixels goes to a second kernel, workgroup = face, thread = cell;
+//      a face whose cells hold more than 256 pixels is handed to a wavefront (or, above 1024 cells, a workgroup) of its
+//      own, 4 lanes per cell;
 //   3. rows are put in mesh order afterwards (they hold a handful of entries).  A pixel that collected MORE than knum
 //      hits needs "the first knum in mesh order": those (rare) pixels are redone the reference's way, one wavefront per
 //      pixel streaming the faces in order with ballot-prefix appends.
@@ -26,6 +27,7 @@ using kamd::Box4;
 
 constexpr int DT_THREADS = 256;
 constexpr int DT_NB = 64;              // extent partials per batch item
+constexpr int DT_EXT_THREADS = 1024;
 constexpr int DT_MAX_GSHIFT = 8;       // at most 256 x 256 cells
 constexpr int DT_SMALL_CELLS = 16;     // thread = face handles a box over at most this many cells ...
 constexpr int DT_SMALL_CAND = 256;     // ... holding at most this many pixels
@@ -101,12 +103,12 @@ __device__ __forceinline__ float dt_round_up(T v) {
   return f;
 }
 template <typename T>
-__global__ __launch_bounds__(DT_THREADS) void dt_extent_kernel(int P, const T* __restrict__ pix, float* __restrict__ part) {
-  __shared__ float s[4][DT_THREADS];
+__global__ __launch_bounds__(DT_EXT_THREADS) void dt_extent_kernel(int P, const T* __restrict__ pix, float* __restrict__ part) {
+  __shared__ float s[4][DT_EXT_THREADS];
   const int b = blockIdx.y;
   const T* X = pix + (size_t)b * P * 2;
   float lo0 = INFINITY, lo1 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY;
-  for (int i = blockIdx.x * DT_THREADS + threadIdx.x; i < P; i += gridDim.x * DT_THREADS) {
+  for (int i = blockIdx.x * DT_EXT_THREADS + threadIdx.x; i < P; i += gridDim.x * DT_EXT_THREADS) {
     const T x = X[(size_t)i * 2], y = X[(size_t)i * 2 + 1];
     if (isfinite(x) && isfinite(y)) {  // a pixel with a non-finite coordinate is inside no face (see dt_face_kernel)
       lo0 = fminf(lo0, dt_round_down<T>(x));
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(DT_THREADS) void dt_extent_kernel(int P, const T* _
   s[2][threadIdx.x] = hi0;
   s[3][threadIdx.x] = hi1;
   __syncthreads();
-  for (int d = DT_THREADS / 2; d >= 1; d >>= 1) {
+  for (int d = DT_EXT_THREADS / 2; d >= 1; d >>= 1) {
     if (threadIdx.x < d) {
       s[0][threadIdx.x] = fminf(s[0][threadIdx.x], s[0][threadIdx.x + d]);
       s[1][threadIdx.x] = fminf(s[1][threadIdx.x], s[1][threadIdx.x + d]);
@@ -192,16 +194,11 @@ __global__ __launch_bounds__(DT_THREADS) void dt_count_kernel(int P, const T* __
   if (i < P) atomicAdd(&w.start[(size_t)b * (w.nc + 4) + dt_cell<T>(s_g, pix + (size_t)b * P * 2, i)], 1);
 }
 
-// ---- 3. exclusive scan of the NC counts (one workgroup per batch item); cursors start at the cell starts -----------
-__global__ __launch_bounds__(1024) void dt_scan_kernel(DtWs w) {
-  __shared__ int s_wave[16];
-  int* start = w.start + (size_t)blockIdx.x * (w.nc + 4);
-  int* cursor = w.cursor + (size_t)blockIdx.x * w.nc;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int per = (w.nc + 1023) / 1024, i0 = t * per, i1 = min(w.nc, i0 + per);
-  int sum = 0;
-  for (int i = i0; i < i1; ++i) sum += start[i];
-  int inc = sum;
+// ---- 3. exclusive scan of the NC counts in two launches: sums of 1024-entry blocks, then every block adds the sums
+//         before it and scans itself (entry NC receives the total); cursors start at the cell starts -----------------
+__device__ __forceinline__ int dt_block_inclusive(int v, int* s_wave) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     const int o = __shfl_up(inc, d, 64);
@@ -209,15 +206,38 @@ __global__ __launch_bounds__(1024) void dt_scan_kernel(DtWs w) {
   }
   if (lane == 63) s_wave[wave] = inc;
   __syncthreads();
-  int off = inc - sum;
-  for (int k = 0; k < wave; ++k) off += s_wave[k];
-  for (int i = i0; i < i1; ++i) {
-    const int v = start[i];
-    start[i] = off;
-    cursor[i] = off;
-    off += v;
+  int woff = 0;
+  for (int k = 0; k < wave; ++k) woff += s_wave[k];
+  return woff + inc;
+}
+__global__ __launch_bounds__(1024) void dt_scan_sums_kernel(DtWs w, int* __restrict__ sums) {
+  __shared__ int s_wave[16];
+  const int* start = w.start + (size_t)blockIdx.y * (w.nc + 4);
+  const int i = blockIdx.x * 1024 + threadIdx.x;
+  const int tot = dt_block_inclusive(i < w.nc ? start[i] : 0, s_wave);
+  if (threadIdx.x == 1023) sums[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(1024) void dt_scan_apply_kernel(DtWs w, const int* __restrict__ sums) {
+  __shared__ int s_wave[16];
+  __shared__ int s_off;
+  int* start = w.start + (size_t)blockIdx.y * (w.nc + 4);
+  int* cursor = w.cursor + (size_t)blockIdx.y * w.nc;
+  const int* my = sums + blockIdx.y * gridDim.x;
+  int part = 0;
+  for (int k = threadIdx.x; k < (int)blockIdx.x; k += 1024) part += my[k];
+  const int before = dt_block_inclusive(part, s_wave);
+  if (threadIdx.x == 1023) s_off = before;
+  __syncthreads();
+  const int off = s_off;
+  __syncthreads();
+  const int i = blockIdx.x * 1024 + threadIdx.x;
+  const int v = i < w.nc ? start[i] : 0;
+  const int inc = dt_block_inclusive(v, s_wave);
+  if (i < w.nc) {
+    start[i] = off + inc - v;
+    cursor[i] = off + inc - v;
   }
-  if (t == 1023) start[w.nc] = off;
+  if (i == w.nc - 1) start[w.nc] = off + inc;
 }
 
 // ---- 4. scatter into cell order, with a contiguous copy of (x, y, min depth, max depth) -----------------------------
@@ -619,9 +639,13 @@ int dt_search(hipStream_t st, int B, int F, int P, int K, const T* fz, const T* 
   o.w0 = w0;
   o.w1 = w1;
   const int nblk = kamd_cdiv(P, DT_THREADS);
-  hipLaunchKernelGGL(dt_extent_kernel<T>, dim3(DT_NB, B), dim3(DT_THREADS), 0, st, P, pix, w.part);
+  hipLaunchKernelGGL(dt_extent_kernel<T>, dim3(DT_NB, B), dim3(DT_EXT_THREADS), 0, st, P, pix, w.part);
   hipLaunchKernelGGL(dt_count_kernel<T>, dim3(nblk, B), dim3(DT_THREADS), 0, st, P, pix, w);
-  hipLaunchKernelGGL(dt_scan_kernel, dim3(B), dim3(1024), 0, st, w);
+  {  // the block sums live in the (not yet used) overflow list
+    const int nsb = kamd_cdiv(w.nc, 1024);
+    hipLaunchKernelGGL(dt_scan_sums_kernel, dim3(nsb, B), dim3(1024), 0, st, w, w.over);
+    hipLaunchKernelGGL(dt_scan_apply_kernel, dim3(nsb, B), dim3(1024), 0, st, w, (const int*)w.over);
+  }
   hipLaunchKernelGGL(dt_scatter_kernel<T>, dim3(nblk, B), dim3(DT_THREADS), 0, st, P, pix, range, w);
   if (F > 0) {
     hipLaunchKernelGGL(dt_face_kernel<T>, dim3(kamd_cdiv(F, DT_THREADS), B), dim3(DT_THREADS), 0, st, F, P, K, fz, fimg, fbb,
