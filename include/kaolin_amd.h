@@ -355,6 +355,41 @@ int kamd_deftet_sparse_render_backward_f64(void* stream, int B, int F, int P, in
         double* grad_face_vertices_image, double* grad_face_features);
 
 /* ------------------------------------------------------------------------- */
+/* ops.conversions.mesh_to_spc_cuda(face_vertices, level)                      */
+/*     -> [octree uint8 (num_nodes), face_ids int64 (num_voxels),              */
+/*         barycoords float (num_voxels, 2)]                                   */
+/* (reference: kaolin/csrc/ops/conversions/mesh_to_spc/      */
+/* mesh_to_spc.cpp:27-42, mesh_to_spc_cuda.cu:98-467, ops/spc/spc_cuda.cu:46-160)*/
+/* face_vertices (F,3,3) float32 in [-1,1]^3.  Result sizes depend on the data, */
+/* the library never allocates, so the operator is a short host sequence:      */
+/*  1. proposals = (Morton code 0, triangle f) for every f; level_from = 0.     */
+/*  2. stage_count(level_from, level_to = min(level_from + stage_levels(),     */
+/*     level)): counts + offsets (n + 1, offsets[n] = total, read by the host); */
+/*     stage_emit writes the `total` surviving (code, triangle) pairs at        */
+/*     level_to; repeat from level_to with tested = 1 until level_to == level.  */
+/*  3. build: stable sort by code, first triangle of every voxel, all octree    */
+/*     levels, into the workspace; sizes[0] = voxels, sizes[1 + l] = nodes of   */
+/*     octree level l (device int64[1 + level], read by the host).              */
+/*  4. results: face_ids, barycoords of the point of the triangle closest to    */
+/*     the voxel centre, octree bytes (levels concatenated root first).         */
+/* ------------------------------------------------------------------------- */
+int kamd_mesh_to_spc_stage_levels(void);
+size_t kamd_mesh_to_spc_scan_workspace(int64_t n);
+int kamd_mesh_to_spc_stage_count(void* stream, int64_t n, const float* face_vertices, const int64_t* morton,
+                                 const int64_t* triangle_id, int level_from, int level_to, int tested,
+                                 int32_t* counts, int64_t* offsets, void* scan_workspace);
+int kamd_mesh_to_spc_stage_emit(void* stream, int64_t n, const float* face_vertices, const int64_t* morton,
+                                const int64_t* triangle_id, int level_from, int level_to, int tested,
+                                const int64_t* offsets, int64_t* morton_out, int64_t* triangle_id_out);
+size_t kamd_mesh_to_spc_build_workspace(int64_t n, int level);
+int kamd_mesh_to_spc_build(void* stream, int64_t n, int level, const int64_t* morton,
+                           const int64_t* triangle_id, void* workspace, size_t workspace_bytes,
+                           int64_t* sizes);
+int kamd_mesh_to_spc_results(void* stream, int64_t n, int level, const float* face_vertices,
+                             const void* workspace, int64_t num_voxels, int64_t octree_bytes,
+                             uint8_t* octree, int64_t* face_ids, float* barycoords);
+
+/* ------------------------------------------------------------------------- */
 /* ops.mesh.unbatched_mesh_intersection_cuda(points, v1, v2, v3) -> result     */
 /* (reference: kaolin/csrc/ops/mesh/mesh_intersection.cpp,  */
 /* mesh_intersection_cuda.cu:101-253).  points (N,3); v1,v2,v3 (F,3) = the      */

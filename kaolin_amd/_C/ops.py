@@ -49,3 +49,76 @@ def unbatched_mesh_intersection_cuda(points, verts_1, verts_2, verts_3):
             _lib.ptr(verts_3), _lib.ptr(result))
     _lib.check(st, fn)
     return result
+
+
+def mesh_to_spc_cuda(face_vertices, level):
+    """reference: kaolin/csrc/ops/conversions/mesh_to_spc/mesh_to_spc.cpp:27-42 (``_C.ops.conversions.mesh_to_spc_cuda``):
+    face_vertices (F,3,3) float32 in [-1,1]^3 -> [octree uint8 (num_nodes), face_ids int64 (num_voxels),
+    barycoords float (num_voxels, 2)]; nothing occupied -> sizes (0,), (0,), (0, 3) as in the reference.
+
+    Result sizes depend on the data, so the host reads one count per stage of three octree levels and the level
+    sizes once (the reference reads one count per level, twice); see include/kaolin_amd.h for the sequence."""
+    fn = 'mesh_to_spc_cuda'
+    torch_check(face_vertices.is_cuda, 'face_vertices must be a CUDA tensor')
+    torch_check(face_vertices.is_contiguous(), 'face_vertices must be contiguous')
+    torch_check(face_vertices.dim() == 3, f'face_vertices must have 3 dimensions, but got {face_vertices.dim()}')
+    torch_check(face_vertices.size(1) == 3, f'face_vertices must have size 3 on dimension 1, but got {face_vertices.size(1)}')
+    torch_check(face_vertices.size(2) == 3, f'face_vertices must have size 3 on dimension 2, but got {face_vertices.size(2)}')
+    torch_check(face_vertices.dtype == torch.float32, 'expected scalar type Float but found ' + _lib.pretty_dtype(face_vertices.dtype))
+    level = int(level)
+    torch_check(0 <= level <= 15, 'level must be in [0, 15]')
+    dev = face_vertices.device
+    lib = _lib.load()
+    sp = _lib.stream_ptr(dev)
+    depth = lib.kamd_mesh_to_spc_stage_levels()
+
+    def empty_result():
+        return [torch.empty(0, dtype=torch.uint8, device=dev), torch.empty(0, dtype=torch.long, device=dev),
+                torch.zeros((0, 3), dtype=torch.float32, device=dev)]
+
+    with torch.cuda.device(dev):
+        n = face_vertices.size(0)
+        if n == 0:
+            return empty_result()
+        morton = torch.zeros(n, dtype=torch.long, device=dev)
+        tri = torch.arange(n, dtype=torch.long, device=dev)
+        level_from, tested = 0, 0
+        while True:
+            level_to = min(level_from + depth, level)
+            counts = torch.empty(n, dtype=torch.int32, device=dev)
+            offsets = torch.empty(n + 1, dtype=torch.long, device=dev)
+            scan_ws = torch.empty(lib.kamd_mesh_to_spc_scan_workspace(n), dtype=torch.uint8, device=dev)
+            _lib.check(lib.kamd_mesh_to_spc_stage_count(sp, n, _lib.ptr(face_vertices), _lib.ptr(morton), _lib.ptr(tri),
+                                                        level_from, level_to, tested, _lib.ptr(counts), _lib.ptr(offsets),
+                                                        _lib.ptr(scan_ws)), fn)
+            total = int(offsets[n].item())                     # data-dependent size: one host read per stage
+            if total == 0:
+                return empty_result()
+            morton_out = torch.empty(total, dtype=torch.long, device=dev)
+            tri_out = torch.empty(total, dtype=torch.long, device=dev)
+            _lib.check(lib.kamd_mesh_to_spc_stage_emit(sp, n, _lib.ptr(face_vertices), _lib.ptr(morton), _lib.ptr(tri),
+                                                       level_from, level_to, tested, _lib.ptr(offsets), _lib.ptr(morton_out),
+                                                       _lib.ptr(tri_out)), fn)
+            morton, tri, n = morton_out, tri_out, total
+            if level_to == level:
+                break
+            level_from, tested = level_to, 1
+        nbytes = lib.kamd_mesh_to_spc_build_workspace(n, level)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        sizes = torch.empty(1 + level, dtype=torch.long, device=dev)
+        _lib.check(lib.kamd_mesh_to_spc_build(sp, n, level, _lib.ptr(morton), _lib.ptr(tri), _lib.ptr(ws), nbytes,
+                                              _lib.ptr(sizes)), fn)
+        host_sizes = sizes.tolist()                            # voxels + nodes per octree level: one host read
+        num_voxels, octree_bytes = host_sizes[0], sum(host_sizes[1:])
+        octree = torch.empty(octree_bytes, dtype=torch.uint8, device=dev)
+        face_ids = torch.empty(num_voxels, dtype=torch.long, device=dev)
+        bary = torch.empty((num_voxels, 2), dtype=torch.float32, device=dev)
+        _lib.check(lib.kamd_mesh_to_spc_results(sp, n, level, _lib.ptr(face_vertices), _lib.ptr(ws), num_voxels, octree_bytes,
+                                                _lib.ptr(octree), _lib.ptr(face_ids), _lib.ptr(bary)), fn)
+    return [octree, face_ids, bary]
+
+
+# the reference groups these operators in sub-modules: kaolin._C.ops.mesh / kaolin._C.ops.conversions (bindings.cpp)
+import types as _types  # noqa: E402
+mesh = _types.SimpleNamespace(unbatched_mesh_intersection_cuda=unbatched_mesh_intersection_cuda)
+conversions = _types.SimpleNamespace(mesh_to_spc_cuda=mesh_to_spc_cuda)

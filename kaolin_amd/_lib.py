@@ -31,6 +31,13 @@ SIGNATURES = {
     'kamd_triangle_distance_forward_workspace': (_sz, [_i, _i, _i]),
     'kamd_dibr_soft_mask_lean_capacity': (_sz, [_i, _i, _i, _i]),
     'kamd_deftet_forward_workspace': (_sz, [_i, _i, _i, _i]),
+    'kamd_mesh_to_spc_stage_levels': (_i, []),
+    'kamd_mesh_to_spc_scan_workspace': (_sz, [_i64]),
+    'kamd_mesh_to_spc_stage_count': (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    'kamd_mesh_to_spc_stage_emit': (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    'kamd_mesh_to_spc_build_workspace': (_sz, [_i64, _i]),
+    'kamd_mesh_to_spc_build': (_i, [_vp, _i64, _i, _vp, _vp, _vp, _sz, _vp]),
+    'kamd_mesh_to_spc_results': (_i, [_vp, _i64, _i, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     'kamd_profile_enable': (_i, [_i]),
     'kamd_profile_reset': (_i, []),
     'kamd_profile_num_kernels': (_i, []),
@@ -119,6 +126,10 @@ def dtype_suffix(dtype, what, allowed=('f32', 'f64')):
         # reference: AT_ERROR(name, " not implemented for '", toString(TYPE), "'")
         raise RuntimeError(f'"{what}" not implemented for \'{_PRETTY.get(dtype, dtype)}\'')
     return s
+
+
+def pretty_dtype(dtype):
+    return _PRETTY.get(dtype, str(dtype))
 
 
 def stream_ptr(device):

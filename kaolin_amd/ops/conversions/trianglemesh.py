@@ -3,7 +3,7 @@ import torch
 
 from ... import _C
 
-__all__ = ['trianglemeshes_to_voxelgrids']
+__all__ = ['trianglemeshes_to_voxelgrids', 'unbatched_mesh_to_spc']
 
 
 def _torch_dense(points_per_item, faces, resolution):
@@ -64,3 +64,24 @@ def trianglemeshes_to_voxelgrids(vertices, faces, resolution, origin=None, scale
         assert resolution > 1
         dense = _torch_dense(normalized, faces, resolution)
     return dense.to_sparse() if return_sparse else dense
+
+
+def unbatched_mesh_to_spc(face_vertices, level):
+    r"""Conservatively voxelizes a triangle soup into a structured point cloud octree: every cell of the
+    :math:`2^\text{level}` grid over :math:`[-1, 1]^3` that a triangle touches (13-axis separating-axis test) becomes a
+    point of the SPC (reference: kaolin/ops/conversions/trianglemesh.py:112-140).
+
+    Args:
+        face_vertices (torch.FloatTensor): vertices gathered per face, of shape :math:`(\text{num_faces}, 3, 3)`.
+        level (int): depth of the octree.
+
+    Returns:
+        (torch.ByteTensor, torch.LongTensor, torch.FloatTensor):
+            the octree (one byte per node, levels root first), of shape :math:`(\text{num_nodes})`; for every occupied
+            voxel of the last level, in Morton order, the smallest index of a face touching it,
+            :math:`(\text{num_voxels})`; and the first two barycentric weights, w.r.t. that face, of its point closest to
+            the voxel centre, :math:`(\text{num_voxels}, 2)`.
+    """
+    if face_vertices.shape[-1] != 3:
+        raise NotImplementedError('unbatched_mesh_to_spc is only implemented for triangle meshes')
+    return tuple(_C.ops.conversions.mesh_to_spc_cuda(face_vertices.contiguous(), level))

@@ -308,3 +308,22 @@ def deftet_sparse_render(pixel_coords, render_ranges, face_vertices_z, face_vert
     features = (weights[..., 0, None] * sel[..., 0, :] + weights[..., 1, None] * sel[..., 1, :]) + \
         weights[..., 2, None] * sel[..., 2, :]
     return dict(features=features.contiguous(), face_idx=face_idx, weights=weights)
+
+
+# ---- unbatched_mesh_to_spc (conservative voxelization into an SPC octree) ------------------------
+def mesh_to_spc(face_vertices, level, omp=False, return_mortons=False):
+    """kaolin/csrc/ops/conversions/mesh_to_spc/mesh_to_spc.cpp:27-42 -> (octree uint8, face_ids int64, barycoords (n,2) float)
+    [+ the Morton codes of the occupied voxels]; the empty result is (0,), (0,), (0, 3) as in the reference (:347-351)."""
+    fv = _cpu(face_vertices, torch.float32)
+    nb = ctypes.c_int64(0)
+    f = lib(omp).oracle_mesh_to_spc
+    f.restype = ctypes.c_int64
+    n = int(f(_ci(fv.shape[0]), _p(fv), _ci(level), ctypes.byref(nb)))
+    if n == 0:
+        out = (torch.empty(0, dtype=torch.uint8), torch.empty(0, dtype=torch.long), torch.zeros(0, 3))
+        return out + (torch.empty(0, dtype=torch.long),) if return_mortons else out
+    octree = torch.empty(nb.value, dtype=torch.uint8)
+    face_ids, mortons = torch.empty(n, dtype=torch.long), torch.empty(n, dtype=torch.long)
+    bary = torch.empty(n, 2, dtype=torch.float32)
+    lib(omp).oracle_mesh_to_spc_fetch(_p(octree), _p(face_ids), _p(bary), _p(mortons))
+    return (octree, face_ids, bary, mortons) if return_mortons else (octree, face_ids, bary)

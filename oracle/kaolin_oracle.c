@@ -273,3 +273,6 @@ DEFINE_SIDED_BWD(oracle_sided_distance_backward_f64, double)
 #include "deftet_oracle.inc"
 #undef T
 #undef FN
+
+/* ---- unbatched_mesh_to_spc (float only) ---- */
+#include "mesh_to_spc_oracle.inc"
