@@ -92,18 +92,32 @@ __global__ __launch_bounds__(TILE_THREADS) void raster_tile_kernel(
         for (int k0 = 0; k0 < n; k0 += 64) {
           const int k = k0 + lane;
           bool keep = false;
+          Box4<T> fb = {0, 0, 0, 0};
           if (k < n) {
-            const T xmin = s_bbox[k * 4 + 0], ymin = s_bbox[k * 4 + 1], xmax = s_bbox[k * 4 + 2], ymax = s_bbox[k * 4 + 3];
+            fb = reinterpret_cast<const Box4<T>*>(s_bbox)[k];
             // a face is dropped only if NO pixel centre of the sub-tile can pass the reference's reject test
-            keep = !(sx_max < xmin || sx_min >= xmax || sy_max < ymin || sy_min >= ymax);
+            keep = !((sx_max < fb.x0) | (sx_min >= fb.x1) | (sy_max < fb.y0) | (sy_min >= fb.y1));
           }
-          unsigned long long m = __ballot(keep);
-          while (m) {
-            const int j = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int kk = k0 + j;
-            const Box4<T> bb = reinterpret_cast<const Box4<T>*>(s_bbox)[kk];  // one uniform ds_read_b128
-            if (box_rejects<T>(bb, x0, y0)) continue;
+          const unsigned long long m = __ballot(keep);
+          if (m == 0ull) continue;
+          // (1) lane = pixel: which of the kept faces have this pixel inside their box?  The boxes sit in the registers
+          // of the lanes that tested them; a readlane per limit broadcasts them (no LDS round trip, no divergence).
+          unsigned long long hm = 0ull;
+          for (unsigned long long mm = m; mm != 0ull; mm &= mm - 1ull) {
+            const int j = __ffsll((long long)mm) - 1;
+            Box4<T> bb;
+            bb.x0 = wave_bcast<T>(fb.x0, j);
+            bb.y0 = wave_bcast<T>(fb.y0, j);
+            bb.x1 = wave_bcast<T>(fb.x1, j);
+            bb.y1 = wave_bcast<T>(fb.y1, j);
+            hm |= box_rejects<T>(bb, x0, y0) ? 0ull : (1ull << j);
+          }
+          if (!in_image) hm = 0ull;
+          // (2) every lane walks ITS OWN boxes in ascending (= mesh) order: the edge functions run on full lanes
+          while (__any(hm != 0ull)) {
+            if (hm == 0ull) continue;
+            const int kk = k0 + (__ffsll((long long)hm) - 1);
+            hm &= hm - 1ull;
             const T* v = s_rest + kk * 12;
             const T aex = v[0] - x0, aey = v[1] - y0;
             const T bex = v[2] - x0, bey = v[3] - y0;

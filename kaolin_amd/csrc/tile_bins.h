@@ -41,6 +41,17 @@ __device__ __forceinline__ bool box_rejects(const Box4<T>& b, T x, T y) {
   return (x < b.x0) | (x >= b.x1) | (y < b.y0) | (y >= b.y1);
 }
 
+// value of lane j (wave-uniform j) in every lane: v_readlane, no LDS crossbar
+__device__ __forceinline__ float wave_bcast_f(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); }
+template <typename T>
+__device__ __forceinline__ T wave_bcast(T v, int j);
+template <>
+__device__ __forceinline__ float wave_bcast<float>(float v, int j) { return wave_bcast_f(v, j); }
+template <>
+__device__ __forceinline__ double wave_bcast<double>(double v, int j) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), j), __builtin_amdgcn_readlane(__double2loint(v), j));
+}
+
 struct TileGeom {
   int H, W, tiles_x, tiles_y, ntiles;
 };
