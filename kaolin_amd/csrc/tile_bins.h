@@ -172,63 +172,131 @@ __global__ __launch_bounds__(256) void bin_faces_kernel(
 //   bbox   = [min over the 3 vertices - margin, max + margin]   (margin = boxlen*multiplier, 0 for rasterize)
 //   faces with valid[b,f] == 0 are skipped (they are what the reference's packing removes)
 // No torch.where (a host sync), no gathers, no packed copies.
+// sets, for every tile some lane's box touches, the bits of the touching lanes' faces in that tile's mask.
+// Consecutive lanes hold consecutive faces of (usually) one mesh, so the 32 faces of a mask word live in one wavefront:
+// a per-lane atomicOr would send up to 32 same-address atomics to L2 for every word.  Here the wavefront walks the tiles
+// of the union of its boxes, takes ONE ballot per tile and issues at most three atomicOr per (tile, mesh) -- the words
+// its 64 faces straddle.  A wavefront whose union is large (a huge face, or an incoherent face order) keeps the per-lane path.
+__device__ __forceinline__ void bin_emit_wave(bool active, int b, long long j, int tx0, int tx1, int ty0, int ty1, int F,
+                                              const TileGeom& g, unsigned int* __restrict__ masks,
+                                              unsigned int* __restrict__ tile_flags) {
+  const int lane = threadIdx.x & 63;
+  const int stride_b = (F + 31) / 32;
+  unsigned long long remaining = __ballot(active);
+  while (remaining != 0ull) {
+    const int leader = __ffsll((long long)remaining) - 1;
+    const int bL = __builtin_amdgcn_readlane(b, leader);
+    const bool mine = active && b == bL;
+    remaining &= ~__ballot(mine);
+    // union of the group's tile rectangles
+    int ux0 = mine ? tx0 : 0x7fffffff, uy0 = mine ? ty0 : 0x7fffffff, ux1 = mine ? tx1 : -1, uy1 = mine ? ty1 : -1;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      ux0 = min(ux0, __shfl_xor(ux0, d, 64));
+      uy0 = min(uy0, __shfl_xor(uy0, d, 64));
+      ux1 = max(ux1, __shfl_xor(ux1, d, 64));
+      uy1 = max(uy1, __shfl_xor(uy1, d, 64));
+    }
+    const long long first_b = (long long)bL * F;
+    if ((ux1 - ux0 + 1) * (uy1 - uy0 + 1) > 36) {  // not a compact patch: per-lane atomics
+      if (mine) {
+        const unsigned int bit = 1u << (unsigned)(j & 31);
+        for (int ty = ty0; ty <= ty1; ++ty)
+          for (int tx = tx0; tx <= tx1; ++tx) {
+            const int t = ty * g.tiles_x + tx;
+            atomicOr(masks + mask_base(g.ntiles, first_b, bL, t, stride_b) + (size_t)(j >> 5), bit);
+            if (tile_flags[(size_t)bL * g.ntiles + t] == 0u) tile_flags[(size_t)bL * g.ntiles + t] = 1u;
+          }
+      }
+      continue;
+    }
+    // lanes of the group hold consecutive faces: lane l has face j0 + l, j0 = (face of lane 0, possibly virtual)
+    const long long j0 = __shfl(j, leader, 64) - leader;
+    const int s = (int)(j0 & 31);                // lane l's bit = (s + l) & 31, word = (j0 >> 5) + ((s + l) >> 5)
+    for (int ty = uy0; ty <= uy1; ++ty)
+      for (int tx = ux0; tx <= ux1; ++tx) {
+        const unsigned long long bal = __ballot(mine && tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1);
+        if (bal == 0ull) continue;
+        const int t = ty * g.tiles_x + tx;
+        if (lane < 3) {
+          // word k (k = 0,1,2) collects lanes [32k - s, 32k - s + 32) at bit (lane - (32k - s))
+          const int lo = 32 * lane - s;
+          const unsigned long long part = lo >= 0 ? (lo < 64 ? bal >> lo : 0ull) : bal << (-lo);
+          const unsigned int bits = (unsigned int)(part & 0xffffffffull);
+          if (bits != 0u)
+            atomicOr(masks + mask_base(g.ntiles, first_b, bL, t, stride_b) + (size_t)((j0 >> 5) + lane), bits);
+        }
+        if (lane == 0) tile_flags[(size_t)bL * g.ntiles + t] = 1u;
+      }
+  }
+}
+
+template <typename T>
+struct alignas(16) Rec4 {
+  T a, b, c, d;
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void bin_faces_raw_kernel(
     int B, int F, const T* __restrict__ img, const T* __restrict__ z, const uint8_t* __restrict__ valid,
     T mult, T margin, TileGeom g, float multiplier, T* __restrict__ rec, unsigned int* __restrict__ masks,
     unsigned int* __restrict__ tile_flags, uint8_t* __restrict__ sub_flags) {
   const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (f >= (long long)B * F) return;
-  if (valid != nullptr && valid[f] == 0) return;
-  const int b = (int)(f / F);
-  const long long first_b = (long long)b * F;
-  T v[6];
+  bool active = f < (long long)B * F;
+  if (active && valid != nullptr && valid[f] == 0) active = false;
+  int b = 0, tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+  long long j = 0;
+  if (active) {
+    b = (int)(f / F);
+    j = f - (long long)b * F;
+    T v[6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) v[i] = img[f * 6 + i] * mult;
-  T xmin = fmin(fmin(v[0], v[2]), v[4]), xmax = fmax(fmax(v[0], v[2]), v[4]);
-  T ymin = fmin(fmin(v[1], v[3]), v[5]), ymax = fmax(fmax(v[1], v[3]), v[5]);
-  if (margin != (T)0) {
-    xmin = xmin - margin;
-    ymin = ymin - margin;
-    xmax = xmax + margin;
-    ymax = ymax + margin;
-  }
-  T* r = rec + (size_t)f * REC_STRIDE;
-  r[0] = xmin;
-  r[1] = ymin;
-  r[2] = xmax;
-  r[3] = ymax;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) r[4 + i] = v[i];
-  if (z != nullptr) {
-    r[10] = z[f * 3 + 0];
-    r[11] = z[f * 3 + 1];
-    r[12] = z[f * 3 + 2];
-  }
-  int c_lo = 0, c_hi = g.W - 1, r_lo = 0, r_hi = g.H - 1;
-  const double dxmin = (double)xmin, dxmax = (double)xmax, dymin = (double)ymin, dymax = (double)ymax;
-  const bool has_nan = !(multiplier > 0.f) || !(dxmin == dxmin) || !(dxmax == dxmax) || !(dymin == dymin) || !(dymax == dymax);
-  if (!has_nan) {
-    const double sx = (double)g.W / (double)multiplier, sy = (double)g.H / (double)multiplier;
-    const double cl = floor((dxmin * sx + g.W - 1) * 0.5) - 1.0, ch = ceil((dxmax * sx + g.W - 1) * 0.5) + 1.0;
-    const double rl = floor((g.H - 1 - dymax * sy) * 0.5) - 1.0, rh = ceil((g.H - 1 - dymin * sy) * 0.5) + 1.0;
-    if (ch < 0.0 || cl > (double)(g.W - 1) || rh < 0.0 || rl > (double)(g.H - 1)) return;
-    c_lo = (int)fmax(cl, 0.0);
-    c_hi = (int)fmin(ch, (double)(g.W - 1));
-    r_lo = (int)fmax(rl, 0.0);
-    r_hi = (int)fmin(rh, (double)(g.H - 1));
-  }
-  const int tx0 = c_lo / TILE_W, tx1 = c_hi / TILE_W, ty0 = r_lo / TILE_H, ty1 = r_hi / TILE_H;
-  const long long j = f - first_b;
-  const int stride_b = (F + 31) / 32;
-  const unsigned int bit = 1u << (unsigned)(j & 31);
-  for (int ty = ty0; ty <= ty1; ++ty)
-    for (int tx = tx0; tx <= tx1; ++tx) {
-      const int t = ty * g.tiles_x + tx;
-      atomicOr(masks + mask_base(g.ntiles, first_b, b, t, stride_b) + (size_t)(j >> 5), bit);
-      if (tile_flags[(size_t)b * g.ntiles + t] == 0u) tile_flags[(size_t)b * g.ntiles + t] = 1u;
+    for (int i = 0; i < 6; ++i) v[i] = img[f * 6 + i] * mult;
+    T xmin = fmin(fmin(v[0], v[2]), v[4]), xmax = fmax(fmax(v[0], v[2]), v[4]);
+    T ymin = fmin(fmin(v[1], v[3]), v[5]), ymax = fmax(fmax(v[1], v[3]), v[5]);
+    if (margin != (T)0) {
+      xmin = xmin - margin;
+      ymin = ymin - margin;
+      xmax = xmax + margin;
+      ymax = ymax + margin;
     }
-  if (sub_flags != nullptr) mark_sub_tiles(sub_flags, g, B, b, c_lo, c_hi, r_lo, r_hi);
+    // the 16-scalar record as four 16-byte stores: box | a.xy b.xy | c.xy z.ab | z.c pad
+    Rec4<T>* r = reinterpret_cast<Rec4<T>*>(rec + (size_t)f * REC_STRIDE);
+    T z0 = 0, z1 = 0, z2 = 0;
+    if (z != nullptr) {
+      z0 = z[f * 3 + 0];
+      z1 = z[f * 3 + 1];
+      z2 = z[f * 3 + 2];
+    }
+    r[0] = Rec4<T>{xmin, ymin, xmax, ymax};
+    r[1] = Rec4<T>{v[0], v[1], v[2], v[3]};
+    r[2] = Rec4<T>{v[4], v[5], z0, z1};
+    r[3] = Rec4<T>{z2, 0, 0, 0};
+    int c_lo = 0, c_hi = g.W - 1, r_lo = 0, r_hi = g.H - 1;
+    const double dxmin = (double)xmin, dxmax = (double)xmax, dymin = (double)ymin, dymax = (double)ymax;
+    const bool has_nan = !(multiplier > 0.f) || !(dxmin == dxmin) || !(dxmax == dxmax) || !(dymin == dymin) || !(dymax == dymax);
+    if (!has_nan) {
+      const double sx = (double)g.W / (double)multiplier, sy = (double)g.H / (double)multiplier;
+      const double cl = floor((dxmin * sx + g.W - 1) * 0.5) - 1.0, ch = ceil((dxmax * sx + g.W - 1) * 0.5) + 1.0;
+      const double rl = floor((g.H - 1 - dymax * sy) * 0.5) - 1.0, rh = ceil((g.H - 1 - dymin * sy) * 0.5) + 1.0;
+      if (ch < 0.0 || cl > (double)(g.W - 1) || rh < 0.0 || rl > (double)(g.H - 1)) {
+        active = false;  // off screen (the record is still written: nothing reads it)
+      } else {
+        c_lo = (int)fmax(cl, 0.0);
+        c_hi = (int)fmin(ch, (double)(g.W - 1));
+        r_lo = (int)fmax(rl, 0.0);
+        r_hi = (int)fmin(rh, (double)(g.H - 1));
+      }
+    }
+    if (active) {
+      tx0 = c_lo / TILE_W;
+      tx1 = c_hi / TILE_W;
+      ty0 = r_lo / TILE_H;
+      ty1 = r_hi / TILE_H;
+      if (sub_flags != nullptr) mark_sub_tiles(sub_flags, g, B, b, c_lo, c_hi, r_lo, r_hi);
+    }
+  }
+  bin_emit_wave(active, b, j, tx0, tx1, ty0, ty1, F, g, masks, tile_flags);
 }
 
 // ---- block-wide exclusive scan over 1024 threads (16 wavefronts) -------------------------------------
