@@ -116,6 +116,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
+        timed.enqueue_ms = (time.perf_counter() - t0) / steps * 1e3   # host time to enqueue a step (GPU still running)
         torch.cuda.synchronize()
         D.barrier()
         dt = time.perf_counter() - t0
@@ -131,6 +132,7 @@ def main():
     lib.kamd_profile_reset()
     lib.kamd_profile_enable(1)
     dt = timed(dibr_step, args.steps, 0)
+    dibr_enqueue_ms = timed.enqueue_ms
     lib.kamd_profile_enable(0)
     prof = _lib.kernel_profile(reset=True)
     ms_per_step = dt / args.steps * 1e3
@@ -296,6 +298,7 @@ def main():
                        'views_per_gpu': V, 'global_views': V * world, 'height': H, 'width': W, 'faces': F,
                        'covered_pixel_fraction': round(covered, 4), 'parallelism': f'views sharded {world}-way'},
             'roofline': roofline, 'step_roofline': step_roofline, 'kernels': kernels,
+            'host_enqueue_ms_per_step': round(dibr_enqueue_ms, 4),
             'cpu_baseline': cpu, 'chamfer': chamfer, 'c5': c5,
         }
         print(json.dumps(out))

@@ -20,11 +20,14 @@ class _SidedDistanceFunction(torch.autograd.Function):
         queries, targets = p1.contiguous(), p2.contiguous()
         dist, nearest = _C.metrics.sided_distance_forward_cuda(queries, targets)
         ctx.mark_non_differentiable(nearest)
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(queries, targets, nearest)
         return dist, nearest
 
     @staticmethod
     def backward(ctx, grad_dist, _grad_idx):
+        if grad_dist is None:
+            return None, None
         queries, targets, nearest = ctx.saved_tensors
         return tuple(_C.metrics.sided_distance_backward_cuda(grad_dist.contiguous(), queries, targets, nearest))
 

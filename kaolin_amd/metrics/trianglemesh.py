@@ -23,11 +23,14 @@ class _UnbatchedTriangleDistanceCuda(torch.autograd.Function):
                torch.zeros(n, device=dev, dtype=torch.int32))
         _C.metrics.unbatched_triangle_distance_forward_cuda(pts, tris, *out)
         ctx.mark_non_differentiable(out[1], out[2])
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(pts, tris, out[1], out[2])
         return out
 
     @staticmethod
     def backward(ctx, grad_dist, _grad_idx, _grad_type):
+        if grad_dist is None:
+            return None, None
         pts, tris, nearest_face, region = ctx.saved_tensors
         g_pts, g_tris = torch.zeros_like(pts), torch.zeros_like(tris)
         _C.metrics.unbatched_triangle_distance_backward_cuda(grad_dist.contiguous(), pts, tris, nearest_face, region,

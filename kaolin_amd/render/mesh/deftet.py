@@ -25,11 +25,14 @@ class DeftetSparseRenderer(torch.autograd.Function):
             face_vertices_z, face_vertices_image, boxes, pixel_coords, render_ranges, face_features, knum, eps)
         ctx.save_for_backward(face_idx, weights, face_vertices_image, face_features)
         ctx.mark_non_differentiable(face_idx)
+        ctx.set_materialize_grads(False)   # no (B, P, knum) int64 zeros for the index output's gradient
         ctx.eps = eps
         return features, face_idx
 
     @staticmethod
     def backward(ctx, grad_features, grad_face_idx):
+        if grad_features is None:
+            return (None,) * 7
         face_idx, weights, face_vertices_image, face_features = ctx.saved_tensors
         g_img, g_feat = _C.render.mesh.deftet_sparse_render_backward_cuda(
             grad_features.contiguous(), face_idx, weights, face_vertices_image, face_features, ctx.eps)

@@ -67,6 +67,8 @@ class DibrRasterizationCuda(torch.autograd.Function):
             sigmainv, boxlen, knum, multiplier, eps)
         ctx.save_for_backward(face_idx, weights, soft_mask, face_vertices_image, face_features, *hits)
         ctx.mark_non_differentiable(face_idx)
+        # no zero tensors for the gradients of outputs nobody differentiates (the index output alone is B*H*W*8 bytes)
+        ctx.set_materialize_grads(False)
         ctx.cfg = (sigmainv, knum, multiplier, eps)
         return feats, soft_mask, face_idx
 
@@ -74,6 +76,8 @@ class DibrRasterizationCuda(torch.autograd.Function):
     def backward(ctx, grad_feats, grad_soft_mask, grad_face_idx):
         face_idx, weights, soft_mask, face_vertices_image, face_features = ctx.saved_tensors[:5]
         sigmainv, knum, multiplier, eps = ctx.cfg
+        if grad_feats is None and grad_soft_mask is None:
+            return (None,) * 11
         if grad_feats is None:
             grad_feats = torch.zeros(soft_mask.shape + (face_features.shape[-1],), dtype=soft_mask.dtype, device=soft_mask.device)
         if grad_soft_mask is None:

@@ -27,11 +27,15 @@ class RasterizeCuda(torch.autograd.Function):
             height, width, face_vertices_z.contiguous(), face_vertices_image, face_features, valid, multiplier, eps)
         ctx.save_for_backward(interpolated_features, face_idx, output_weights, face_vertices_image, face_features)
         ctx.mark_non_differentiable(face_idx)
+        # no zero tensors for the gradients of outputs nobody differentiates (the index output alone is B*H*W*8 bytes)
+        ctx.set_materialize_grads(False)
         ctx.eps = eps
         return interpolated_features, face_idx
 
     @staticmethod
     def backward(ctx, grad_interpolated_features, grad_face_idx):
+        if grad_interpolated_features is None:
+            return (None,) * 8
         interpolated_features, face_idx, output_weights, face_vertices_image, face_features = ctx.saved_tensors
         grad_img, grad_feat = _C.render.mesh.rasterize_backward_cuda(
             grad_interpolated_features.contiguous(), interpolated_features, face_idx, output_weights,
