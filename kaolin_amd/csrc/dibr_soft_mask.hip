@@ -290,7 +290,6 @@ __global__ __launch_bounds__(64) void soft_search_kernel(
     uint8_t* __restrict__ hit_count, HitList<T> list) {
   __shared__ int s_tmp[SM_IDCAP];
   __shared__ int s_cand[128];
-  __shared__ __attribute__((aligned(16))) T s_bb[64 * 4];  // the chunk's boxes
   __shared__ T s_fv[6][64];  // the chunk's face vertices (structure of arrays: conflict-free gathers)
   __shared__ int s_fid[64];
   __shared__ unsigned short s_pair[SM_PAIRCAP];
@@ -340,30 +339,26 @@ __global__ __launch_bounds__(64) void soft_search_kernel(
     bool active = uncovered && K > 0;
 
     // takes the first n (<= 64) candidates of s_cand.
-    //   a. lane = FACE: park bbox, vertices and id of the lane's face in LDS;
-    //   b. lane = PIXEL: walk the n boxes (uniform LDS reads) and collect the faces holding the pixel centre in a
+    //   a. lane = FACE: the pixels of the sub-tile inside its box (64-bit mask); vertices and id parked in LDS;
+    //   b. a 64 x 64 bit transpose across the wavefront turns those into, lane = PIXEL, the faces holding its centre as a
     //      64-bit mask -- ascending face order for free; the first (knum - kid) set bits are this pixel's new hits;
     //   c. a wave scan of the hit counts gives every pixel a slice of the PAIR list; pairs are evaluated one per
     //      lane (every evaluated pair is an accepted hit) in windows of SM_PAIRCAP;
     //   d. each pixel folds the probabilities of its slice, in order, into prod(1 - prob).
     auto process_chunk = [&](int n) {
+      unsigned long long inside = 0ull;  // lane = face: the pixels of this sub-tile whose centre its box holds
       if (lane < n) {
         const int id = s_cand[lane];
         const T* r = rec + ((size_t)first_b + id) * REC_STRIDE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s_bb[lane * 4 + i] = r[i];
+        const Box4<T> bb = *reinterpret_cast<const Box4<T>*>(r);
+        inside = sub_tile_pixels_in_box<T>(bb, multiplier, g, sub_x, sub_y);
 #pragma unroll
         for (int i = 0; i < 6; ++i) s_fv[i][lane] = r[4 + i];
         s_fid[lane] = id;
       }
+      // lane = pixel: the faces (ascending) whose box holds its centre
+      const unsigned long long hm = wave_transpose64(inside);
       __syncthreads();
-      unsigned long long hm = 0;
-      const Box4<T>* boxes = reinterpret_cast<const Box4<T>*>(s_bb);
-#pragma unroll 8
-      for (int k = 0; k < n; ++k) {
-        const Box4<T> bb = boxes[k];  // one uniform ds_read_b128
-        hm |= box_rejects<T>(bb, x0, y0) ? 0ull : (1ull << k);
-      }
       const int cnt = active ? min(__popcll(hm), K - kid) : 0;
       const int incl = wave_inclusive_scan(cnt);
       const int start = incl - cnt;
