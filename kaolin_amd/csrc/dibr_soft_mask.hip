@@ -179,7 +179,9 @@ __global__ __launch_bounds__(TILE_THREADS) void soft_classify_kernel(
   // kernel then starts from a short candidate list instead of scanning F/32 mask words per sub-tile.
   __shared__ int s_slot[SM_SUBS];
   __shared__ int s_nneed;
-  __shared__ int s_ids[CL_IDCAP];
+  constexpr int IDCAP = sizeof(T) == 4 ? CL_IDCAP : CL_IDCAP / 2;  // ids + boxes of a tile in <= 40 KiB of LDS
+  __shared__ int s_ids[IDCAP];
+  __shared__ Box4<T> s_box[IDCAP];
   __shared__ int s_scan[TILE_THREADS / 64 + 1];
   const int b = blockIdx.x % B, tile = blockIdx.x / B;
   const int tid = threadIdx.x, sub = tid >> 6, lane = tid & 63;
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(TILE_THREADS) void soft_classify_kernel(
     const int wi = 2 * tid;
     const unsigned int w0 = wi < nwords ? tmask[wi] : 0u, w1 = wi + 1 < nwords ? tmask[wi + 1] : 0u;
     const int excl = block_exclusive_scan(__popc(w0) + __popc(w1), s_scan, &total);
-    overflow = total > CL_IDCAP;
+    overflow = total > IDCAP;
     if (!overflow) {
       int pos = excl;
 #pragma unroll
@@ -242,6 +244,11 @@ __global__ __launch_bounds__(TILE_THREADS) void soft_classify_kernel(
       }
     }
   }
+  __syncthreads();
+  // the 16 wavefronts cull the same faces: their boxes are fetched once (one 16-byte load per face) and shared
+  if (!overflow)
+    for (int k = tid; k < total; k += TILE_THREADS)
+      s_box[k] = *reinterpret_cast<const Box4<T>*>(rec + ((size_t)first_b + s_ids[k]) * REC_STRIDE);
   __syncthreads();
   if (slot < 0) return;  // (whole wavefront)
   if (overflow) {
@@ -268,9 +275,8 @@ __global__ __launch_bounds__(TILE_THREADS) void soft_classify_kernel(
     int id = 0;
     if (k < total) {
       id = s_ids[k];
-      const T* r = rec + ((size_t)first_b + id) * REC_STRIDE;
-      const T b0 = r[0], b1 = r[1], b2 = r[2], b3 = r[3];
-      keep = !(ux_max < b0 || ux_min >= b2 || uy_max < b1 || uy_min >= b3);
+      const Box4<T> bb = s_box[k];
+      keep = !((ux_max < bb.x0) | (ux_min >= bb.x1) | (uy_max < bb.y0) | (uy_min >= bb.y1));
     }
     const unsigned long long m = __ballot(keep);
     const int pos = ncand + __popcll(m & ((1ull << lane) - 1ull));
