@@ -522,19 +522,23 @@ __global__ __launch_bounds__(64) void soft_search_kernel(
 // global atomic per touched (face, coordinate).
 constexpr int SB_HT = 512;  // hash slots (a sub-tile rarely sees more than ~300 distinct faces; overflow -> global atomics)
 
-template <typename T>
-__device__ __forceinline__ void sb_accumulate(int* s_key, T* s_acc, T* __restrict__ g_face, int f, int off, T v) {
-  // open addressing on the face id; falls back to a global atomic if the table is full
+// open addressing on the face id: the slot of face f (claimed on first use), or -1 when 16 probes find neither f nor a
+// free slot (a crowded table degrades to global atomics, not to a scan).  One probe sequence per hit, not per value.
+__device__ __forceinline__ int sb_find(int* s_key, int f) {
   int slot = (int)(((unsigned)f * 2654435761u) >> 22) & (SB_HT - 1);
-  for (int probe = 0; probe < 16; ++probe) {  // bounded probing: a crowded table degrades to global atomics, not to a scan
+  for (int probe = 0; probe < 16; ++probe) {
     const int k = atomicCAS(&s_key[slot], -1, f);
-    if (k == -1 || k == f) {
-      atomicAdd(&s_acc[slot * 6 + off], v);
-      return;
-    }
+    if (k == -1 || k == f) return slot;
     slot = (slot + 1) & (SB_HT - 1);
   }
-  kamd_atomic_add(g_face + off, v);
+  return -1;
+}
+template <typename T>
+__device__ __forceinline__ void sb_add(T* s_acc, T* __restrict__ g_face, int slot, int off, T v) {
+  if (slot >= 0)
+    atomicAdd(&s_acc[slot * 6 + off], v);
+  else
+    kamd_atomic_add(g_face + off, v);
 }
 
 template <typename T>
@@ -586,6 +590,7 @@ __global__ __launch_bounds__(64) void soft_mask_backward_kernel(
     }
     const size_t s6 = ((size_t)b * F + f) * 6;
     const int key = f;  // the table is per image: b is fixed for the workgroup
+    const int slot = sb_find(s_key, key);
     const T pr = prob_in[pk + kid];
     const T dLdz = (T)(-1.0 * sigmainv * dLdp * (1.0 - all) / (1.0 - pr + DIBR_EPS) * pr);
     const int e = (int)type_in[pk + kid] - 1;
@@ -594,8 +599,8 @@ __global__ __launch_bounds__(64) void soft_mask_backward_kernel(
       const T x1 = img[s6 + o], y1 = img[s6 + o + 1];
       const T dLdx1 = dLdz * 2 * (x1 - x0);
       const T dLdy1 = dLdz * 2 * (y1 - y0);
-      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o, (T)(dLdx1 / multiplier));
-      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o + 1, (T)(dLdy1 / multiplier));
+      sb_add<T>(s_acc, g_img + s6, slot, o, (T)(dLdx1 / multiplier));
+      sb_add<T>(s_acc, g_img + s6, slot, o + 1, (T)(dLdy1 / multiplier));
     } else {
       const int o = e * 2, o2 = ((e + 1) % 3) * 2;
       const T x1 = img[s6 + o], y1 = img[s6 + o + 1], x2 = img[s6 + o2], y2 = img[s6 + o2 + 1];
@@ -610,10 +615,10 @@ __global__ __launch_bounds__(64) void soft_mask_backward_kernel(
       const T dLdy1 = dLdz * (x2 * dzdC - dzdA);
       const T dLdx2 = dLdz * (y1 * dzdC - dzdB);
       const T dLdy2 = dLdz * (dzdA - x1 * dzdC);
-      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o, (T)(dLdx1 / multiplier));
-      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o + 1, (T)(dLdy1 / multiplier));
-      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o2, (T)(dLdx2 / multiplier));
-      sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o2 + 1, (T)(dLdy2 / multiplier));
+      sb_add<T>(s_acc, g_img + s6, slot, o, (T)(dLdx1 / multiplier));
+      sb_add<T>(s_acc, g_img + s6, slot, o + 1, (T)(dLdy1 / multiplier));
+      sb_add<T>(s_acc, g_img + s6, slot, o2, (T)(dLdx2 / multiplier));
+      sb_add<T>(s_acc, g_img + s6, slot, o2 + 1, (T)(dLdy2 / multiplier));
     }
   }
   __syncthreads();
@@ -660,14 +665,15 @@ __global__ __launch_bounds__(SL_THREADS) void soft_mask_backward_list_kernel(
       const T all = soft_mask[pix];
       const size_t s6 = ((size_t)b * F + f) * 6;
       const int key = (int)(((long long)b * F + f) & 0x7fffffff);
+      const int slot = sb_find(s_key, key);
       const T dLdz = (T)(-1.0 * sigmainv * dLdp * (1.0 - all) / (1.0 - pr + DIBR_EPS) * pr);
       if (e >= 3) {
         const int o = (e - 3) * 2;
         const T x1 = img[s6 + o] * img_scale, y1 = img[s6 + o + 1] * img_scale;
         const T dLdx1 = dLdz * 2 * (x1 - x0);
         const T dLdy1 = dLdz * 2 * (y1 - y0);
-        sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o, (T)(dLdx1 / multiplier));
-        sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o + 1, (T)(dLdy1 / multiplier));
+        sb_add<T>(s_acc, g_img + s6, slot, o, (T)(dLdx1 / multiplier));
+        sb_add<T>(s_acc, g_img + s6, slot, o + 1, (T)(dLdy1 / multiplier));
       } else {
         const int o = e * 2, o2 = ((e + 1) % 3) * 2;
         const T x1 = img[s6 + o] * img_scale, y1 = img[s6 + o + 1] * img_scale;
@@ -683,10 +689,10 @@ __global__ __launch_bounds__(SL_THREADS) void soft_mask_backward_list_kernel(
         const T dLdy1 = dLdz * (x2 * dzdC - dzdA);
         const T dLdx2 = dLdz * (y1 * dzdC - dzdB);
         const T dLdy2 = dLdz * (dzdA - x1 * dzdC);
-        sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o, (T)(dLdx1 / multiplier));
-        sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o + 1, (T)(dLdy1 / multiplier));
-        sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o2, (T)(dLdx2 / multiplier));
-        sb_accumulate<T>(s_key, s_acc, g_img + s6, key, o2 + 1, (T)(dLdy2 / multiplier));
+        sb_add<T>(s_acc, g_img + s6, slot, o, (T)(dLdx1 / multiplier));
+        sb_add<T>(s_acc, g_img + s6, slot, o + 1, (T)(dLdy1 / multiplier));
+        sb_add<T>(s_acc, g_img + s6, slot, o2, (T)(dLdx2 / multiplier));
+        sb_add<T>(s_acc, g_img + s6, slot, o2 + 1, (T)(dLdy2 / multiplier));
       }
     }
     __syncthreads();
