@@ -525,22 +525,40 @@ __global__ __launch_bounds__(DT_THREADS) void dt_overflow_kernel(int F, int P, i
 }
 
 // ---- 7. depth sort + weights + interpolation (deftet.py:297-311) ------------------------------------------------
-// thread = (pixel, k): rank of entry k among the pixel's n hits by (depth descending, then face number) = its output
-// slot; slots >= n get the defaults.  Rows arrive in any order; equal depths are ordered by face number = mesh order
+// rank of entry k among the pixel's n hits by (depth descending, then face number) = its output slot; slots >= n keep
+// the defaults.  Rows arrive in any order; equal depths are ordered by face number = mesh order
 // (torch.argsort in the reference leaves that case open).
-template <typename T>
+// the sorted result is mostly defaults (knum slots, a handful of hits): they go out as flat 16-byte stores ...
+__global__ __launch_bounds__(256) void dt_fill16_kernel(uint4* __restrict__ p, size_t n16, unsigned int word) {
+  const uint4 v = make_uint4(word, word, word, word);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = v;
+}
+inline int dt_fill_bytes(void* ptr, size_t bytes, unsigned char byte, hipStream_t st) {  // byte pattern, any size
+  const size_t n16 = bytes / 16, tail = bytes - n16 * 16;
+  if (n16 > 0) {
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > (size_t)KAMD_NUM_CU * 16) blocks = (size_t)KAMD_NUM_CU * 16;
+    hipLaunchKernelGGL(dt_fill16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint4*)ptr, n16, 0x01010101u * byte);
+  }
+  if (tail) return (int)hipMemsetAsync((char*)ptr + n16 * 16, byte, tail, st);
+  return (int)hipGetLastError();
+}
+// ... and the hits are then ranked and written over them: KH lanes per pixel, lane k takes entries k, k + KH, ...
+template <typename T, int KH>
 __global__ __launch_bounds__(256) void dt_sort_interp_kernel(int B, int F, int P, int K, int D,
                                                              const int64_t* __restrict__ face_idx,
                                                              const T* __restrict__ depth, const T* __restrict__ w0a,
                                                              const T* __restrict__ w1a, const int* __restrict__ hit_count,
                                                              const T* __restrict__ feat, int64_t* __restrict__ out_idx,
                                                              T* __restrict__ out_w, T* __restrict__ out_feat) {
-  const size_t total = (size_t)B * P * K;
+  // KH == 0: small results, one pass -- a thread per (pixel, slot) that also writes the defaults of the unused slots
+  const int kh = KH > 0 ? KH : K;
+  const size_t total = (size_t)B * P * kh;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const size_t bp = i / K;
-    const int k = (int)(i - bp * K);
-    const int n = hit_count[bp];
-    if (k >= n) {
+    const size_t bp = i / kh;
+    const int n = min(hit_count[bp], K);
+    const size_t row = bp * K;
+    if (KH == 0 && (int)(i - bp * kh) >= n) {
       out_idx[i] = -1;
       out_w[i * 3 + 0] = 0;
       out_w[i * 3 + 1] = 0;
@@ -548,24 +566,25 @@ __global__ __launch_bounds__(256) void dt_sort_interp_kernel(int B, int F, int P
       for (int d = 0; d < D; ++d) out_feat[i * D + d] = 0;
       continue;
     }
-    const size_t row = bp * K;
-    const T dk = depth[i];
-    const int64_t f = face_idx[i];
-    int r = 0;
-    for (int j = 0; j < n; ++j) {
-      const T dj = depth[row + j];
-      r += (dj > dk) | ((dj == dk) & (face_idx[row + j] < f));
+    for (int k = (int)(i - bp * kh); k < n; k += kh) {
+      const T dk = depth[row + k];
+      const int64_t f = face_idx[row + k];
+      int r = 0;
+      for (int j = 0; j < n; ++j) {
+        const T dj = depth[row + j];
+        r += (dj > dk) | ((dj == dk) & (face_idx[row + j] < f));
+      }
+      const T w0 = w0a[row + k], w1 = w1a[row + k];
+      const T w2 = (T)1 - (w0 + w1);
+      const size_t o = row + r;
+      out_idx[o] = f;
+      out_w[o * 3 + 0] = w0;
+      out_w[o * 3 + 1] = w1;
+      out_w[o * 3 + 2] = w2;
+      const int b = (int)(bp / P);
+      const T* c = feat + ((size_t)b * F + (size_t)f) * 3 * D;
+      for (int d = 0; d < D; ++d) out_feat[o * D + d] = (w0 * c[d] + w1 * c[D + d]) + w2 * c[2 * D + d];
     }
-    const T w0 = w0a[i], w1 = w1a[i];
-    const T w2 = (T)1 - (w0 + w1);
-    const size_t o = row + r;
-    out_idx[o] = f;
-    out_w[o * 3 + 0] = w0;
-    out_w[o * 3 + 1] = w1;
-    out_w[o * 3 + 2] = w2;
-    const int b = (int)(bp / P);
-    const T* c = feat + ((size_t)b * F + (size_t)f) * 3 * D;
-    for (int d = 0; d < D; ++d) out_feat[o * D + d] = (w0 * c[d] + w1 * c[D + d]) + w2 * c[2 * D + d];
   }
 }
 
@@ -688,8 +707,16 @@ int dt_forward_fused(hipStream_t st, int B, int F, int P, int K, int D, const T*
   KAMD_CHECK(dt_search<T>(st, B, F, P, K, fz, fimg, fbb, pix, range, eps, tmp_idx, tmp_depth, tmp_w0, tmp_w1, hit_count, 0,
                           ws, ws_bytes));
   kamd::ProfScope prof_(kamd::K_DEFTET_SORT, st);
-  hipLaunchKernelGGL(dt_sort_interp_kernel<T>, dim3(dt_grid_for(n)), dim3(256), 0, st, B, F, P, K, D, tmp_idx, tmp_depth,
-                     tmp_w0, tmp_w1, hit_count, feat, out_idx, out_w, out_feat);
+  if (n < ((size_t)1 << 22)) {  // a few launches cost more than the strided default stores they avoid
+    hipLaunchKernelGGL((dt_sort_interp_kernel<T, 0>), dim3(dt_grid_for(n)), dim3(256), 0, st, B, F, P, K, D, tmp_idx,
+                       tmp_depth, tmp_w0, tmp_w1, hit_count, feat, out_idx, out_w, out_feat);
+  } else {
+    KAMD_CHECK(dt_fill_bytes(out_idx, n * 8, 0xFF, st));  // -1
+    KAMD_CHECK(dt_fill_bytes(out_w, n * 3 * sizeof(T), 0, st));
+    KAMD_CHECK(dt_fill_bytes(out_feat, n * (size_t)D * sizeof(T), 0, st));
+    hipLaunchKernelGGL((dt_sort_interp_kernel<T, 4>), dim3(dt_grid_for((size_t)B * P * 4)), dim3(256), 0, st, B, F, P, K, D,
+                       tmp_idx, tmp_depth, tmp_w0, tmp_w1, hit_count, feat, out_idx, out_w, out_feat);
+  }
   KAMD_RETURN_LAST_ERROR();
 }
 
