@@ -64,6 +64,12 @@ def all_reduce_gradients(params, average=False):
     params = [p for p in params if p.requires_grad]
     if not params or not is_distributed():
         return
+    if len(params) == 1 and params[0].grad is not None and params[0].grad.is_contiguous():
+        # one shared tensor (the usual case: the mesh vertices): reduce its gradient in place, no bucket copy
+        dist.all_reduce(params[0].grad, op=dist.ReduceOp.SUM)
+        if average:
+            params[0].grad /= world_size()
+        return
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(params[0].dtype)
                       for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)

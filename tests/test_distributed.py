@@ -52,9 +52,17 @@ def _worker(rank, world, port, out):
     unused = torch.zeros(2, requires_grad=True, dtype=torch.double)  # a parameter with no grad on this rank
     D.all_reduce_gradients([offset, unused])
     gathered = D.all_gather_batch(torch.full((2, 1), float(rank)))
+    # a single shared tensor takes the in-place path (no bucket): same sum, and the average
+    single = torch.zeros(3, dtype=torch.double, requires_grad=True)
+    single.grad = g.clone()
+    D.all_reduce_gradients([single])
+    mean = torch.zeros(3, dtype=torch.double, requires_grad=True)
+    mean.grad = g.clone()
+    D.all_reduce_gradients([mean], average=True)
     D.barrier()
     if rank == 0:
-        torch.save({'grad': offset.grad, 'unused': unused.grad, 'gathered': gathered}, out)
+        torch.save({'grad': offset.grad, 'unused': unused.grad, 'gathered': gathered, 'single': single.grad,
+                    'mean': mean.grad}, out)
     torch.distributed.destroy_process_group()
 
 
@@ -67,6 +75,7 @@ def test_two_rank_gloo_sharded_chamfer_matches_full_batch(tmp_path):
     g_full, _ = _chamfer_grad_wrt_offset(base, p2, torch.zeros(3, dtype=torch.double))
     assert torch.allclose(res['grad'], g_full, rtol=1e-12, atol=1e-14)
     assert torch.equal(res['unused'], torch.zeros(2, dtype=torch.double))
+    assert torch.equal(res['single'], res['grad']) and torch.allclose(res['mean'], g_full / 2, rtol=1e-12, atol=1e-14)
     assert torch.equal(res['gathered'], torch.tensor([[0.], [0.], [1.], [1.]]))
 
 
