@@ -201,6 +201,19 @@ __device__ __forceinline__ T barycentric_jacobian(const T* v, T aw, T bw, T cw, 
   return k3;
 }
 
+// value of the lane N places to the left / right inside the same row of 16 lanes (DPP row_shr / row_shl: a register
+// move, no LDS crossbar); lanes without a source read 0
+template <int N>
+__device__ __forceinline__ int row_shr(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + N, 0xF, 0xF, true); }
+template <int N>
+__device__ __forceinline__ int row_shl(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x100 + N, 0xF, 0xF, true); }
+template <int N>
+__device__ __forceinline__ float row_shr(float v) { return __int_as_float(row_shr<N>(__float_as_int(v))); }
+template <int N>
+__device__ __forceinline__ double row_shr(double v) {
+  return __hiloint2double(row_shr<N>(__double2hiint(v)), row_shr<N>(__double2loint(v)));
+}
+
 // DT > 0: feature count known at compile time (block-merged through LDS); DT == 0: any D, per-lane global atomics
 template <typename T, int DT>
 __global__ __launch_bounds__(256) void raster_backward_kernel(
@@ -264,25 +277,35 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(
     // every run (6 shuffle steps per value), and only the LAST lane of a run touches the LDS table: same-address LDS
     // atomics were 56 % of this kernel's wave time (SQ_WAIT_INST_LDS) when every lane added on its own.
     if (__ballot(f >= 0) != 0ull) {
-    const int prev_f = __shfl_up(f, 1, 64);
-    const int next_f = __shfl_down(f, 1, 64);
-    const bool run_start = lane == 0 || prev_f != f;
-    int start_lane = run_start ? lane : 0;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(start_lane, d, 64);
-      if (lane >= d) start_lane = max(start_lane, o);
+    // rows of 16 lanes = 16 horizontally adjacent pixels: runs are merged inside a row with DPP row shifts (register
+    // moves).  The 64-lane version went through ds_bpermute: 96 LDS-crossbar operations per wavefront, and this kernel
+    // spent 42 % of its wave cycles waiting on LDS (SQ_WAIT_INST_LDS).
+    const int rl = lane & 15;
+    const int prev_f = row_shr<1>(f);
+    const int next_f = row_shl<1>(f);
+    const bool run_start = rl == 0 || prev_f != f;
+    int start_lane = run_start ? rl : 0;
+    {
+      int o;
+      o = row_shr<1>(start_lane); if (rl >= 1) start_lane = max(start_lane, o);
+      o = row_shr<2>(start_lane); if (rl >= 2) start_lane = max(start_lane, o);
+      o = row_shr<4>(start_lane); if (rl >= 4) start_lane = max(start_lane, o);
+      o = row_shr<8>(start_lane); if (rl >= 8) start_lane = max(start_lane, o);
     }
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const bool take = lane >= d && start_lane <= lane - d;
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const T o = __shfl_up(vals[i], d, 64);
-        if (take) vals[i] += o;
-      }
+#define KAMD_RB_STAGE(DD)                                        \
+    {                                                            \
+      const bool take = rl >= DD && start_lane <= rl - DD;       \
+      _Pragma("unroll") for (int i = 0; i < NV; ++i) {           \
+        const T o = row_shr<DD>(vals[i]);                        \
+        if (take) vals[i] += o;                                  \
+      }                                                          \
     }
-    const bool run_end = lane == 63 || next_f != f;
+    KAMD_RB_STAGE(1)
+    KAMD_RB_STAGE(2)
+    KAMD_RB_STAGE(4)
+    KAMD_RB_STAGE(8)
+#undef KAMD_RB_STAGE
+    const bool run_end = rl == 15 || next_f != f;
     if (f >= 0 && run_end) {
       int slot = (int)(((unsigned)f * 2654435761u) >> 24) & (RB_HT - 1);
       for (;;) {  // at most 256 distinct faces for 256 slots: an empty slot always exists
