@@ -79,13 +79,14 @@ __global__ __launch_bounds__(TILE_THREADS) void raster_tile_kernel(
       }
       __syncthreads();
       const int n = min(CAP, total - c0);
-      for (int i = tid; i < n * REC_STRIDE; i += TILE_THREADS) {
-        const int k = i / REC_STRIDE, e = i % REC_STRIDE;
-        const T v = rec[((size_t)first_b + s_ids[k]) * REC_STRIDE + e];
-        if (e < 4)
-          s_bbox[k * 4 + e] = v;
+      // a record is four 16-byte quads: box | a.xy b.xy | c.xy z.ab | z.c pad -- copied as such (4 lanes per record)
+      for (int i = tid; i < n * 4; i += TILE_THREADS) {
+        const int k = i >> 2, q = i & 3;
+        const Rec4<T> v = reinterpret_cast<const Rec4<T>*>(rec + ((size_t)first_b + s_ids[k]) * REC_STRIDE)[q];
+        if (q == 0)
+          reinterpret_cast<Rec4<T>*>(s_bbox)[k] = v;
         else
-          s_rest[k * 12 + (e - 4)] = v;
+          reinterpret_cast<Rec4<T>*>(s_rest)[k * 3 + (q - 1)] = v;
       }
       __syncthreads();
       if (sub_in_image) {
