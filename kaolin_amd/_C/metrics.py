@@ -19,8 +19,11 @@ def sided_distance_forward_cuda(p1, p2):
     sfx = _lib.dtype_suffix(p1.dtype, fn, ('f32', 'f64', 'f16'))
     lib = _lib.load()
     with torch.cuda.device(p1.device):
-        dist = torch.zeros((batch_size, num_p1), dtype=p1.dtype, device=p1.device)
-        idx = torch.zeros((batch_size, num_p1), dtype=torch.long, device=p1.device)
+        # the reference allocates zeros (sided_distance.cpp:80-81); every kernel path writes all B x N entries, so only
+        # the degenerate "no target" case (nothing is launched) needs them
+        alloc = torch.zeros if num_p2 == 0 else torch.empty
+        dist = alloc((batch_size, num_p1), dtype=p1.dtype, device=p1.device)
+        idx = alloc((batch_size, num_p1), dtype=torch.long, device=p1.device)
         ws = _lib.workspace(
             lib.kamd_sided_distance_forward_workspace(batch_size, num_p1, num_p2, p1.element_size()), p1.device)
         st = getattr(lib, f'kamd_sided_distance_forward_{sfx}')(
