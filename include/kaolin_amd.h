@@ -439,14 +439,22 @@ int kamd_triangle_distance_backward_f64(void* stream, int N, int F,
 /* NO native kernel here (pure torch: kaolin/ops/conversions/trianglemesh.py: */
 /* 29-110, ops/mesh/trianglemesh.py:410-458, ops/conversions/pointcloud.py:   */
 /* 42-75); this entry point fuses subdivide-until-dense + point binning.      */
-/* vertices (B,V,3) ALREADY normalised ((v-origin)/scale), faces (F,3) int64  */
-/* shared by the batch; grid (B,R,R,R) is fully written (0/1 in dtype).       */
+/* vertices (B,V,3) RAW, faces (F,3) int64 shared by the batch.  origin (B,3)  */
+/* and scale (B) of the normalisation (v - origin) / scale, either may be NULL:*/
+/* then origin = per-mesh minimum, scale = largest extent above the origin     */
+/* (trianglemesh.py:84-96).  norm: scratch of                                 */
+/* kamd_trianglemeshes_to_voxelgrids_workspace(B,V,elem_size) bytes (its first */
+/* 4*B scalars return origin xyz + scale per mesh).  grid (B,R,R,R) is fully   */
+/* written (0/1 in dtype).                                                     */
 /* ------------------------------------------------------------------------- */
+size_t kamd_trianglemeshes_to_voxelgrids_workspace(int B, int V, int elem_size);
 int kamd_trianglemeshes_to_voxelgrids_f32(void* stream, int B, int V, int F, int R,
                                           const float* vertices, const int64_t* faces,
+                                          const float* origin, const float* scale, float* norm,
                                           float* grid);
 int kamd_trianglemeshes_to_voxelgrids_f64(void* stream, int B, int V, int F, int R,
                                           const double* vertices, const int64_t* faces,
+                                          const double* origin, const double* scale, double* norm,
                                           double* grid);
 
 /* ------------------------------------------------------------------------- */

@@ -1,28 +1,37 @@
-"""Host shim for the fused voxelizer.  The reference has no ``kaolin._C`` operator here (the op is pure
-PyTorch, kaolin/ops/conversions/trianglemesh.py:29-110); this entry point exists only on our side."""
+"""Host shims of ``kaolin._C.ops`` operators, plus the fused voxelizer (the reference has no ``kaolin._C`` operator for
+it: the op is pure PyTorch, kaolin/ops/conversions/trianglemesh.py:29-110; that entry point exists only on our side)."""
 import torch
 
 from .. import _lib
 from .._checks import torch_check
 
 
-def trianglemeshes_to_voxelgrids_cuda(normalized_vertices, faces, resolution):
-    """normalized_vertices (B, V, 3) already mapped by (v - origin) / scale; faces (F, 3) int64 shared by the
-    batch -> dense (B, R, R, R) grid of 0/1 in the vertices' dtype."""
+def trianglemeshes_to_voxelgrids_cuda(vertices, faces, resolution, origin=None, scale=None):
+    """vertices (B, V, 3) raw; faces (F, 3) int64 shared by the batch; origin (B, 3) / scale (B) of the normalisation
+    ``(vertices - origin) / scale`` or None (per-mesh minimum / largest extent, computed on the device)
+    -> dense (B, R, R, R) grid of 0/1 in the vertices' dtype."""
     fn = 'trianglemeshes_to_voxelgrids_cuda'
-    torch_check(normalized_vertices.is_cuda and faces.is_cuda, f'{fn}: vertices and faces must be CUDA tensors')
-    torch_check(normalized_vertices.dim() == 3 and normalized_vertices.size(2) == 3, 'vertices must of size {batch_size, num_vertices, 3}')
+    torch_check(vertices.is_cuda and faces.is_cuda, f'{fn}: vertices and faces must be CUDA tensors')
+    torch_check(vertices.dim() == 3 and vertices.size(2) == 3, 'vertices must of size {batch_size, num_vertices, 3}')
     torch_check(faces.dim() == 2 and faces.size(1) == 3, 'faces must of size {num_faces, 3}')
     torch_check(faces.dtype == torch.long, 'faces must be long')
-    v = normalized_vertices.contiguous()
+    v = vertices.contiguous()
     f = faces.contiguous()
     sfx = _lib.dtype_suffix(v.dtype, fn)
     B, V, F, R = v.size(0), v.size(1), f.size(0), int(resolution)
+    if origin is not None:
+        torch_check(origin.is_cuda and tuple(origin.shape) == (B, 3), 'origin must be a CUDA tensor of size {batch_size, 3}')
+        origin = origin.to(v.dtype).contiguous()
+    if scale is not None:
+        torch_check(scale.is_cuda and scale.numel() == B, 'scale must be a CUDA tensor of size {batch_size}')
+        scale = scale.to(v.dtype).reshape(B).contiguous()
     lib = _lib.load()
     with torch.cuda.device(v.device):
         grid = torch.empty((B, R, R, R), dtype=v.dtype, device=v.device)
+        norm = _lib.workspace(lib.kamd_trianglemeshes_to_voxelgrids_workspace(B, V, v.element_size()), v.device)
         st = getattr(lib, f'kamd_trianglemeshes_to_voxelgrids_{sfx}')(
-            _lib.stream_ptr(v.device), B, V, F, R, _lib.ptr(v), _lib.ptr(f), _lib.ptr(grid))
+            _lib.stream_ptr(v.device), B, V, F, R, _lib.ptr(v), _lib.ptr(f), _lib.ptr(origin), _lib.ptr(scale), _lib.ptr(norm),
+            _lib.ptr(grid))
     _lib.check(st, fn)
     return grid
 

@@ -30,6 +30,7 @@ SIGNATURES = {
     'kamd_dibr_soft_mask_forward_workspace': (_sz, [_i, _i, _i, _i, _i]),
     'kamd_triangle_distance_forward_workspace': (_sz, [_i, _i, _i]),
     'kamd_dibr_soft_mask_lean_capacity': (_sz, [_i, _i, _i, _i]),
+    'kamd_trianglemeshes_to_voxelgrids_workspace': (_sz, [_i, _i, _i]),
     'kamd_deftet_forward_workspace': (_sz, [_i, _i, _i, _i]),
     'kamd_mesh_to_spc_stage_levels': (_i, []),
     'kamd_mesh_to_spc_scan_workspace': (_sz, [_i64]),
@@ -81,7 +82,7 @@ for _t in ('f32', 'f64'):
         _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp])
     SIGNATURES[f'kamd_triangle_distance_forward_{_t}'] = (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_triangle_distance_backward_{_t}'] = (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
-    SIGNATURES[f'kamd_trianglemeshes_to_voxelgrids_{_t}'] = (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp])
+    SIGNATURES[f'kamd_trianglemeshes_to_voxelgrids_{_t}'] = (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp])
 
 _lock = threading.Lock()
 _lib = None

@@ -7,13 +7,15 @@
 // torch.unique and a host sync per round, then round(p*(R-1)), unique again, scatter into a dense grid.
 // The result only depends on the SET {original vertices} U {all midpoints}, and marking a voxel is
 // idempotent, so the whole op becomes one streaming pass with no sort, no de-duplication and no host sync:
-//   vox_vertices_kernel : one thread per vertex marks its voxel;
+//   vox_extent_partial_kernel : per-mesh minimum / maximum in 32 partials (origin / scale of the normalisation when the
+//                         caller gives none);
+//   vox_vertices_kernel : one thread per vertex normalises it ((v - origin) / scale), keeps it, marks its voxel;
 //   vox_faces_kernel    : the subdivision tree of a face is deterministic, so a thread is given
 //                         (face, a base-4 path of L0 levels): it re-derives its sub-triangle by descending
 //                         the path (the thread whose remaining path digits are all 0 marks the ancestors'
-//                         midpoints, exactly once), then finishes the subtree depth-first with a small
-//                         per-level stack.  L0 is picked on the host from B*F alone so that ~2M threads exist
-//                         whatever the mesh (12 huge faces or 10^6 tiny ones).
+//                         midpoints, exactly once), then finishes the subtree depth-first, stackless, in registers.
+//                         L0 is picked on the host from B*F alone so that >= 256k threads exist whatever the mesh (12
+//                         huge faces or 10^6 tiny ones); more threads only repeat the shared path prefix.
 // Arithmetic as the reference's torch ops, in the tensor's dtype: midpoint (a+b)/2, squared edge
 // (dx*dx + dy*dy) + dz*dz (torch.sum's order for 3 elements), threshold rounded to the dtype,
 // round-half-even of p*(R-1).  -ffp-contract=off.
@@ -74,13 +76,106 @@ __device__ __forceinline__ void vox_child(const T* t, const T* m, int c, T* out)
   }
 }
 
+// origin (B,3) / scale (B) of the reference's normalisation (trianglemesh.py:84-96) when the caller gives none:
+// origin = per-mesh minimum, scale = largest extent above the origin.  torch.min / torch.max propagate NaN: so do these.
 template <typename T>
-__global__ __launch_bounds__(256) void vox_vertices_kernel(long long total, int V, int R, const T* __restrict__ vertices,
-                                                           T* __restrict__ grid) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const int b = (int)(i / V);
-  vox_mark<T>(grid + (size_t)b * R * R * R, R, vertices[i * 3], vertices[i * 3 + 1], vertices[i * 3 + 2]);
+__device__ __forceinline__ T vox_nan_min(T a, T b) { return (a != a || a < b) ? a : b; }
+template <typename T>
+__device__ __forceinline__ T vox_nan_max(T a, T b) { return (a != a || a > b) ? a : b; }
+constexpr int VOX_NP = 32;  // partial extents per mesh
+// scratch layout (scalars): [B*4] origin xyz + scale | [B*VOX_NP*6] partial min xyz, max xyz | [B*V*3] normalised vertices
+template <typename T>
+__global__ __launch_bounds__(256) void vox_extent_partial_kernel(int V, const T* __restrict__ vertices, T* __restrict__ part) {
+  __shared__ T s_lo[3][4], s_hi[3][4];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const T* vb = vertices + (size_t)b * V * 3;
+  T lo[3], hi[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) lo[a] = hi[a] = vb[a];  // vertex 0 is neutral for min and max alike
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < V; i += VOX_NP * 256)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const T v = vb[(size_t)i * 3 + a];
+      lo[a] = vox_nan_min<T>(lo[a], v);
+      hi[a] = vox_nan_max<T>(hi[a], v);
+    }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      lo[a] = vox_nan_min<T>(lo[a], __shfl_xor(lo[a], d, 64));
+      hi[a] = vox_nan_max<T>(hi[a], __shfl_xor(hi[a], d, 64));
+    }
+    if (lane == 0) {
+      s_lo[a][wave] = lo[a];
+      s_hi[a][wave] = hi[a];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x;
+    T l = s_lo[a][0], h = s_hi[a][0];
+    for (int w = 1; w < 4; ++w) {
+      l = vox_nan_min<T>(l, s_lo[a][w]);
+      h = vox_nan_max<T>(h, s_hi[a][w]);
+    }
+    T* o = part + ((size_t)b * VOX_NP + blockIdx.x) * 6;
+    o[a] = l;
+    o[3 + a] = h;
+  }
+}
+// origin / scale of mesh b from the partials (re-derived by whoever needs them: 32 x 6 scalars from L2)
+template <typename T>
+__device__ __forceinline__ void vox_norm_of(const T* __restrict__ part, const T* __restrict__ origin_in,
+                                            const T* __restrict__ scale_in, int b, T* o, T* sc) {
+  T s = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const T* p = part + (size_t)b * VOX_NP * 6;
+    T l = p[a], h = p[3 + a];
+    for (int k = 1; k < VOX_NP; ++k) {
+      l = vox_nan_min<T>(l, p[k * 6 + a]);
+      h = vox_nan_max<T>(h, p[k * 6 + 3 + a]);
+    }
+    o[a] = origin_in ? origin_in[b * 3 + a] : l;
+    const T ext = h - o[a];
+    s = a == 0 ? ext : vox_nan_max<T>(s, ext);
+  }
+  *sc = scale_in ? scale_in[b] : s;
+}
+
+// one thread per vertex: normalises it ((v - origin) / scale, two roundings as the reference's torch ops), keeps the
+// result for the face kernel and marks its voxel
+template <typename T>
+__global__ __launch_bounds__(256) void vox_vertices_kernel(int V, int R, const T* __restrict__ vertices,
+                                                           const T* __restrict__ origin_in, const T* __restrict__ scale_in,
+                                                           const T* __restrict__ part, T* __restrict__ norm,
+                                                           T* __restrict__ nverts, T* __restrict__ grid) {
+  __shared__ T s_n[4];
+  const int b = blockIdx.y;
+  if (threadIdx.x == 0) {
+    T o[3], sc;
+    vox_norm_of<T>(part, origin_in, scale_in, b, o, &sc);
+    s_n[0] = o[0];
+    s_n[1] = o[1];
+    s_n[2] = o[2];
+    s_n[3] = sc;
+    if (blockIdx.x == 0) {
+      norm[b * 4 + 0] = o[0];
+      norm[b * 4 + 1] = o[1];
+      norm[b * 4 + 2] = o[2];
+      norm[b * 4 + 3] = sc;
+    }
+  }
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= V) return;
+  const size_t g = ((size_t)b * V + i) * 3;
+  const T x = (vertices[g] - s_n[0]) / s_n[3], y = (vertices[g + 1] - s_n[1]) / s_n[3], z = (vertices[g + 2] - s_n[2]) / s_n[3];
+  nverts[g] = x;
+  nverts[g + 1] = y;
+  nverts[g + 2] = z;
+  vox_mark<T>(grid + (size_t)b * R * R * R, R, x, y, z);
 }
 
 template <typename T>
@@ -152,26 +247,29 @@ __global__ __launch_bounds__(256) void vox_faces_kernel(long long total, int V, 
 }
 
 template <typename T>
-int vox_launch(hipStream_t st, int B, int V, int F, int R, const T* vertices, const int64_t* faces, T* grid) {
+int vox_launch(hipStream_t st, int B, int V, int F, int R, const T* vertices, const int64_t* faces, const T* origin,
+               const T* scale, T* scratch, T* grid) {
   if (B <= 0 || R <= 1) return 0;
   KAMD_CHECK(kamd_zero_async(grid, (size_t)B * R * R * R * sizeof(T), st));
+  T* norm = scratch;
+  T* part = scratch + (size_t)B * 4;
+  T* nverts = part + (size_t)B * VOX_NP * 6;
   if (V > 0) {
-    const long long tv = (long long)B * V;
-    {
-      kamd::ProfScope prof_(kamd::K_VOX_VERTICES, st);
-      hipLaunchKernelGGL(vox_vertices_kernel<T>, dim3(kamd_cdiv(tv, 256)), dim3(256), 0, st, tv, V, R, vertices, grid);
-    }
+    kamd::ProfScope prof_(kamd::K_VOX_VERTICES, st);
+    hipLaunchKernelGGL(vox_extent_partial_kernel<T>, dim3(VOX_NP, B), dim3(256), 0, st, V, vertices, part);
+    hipLaunchKernelGGL(vox_vertices_kernel<T>, dim3(kamd_cdiv(V, 256), B), dim3(256), 0, st, V, R, vertices, origin, scale,
+                       (const T*)part, norm, nverts, grid);
     KAMD_CHECK(hipGetLastError());
   }
   if (F > 0 && V > 0) {
     int L0 = 0;
-    while (L0 < VOX_MAXL0 && (long long)B * F * (1ll << (2 * L0)) < (1ll << 21)) ++L0;
+    while (L0 < VOX_MAXL0 && (long long)B * F * (1ll << (2 * L0)) < (1ll << 18)) ++L0;
     const long long total = (long long)B * F * (1ll << (2 * L0));
     const double thr = ((double)(R - 1) / ((double)R * (double)R)) * ((double)(R - 1) / ((double)R * (double)R));
     {
       kamd::ProfScope prof_(kamd::K_VOX_FACES, st);
       hipLaunchKernelGGL(vox_faces_kernel<T>, dim3(kamd_cdiv(total, 256)), dim3(256), 0, st, total, V, F, R, L0, thr,
-                       vertices, faces, grid);
+                         (const T*)nverts, faces, grid);
     }
     KAMD_CHECK(hipGetLastError());
   }
@@ -181,12 +279,18 @@ int vox_launch(hipStream_t st, int B, int V, int F, int R, const T* vertices, co
 }  // namespace
 
 extern "C" {
+size_t kamd_trianglemeshes_to_voxelgrids_workspace(int B, int V, int elem_size) {
+  if (B <= 0) return 0;
+  return ((size_t)B * 4 + (size_t)B * VOX_NP * 6 + (size_t)B * (V > 0 ? V : 0) * 3) * (size_t)elem_size;
+}
 int kamd_trianglemeshes_to_voxelgrids_f32(void* stream, int B, int V, int F, int R, const float* vertices,
-                                          const int64_t* faces, float* grid) {
-  return vox_launch<float>((hipStream_t)stream, B, V, F, R, vertices, faces, grid);
+                                          const int64_t* faces, const float* origin, const float* scale, float* norm,
+                                          float* grid) {
+  return vox_launch<float>((hipStream_t)stream, B, V, F, R, vertices, faces, origin, scale, norm, grid);
 }
 int kamd_trianglemeshes_to_voxelgrids_f64(void* stream, int B, int V, int F, int R, const double* vertices,
-                                          const int64_t* faces, double* grid) {
-  return vox_launch<double>((hipStream_t)stream, B, V, F, R, vertices, faces, grid);
+                                          const int64_t* faces, const double* origin, const double* scale, double* norm,
+                                          double* grid) {
+  return vox_launch<double>((hipStream_t)stream, B, V, F, R, vertices, faces, origin, scale, norm, grid);
 }
 }  // extern "C"

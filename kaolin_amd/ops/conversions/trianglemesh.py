@@ -52,16 +52,16 @@ def trianglemeshes_to_voxelgrids(vertices, faces, resolution, origin=None, scale
     if not isinstance(resolution, int):
         raise TypeError(f"Expected resolution to be int "
                         f"but got {type(resolution)}.")
-    if origin is None:
-        origin = torch.min(vertices, dim=1)[0]
-    if scale is None:
-        scale = torch.max(torch.max(vertices, dim=1)[0] - origin, dim=1)[0]
-    normalized = (vertices - origin.unsqueeze(1)) / scale.view(-1, 1, 1)
-    if vertices.is_cuda and vertices.dtype in (torch.float32, torch.float64):
-        assert resolution > 1
-        dense = _C.ops.trianglemeshes_to_voxelgrids_cuda(normalized, faces, resolution)
+    assert resolution > 1
+    if vertices.is_cuda and vertices.dtype in (torch.float32, torch.float64) and vertices.shape[1] > 0:
+        # the normalisation (and its default origin / scale) is part of the device pass: no torch glue kernels
+        dense = _C.ops.trianglemeshes_to_voxelgrids_cuda(vertices, faces, resolution, origin, scale)
     else:
-        assert resolution > 1
+        if origin is None:
+            origin = torch.min(vertices, dim=1)[0]
+        if scale is None:
+            scale = torch.max(torch.max(vertices, dim=1)[0] - origin, dim=1)[0]
+        normalized = (vertices - origin.unsqueeze(1)) / scale.view(-1, 1, 1)
         dense = _torch_dense(normalized, faces, resolution)
     return dense.to_sparse() if return_sparse else dense
 
