@@ -21,7 +21,12 @@
 //     |p - c| - r exceeds sqrt(best) by more than a conservative margin (such a face cannot win, not even a
 //     tie), and a wavefront skips it when all 64 lanes do: 11 VALU instead of the full evaluation;
 //   * face records are staged through LDS in tiles and read with broadcast ds_read_b128;
-//   * when N alone cannot fill 256 CUs the face range is split over blockIdx.y and merged in index order.
+//   * when N alone cannot fill 256 CUs the face range is split over blockIdx.y and merged in index order;
+//   * from 65536 queries on, triangle_sweep.inc: faces and queries Morton-sorted, a bounding sphere per tile of 64 faces,
+//     and only the tiles that come closer than a query's best bound are staged and walked (identical results).
+#include <string.h>
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
 #include "common.h"
 #include <stdlib.h>
 #include "profile.h"
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(256) void td_prep_kernel(int F, const T* __restrict
   const T rad = td_sqrt(r2) * (T)1.0001;
   st3(r + 36, c);
   r[39] = rad + (T)1e-5 * (max3abs(c) + rad);
-  if (centres != nullptr) {  // float copies for the uniform grid (radius rounded up)
+  if (centres != nullptr) {  // float copies for the Morton sort / tile spheres (radius rounded up)
     centres[(size_t)f * 3 + 0] = (float)c.x;
     centres[(size_t)f * 3 + 1] = (float)c.y;
     centres[(size_t)f * 3 + 2] = (float)c.z;
@@ -293,259 +298,16 @@ __global__ __launch_bounds__(256) void td_backward_kernel(
   }
 }
 
-// ---- exact uniform-grid search (large meshes x many points) -------------------------------------------------
-// Same idea as sided_distance_grid.hip, for triangles.  Faces are binned by the centre of their bounding sphere
-// (td_prep_kernel); a face whose sphere is larger than a grid cell goes to a short "large" list that every query
-// evaluates (with the per-face sphere cull).  A query is seeded with face 0 exactly as the reference does, takes the
-// large list, then visits the cube of cells around it ring by ring: a small face not yet visited has its centre
-// outside the cube, so it is at least (distance to the cube faces) - (largest small radius) away; the search stops
-// when the best distance is safely below that.  Every evaluation is td_eval() on the same face record as the
-// all-pairs kernel and ties go to the lower face index explicitly => identical dist / face_idx / dist_type.
-constexpr int TDG_GROUP = 8;
-
-struct TdgGeom {
-  int G, NC;
-};
-inline TdgGeom tdg_geom(int F) {
-  int G = (int)floor(cbrt((double)F / 2.0) + 0.5);
-  if (G < 1) G = 1;
-  if (G > kamd::SDG_MAXG) G = kamd::SDG_MAXG;
-  return TdgGeom{G, G * G * G};
-}
 inline size_t td_align(size_t x) { return (x + 255) & ~(size_t)255; }
-struct TdgWs {
-  int *t_count, *q_count, *t_fill, *q_fill, *large_count, *rmax_bits;  // zeroed prefix
-  float *bbox_part, *centres, *radius;
-  int *t_cell, *q_cell, *t_sorted, *q_sorted, *large_list, *scan_sums;
-  size_t zero_bytes, total;
-};
-inline TdgWs tdg_layout(char* base, int N, int F) {
-  const TdgGeom g = tdg_geom(F);
-  TdgWs w;
-  size_t off = 0;
-  auto take = [&](size_t bytes) {
-    char* r = base + off;
-    off += (bytes + 255) & ~(size_t)255;
-    return r;
-  };
-  w.t_count = (int*)take((size_t)(g.NC + 1) * 4);
-  w.q_count = (int*)take((size_t)(g.NC + 1) * 4);
-  w.t_fill = (int*)take((size_t)g.NC * 4);
-  w.q_fill = (int*)take((size_t)g.NC * 4);
-  w.large_count = (int*)take(4);
-  w.rmax_bits = (int*)take(4);
-  w.zero_bytes = off;
-  w.bbox_part = (float*)take((size_t)kamd::SDG_NB * 6 * 4);
-  w.centres = (float*)take((size_t)F * 12);
-  w.radius = (float*)take((size_t)F * 4);
-  w.t_cell = (int*)take((size_t)F * 4);
-  w.q_cell = (int*)take((size_t)N * 4);
-  w.t_sorted = (int*)take((size_t)F * 4);
-  w.q_sorted = (int*)take((size_t)N * 4);
-  w.large_list = (int*)take((size_t)F * 4);
-  w.scan_sums = (int*)take((size_t)2 * ((g.NC + 1023) / 1024) * 4);
-  w.total = off;
-  return w;
-}
 
-template <typename T>
-__global__ __launch_bounds__(256) void tdg_cells(int F, int N, int nb, int G, const float* __restrict__ centres,
-                                                 const float* __restrict__ radius, const T* __restrict__ points,
-                                                 const float* __restrict__ part, int* __restrict__ t_cell,
-                                                 int* __restrict__ q_cell, int* __restrict__ t_count, int* __restrict__ q_count,
-                                                 int* __restrict__ large_list, int* __restrict__ large_count,
-                                                 int* __restrict__ rmax_bits) {
-  __shared__ kamd::Box s_box;
-  if (threadIdx.x == 0) s_box = kamd::sdg_box(part, 0, nb, G);
-  __syncthreads();
-  const int fb = (F + 255) / 256;
-  if ((int)blockIdx.x < fb) {
-    const int f = blockIdx.x * 256 + threadIdx.x;
-    if (f >= F) return;
-    const float r = radius[f];
-    const float tau = fminf(s_box.size[0], fminf(s_box.size[1], s_box.size[2]));
-    const float cx_ = centres[(size_t)f * 3], cy_ = centres[(size_t)f * 3 + 1], cz_ = centres[(size_t)f * 3 + 2];
-    if (!(r <= tau) || !isfinite(cx_) || !isfinite(cy_) || !isfinite(cz_)) {  // large (or non-finite): evaluated by every query
-      large_list[atomicAdd(large_count, 1)] = f;
-      t_cell[f] = -1;
-      return;
-    }
-    const int cx = kamd::sdg_axis_cell(cx_, s_box.lo[0], s_box.inv[0], G);
-    const int cy = kamd::sdg_axis_cell(cy_, s_box.lo[1], s_box.inv[1], G);
-    const int cz = kamd::sdg_axis_cell(cz_, s_box.lo[2], s_box.inv[2], G);
-    const int c = (cz * G + cy) * G + cx;
-    t_cell[f] = c;
-    atomicAdd(t_count + c, 1);
-    atomicMax(rmax_bits, __float_as_int(r));  // r >= 0: integer order = float order
-  } else {
-    const int i = (blockIdx.x - fb) * 256 + threadIdx.x;
-    if (i >= N) return;
-    const int cx = kamd::sdg_axis_cell((float)points[(size_t)i * 3], s_box.lo[0], s_box.inv[0], G);
-    const int cy = kamd::sdg_axis_cell((float)points[(size_t)i * 3 + 1], s_box.lo[1], s_box.inv[1], G);
-    const int cz = kamd::sdg_axis_cell((float)points[(size_t)i * 3 + 2], s_box.lo[2], s_box.inv[2], G);
-    const int c = (cz * G + cy) * G + cx;
-    q_cell[i] = c;
-    atomicAdd(q_count + c, 1);
-  }
-}
+#include "triangle_sweep.inc"
 
-__global__ __launch_bounds__(256) void tdg_scatter(int F, int N, const int* __restrict__ t_cell, const int* __restrict__ q_cell,
-                                                   const int* __restrict__ t_start, const int* __restrict__ q_start,
-                                                   int* __restrict__ t_fill, int* __restrict__ q_fill,
-                                                   int* __restrict__ t_sorted, int* __restrict__ q_sorted) {
-  const int fb = (F + 255) / 256;
-  if ((int)blockIdx.x < fb) {
-    const int f = blockIdx.x * 256 + threadIdx.x;
-    if (f >= F) return;
-    const int c = t_cell[f];
-    if (c < 0) return;
-    t_sorted[t_start[c] + atomicAdd(t_fill + c, 1)] = f;
-  } else {
-    const int i = (blockIdx.x - fb) * 256 + threadIdx.x;
-    if (i >= N) return;
-    const int c = q_cell[i];
-    q_sorted[q_start[c] + atomicAdd(q_fill + c, 1)] = i;
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void tdg_query(int N, int F, int nb, int G, const T* __restrict__ points,
-                                                 const T* __restrict__ rec, const float* __restrict__ part,
-                                                 const int* __restrict__ q_sorted, const int* __restrict__ q_cell,
-                                                 const int* __restrict__ t_start, const int* __restrict__ t_sorted,
-                                                 const int* __restrict__ large_list, const int* __restrict__ large_count,
-                                                 const int* __restrict__ rmax_bits, T* __restrict__ out_dist,
-                                                 int64_t* __restrict__ out_idx, int32_t* __restrict__ out_type) {
-  __shared__ kamd::Box s_box;
-  if (threadIdx.x == 0) s_box = kamd::sdg_box(part, 0, nb, G);
-  __syncthreads();
-  const int sub = threadIdx.x % TDG_GROUP;
-  const int slot = (blockIdx.x * 256 + threadIdx.x) / TDG_GROUP;
-  const bool live = slot < N;
-  const int qi = live ? q_sorted[slot] : 0;
-  const V3<T> p = ld3(points + (size_t)qi * 3);
-  const T pmag = (T)1e-5 * max3abs(p);
-  // seed: face 0 unconditionally (unbatched_triangle_distance_cuda.cu:303,309)
-  int best_type;
-  T best = td_eval<T>(rec, p, &best_type);
-  int best_face = 0;
-  T bound = td_sqrt(best) * (T)1.001 + pmag;  // NaN seed: every comparison below is false, the seed sticks
-
-  auto consider = [&](int f) {
-    const T* r = rec + (size_t)f * TD_REC;
-    const V3<T> pc = p - ld3(r + 36);
-    const T d2c = dot(pc, pc);
-    const T reach = bound + r[39];
-    if (d2c > reach * reach) return;  // the face's sphere is farther than the best distance (+ margin): cannot win
-    int type;
-    const float dist = td_eval<T>(r, p, &type);
-    if (dist < best || (dist == best && f < best_face)) {
-      best = dist;
-      best_type = type;
-      best_face = f;
-      bound = td_sqrt(best) * (T)1.001 + pmag;
-    }
-  };
-  auto merge_group = [&]() {
-#pragma unroll
-    for (int m = 1; m < TDG_GROUP; m <<= 1) {
-      const T od = __shfl_xor(best, m, 64);
-      const int of = __shfl_xor(best_face, m, 64);
-      const int ot = __shfl_xor(best_type, m, 64);
-      if (od < best || (od == best && of < best_face)) {
-        best = od;
-        best_face = of;
-        best_type = ot;
-      }
-    }
-    bound = td_sqrt(best) * (T)1.001 + pmag;
-  };
-
-  const int nlarge = *large_count;
-  for (int j = sub; j < nlarge; j += TDG_GROUP) consider(large_list[j]);
-  merge_group();
-
-  if (best == best) {
-    const float rmax = __int_as_float(*rmax_bits);
-    const int c = q_cell[qi];
-    const int cx = c % G, cy = (c / G) % G, cz = c / (G * G);
-    const float q[3] = {(float)p.x, (float)p.y, (float)p.z};
-    float slack[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) slack[a] = 4e-6f * (fabsf(q[a]) + fabsf(s_box.lo[a]) + s_box.size[a] * (float)G);
-    const int cq[3] = {cx, cy, cz};
-    for (int r = 0; r < G; ++r) {
-      const int z0 = max(cz - r, 0), z1 = min(cz + r, G - 1);
-      const int y0 = max(cy - r, 0), y1 = min(cy + r, G - 1);
-      const int x0 = max(cx - r, 0), x1 = min(cx + r, G - 1);
-      const int ny = y1 - y0 + 1, nrows = (z1 - z0 + 1) * ny;
-      for (int j = sub; j < nrows; j += TDG_GROUP) {
-        const int z = z0 + j / ny, y = y0 + j % ny;
-        const int row = (z * G + y) * G;
-        const bool shell_row = (abs(z - cz) == r) || (abs(y - cy) == r);
-        int k0[2], k1[2], nseg;
-        if (shell_row) {
-          k0[0] = t_start[row + x0];
-          k1[0] = t_start[row + x1 + 1];
-          nseg = 1;
-        } else {
-          nseg = 0;
-          if (cx - r >= 0) {
-            k0[nseg] = t_start[row + cx - r];
-            k1[nseg] = t_start[row + cx - r + 1];
-            ++nseg;
-          }
-          if (cx + r <= G - 1) {
-            k0[nseg] = t_start[row + cx + r];
-            k1[nseg] = t_start[row + cx + r + 1];
-            ++nseg;
-          }
-        }
-        for (int sgm = 0; sgm < nseg; ++sgm)
-          for (int k = k0[sgm]; k < k1[sgm]; ++k) consider(t_sorted[k]);
-      }
-      merge_group();
-      // a small face not visited yet has its sphere centre outside the cube [c - r, c + r]: its distance to the query
-      // is at least (distance to the cube's faces) - (largest small radius)
-      float face_d = INFINITY;
-      bool whole_grid = true;
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        if (cq[a] - r > 0) {
-          whole_grid = false;
-          face_d = fminf(face_d, q[a] - (s_box.lo[a] + (float)(cq[a] - r) * s_box.size[a]) - slack[a]);
-        }
-        if (cq[a] + r < G - 1) {
-          whole_grid = false;
-          face_d = fminf(face_d, (s_box.lo[a] + (float)(cq[a] + r + 1) * s_box.size[a]) - q[a] - slack[a]);
-        }
-      }
-      if (whole_grid) break;
-      const float lower = face_d - rmax;
-      // `bound` = sqrt(best) * 1.001 + 1e-5 |p|: the same head-room the per-face sphere cull uses
-      const float mag = 1e-5f * (fabsf(s_box.lo[0]) + fabsf(s_box.lo[1]) + fabsf(s_box.lo[2]) +
-                                 (s_box.size[0] + s_box.size[1] + s_box.size[2]) * (float)G);
-      if (lower > 0.f && (float)bound * 1.0001f + mag < lower) break;
-    }
-  }
-  if (live && sub == 0) {
-    out_dist[qi] = best;
-    out_idx[qi] = best_face;
-    out_type[qi] = best_type;
-  }
-}
-
-inline bool td_grid_applicable(int N, int F) {
+inline bool td_sweep_applicable(int N, int F) {
   const char* e = getenv("KAMD_TRIANGLE_DISTANCE");
-  if (e != nullptr && e[0] == 'b') return false;  // =brute keeps the all-pairs kernels (A/B timing, tests of both paths)
-  // The ring search pays off when most queries lie within a few cells of the surface.  Queries deep inside / far
-  // outside a closed mesh are nearly equidistant from a large part of it and make ANY exact search touch most faces;
-  // for those the LDS-tiled all-pairs kernel is the better tool, and a single such query bounds the grid kernel's run
-  // time from below (~20 ms measured for the centre of a 50k-face sphere).  Until a hierarchical fallback exists the
-  // grid is therefore used only for very large query sets (measured: 1M x 50k 42 ms vs 56 ms; 100k x 50k 25 vs 9.5 ms).
-  const char* f = getenv("KAMD_TRIANGLE_DISTANCE");
-  if (f != nullptr && f[0] == 'g') return F >= 2048 && N >= 4096;  // =grid forces it (tests)
-  return F >= 2048 && N >= 400000;
+  if (e != nullptr) return e[0] == 's' && F >= 1;  // =sweep forces it, =brute keeps the all-pairs kernels (A/B timing, tests)
+  // measured at F = 50k: 100k queries 4.6 ms vs 9.5 ms all-pairs, 1M queries 12 ms vs 56 ms; below ~64k queries the
+  // all-pairs kernel with its face-range split fills the machine better than <= 256 sweep workgroups
+  return F >= 2048 && N >= 65536;
 }
 
 struct TdPlan {
@@ -568,34 +330,7 @@ int td_forward_launch(hipStream_t st, int N, int F, const T* points, const T* fa
                       int32_t* dist_type, void* workspace) {
   if (N <= 0 || F <= 0) return 0;  // the caller's zero-initialised outputs stay (reference: the loops never run)
   if (workspace == nullptr) return (int)hipErrorInvalidValue;
-  if (td_grid_applicable(N, F)) {
-    const TdgGeom g = tdg_geom(F);
-    T* rec = (T*)workspace;
-    const TdgWs w = tdg_layout((char*)workspace + td_align((size_t)F * TD_REC * sizeof(T)), N, F);
-    const int nb = kamd_cdiv(F, 4096) < kamd::SDG_NB ? kamd_cdiv(F, 4096) : kamd::SDG_NB;
-    KAMD_CHECK(hipMemsetAsync(w.t_count, 0, w.zero_bytes, st));
-    {
-      kamd::ProfScope prof_(kamd::K_TD_PREP, st);
-      hipLaunchKernelGGL(td_prep_kernel<T>, dim3(kamd_cdiv(F, 256)), dim3(256), 0, st, F, faces, rec, w.centres, w.radius);
-      hipLaunchKernelGGL(kamd::sdg_bbox, dim3(nb, 1), dim3(256), 0, st, F, w.centres, w.bbox_part);
-      hipLaunchKernelGGL(tdg_cells<T>, dim3(kamd_cdiv(F, 256) + kamd_cdiv(N, 256)), dim3(256), 0, st, F, N, nb, g.G, w.centres,
-                         w.radius, points, w.bbox_part, w.t_cell, w.q_cell, w.t_count, w.q_count, w.large_list,
-                         w.large_count, w.rmax_bits);
-      const int nblk = kamd_cdiv(g.NC, 1024);
-      hipLaunchKernelGGL(kamd::sdg_scan_sums, dim3(nblk, 1, 2), dim3(1024), 0, st, g.NC, nblk, w.t_count, w.q_count, w.scan_sums);
-      hipLaunchKernelGGL(kamd::sdg_scan_apply, dim3(nblk, 1, 2), dim3(1024), 0, st, g.NC, nblk, w.t_count, w.q_count, w.scan_sums);
-      hipLaunchKernelGGL(tdg_scatter, dim3(kamd_cdiv(F, 256) + kamd_cdiv(N, 256)), dim3(256), 0, st, F, N, w.t_cell, w.q_cell,
-                         w.t_count, w.q_count, w.t_fill, w.q_fill, w.t_sorted, w.q_sorted);
-    }
-    KAMD_CHECK(hipGetLastError());
-    {
-      kamd::ProfScope prof_(kamd::K_TD_MAIN, st);
-      hipLaunchKernelGGL(tdg_query<T>, dim3(kamd_cdiv((long long)N * TDG_GROUP, 256)), dim3(256), 0, st, N, F, nb, g.G, points,
-                         rec, w.bbox_part, w.q_sorted, w.q_cell, w.t_count, w.t_sorted, w.large_list, w.large_count,
-                         w.rmax_bits, dist, face_idx, dist_type);
-    }
-    KAMD_RETURN_LAST_ERROR();
-  }
+  if (td_sweep_applicable(N, F)) return ts_forward_launch<T>(st, N, F, points, faces, dist, face_idx, dist_type, workspace);
   const TdPlan p = td_plan(N, F);
   T* rec = (T*)workspace;
   char* w = (char*)workspace + td_align((size_t)F * TD_REC * sizeof(T));
@@ -645,8 +380,8 @@ size_t kamd_triangle_distance_forward_workspace(int N, int F, int elem_size) {
   const TdPlan p = td_plan(N, F);
   const size_t brute = td_align((size_t)F * TD_REC * elem_size) + td_align((size_t)p.S * N * elem_size) +
                        2 * td_align((size_t)p.S * N * sizeof(int));
-  const size_t grid = td_align((size_t)F * TD_REC * elem_size) + tdg_layout(nullptr, N, F).total;
-  return brute > grid ? brute : grid;  // either path may be taken (KAMD_TRIANGLE_DISTANCE)
+  const size_t sweep = td_align((size_t)F * TD_REC * elem_size) + ts_layout(nullptr, N, F, elem_size).total;
+  return brute > sweep ? brute : sweep;  // either path may be taken (KAMD_TRIANGLE_DISTANCE)
 }
 int kamd_triangle_distance_forward_f32(void* stream, int N, int F, const float* points, const float* faces, float* dist,
                                        int64_t* face_idx, int32_t* dist_type, void* workspace) {

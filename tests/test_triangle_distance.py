@@ -182,10 +182,10 @@ def test_gpu_full_size_properties():
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [torch.float, torch.double])
 @pytest.mark.parametrize('kind', ['sphere', 'sphere_plus_large', 'soup', 'two_blobs'])
-def test_gpu_grid_search_vs_oracle_and_brute(dtype, kind):
-    """F >= 2048 and N >= 4096 take the exact uniform-grid search: dist / face_idx / dist_type must equal the oracle
-    and the all-pairs kernels (KAMD_TRIANGLE_DISTANCE=brute) bit for bit -- small faces, faces larger than a grid
-    cell (the "large" list), a random triangle soup (every face large), and a mesh far from part of the queries."""
+def test_gpu_sweep_vs_oracle_and_brute(dtype, kind):
+    """The Morton-tile sweep (forced here; by default it takes over from 65536 queries): dist / face_idx / dist_type must
+    equal the oracle and the all-pairs kernels (KAMD_TRIANGLE_DISTANCE=brute) bit for bit -- small faces, a few huge
+    faces among them, a random triangle soup (every tile sphere is huge), and a mesh far from part of the queries."""
     from kaolin_amd.utils.testing import geodesic_sphere
     torch.manual_seed(11)
     v, f = geodesic_sphere(16)                      # 5120 faces
@@ -203,7 +203,7 @@ def test_gpu_grid_search_vs_oracle_and_brute(dtype, kind):
         fv = torch.cat([fv * 0.2 + 3.0, fv * 0.1 - 2.0])
         pts = torch.cat([torch.rand(3000, 3, dtype=dtype) * 8 - 4, torch.randn(3000, 3, dtype=dtype) * 0.3 + 3.0])
     d_ref, i_ref, t_ref = oracle.triangle_distance_forward(pts, fv, omp=True)
-    os.environ['KAMD_TRIANGLE_DISTANCE'] = 'grid'     # (by default the grid is reserved for >= 400k queries)
+    os.environ['KAMD_TRIANGLE_DISTANCE'] = 'sweep'
     try:
         dist, idx, typ = _gpu_fwd(pts, fv)
     finally:
@@ -215,3 +215,29 @@ def test_gpu_grid_search_vs_oracle_and_brute(dtype, kind):
     finally:
         del os.environ['KAMD_TRIANGLE_DISTANCE']
     assert torch.equal(i2, idx) and torch.equal(t2, typ) and torch.equal(d2, dist)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float, torch.double])
+def test_gpu_sweep_ties_duplicates_and_non_finite(dtype):
+    """The Morton-tile sweep (the default from 65536 queries) on inputs where only the tie rule (lowest face index) and
+    the NaN conventions decide: every face duplicated in several orders (equal distances), queries on vertices / edge
+    midpoints, NaN and inf queries, a NaN face; compared with the all-pairs kernels and the oracle, default dispatch."""
+    from kaolin_amd.utils.testing import geodesic_sphere
+    torch.manual_seed(3)
+    v, f = geodesic_sphere(12)                      # 2880 faces
+    fv = v.to(dtype)[f]
+    fv = torch.cat([fv, fv.flip(0), fv[::3]])
+    fv[777] = float('nan')
+    pts = torch.cat([torch.rand(66000, 3, dtype=dtype) * 1.6 - 0.8, fv[:500, 0], (fv[500:900, 0] + fv[500:900, 1]) / 2,
+                     torch.tensor([[float('nan'), 0., 0.], [float('inf'), 0., 0.], [0., float('-inf'), 1.]], dtype=dtype)])
+    d_ref, i_ref, t_ref = oracle.triangle_distance_forward(pts, fv, omp=True)
+    os.environ['KAMD_TRIANGLE_DISTANCE'] = 'brute'
+    try:
+        d_b, i_b, t_b = _gpu_fwd(pts, fv)
+    finally:
+        del os.environ['KAMD_TRIANGLE_DISTANCE']
+    d_s, i_s, t_s = _gpu_fwd(pts, fv)               # >= 65536 queries and >= 2048 faces: the sweep
+    same = lambda a, b: torch.equal(torch.nan_to_num(a.double(), nan=-7.), torch.nan_to_num(b.double(), nan=-7.))  # noqa: E731
+    assert torch.equal(i_s, i_b) and torch.equal(t_s, t_b) and same(d_s, d_b)
+    assert torch.equal(i_s.cpu(), i_ref) and torch.equal(t_s.cpu(), t_ref) and same(d_s.cpu(), d_ref)
