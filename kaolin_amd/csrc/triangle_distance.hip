@@ -22,7 +22,7 @@
 //     tie), and a wavefront skips it when all 64 lanes do: 11 VALU instead of the full evaluation;
 //   * face records are staged through LDS in tiles and read with broadcast ds_read_b128;
 //   * when N alone cannot fill 256 CUs the face range is split over blockIdx.y and merged in index order;
-//   * from 65536 queries on, triangle_sweep.inc: faces and queries Morton-sorted, a bounding sphere per tile of 64 faces,
+//   * from 65536 queries on, triangle_sweep.inc: faces and queries sorted along a Hilbert curve, a bounding sphere per tile of 64 faces,
 //     and only the tiles that come closer than a query's best bound are staged and walked (identical results).
 #include <string.h>
 #include <hip/hip_runtime.h>
@@ -305,7 +305,7 @@ inline size_t td_align(size_t x) { return (x + 255) & ~(size_t)255; }
 inline bool td_sweep_applicable(int N, int F) {
   const char* e = getenv("KAMD_TRIANGLE_DISTANCE");
   if (e != nullptr) return e[0] == 's' && F >= 1;  // =sweep forces it, =brute keeps the all-pairs kernels (A/B timing, tests)
-  // measured at F = 50k: 100k queries 4.6 ms vs 9.5 ms all-pairs, 1M queries 12 ms vs 56 ms; below ~64k queries the
+  // measured at F = 50k: 100k queries 4.3 ms vs 9.5 ms all-pairs, 1M queries 10.5 ms vs 56 ms; below ~64k queries the
   // all-pairs kernel with its face-range split fills the machine better than <= 256 sweep workgroups
   return F >= 2048 && N >= 65536;
 }
