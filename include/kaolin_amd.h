@@ -207,6 +207,22 @@ int kamd_rasterize_forward_fused_f64(void* stream, int B, int H, int W, int F, i
                                      const uint8_t* valid, double multiplier, float eps,
                                      double* interp, int64_t* face_idx, double* weights,
                                      void* workspace);
+/* _strided: z (B,F,3) and the optional per-face scalar `front` (B,F) are read in place through ELEMENT strides    */
+/* (z[f * z_face_stride + k * z_vertex_stride], front[f * front_stride]; batch items must be F faces apart), e.g. */
+/* the [..., 2] views of the camera-space vertices / face normals; a face is kept when valid[f] != 0 (if given)   */
+/* and front[f] >= 0 (if given) -- the mask `face_normals_z >= 0` of dibr_rasterization (dibr.py:188).           */
+int kamd_rasterize_forward_fused_strided_f32(void* stream, int B, int H, int W, int F, int D, const float* z,
+                                             int64_t z_face_stride, int64_t z_vertex_stride,
+                                             const float* img, const float* feat, const uint8_t* valid,
+                                             const float* front, int64_t front_stride, double multiplier,
+                                             float eps, float* interp, int64_t* face_idx, float* weights,
+                                             void* workspace);
+int kamd_rasterize_forward_fused_strided_f64(void* stream, int B, int H, int W, int F, int D, const double* z,
+                                             int64_t z_face_stride, int64_t z_vertex_stride,
+                                             const double* img, const double* feat, const uint8_t* valid,
+                                             const double* front, int64_t front_stride, double multiplier,
+                                             float eps, double* interp, int64_t* face_idx, double* weights,
+                                             void* workspace);
 int kamd_dibr_soft_mask_forward_fused_f32(void* stream, int B, int H, int W, int F, int K,
                                           const float* img, double multiplier, double margin,
                                           const int64_t* sel_idx, float sigmainv,
@@ -230,17 +246,19 @@ int kamd_dibr_soft_mask_forward_fused_f64(void* stream, int B, int H, int W, int
 /* (zeroed by the caller) receives BOTH gradient contributions.               */
 /* ------------------------------------------------------------------------- */
 int kamd_dibr_rasterization_forward_f32(void* stream, int B, int H, int W, int F, int D, int K,
-                                        const float* z, const float* img, const float* feat,
-                                        const uint8_t* valid, double multiplier, float eps,
-                                        float sigmainv, double margin, float* interp,
+                                        const float* z, int64_t z_face_stride, int64_t z_vertex_stride,
+                                        const float* img, const float* feat, const uint8_t* valid,
+                                        const float* front, int64_t front_stride, double multiplier,
+                                        float eps, float sigmainv, double margin, float* interp,
                                         int64_t* face_idx, float* weights, float* soft_mask,
                                         int32_t* hit_pix, int32_t* hit_face, float* hit_prob,
                                         uint8_t* hit_type, int32_t* item_count, uint32_t* n_items,
                                         void* ws_raster, void* ws_soft);
 int kamd_dibr_rasterization_forward_f64(void* stream, int B, int H, int W, int F, int D, int K,
-                                        const double* z, const double* img, const double* feat,
-                                        const uint8_t* valid, double multiplier, float eps,
-                                        float sigmainv, double margin, double* interp,
+                                        const double* z, int64_t z_face_stride, int64_t z_vertex_stride,
+                                        const double* img, const double* feat, const uint8_t* valid,
+                                        const double* front, int64_t front_stride, double multiplier,
+                                        float eps, float sigmainv, double margin, double* interp,
                                         int64_t* face_idx, double* weights, double* soft_mask,
                                         int32_t* hit_pix, int32_t* hit_face, double* hit_prob,
                                         uint8_t* hit_type, int32_t* item_count, uint32_t* n_items,

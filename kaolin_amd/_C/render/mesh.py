@@ -309,31 +309,56 @@ def rasterize_forward_fused(height, width, face_vertices_z, face_vertices_image,
     return [interp, face_idx, wts]
 
 
+def _face_strides(t, inner):
+    """(tensor to pass, face stride, inner stride) in ELEMENTS when `t` (B, F[, 3]) can be read in place -- dense, or a
+    last-index view such as ``face_vertices_camera[..., 2]`` -- else of its contiguous copy."""
+    if inner:
+        ok = t.dim() == 3 and t.size(0) * t.size(1) > 0 and t.stride(0) == t.size(1) * t.stride(1) and t.stride(2) > 0
+        if not ok:
+            t = t.contiguous()
+        return t, t.stride(1), t.stride(2)
+    ok = t.dim() == 2 and t.numel() > 0 and t.stride(0) == t.size(1) * t.stride(1) and t.stride(1) > 0
+    if not ok:
+        t = t.contiguous()
+    return t, t.stride(1), 1
+
+
 def dibr_rasterization_forward_fused(height, width, face_vertices_z, face_vertices_image, face_features, valid_faces,
                                      sigmainv, boxlen, knum, multiplier, eps):
     """``rasterize_forward_fused`` + ``dibr_soft_mask_forward_fused`` in one library call (ours): the same kernels,
-    with the soft mask's binning enqueued on an internal side stream next to the rasterizer.
-    -> (interpolated_features, face_idx, output_weights, soft_mask, hits)"""
+    with the soft mask's binning enqueued on an internal side stream next to the rasterizer.  ``valid_faces`` is either
+    the bool mask of the faces to rasterize or a FLOAT (B, F) tensor ``n`` standing for the mask ``n >= 0`` (the face
+    normals' z of ``dibr_rasterization``): that one, and ``face_vertices_z``, may be last-index views and are read in
+    place.  -> (interpolated_features, face_idx, output_weights, soft_mask, hits)"""
     fn = 'dibr_rasterization_forward_fused'
+    front = None
+    if valid_faces is not None and valid_faces.is_floating_point():
+        front, valid_faces = valid_faces, None
     args = [Arg(face_vertices_z, 'face_vertices_z', 3), Arg(face_vertices_image, 'face_vertices_image', 4),
             Arg(face_features, 'face_features', 5)]
     if valid_faces is not None:
         args.append(Arg(valid_faces, 'valid_faces', 6))
+    if front is not None:
+        args.append(Arg(front, 'face_normals_z', 6))
     check_all_same_gpu(fn, args)
-    check_all_contiguous(fn, args)
+    check_all_contiguous(fn, args[1:3] + ([args[3]] if valid_faces is not None else []))
     batch_size, num_faces, feat_dim = face_vertices_z.size(0), face_vertices_z.size(1), face_features.size(3)
     check_size(fn, args[0], [batch_size, num_faces, 3])
     check_size(fn, args[1], [batch_size, num_faces, 3, 2])
     check_size(fn, args[2], [batch_size, num_faces, 3, feat_dim])
-    if valid_faces is not None:
+    if len(args) > 3:
         check_size(fn, args[3], [batch_size, num_faces])
     dtype, device = face_vertices_z.dtype, face_vertices_z.device
     sfx = _lib.dtype_suffix(dtype, fn)
-    for a in args[1:3]:
+    for a in args[1:3] + ([args[3]] if front is not None else []):
         if a.t.dtype != dtype:
             raise RuntimeError(f'expected scalar type {_lib._PRETTY[dtype]} but found {_lib._PRETTY.get(a.t.dtype, a.t.dtype)}')
     lib = _lib.load()
     esz = face_vertices_z.element_size()
+    z, z_face, z_vertex = _face_strides(face_vertices_z, True)
+    front_stride = 1
+    if front is not None:
+        front, front_stride, _ = _face_strides(front, False)
     with torch.cuda.device(device):
         face_idx = torch.empty((batch_size, height, width), dtype=torch.long, device=device)
         wts = torch.empty((batch_size, height, width, 3), dtype=dtype, device=device)
@@ -344,7 +369,8 @@ def dibr_rasterization_forward_fused(height, width, face_vertices_z, face_vertic
         ws_s = _lib.workspace(lib.kamd_dibr_soft_mask_forward_workspace(batch_size, height, width, num_faces, esz), device)
         st = getattr(lib, f'kamd_dibr_rasterization_forward_{sfx}')(
             _lib.stream_ptr(device), batch_size, height, width, num_faces, feat_dim, int(knum),
-            _lib.ptr(face_vertices_z), _lib.ptr(face_vertices_image), _lib.ptr(face_features), _lib.ptr(valid_faces),
+            _lib.ptr(z), int(z_face), int(z_vertex), _lib.ptr(face_vertices_image), _lib.ptr(face_features),
+            _lib.ptr(valid_faces), _lib.ptr(front), int(front_stride),
             float(multiplier), float(eps), float(sigmainv), float(boxlen * multiplier),
             _lib.ptr(interp), _lib.ptr(face_idx), _lib.ptr(wts), _lib.ptr(soft_mask),
             _lib.ptr(hits[0]), _lib.ptr(hits[1]), _lib.ptr(hits[2]), _lib.ptr(hits[3]), _lib.ptr(hits[4]), _lib.ptr(hits[5]),

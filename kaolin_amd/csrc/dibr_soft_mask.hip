@@ -749,8 +749,8 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
       kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
       if (raw)
         hipLaunchKernelGGL(bin_faces_raw_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, F, img,
-                           (const T*)nullptr, (const uint8_t*)nullptr, (T)raw_multiplier, (T)raw_margin, g, multiplier, rec,
-                           masks, flags, sub_flags);
+                           (const T*)nullptr, FaceLayout{3, 1, 1}, (const uint8_t*)nullptr, (const T*)nullptr,
+                           (T)raw_multiplier, (T)raw_margin, g, multiplier, rec, masks, flags, sub_flags);
       else
         hipLaunchKernelGGL(bin_faces_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, F, total_faces,
                            (const int64_t*)nullptr, large_bbox, img, (const T*)nullptr, g, multiplier, rec, masks, flags,
@@ -923,8 +923,9 @@ int side_stream(SideStream** out) {
 }
 
 template <typename T>
-int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K, const T* z, const T* img, const T* feat,
-                       const uint8_t* valid, double multiplier, float eps, float sigmainv, double margin, T* interp,
+int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K, const T* z, int64_t z_face_stride,
+                       int64_t z_vertex_stride, const T* img, const T* feat, const uint8_t* valid, const T* front,
+                       int64_t front_stride, double multiplier, float eps, float sigmainv, double margin, T* interp,
                        int64_t* face_idx, T* weights, T* soft_mask, const HitList<T>& list, void* ws_raster, void* ws_soft) {
   std::lock_guard<std::mutex> lk(g_side_mu);
   SideStream* ss;
@@ -939,11 +940,15 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
   KAMD_CHECK(hipEventRecord(ss->join, side));
   int rc;
   if (sizeof(T) == 4)
-    rc = kamd_rasterize_forward_fused_f32(st, B, H, W, F, D, (const float*)z, (const float*)img, (const float*)feat, valid,
-                                          multiplier, eps, (float*)interp, face_idx, (float*)weights, ws_raster);
+    rc = kamd_rasterize_forward_fused_strided_f32(st, B, H, W, F, D, (const float*)z, z_face_stride, z_vertex_stride,
+                                                  (const float*)img, (const float*)feat, valid, (const float*)front,
+                                                  front_stride, multiplier, eps, (float*)interp, face_idx, (float*)weights,
+                                                  ws_raster);
   else
-    rc = kamd_rasterize_forward_fused_f64(st, B, H, W, F, D, (const double*)z, (const double*)img, (const double*)feat,
-                                          valid, multiplier, eps, (double*)interp, face_idx, (double*)weights, ws_raster);
+    rc = kamd_rasterize_forward_fused_strided_f64(st, B, H, W, F, D, (const double*)z, z_face_stride, z_vertex_stride,
+                                                  (const double*)img, (const double*)feat, valid, (const double*)front,
+                                                  front_stride, multiplier, eps, (double*)interp, face_idx,
+                                                  (double*)weights, ws_raster);
   KAMD_CHECK(rc);
   KAMD_CHECK(hipStreamWaitEvent(st, ss->join, 0));
   return soft_mask_forward_launch<T>(st, B, H, W, F, K, img, nullptr, face_idx, sigmainv, (float)multiplier, soft_mask,
@@ -979,13 +984,15 @@ int dibr_backward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K
 extern "C" {
 #define KAMD_DIBR_ENTRY(SFX, T)                                                                                       \
   int kamd_dibr_rasterization_forward_##SFX(                                                                          \
-      void* stream, int B, int H, int W, int F, int D, int K, const T* z, const T* img, const T* feat,                \
-      const uint8_t* valid, double multiplier, float eps, float sigmainv, double margin, T* interp, int64_t* face_idx, \
+      void* stream, int B, int H, int W, int F, int D, int K, const T* z, int64_t z_face_stride,                      \
+      int64_t z_vertex_stride, const T* img, const T* feat, const uint8_t* valid, const T* front,                     \
+      int64_t front_stride, double multiplier, float eps, float sigmainv, double margin, T* interp, int64_t* face_idx, \
       T* weights, T* soft_mask, int32_t* hit_pix, int32_t* hit_face, T* hit_prob, uint8_t* hit_type,                  \
       int32_t* item_count, uint32_t* n_items, void* ws_raster, void* ws_soft) {                                       \
     HitList<T> l{hit_pix, hit_face, hit_prob, hit_type, item_count, n_items};                                         \
-    return dibr_forward_fused<T>((hipStream_t)stream, B, H, W, F, D, K, z, img, feat, valid, multiplier, eps, sigmainv, \
-                                 margin, interp, face_idx, weights, soft_mask, l, ws_raster, ws_soft);                \
+    return dibr_forward_fused<T>((hipStream_t)stream, B, H, W, F, D, K, z, z_face_stride, z_vertex_stride, img, feat,  \
+                                 valid, front, front_stride, multiplier, eps, sigmainv, margin, interp, face_idx,     \
+                                 weights, soft_mask, l, ws_raster, ws_soft);                                          \
   }                                                                                                                   \
   int kamd_dibr_rasterization_backward_##SFX(                                                                         \
       void* stream, int B, int H, int W, int F, int D, int K, const T* grad_feat, const T* grad_soft,                 \

@@ -365,9 +365,9 @@ int rasterize_forward_launch(hipStream_t st, int B, int H, int W, int D, int64_t
 // fused front door: raw (B,F,...) inputs + optional valid mask; scaling, bounding boxes and packing happen in
 // bin_faces_raw_kernel; sel_idx comes out as the mesh-relative face index (what the Python layer returns)
 template <typename T>
-int rasterize_forward_fused_launch(hipStream_t st, int B, int H, int W, int F, int D, const T* z, const T* img,
-                                   const T* feat, const uint8_t* valid, double multiplier, float eps, T* interp,
-                                   int64_t* face_idx, T* weights, void* workspace) {
+int rasterize_forward_fused_launch(hipStream_t st, int B, int H, int W, int F, int D, const T* z, FaceLayout lay, const T* img,
+                                   const T* feat, const uint8_t* valid, const T* front, double multiplier, float eps,
+                                   T* interp, int64_t* face_idx, T* weights, void* workspace) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
   const TileGeom g = tile_geom(H, W);
   const long long total_faces = (long long)B * F;
@@ -378,8 +378,8 @@ int rasterize_forward_fused_launch(hipStream_t st, int B, int H, int W, int F, i
   if (total_faces > 0) {
     KAMD_CHECK(kamd_zero_async(masks, (mask_words(g.ntiles, B, total_faces) + flag_words(g.ntiles, B)) * 4, st));
     kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
-    hipLaunchKernelGGL(bin_faces_raw_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, F, img, z, valid,
-                       (T)multiplier, (T)0, g, (float)multiplier, rec, masks, flags, (uint8_t*)nullptr);
+    hipLaunchKernelGGL(bin_faces_raw_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, F, img, z, lay, valid,
+                       front, (T)multiplier, (T)0, g, (float)multiplier, rec, masks, flags, (uint8_t*)nullptr);
   }
   KAMD_CHECK(hipGetLastError());
   {
@@ -438,14 +438,33 @@ int kamd_packed_rasterize_forward_f64(void* stream, int B, int H, int W, int D, 
 int kamd_rasterize_forward_fused_f32(void* stream, int B, int H, int W, int F, int D, const float* z, const float* img,
                                      const float* feat, const uint8_t* valid, double multiplier, float eps,
                                      float* interp, int64_t* face_idx, float* weights, void* workspace) {
-  return rasterize_forward_fused_launch<float>((hipStream_t)stream, B, H, W, F, D, z, img, feat, valid, multiplier, eps,
-                                               interp, face_idx, weights, workspace);
+  return rasterize_forward_fused_launch<float>((hipStream_t)stream, B, H, W, F, D, z, FaceLayout{3, 1, 1}, img, feat, valid,
+                                               (const float*)nullptr, multiplier, eps, interp, face_idx, weights, workspace);
 }
 int kamd_rasterize_forward_fused_f64(void* stream, int B, int H, int W, int F, int D, const double* z, const double* img,
                                      const double* feat, const uint8_t* valid, double multiplier, float eps,
                                      double* interp, int64_t* face_idx, double* weights, void* workspace) {
-  return rasterize_forward_fused_launch<double>((hipStream_t)stream, B, H, W, F, D, z, img, feat, valid, multiplier, eps,
-                                                interp, face_idx, weights, workspace);
+  return rasterize_forward_fused_launch<double>((hipStream_t)stream, B, H, W, F, D, z, FaceLayout{3, 1, 1}, img, feat, valid,
+                                                (const double*)nullptr, multiplier, eps, interp, face_idx, weights, workspace);
+}
+// same, with z and the front-facing scalar read in place through element strides (used by kamd_dibr_rasterization_forward_*)
+int kamd_rasterize_forward_fused_strided_f32(void* stream, int B, int H, int W, int F, int D, const float* z,
+                                             int64_t z_face_stride, int64_t z_vertex_stride, const float* img,
+                                             const float* feat, const uint8_t* valid, const float* front,
+                                             int64_t front_stride, double multiplier, float eps, float* interp,
+                                             int64_t* face_idx, float* weights, void* workspace) {
+  return rasterize_forward_fused_launch<float>((hipStream_t)stream, B, H, W, F, D, z,
+                                               FaceLayout{z_face_stride, z_vertex_stride, front_stride}, img, feat, valid, front,
+                                               multiplier, eps, interp, face_idx, weights, workspace);
+}
+int kamd_rasterize_forward_fused_strided_f64(void* stream, int B, int H, int W, int F, int D, const double* z,
+                                             int64_t z_face_stride, int64_t z_vertex_stride, const double* img,
+                                             const double* feat, const uint8_t* valid, const double* front,
+                                             int64_t front_stride, double multiplier, float eps, double* interp,
+                                             int64_t* face_idx, double* weights, void* workspace) {
+  return rasterize_forward_fused_launch<double>((hipStream_t)stream, B, H, W, F, D, z,
+                                                FaceLayout{z_face_stride, z_vertex_stride, front_stride}, img, feat, valid,
+                                                front, multiplier, eps, interp, face_idx, weights, workspace);
 }
 int kamd_rasterize_backward_f32(void* stream, int B, int H, int W, int F, int D, const float* grad,
                                 const int64_t* face_idx, const float* weights, const float* img, const float* feat,

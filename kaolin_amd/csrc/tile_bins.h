@@ -275,6 +275,11 @@ __device__ __forceinline__ void bin_emit_wave(bool active, int b, long long j, i
   }
 }
 
+// element strides of the optional per-face inputs of the fused front doors (dense: z_face 3, z_vertex 1, front_stride 1)
+struct FaceLayout {
+  long long z_face, z_vertex, front_stride;
+};
+
 template <typename T>
 struct alignas(16) Rec4 {
   T a, b, c, d;
@@ -282,12 +287,15 @@ struct alignas(16) Rec4 {
 
 template <typename T>
 __global__ __launch_bounds__(256) void bin_faces_raw_kernel(
-    int B, int F, const T* __restrict__ img, const T* __restrict__ z, const uint8_t* __restrict__ valid,
-    T mult, T margin, TileGeom g, float multiplier, T* __restrict__ rec, unsigned int* __restrict__ masks,
-    unsigned int* __restrict__ tile_flags, uint8_t* __restrict__ sub_flags) {
+    int B, int F, const T* __restrict__ img, const T* __restrict__ z, FaceLayout lay, const uint8_t* __restrict__ valid,
+    const T* __restrict__ front, T mult, T margin, TileGeom g, float multiplier, T* __restrict__ rec,
+    unsigned int* __restrict__ masks, unsigned int* __restrict__ tile_flags, uint8_t* __restrict__ sub_flags) {
   const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
   bool active = f < (long long)B * F;
   if (active && valid != nullptr && valid[f] == 0) active = false;
+  // `front`: a per-face scalar (the z of the face normal) read in place; the face is kept when it is >= 0, which is the
+  // mask `face_normals_z >= 0` of the reference's dibr_rasterization (dibr.py:188) without the compare kernel
+  if (active && front != nullptr && !(front[f * lay.front_stride] >= (T)0)) active = false;
   int b = 0, tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
   long long j = 0;
   if (active) {
@@ -307,10 +315,10 @@ __global__ __launch_bounds__(256) void bin_faces_raw_kernel(
     // the 16-scalar record as four 16-byte stores: box | a.xy b.xy | c.xy z.ab | z.c pad
     Rec4<T>* r = reinterpret_cast<Rec4<T>*>(rec + (size_t)f * REC_STRIDE);
     T z0 = 0, z1 = 0, z2 = 0;
-    if (z != nullptr) {
-      z0 = z[f * 3 + 0];
-      z1 = z[f * 3 + 1];
-      z2 = z[f * 3 + 2];
+    if (z != nullptr) {  // read in place: z may be the [..., 2] view of the (B, F, 3, 3) camera-space vertices
+      z0 = z[f * lay.z_face + 0 * lay.z_vertex];
+      z1 = z[f * lay.z_face + 1 * lay.z_vertex];
+      z2 = z[f * lay.z_face + 2 * lay.z_vertex];
     }
     r[0] = Rec4<T>{xmin, ymin, xmax, ymax};
     r[1] = Rec4<T>{v[0], v[1], v[2], v[3]};

@@ -62,8 +62,12 @@ class DibrRasterizationCuda(torch.autograd.Function):
                 sigmainv, boxlen, knum, multiplier, eps):
         face_vertices_image = face_vertices_image.contiguous()
         face_features = face_features.contiguous()
+        # valid_faces: the bool mask, or the float face-normal z (kept faces: >= 0); z and that scalar may be [..., 2] views
+        # of prepare_vertices' outputs -- the library reads them in place (no compare kernel, no contiguous copies)
+        if not valid_faces.is_floating_point():
+            valid_faces = valid_faces.contiguous()
         feats, face_idx, weights, soft_mask, hits = _C.render.mesh.dibr_rasterization_forward_fused(
-            height, width, face_vertices_z.contiguous(), face_vertices_image, face_features, valid_faces.contiguous(),
+            height, width, face_vertices_z, face_vertices_image, face_features, valid_faces,
             sigmainv, boxlen, knum, multiplier, eps)
         ctx.save_for_backward(face_idx, weights, soft_mask, face_vertices_image, face_features, *hits)
         ctx.mark_non_differentiable(face_idx)
@@ -106,8 +110,9 @@ def dibr_rasterization(height, width, face_vertices_z, face_vertices_image, face
     is_list = isinstance(face_features, (list, tuple))
     _features = torch.cat(face_features, dim=-1) if is_list else face_features
     # rasterize()'s defaults (multiplier 1000, eps 1e-8) and dibr_soft_mask's multiplier (1000.) coincide numerically
+    front = face_normals_z if face_normals_z.dtype == face_vertices_z.dtype else face_normals_z >= 0.
     image_features, soft_mask, face_idx = DibrRasterizationCuda.apply(
-        height, width, face_vertices_z, face_vertices_image, _features, face_normals_z >= 0., sigmainv, boxlen, knum,
+        height, width, face_vertices_z, face_vertices_image, _features, front.detach(), sigmainv, boxlen, knum,
         _multiplier, 1e-8 if eps is None else eps)
     if is_list:
         out, cur = [], 0

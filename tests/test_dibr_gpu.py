@@ -356,3 +356,31 @@ def test_fused_front_door_equals_reference_glue_plus_contract_operator(dtype, wi
     g1 = m.dibr_soft_mask_backward_lean(g, s1, h1, scaled, 7000, 30, 1000.)
     g2 = m.dibr_soft_mask_backward_lean(g, s2, h2, fimg.cuda(), 7000, 30, 1000., img_scale=1000.)
     assert rel_close(g1, g2, 1e-6 if dtype == torch.float else 1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float, torch.double])
+def test_dibr_rasterization_reads_views_in_place(dtype):
+    """`dibr_rasterization` fed with the `[..., 2]` views of `prepare_vertices`' outputs (what the tutorial does) reads
+    them through strides -- no contiguous copy, no `>= 0` kernel: the result must equal the one for dense copies, and
+    the one where the front-face mask is applied by hand through `rasterize` + `dibr_soft_mask`."""
+    import kaolin_amd as kal
+    from kaolin_amd.utils import testing as T
+    v, f = T.geodesic_sphere(6)
+    cams = T.fibonacci_cameras(3, 2.5, dtype)
+    rot, trans = kal.render.camera.generate_rotate_translate_matrices(cams.cuda(), torch.zeros(3, 3, dtype=dtype, device='cuda'),
+                                                                      torch.tensor([[0., 1., 0.]], dtype=dtype, device='cuda').repeat(3, 1))
+    proj = kal.render.camera.generate_perspective_projection(0.785, dtype=dtype).cuda()
+    verts = v.to(dtype).cuda().unsqueeze(0).expand(3, -1, -1)
+    fv_cam, fv_img, normals = kal.render.mesh.prepare_vertices(verts, f.cuda(), proj, camera_rot=rot, camera_trans=trans)
+    feat = torch.rand(3, f.shape[0], 3, 2, dtype=dtype, device='cuda')
+    z_view, n_view = fv_cam[..., 2], normals[..., 2]
+    assert not z_view.is_contiguous() and not n_view.is_contiguous()
+    a = kal.render.mesh.dibr_rasterization(48, 40, z_view, fv_img, feat, n_view)
+    b = kal.render.mesh.dibr_rasterization(48, 40, z_view.contiguous(), fv_img, feat, n_view.contiguous())
+    feats, idx = kal.render.mesh.rasterize(48, 40, z_view.contiguous(), fv_img, feat, valid_faces=n_view >= 0.)
+    soft = kal.render.mesh.dibr_soft_mask(fv_img, idx)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert torch.equal(a[2], idx) and torch.equal(a[0], feats) and torch.equal(a[1], soft)
+    assert int((idx >= 0).sum()) > 0
