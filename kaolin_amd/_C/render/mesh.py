@@ -175,7 +175,7 @@ def dibr_soft_mask_forward_lean(face_vertices_image, face_large_bboxes, selected
     lib = _lib.load()
     with torch.cuda.device(device):
         soft_mask = torch.empty((batch_size, height, width), dtype=dtype, device=device)
-        hits = _hit_list(batch_size, height, width, knum, dtype, device)
+        hits = _hit_list(batch_size, height, width, knum, dtype, device, num_faces)
         ws = _lib.workspace(lib.kamd_dibr_soft_mask_forward_workspace(batch_size, height, width, num_faces,
                                                                       face_vertices_image.element_size()), device)
         st = getattr(lib, f'kamd_dibr_soft_mask_forward_lean_{sfx}')(
@@ -215,14 +215,16 @@ def dibr_soft_mask_backward_lean(grad_soft_mask, soft_mask, hits, face_vertices_
     return g_img
 
 
-def _hit_list(batch_size, height, width, knum, dtype, device):
+def _hit_list(batch_size, height, width, knum, dtype, device, num_faces=0):
     """Storage of the segmented hit list: capacity B*H*W*K records (just the used parts are ever touched), one count
     per potential work item (16x4-pixel sub-tile), and the number of work items."""
     cap = max(int(_lib.load().kamd_dibr_soft_mask_lean_capacity(batch_size, height, width, int(knum))), 1)
     n_sub = ((width + 31) // 32) * ((height + 31) // 32) * 16 * batch_size
     return (torch.empty(cap, dtype=torch.int32, device=device), torch.empty(cap, dtype=torch.int32, device=device),
             torch.empty(cap, dtype=dtype, device=device), torch.empty(cap, dtype=torch.uint8, device=device),
-            torch.empty(max(n_sub, 1), dtype=torch.int32, device=device), torch.zeros(1, dtype=torch.int32, device=device))
+            torch.empty(max(n_sub, 1), dtype=torch.int32, device=device),
+            # the search kernel writes the number of work items whenever it runs, i.e. whenever there are faces
+            (torch.empty if num_faces > 0 else torch.zeros)(1, dtype=torch.int32, device=device))
 
 
 def hit_list_entries(hits, knum):
@@ -256,7 +258,7 @@ def dibr_soft_mask_forward_fused(face_vertices_image, selected_face_idx, sigmain
     lib = _lib.load()
     with torch.cuda.device(device):
         soft_mask = torch.empty((batch_size, height, width), dtype=dtype, device=device)
-        hits = _hit_list(batch_size, height, width, knum, dtype, device)
+        hits = _hit_list(batch_size, height, width, knum, dtype, device, num_faces)
         ws = _lib.workspace(lib.kamd_dibr_soft_mask_forward_workspace(batch_size, height, width, num_faces,
                                                                       face_vertices_image.element_size()), device)
         st = getattr(lib, f'kamd_dibr_soft_mask_forward_fused_{sfx}')(
@@ -364,7 +366,7 @@ def dibr_rasterization_forward_fused(height, width, face_vertices_z, face_vertic
         wts = torch.empty((batch_size, height, width, 3), dtype=dtype, device=device)
         interp = torch.empty((batch_size, height, width, feat_dim), dtype=dtype, device=device)
         soft_mask = torch.empty((batch_size, height, width), dtype=dtype, device=device)
-        hits = _hit_list(batch_size, height, width, knum, dtype, device)
+        hits = _hit_list(batch_size, height, width, knum, dtype, device, num_faces)
         ws_r = _lib.workspace(lib.kamd_rasterize_forward_workspace(batch_size, height, width, batch_size * num_faces, esz), device)
         ws_s = _lib.workspace(lib.kamd_dibr_soft_mask_forward_workspace(batch_size, height, width, num_faces, esz), device)
         st = getattr(lib, f'kamd_dibr_rasterization_forward_{sfx}')(

@@ -744,8 +744,9 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
     }
     KAMD_CHECK(hipGetLastError());
     if (total_faces > 0) {
-      KAMD_CHECK(kamd_zero_async(masks, (mask_words(g.ntiles, B, total_faces) + flag_words(g.ntiles, B) + 2) * 4 +
-                                           align256((size_t)n_sub), st));
+      // rounded up to 16 bytes (one fill kernel, no tail memset): the few extra bytes are worklist items, written before read
+      KAMD_CHECK(kamd_zero_async(masks, ((mask_words(g.ntiles, B, total_faces) + flag_words(g.ntiles, B) + 2) * 4 +
+                                         align256((size_t)n_sub) + 15) & ~(size_t)15, st));
       kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
       if (raw)
         hipLaunchKernelGGL(bin_faces_raw_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, F, img,

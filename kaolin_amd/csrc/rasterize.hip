@@ -346,7 +346,7 @@ int rasterize_forward_launch(hipStream_t st, int B, int H, int W, int D, int64_t
   unsigned int* masks = (unsigned int*)((char*)workspace + align256((size_t)total_faces * REC_STRIDE * sizeof(T)));
   unsigned int* flags = total_faces > 0 ? masks + mask_words(g.ntiles, B, total_faces) : nullptr;
   if (total_faces > 0) {
-    KAMD_CHECK(kamd_zero_async(masks, (mask_words(g.ntiles, B, total_faces) + flag_words(g.ntiles, B)) * 4, st));
+    KAMD_CHECK(kamd_zero_async(masks, ((mask_words(g.ntiles, B, total_faces) + flag_words(g.ntiles, B)) * 4 + 15) & ~(size_t)15, st));  // inside the 256-byte padding
     {
       kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
       hipLaunchKernelGGL(bin_faces_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, 0,
@@ -376,7 +376,7 @@ int rasterize_forward_fused_launch(hipStream_t st, int B, int H, int W, int F, i
   unsigned int* masks = (unsigned int*)((char*)workspace + align256((size_t)total_faces * REC_STRIDE * sizeof(T)));
   unsigned int* flags = total_faces > 0 ? masks + mask_words(g.ntiles, B, total_faces) : nullptr;
   if (total_faces > 0) {
-    KAMD_CHECK(kamd_zero_async(masks, (mask_words(g.ntiles, B, total_faces) + flag_words(g.ntiles, B)) * 4, st));
+    KAMD_CHECK(kamd_zero_async(masks, ((mask_words(g.ntiles, B, total_faces) + flag_words(g.ntiles, B)) * 4 + 15) & ~(size_t)15, st));  // inside the 256-byte padding
     kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
     hipLaunchKernelGGL(bin_faces_raw_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, F, img, z, lay, valid,
                        front, (T)multiplier, (T)0, g, (float)multiplier, rec, masks, flags, (uint8_t*)nullptr);
