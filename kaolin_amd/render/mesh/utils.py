@@ -19,6 +19,9 @@ class _PrepareVerticesCuda(torch.autograd.Function):
         ctx.save_for_backward(vertices, faces, camera_proj,
                               *(t for t in (camera_rot, camera_trans, camera_transform) if t is not None))
         ctx.has_transform = camera_transform is not None
+        # an output nobody differentiates (typically the camera-space vertices and the normals: only their z feeds the
+        # rasterizer, without gradient) arrives as None, not as a zero tensor the backward kernel would have to read
+        ctx.set_materialize_grads(False)
         return out
 
     @staticmethod
@@ -26,6 +29,8 @@ class _PrepareVerticesCuda(torch.autograd.Function):
         vertices, faces, camera_proj = ctx.saved_tensors[:3]
         rest = ctx.saved_tensors[3:]
         rot, trans, tf = (None, None, rest[0]) if ctx.has_transform else (rest[0], rest[1], None)
+        if grad_cam is None and grad_img is None and grad_nrm is None:
+            return (None,) * 6
         g = _C.render.mesh.prepare_vertices_backward_fused(vertices, faces, camera_proj, rot, trans, tf,
                                                            grad_cam, grad_img, grad_nrm)
         if g.shape[0] != vertices.shape[0]:      # one shared (1, V, 3) mesh: sum the per-view gradients
