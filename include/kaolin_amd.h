@@ -55,6 +55,31 @@ int kamd_sided_distance_forward_f16(void* stream, int B, int N, int M,
                                     const uint16_t* p1, const uint16_t* p2,
                                     uint16_t* dist, int64_t* idx, void* workspace);
 
+/* Both directions of chamfer_distance in one pass (kaolin/metrics/pointcloud.py */
+/* :89-136 calls sided_distance(p1, p2) and sided_distance(p2, p1)): both clouds */
+/* are binned once, each on its own grid, and serve as targets of one direction  */
+/* and as queries of the other.  dist1/idx1 (B,N) are p1 -> p2, dist2/idx2 (B,M) */
+/* are p2 -> p1, bit-identical to two kamd_sided_distance_forward calls.         */
+/* The workspace query returns 0 when the shapes do not qualify (a cloud below   */
+/* 8192 points, non-fp32): callers then issue the two calls.                     */
+size_t kamd_sided_distance_pair_forward_workspace(int B, int N, int M, int elem_size);
+int kamd_sided_distance_pair_forward_f32(void* stream, int B, int N, int M,
+                                         const float* p1, const float* p2,
+                                         float* dist1, int64_t* idx1,
+                                         float* dist2, int64_t* idx2, void* workspace);
+
+/* Gradient of chamfer_distance (kaolin/metrics/pointcloud.py:120-136) w.r.t.   */
+/* both clouds in one launch: grad (B) is the gradient of the (B) result; the    */
+/* autograd chain weight -> mean -> [sqrt] -> sided_distance backward            */
+/* (sided_distance_cuda.cu:203-242) of both directions is evaluated per point.  */
+/* g1 (B,N,3) and g2 (B,M,3) are overwritten (no initialisation needed).         */
+int kamd_chamfer_distance_backward_f32(void* stream, int B, int N, int M,
+                                       const float* grad, float w1, float w2, int squared,
+                                       const float* p1, const float* p2,
+                                       const int64_t* idx1, const int64_t* idx2,
+                                       const float* dist1, const float* dist2,
+                                       float* g1, float* g2);
+
 /* metrics.sided_distance_backward_cuda(grad, p1, p2, idx) -> [g1, g2]        */
 /* reference: sided_distance.cpp:91-122, sided_distance_cuda.cu:203-242       */
 /* g1 (B,N,3) is overwritten; g2 (B,M,3) is accumulated (caller zeroes it).   */
@@ -481,6 +506,8 @@ int kamd_trianglemeshes_to_voxelgrids_f64(void* stream, int B, int V, int F, int
 /* line; off by default.  kamd_profile_read synchronises the pending events.  */
 /* ------------------------------------------------------------------------- */
 int kamd_profile_enable(int on);
+/* id >= 0: only that kernel is timed while profiling is on; -1: every kernel */
+int kamd_profile_select(int id);
 int kamd_profile_reset(void);
 int kamd_profile_num_kernels(void);
 const char* kamd_profile_kernel_name(int id);

@@ -33,6 +33,67 @@ def sided_distance_forward_cuda(p1, p2):
     return [dist, idx]
 
 
+def sided_distance_pair_forward(p1, p2):
+    """Both directions of a chamfer distance from one binning pass over both clouds -> [dist1, idx1, dist2, idx2], or ``None`` when the
+    shapes do not qualify (the caller then issues two ``sided_distance_forward_cuda``).  Not part of the reference's
+    ``kaolin._C``: it fuses the two calls kaolin/metrics/pointcloud.py:89-136 makes; results are bit-identical."""
+    fn = 'sided_distance_pair_forward'
+    p1_arg, p2_arg = Arg(p1, 'p1', 1), Arg(p2, 'p2', 2)
+    check_same_gpu(fn, p1_arg, p2_arg)
+    check_all_contiguous(fn, [p1_arg, p2_arg])
+    check_same_type(fn, p1_arg, p2_arg)
+    batch_size, num_p1, num_p2 = p1.size(0), p1.size(1), p2.size(1)
+    check_size(fn, p1_arg, [batch_size, num_p1, 3])
+    check_size(fn, p2_arg, [batch_size, num_p2, 3])
+    if p1.dtype != torch.float32:
+        return None
+    lib = _lib.load()
+    nbytes = lib.kamd_sided_distance_pair_forward_workspace(batch_size, num_p1, num_p2, p1.element_size())
+    if nbytes == 0:
+        return None
+    with torch.cuda.device(p1.device):
+        dist1 = torch.empty((batch_size, num_p1), dtype=p1.dtype, device=p1.device)
+        idx1 = torch.empty((batch_size, num_p1), dtype=torch.long, device=p1.device)
+        dist2 = torch.empty((batch_size, num_p2), dtype=p1.dtype, device=p1.device)
+        idx2 = torch.empty((batch_size, num_p2), dtype=torch.long, device=p1.device)
+        ws = _lib.workspace(nbytes, p1.device)
+        st = lib.kamd_sided_distance_pair_forward_f32(
+            _lib.stream_ptr(p1.device), batch_size, num_p1, num_p2, _lib.ptr(p1), _lib.ptr(p2),
+            _lib.ptr(dist1), _lib.ptr(idx1), _lib.ptr(dist2), _lib.ptr(idx2), _lib.ptr(ws))
+    _lib.check(st, fn)
+    return [dist1, idx1, dist2, idx2]
+
+
+def chamfer_distance_backward(grad_output, w1, w2, squared, p1, p2, idx1, idx2, dist1, dist2):
+    """Gradient of ``chamfer_distance`` (kaolin/metrics/pointcloud.py:120-136) w.r.t. both clouds in one launch
+    -> [grad_p1, grad_p2]; fp32 only.  Not part of the reference's ``kaolin._C`` (it evaluates the autograd chain
+    weight -> mean -> [sqrt] -> two ``sided_distance_backward_cuda`` per point)."""
+    fn = 'chamfer_distance_backward'
+    args = [Arg(grad_output, 'grad_output', 1), Arg(p1, 'p1', 5), Arg(p2, 'p2', 6), Arg(idx1, 'idx1', 7),
+            Arg(idx2, 'idx2', 8), Arg(dist1, 'dist1', 9), Arg(dist2, 'dist2', 10)]
+    check_all_same_gpu(fn, args)
+    check_all_contiguous(fn, args)
+    batch_size, num_p1, num_p2 = p1.size(0), p1.size(1), p2.size(1)
+    check_size(fn, args[0], [batch_size])
+    check_size(fn, args[1], [batch_size, num_p1, 3])
+    check_size(fn, args[2], [batch_size, num_p2, 3])
+    check_size(fn, args[3], [batch_size, num_p1])
+    check_size(fn, args[4], [batch_size, num_p2])
+    check_size(fn, args[5], [batch_size, num_p1])
+    check_size(fn, args[6], [batch_size, num_p2])
+    torch_check(p1.dtype == torch.float32 and p2.dtype == torch.float32 and grad_output.dtype == torch.float32,
+                f'{fn}: only Float clouds are supported')
+    lib = _lib.load()
+    with torch.cuda.device(p1.device):
+        g1, g2 = torch.empty_like(p1), torch.empty_like(p2)     # the kernels write every entry
+        st = lib.kamd_chamfer_distance_backward_f32(
+            _lib.stream_ptr(p1.device), batch_size, num_p1, num_p2, _lib.ptr(grad_output), float(w1), float(w2),
+            1 if squared else 0, _lib.ptr(p1), _lib.ptr(p2), _lib.ptr(idx1), _lib.ptr(idx2), _lib.ptr(dist1),
+            _lib.ptr(dist2), _lib.ptr(g1), _lib.ptr(g2))
+    _lib.check(st, fn)
+    return [g1, g2]
+
+
 def sided_distance_backward_cuda(grad_output, p1, p2, idx):
     """reference: kaolin/csrc/metrics/sided_distance.cpp:91-122 -> [grad_p1, grad_p2]"""
     fn = 'sided_distance_backward_cuda'

@@ -26,6 +26,9 @@ _dbl = ctypes.c_double
 SIGNATURES = {
     'kamd_version': (ctypes.c_char_p, []),
     'kamd_sided_distance_forward_workspace': (_sz, [_i, _i, _i, _i]),
+    'kamd_sided_distance_pair_forward_workspace': (_sz, [_i, _i, _i, _i]),
+    'kamd_chamfer_distance_backward_f32': (_i, [_vp, _i, _i, _i, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'kamd_sided_distance_pair_forward_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'kamd_rasterize_forward_workspace': (_sz, [_i, _i, _i, _i64, _i]),
     'kamd_dibr_soft_mask_forward_workspace': (_sz, [_i, _i, _i, _i, _i]),
     'kamd_triangle_distance_forward_workspace': (_sz, [_i, _i, _i]),
@@ -40,6 +43,7 @@ SIGNATURES = {
     'kamd_mesh_to_spc_build': (_i, [_vp, _i64, _i, _vp, _vp, _vp, _sz, _vp]),
     'kamd_mesh_to_spc_results': (_i, [_vp, _i64, _i, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     'kamd_profile_enable': (_i, [_i]),
+    'kamd_profile_select': (_i, [_i]),
     'kamd_profile_reset': (_i, []),
     'kamd_profile_num_kernels': (_i, []),
     'kamd_profile_kernel_name': (ctypes.c_char_p, [_i]),

@@ -53,22 +53,38 @@ __device__ __forceinline__ void kamd_atomic_add(__half* p, __half v) {
 // reproduces that rounding step on a float carrier.
 __device__ __forceinline__ float kamd_hround(float x) { return __half2float(__float2half(x)); }
 
-// ---- fast zero fill -----------------------------------------------------------------------------------------
-// hipMemsetAsync runs a generic fill kernel at ~2 TB/s on this stack; the workspaces cleared every call (tile bitmasks:
-// ~50 MB per DIB-R call, the 256^3 voxel grid: 67 MB) are 16-byte aligned, so a grid-stride kernel of 16-byte stores
-// (the K-buffer fill measured 5.7 TB/s) does the same job 2-3x faster.  Falls back to hipMemsetAsync for odd sizes.
-__global__ __launch_bounds__(256) static void kamd_zero16_kernel(uint4* __restrict__ p, size_t n16) {
+// ---- fills -------------------------------------------------------------------------------------------------------------
+// hipMemsetAsync runs a generic fill kernel at ~2 TB/s on this stack, and as a memset NODE of a captured HIP graph it
+// faulted on replay (tools/graph_step.py).  The workspaces cleared every call (tile bitmasks: ~50 MB per DIB-R call,
+// the 256^3 voxel grid: 67 MB) are 16-byte aligned, so a grid-stride kernel of 16-byte stores (the K-buffer fill
+// measured 5.7 TB/s) does the same job 2-3x faster; the < 16-byte edges of an unaligned range go through a one-wave
+// byte kernel.  Nothing in the library calls hipMemsetAsync: every operator is a sequence of kernel nodes, capturable.
+__global__ __launch_bounds__(256) static void kamd_fill16_kernel(uint4* __restrict__ p, size_t n16, unsigned int word) {
   const size_t stride = (size_t)gridDim.x * 256;
-  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  const uint4 z = make_uint4(word, word, word, word);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) p[i] = z;
 }
-static inline int kamd_zero_async(void* ptr, size_t bytes, hipStream_t st) {
+__global__ __launch_bounds__(64) static void kamd_fill_edges_kernel(unsigned char* head, int nh, unsigned char* tail, int nt,
+                                                                    unsigned char v) {
+  if ((int)threadIdx.x < nh) head[threadIdx.x] = v;
+  if ((int)threadIdx.x < nt) tail[threadIdx.x] = v;
+}
+// [ptr, ptr + bytes) <- the byte `byte`, any alignment and size
+static inline int kamd_fill_async(void* ptr, size_t bytes, int byte, hipStream_t st) {
   if (bytes == 0) return 0;
-  if (((uintptr_t)ptr & 15) != 0 || bytes < (1u << 16)) return (int)hipMemsetAsync(ptr, 0, bytes, st);
-  const size_t n16 = bytes / 16, tail = bytes - n16 * 16;
-  size_t blocks = (n16 + 255) / 256;
-  if (blocks > (size_t)KAMD_NUM_CU * 16) blocks = (size_t)KAMD_NUM_CU * 16;
-  hipLaunchKernelGGL(kamd_zero16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint4*)ptr, n16);
-  if (tail) return (int)hipMemsetAsync((char*)ptr + n16 * 16, 0, tail, st);
+  unsigned char* c = (unsigned char*)ptr;
+  size_t head = ((uintptr_t)c & 15) ? 16 - ((uintptr_t)c & 15) : 0;
+  if (head > bytes) head = bytes;
+  const size_t n16 = (bytes - head) / 16, tail = bytes - head - n16 * 16;
+  if (n16) {
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > (size_t)KAMD_NUM_CU * 16) blocks = (size_t)KAMD_NUM_CU * 16;
+    hipLaunchKernelGGL(kamd_fill16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint4*)(c + head), n16,
+                       0x01010101u * (unsigned int)(byte & 0xFF));
+  }
+  if (head || tail)
+    hipLaunchKernelGGL(kamd_fill_edges_kernel, dim3(1), dim3(64), 0, st, c, (int)head, c + head + n16 * 16, (int)tail,
+                       (unsigned char)(byte & 0xFF));
   return (int)hipGetLastError();
 }
+static inline int kamd_zero_async(void* ptr, size_t bytes, hipStream_t st) { return kamd_fill_async(ptr, bytes, 0, st); }

@@ -529,19 +529,8 @@ __global__ __launch_bounds__(DT_THREADS) void dt_overflow_kernel(int F, int P, i
 // the defaults.  Rows arrive in any order; equal depths are ordered by face number = mesh order
 // (torch.argsort in the reference leaves that case open).
 // the sorted result is mostly defaults (knum slots, a handful of hits): they go out as flat 16-byte stores ...
-__global__ __launch_bounds__(256) void dt_fill16_kernel(uint4* __restrict__ p, size_t n16, unsigned int word) {
-  const uint4 v = make_uint4(word, word, word, word);
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = v;
-}
 inline int dt_fill_bytes(void* ptr, size_t bytes, unsigned char byte, hipStream_t st) {  // byte pattern, any size
-  const size_t n16 = bytes / 16, tail = bytes - n16 * 16;
-  if (n16 > 0) {
-    size_t blocks = (n16 + 255) / 256;
-    if (blocks > (size_t)KAMD_NUM_CU * 16) blocks = (size_t)KAMD_NUM_CU * 16;
-    hipLaunchKernelGGL(dt_fill16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint4*)ptr, n16, 0x01010101u * byte);
-  }
-  if (tail) return (int)hipMemsetAsync((char*)ptr + n16 * 16, byte, tail, st);
-  return (int)hipGetLastError();
+  return kamd_fill_async(ptr, bytes, byte, st);
 }
 // ... and the hits are then ranked and written over them: KH lanes per pixel, lane k takes entries k, k + KH, ...
 template <typename T, int KH>

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void fill_regions_kernel(uint4* __restrict__ a
   for (size_t i = i0; i < nc; i += stride) c[i] = C;
 }
 
-// fills [p, p+bytes) with the byte `v`: 16-byte body through the kernel above, unaligned head/tail by memset
+// fills [p, p+bytes) with the byte `v`: 16-byte body through the kernel above, unaligned head/tail by the one-wave byte kernel
 struct FillPlan {
   uint4* body;
   size_t n16;
@@ -120,10 +120,13 @@ inline int fill_edges(hipStream_t st, void* p, size_t bytes, int v, FillPlan* pl
   char* c = (char*)p;
   size_t head = ((uintptr_t)c & 15) ? 16 - ((uintptr_t)c & 15) : 0;
   if (head > bytes) head = bytes;
-  if (head) KAMD_CHECK(hipMemsetAsync(c, v, head, st));
   const size_t n16 = (bytes - head) / 16;
   const size_t tail = bytes - head - n16 * 16;
-  if (tail) KAMD_CHECK(hipMemsetAsync(c + head + n16 * 16, v, tail, st));
+  if (head || tail) {
+    hipLaunchKernelGGL(kamd_fill_edges_kernel, dim3(1), dim3(64), 0, st, (unsigned char*)c, (int)head,
+                       (unsigned char*)c + head + n16 * 16, (int)tail, (unsigned char)(v & 0xFF));
+    KAMD_CHECK(hipGetLastError());
+  }
   plan->body = (uint4*)(c + head);
   plan->n16 = n16;
   return 0;
@@ -932,8 +935,8 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
   SideStream* ss;
   KAMD_CHECK(side_stream(&ss));
   // the soft mask's BIN phase needs only the vertices: side stream, concurrently with the rasterizer.  (While the
-  // per-kernel profiler is on everything stays on `st`, so that each kernel's event pair times that kernel alone.)
-  const hipStream_t side = kamd::prof_enabled() ? st : ss->s;
+  // profiler times EVERY kernel everything stays on `st`, so that each kernel's event pair times that kernel alone.)
+  const hipStream_t side = kamd::prof_all() ? st : ss->s;
   KAMD_CHECK(hipEventRecord(ss->fork, st));
   KAMD_CHECK(hipStreamWaitEvent(side, ss->fork, 0));
   KAMD_CHECK(soft_mask_forward_launch<T>(side, B, H, W, F, K, img, nullptr, nullptr, sigmainv, (float)multiplier, soft_mask,
@@ -964,7 +967,7 @@ int dibr_backward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K
   SideStream* ss;
   KAMD_CHECK(side_stream(&ss));
   // the two backward kernels are independent and both accumulate atomically into the same zero-initialised g_img
-  const hipStream_t side = kamd::prof_enabled() ? st : ss->s;
+  const hipStream_t side = kamd::prof_all() ? st : ss->s;
   KAMD_CHECK(hipEventRecord(ss->fork, st));
   KAMD_CHECK(hipStreamWaitEvent(side, ss->fork, 0));
   KAMD_CHECK(soft_mask_backward_list_launch<T>(side, B, H, W, F, K, grad_soft, soft_mask, list, img, multiplier, sigmainv,

@@ -1,6 +1,6 @@
 // Pieces of the uniform-grid pipeline shared by the exact nearest-point (sided_distance_grid.hip) and
 // nearest-triangle (triangle_distance.hip) searches: bounding box of a packed xyz array in partials, the grid geometry
-// every consumer re-derives from them, the cell index of a coordinate, and the two-launch exclusive scan of the cell counts.
+// every consumer re-derives from them, the cell index of a coordinate, and a workgroup scan.
 #pragma once
 #include "common.h"
 
@@ -76,8 +76,7 @@ __device__ __forceinline__ int sdg_axis_cell(float v, float lo, float inv, int G
   return c;
 }
 
-// ---- 3. exclusive scan of NC counts (in place; entry NC receives the total) ------------------------------------
-// two small launches: (a) sums of 1024-entry blocks, (b) every block adds up the sums before it and scans itself
+// ---- inclusive scan over a 1024-thread workgroup (the last thread's result is the total) ----------------------------
 __device__ __forceinline__ int sdg_block_inclusive(int v, int* s_wave) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int inc = v;
@@ -92,33 +91,5 @@ __device__ __forceinline__ int sdg_block_inclusive(int v, int* s_wave) {
   for (int w = 0; w < wave; ++w) woff += s_wave[w];
   return woff + inc;
 }
-__global__ __launch_bounds__(1024) void sdg_scan_sums(int NC, int nblk, const int* __restrict__ t_count,
-                                                      const int* __restrict__ q_count, int* __restrict__ sums) {
-  __shared__ int s_wave[16];
-  const int* cnt = (blockIdx.z == 0 ? t_count : q_count) + (size_t)blockIdx.y * (NC + 1);
-  const int i = blockIdx.x * 1024 + threadIdx.x;
-  const int tot = sdg_block_inclusive(i < NC ? cnt[i] : 0, s_wave);
-  if (threadIdx.x == 1023) sums[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * nblk + blockIdx.x] = tot;
-}
-__global__ __launch_bounds__(1024) void sdg_scan_apply(int NC, int nblk, int* __restrict__ t_count, int* __restrict__ q_count,
-                                                       const int* __restrict__ sums) {
-  __shared__ int s_wave[16];
-  __shared__ int s_off;
-  int* cnt = (blockIdx.z == 0 ? t_count : q_count) + (size_t)blockIdx.y * (NC + 1);
-  const int* my = sums + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * nblk;
-  int part = 0;
-  for (int k = threadIdx.x; k < (int)blockIdx.x; k += 1024) part += my[k];
-  const int before = sdg_block_inclusive(part, s_wave);
-  if (threadIdx.x == 1023) s_off = before;
-  __syncthreads();
-  const int off = s_off;
-  __syncthreads();
-  const int i = blockIdx.x * 1024 + threadIdx.x;
-  const int v = i < NC ? cnt[i] : 0;
-  const int inc = sdg_block_inclusive(v, s_wave);
-  if (i < NC) cnt[i] = off + inc - v;
-  if (i == NC - 1) cnt[NC] = off + inc;
-}
-
 }  // namespace
 }  // namespace kamd

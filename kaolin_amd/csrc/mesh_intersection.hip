@@ -147,7 +147,7 @@ int mesh_intersection_launch(hipStream_t st, int N, int F, const T* points, cons
   if (S < 1) S = 1;
   const int Fs = kamd_cdiv(ntiles, S) * MI_TILE;
   S = kamd_cdiv(F > 0 ? F : 1, Fs);
-  if (S > 1) KAMD_CHECK(hipMemsetAsync(result, 0, (size_t)N * sizeof(T), st));
+  if (S > 1) KAMD_CHECK(kamd_zero_async(result, (size_t)N * sizeof(T), st));
   {
     kamd::ProfScope prof_(kamd::K_MESH_INTERSECTION, st);
     hipLaunchKernelGGL(mesh_intersection_kernel<T>, dim3(nx, S), dim3(MI_THREADS), 0, st, N, F, Fs, points, v1, v2, v3,

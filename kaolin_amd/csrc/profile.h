@@ -1,6 +1,8 @@
 // Optional per-kernel timing with HIP events recorded on the launch stream (off by default, zero cost then).
-// bench.py switches it on around its timed region to obtain each kernel's average launch duration for the
-// roofline line; the same figures come out of `rocprofv3 --kernel-trace --stats` (profiles/).
+// bench.py switches it on to obtain each kernel's average launch duration; the same figures come out of
+// `rocprofv3 --kernel-trace --stats` (profiles/).  Two event records per launch cost a few microseconds of stream time
+// each, so the timed region of bench.py brackets only the kernel of its roofline line (kamd_profile_select) and the
+// full per-kernel table comes from a separate pass.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -16,7 +18,8 @@ enum KernelId {
   K_NUM
 };
 
-bool prof_enabled();
+bool prof_enabled(int id);
+bool prof_all();  // every kernel is being timed: callers keep concurrent launches on one stream so that pairs do not overlap
 void prof_begin(int id, hipStream_t st);
 void prof_end(int id, hipStream_t st);
 
@@ -24,7 +27,7 @@ struct ProfScope {
   int id;
   hipStream_t st;
   bool on;
-  ProfScope(int id_, hipStream_t st_) : id(id_), st(st_), on(prof_enabled()) {
+  ProfScope(int id_, hipStream_t st_) : id(id_), st(st_), on(prof_enabled(id_)) {
     if (on) prof_begin(id, st);
   }
   ~ProfScope() {

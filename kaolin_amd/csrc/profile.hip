@@ -8,11 +8,11 @@
 namespace kamd {
 namespace {
 const char* const kNames[K_NUM] = {
-    "sd_main_f32", "sd_final_f32", "sd_forward_generic", "sd_backward", "sdg_build(5 kernels)", "sdg_query",
+    "sd_main_f32", "sd_final_f32", "sd_forward_generic", "sd_backward", "sdg_build(bbox + cells + scan + scatter)", "sdg_query",
     "bin_faces_kernel", "raster_tile_kernel", "raster_backward_kernel",
     "fill_regions_kernel", "soft_classify_kernel", "soft_search_kernel", "soft_mask_backward_kernel", "soft_mask_backward_list_kernel",
     "td_prep_kernel", "td_main_kernel", "td_final_kernel", "td_backward_kernel",
-    "vox_vertices_kernel", "vox_faces_kernel", "hipMemsetAsync", "pv_forward_kernel", "pv_backward_kernel", "mesh_intersection_kernel",
+    "vox_vertices_kernel", "vox_faces_kernel", "zero_fill", "pv_forward_kernel", "pv_backward_kernel", "mesh_intersection_kernel",
     "deftet_forward(pixel sort + search)", "deftet_sort_interp_kernel", "deftet_backward_kernel",
     "mesh_to_spc_stage(count|emit)", "mesh_to_spc_build(sort + unique + octree + results)"};
 struct Pending {
@@ -20,6 +20,7 @@ struct Pending {
   hipEvent_t start, stop;
 };
 std::atomic<int> g_on{0};
+std::atomic<int> g_only{-1};  // >= 0: only this kernel id is timed
 std::mutex g_mu;
 std::vector<Pending> g_pending;
 std::vector<hipEvent_t> g_pool;
@@ -51,7 +52,12 @@ void drain_locked() {
 }
 }  // namespace
 
-bool prof_enabled() { return g_on.load(std::memory_order_relaxed) != 0; }
+bool prof_enabled(int id) {
+  if (g_on.load(std::memory_order_relaxed) == 0) return false;
+  const int only = g_only.load(std::memory_order_relaxed);
+  return only < 0 || only == id;
+}
+bool prof_all() { return g_on.load(std::memory_order_relaxed) != 0 && g_only.load(std::memory_order_relaxed) < 0; }
 void prof_begin(int id, hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_mu);
   hipEvent_t e = get_event();
@@ -71,6 +77,10 @@ void prof_end(int id, hipStream_t st) {
 extern "C" {
 int kamd_profile_enable(int on) {
   kamd::g_on.store(on ? 1 : 0);
+  return 0;
+}
+int kamd_profile_select(int id) {
+  kamd::g_only.store(id >= 0 && id < kamd::K_NUM ? id : -1);
   return 0;
 }
 int kamd_profile_reset(void) {

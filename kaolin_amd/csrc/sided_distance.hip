@@ -310,6 +310,48 @@ int sd_backward_launch(hipStream_t st, int B, int N, int M, const T* grad, const
   KAMD_RETURN_LAST_ERROR();
 }
 
+// ---- chamfer backward: both directions, both clouds ------------------------------------------------------------------
+// chamfer_distance = w1 * mean_i f(dist1_i) + w2 * mean_j f(dist2_j), f = identity or sqrt (kaolin/metrics/pointcloud.py
+// :120-136).  autograd of that composition hands every point of direction d the upstream value
+// grad[b] * w_d * (1 / n_d) [/ (2 * sqrt(dist))], then runs the sided_distance backward of each direction
+// (sided_distance_cuda.cu:203-242) and adds the two results per cloud.  One thread per point of either cloud does all of
+// it in two launches: SCATTER = false stores the point's own term 2 * (q - t) * g (this initialises g1 / g2, no fill
+// needed), SCATTER = true then adds -that to the nearest point of the other cloud with float atomics.
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void sd_chamfer_backward(int N, int M, const float* __restrict__ grad, float w1, float w2,
+                                                           float inv_n, float inv_m, int squared,
+                                                           const float* __restrict__ p1, const float* __restrict__ p2,
+                                                           const int64_t* __restrict__ idx1,
+                                                           const int64_t* __restrict__ idx2,
+                                                           const float* __restrict__ dist1,
+                                                           const float* __restrict__ dist2, float* __restrict__ g1,
+                                                           float* __restrict__ g2) {
+  const int b = blockIdx.y;
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N + M) return;
+  const bool fwd = i < N;
+  if (!fwd) i -= N;
+  const int nq = fwd ? N : M, nt = fwd ? M : N;
+  const float* Q = (fwd ? p1 : p2) + ((size_t)b * nq + i) * 3;
+  const size_t t = (size_t)(fwd ? idx1 : idx2)[(size_t)b * nq + i] + (size_t)b * nt;
+  const float* T = (fwd ? p2 : p1) + t * 3;
+  float g = grad[b];
+  const float w = fwd ? w1 : w2;
+  if (w != 1.f) g = g * w;
+  g = g * (fwd ? inv_n : inv_m);
+  if (!squared) g = g / (2.f * sqrtf((fwd ? dist1 : dist2)[(size_t)b * nq + i]));
+  float* GQ = (fwd ? g1 : g2) + ((size_t)b * nq + i) * 3;
+  float* GT = (fwd ? g2 : g1) + t * 3;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float q = Q[a], x = T[a];
+    if (SCATTER)
+      kamd_atomic_add(GT + a, 2.f * (x - q) * g);
+    else
+      GQ[a] = 2.f * (q - x) * g;
+  }
+}
+
 // KAMD_SIDED_DISTANCE=brute keeps the all-pairs kernels for every size (A/B timing, tests of both paths)
 inline bool sd_force_brute() {
   const char* e = getenv("KAMD_SIDED_DISTANCE");
@@ -347,6 +389,33 @@ int kamd_sided_distance_forward_f32(void* stream, int B, int N, int M, const flo
     kamd::ProfScope prof_(kamd::K_SD_FINAL, st);
     hipLaunchKernelGGL(sd_final_f32, dim3(kamd_cdiv((long long)B * N, 256)), dim3(256), 0, st, B, N, M, p.S, p1, p2,
                      part_d, part_c, dist, idx);
+  }
+  KAMD_RETURN_LAST_ERROR();
+}
+
+size_t kamd_sided_distance_pair_forward_workspace(int B, int N, int M, int elem_size) {
+  if (elem_size != 4 || !kamd::sdgrid_pair_applicable(B, N, M) || sd_force_brute()) return 0;
+  return kamd::sdgrid_pair_workspace_bytes(B, N, M);
+}
+
+int kamd_sided_distance_pair_forward_f32(void* stream, int B, int N, int M, const float* p1, const float* p2,
+                                         float* dist1, int64_t* idx1, float* dist2, int64_t* idx2, void* workspace) {
+  if (workspace == nullptr || !kamd::sdgrid_pair_applicable(B, N, M)) return (int)hipErrorInvalidValue;
+  return kamd::sdgrid_pair_forward_f32((hipStream_t)stream, B, N, M, p1, p2, dist1, idx1, dist2, idx2, workspace);
+}
+
+int kamd_chamfer_distance_backward_f32(void* stream, int B, int N, int M, const float* grad, float w1, float w2,
+                                       int squared, const float* p1, const float* p2, const int64_t* idx1,
+                                       const int64_t* idx2, const float* dist1, const float* dist2, float* g1, float* g2) {
+  hipStream_t st = (hipStream_t)stream;
+  if (B <= 0 || N <= 0 || M <= 0) return 0;
+  {
+    kamd::ProfScope prof_(kamd::K_SD_BACKWARD, st);
+    const dim3 grid(kamd_cdiv((long long)N + M, 256), B);
+    hipLaunchKernelGGL(sd_chamfer_backward<false>, grid, dim3(256), 0, st, N, M, grad, w1, w2, 1.f / (float)N,
+                       1.f / (float)M, squared, p1, p2, idx1, idx2, dist1, dist2, g1, g2);
+    hipLaunchKernelGGL(sd_chamfer_backward<true>, grid, dim3(256), 0, st, N, M, grad, w1, w2, 1.f / (float)N,
+                       1.f / (float)M, squared, p1, p2, idx1, idx2, dist1, dist2, g1, g2);
   }
   KAMD_RETURN_LAST_ERROR();
 }

@@ -9,4 +9,9 @@ bool sdgrid_applicable(int B, int N, int M);
 size_t sdgrid_workspace_bytes(int B, int N, int M);
 int sdgrid_forward_f32(hipStream_t st, int B, int N, int M, const float* p1, const float* p2, float* dist, int64_t* idx,
                        void* workspace);
+// both directions of a chamfer distance, each cloud binned once (dist1/idx1: p1 -> p2, dist2/idx2: p2 -> p1)
+bool sdgrid_pair_applicable(int B, int N, int M);
+size_t sdgrid_pair_workspace_bytes(int B, int N, int M);
+int sdgrid_pair_forward_f32(hipStream_t st, int B, int N, int M, const float* p1, const float* p2, float* dist1,
+                            int64_t* idx1, float* dist2, int64_t* idx2, void* workspace);
 }  // namespace kamd

@@ -6,16 +6,22 @@
 // pairs while returning the SAME answer: dist = min_j d(p1_i, p2_j) with the identical fp32 expression
 // d = fma(dz,dz, fma(dy,dy, dx*dx)), idx = the lowest j attaining it, and a NaN distance to target 0 sticking
 // (the reference's `k == 0 ||` seed).  A uniform grid over the targets does that:
-//   1. sdg_bbox      bounding box of the finite targets (per batch item), in partials;
-//   2. sdg_cells     cell id of every target and every query; per-cell counts (atomicAdd); one launch for both;
-//   3. sdg_scan      exclusive scan of the counts (one workgroup per batch item and array);
-//   4. sdg_scatter   counting-sort scatter: targets as float4 {x, y, z, original index}; queries as an index list in
-//                    cell order, so that the 64 queries of a wavefront are spatial neighbours (same cells, same lines);
+//   1. sdg_bbox      bounding box of the finite targets (per batch item): block minima / maxima merged with integer
+//                    atomicMax on an order-preserving encoding, so that consumers read six words;
+//   2. sdg_cells     cell id of every point and its rank inside the cell (the value the counting atomicAdd returns);
+//   3. sdg_scan      exclusive scan of the cell counts, one launch (every 1024-cell block sums the counts before it);
+//   4. sdg_scatter   counting sort without further atomics: point -> start[cell] + rank, stored as float4
+//                    {x, y, z, original index};
 //   5. sdg_query     per query: seed with target 0 exactly as the reference does, then visit the cube of cells around
 //                    the query ring by ring; after each ring every unvisited target is provably farther than the
 //                    distance from the query to the cube's faces (minus a rounding margin), so the search stops as soon
 //                    as the best distance is below that bound.  Ties are resolved towards the lower original index
 //                    explicitly, so the arbitrary order inside a cell does not matter.
+// Queries are processed in cell order too (the 64 queries of a wavefront are spatial neighbours: same cells, same
+// cache lines).  One direction (sided_distance) bins the queries on the targets' grid for that.  Both directions
+// (chamfer_distance: sided_distance(p1, p2) and sided_distance(p2, p1)) bin EACH cloud ONCE on its own grid: the sorted
+// copy is the target list of one direction and the spatially coherent query list of the other, and every kernel of
+// the pipeline is launched once for both clouds -- 6 launches instead of 14.
 // Work per query is O(points in a few cells) instead of O(M); the result is bit-identical to the brute-force kernels
 // (tests/test_sided_distance.py compares both with the oracle, incl. duplicates, NaNs, queries outside the box,
 // degenerate boxes).  Non-finite targets are binned at a clamped cell: they yield NaN/inf distances that can never win
@@ -28,35 +34,40 @@
 namespace kamd {
 namespace {
 
-struct SdgGeom {
-  int G, NC;
-};
-inline SdgGeom sdg_geom(int M) {
+inline int sdg_cells_per_axis(int M) {
   // ~2 targets per cell on average for a volume-filling cloud; surfaces leave most cells empty, which is fine
   int G = (int)floor(cbrt((double)M / 2.0) + 0.5);
   if (G < 1) G = 1;
   if (G > SDG_MAXG) G = SDG_MAXG;
-  return SdgGeom{G, G * G * G};
+  return G;
 }
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// one cloud of the pipeline (kernel argument, by value)
+struct Cloud {
+  int n, G;             // points per batch item; cells per axis of the grid it is binned on
+  const float* pts;     // (B, n, 3)
+  unsigned int* box;    // (B, 8) encoded {lo[3], hi[3]} of the grid's box, 0 = no finite point yet
+  int* count;           // (B, G^3) zero before sdg_cells
+  int* start;           // (B, G^3 + 1)
+  int2* cellrank;       // (B, n) {cell, rank inside the cell}
+  float4* sorted;       // (B, n) {x, y, z, original index} in cell order
+};
+
 struct SdgWs {
-  float* bbox_part;   // B * SDG_NB * 6
-  int* t_count;       // B * (NC + 1)   counts -> starts (after the scan)
-  int* q_count;       // B * (NC + 1)
-  int* t_fill;        // B * NC
-  int* q_fill;        // B * NC
-  int* t_cell;        // B * M
-  int* q_cell;        // B * N
-  float4* t_sorted;   // B * M
-  int* q_sorted;      // B * N
-  int* scan_sums;     // 2 * B * ceil(NC / 1024)
-  size_t zero_bytes;  // prefix of the workspace that must be zeroed (counts + fills)
+  Cloud a, b;           // a = p1 (N points), b = p2 (M points)
+  size_t zero_bytes;    // prefix of the workspace that must be zeroed (counts + boxes)
   size_t total;
 };
-inline SdgWs sdg_layout(void* base, int B, int N, int M) {
-  const SdgGeom g = sdg_geom(M);
+// pair = false: sided_distance(p1, p2): both clouds on p2's grid.  pair = true: each cloud on its own grid.
+inline SdgWs sdg_layout(void* base, int B, int N, int M, const float* p1, const float* p2, bool pair) {
   SdgWs w;
+  w.b.n = M;
+  w.b.G = sdg_cells_per_axis(M);
+  w.b.pts = p2;
+  w.a.n = N;
+  w.a.G = pair ? sdg_cells_per_axis(N) : w.b.G;
+  w.a.pts = p1;
   char* p = (char*)base;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -64,66 +75,153 @@ inline SdgWs sdg_layout(void* base, int B, int N, int M) {
     off += al(bytes);
     return r;
   };
-  w.t_count = (int*)take((size_t)B * (g.NC + 1) * 4);
-  w.q_count = (int*)take((size_t)B * (g.NC + 1) * 4);
-  w.t_fill = (int*)take((size_t)B * g.NC * 4);
-  w.q_fill = (int*)take((size_t)B * g.NC * 4);
+  const size_t nca = (size_t)w.a.G * w.a.G * w.a.G, ncb = (size_t)w.b.G * w.b.G * w.b.G;
+  w.b.count = (int*)take((size_t)B * ncb * 4);
+  w.a.count = (int*)take((size_t)B * nca * 4);
+  w.b.box = (unsigned int*)take((size_t)B * 8 * 4);
+  w.a.box = pair ? (unsigned int*)take((size_t)B * 8 * 4) : w.b.box;
   w.zero_bytes = off;
-  w.bbox_part = (float*)take((size_t)B * SDG_NB * 6 * 4);
-  w.t_cell = (int*)take((size_t)B * M * 4);
-  w.q_cell = (int*)take((size_t)B * N * 4);
-  w.t_sorted = (float4*)take((size_t)B * M * 16);
-  w.q_sorted = (int*)take((size_t)B * N * 4);
-  w.scan_sums = (int*)take((size_t)2 * B * ((g.NC + 1023) / 1024) * 4);
+  w.b.start = (int*)take((size_t)B * (ncb + 1) * 4);
+  w.a.start = (int*)take((size_t)B * (nca + 1) * 4);
+  w.b.cellrank = (int2*)take((size_t)B * M * 8);
+  w.a.cellrank = (int2*)take((size_t)B * N * 8);
+  w.b.sorted = (float4*)take((size_t)B * M * 16);
+  w.a.sorted = (float4*)take((size_t)B * N * 16);
   w.total = off;
   return w;
 }
 
-// ---- 2. cell ids + counts (targets and queries in one launch) ------------------------------------------------
-__global__ __launch_bounds__(256) void sdg_cells(int M, int N, int nb, int G, const float* __restrict__ p2,
-                                                 const float* __restrict__ p1, const float* __restrict__ part,
-                                                 int* __restrict__ t_cell, int* __restrict__ q_cell,
-                                                 int* __restrict__ t_count, int* __restrict__ q_count) {
+// ---- 1. bounding box ---------------------------------------------------------------------------------------------------
+// order-preserving float -> uint (negative values reversed below the positives); atomicMax on it is a float max, on
+// its complement a float min, and the all-zero word the workspace memset leaves is below every encoded value
+__device__ __forceinline__ unsigned int sdg_ord(float v) {
+  const unsigned int u = __float_as_uint(v);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float sdg_unord(unsigned int o) {
+  return __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
+// blocks [0, nbx) reduce cloud X into X.box, blocks [nbx, gridDim.x) cloud Y into Y.box (Y.n = 0: one cloud only)
+__global__ __launch_bounds__(256) void sdg_bbox_atomic(Cloud X, Cloud Y, int nbx) {
+  __shared__ float s[6][256];
+  const int b = blockIdx.y;
+  const bool first = (int)blockIdx.x < nbx;
+  const int n = first ? X.n : Y.n;
+  const int blk = first ? blockIdx.x : blockIdx.x - nbx, nblk = first ? nbx : gridDim.x - nbx;
+  const float* P = (first ? X.pts : Y.pts) + (size_t)b * n * 3;
+  unsigned int* box = (first ? X.box : Y.box) + (size_t)b * 8;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = blk * 256 + threadIdx.x; i < n; i += nblk * 256) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float v = P[(size_t)i * 3 + a];
+      if (isfinite(v)) {
+        lo[a] = fminf(lo[a], v);
+        hi[a] = fmaxf(hi[a], v);
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    s[a][threadIdx.x] = lo[a];
+    s[3 + a][threadIdx.x] = hi[a];
+  }
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if (threadIdx.x < d) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        s[a][threadIdx.x] = fminf(s[a][threadIdx.x], s[a][threadIdx.x + d]);
+        s[3 + a][threadIdx.x] = fmaxf(s[3 + a][threadIdx.x], s[3 + a][threadIdx.x + d]);
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 3 && s[threadIdx.x][0] <= s[3 + threadIdx.x][0]) {  // this block saw a finite value on the axis
+    atomicMax(box + threadIdx.x, ~sdg_ord(s[threadIdx.x][0]));
+    atomicMax(box + 3 + threadIdx.x, sdg_ord(s[3 + threadIdx.x][0]));
+  }
+}
+
+// the grid geometry every consumer derives from the six words (same rules as grid_common.h's sdg_box)
+__device__ __forceinline__ Box sdg_box_decode(const unsigned int* __restrict__ w, int G) {
+  Box bx;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const unsigned int ulo = w[a], uhi = w[3 + a];
+    float lo = 0.f, hi = 0.f;  // no finite point on this axis
+    if (ulo != 0u && uhi != 0u) {
+      lo = sdg_unord(~ulo);
+      hi = sdg_unord(uhi);
+    }
+    float size = (hi - lo) / (float)G;
+    if (!(size > 0.f) || !isfinite(size)) size = 1.f;  // degenerate extent: a single slab holds everything
+    bx.lo[a] = lo;
+    bx.size[a] = size;
+    bx.inv[a] = 1.f / size;
+  }
+  return bx;
+}
+
+// ---- 2. cell id + rank inside the cell (both clouds in one launch) ------------------------------------------------
+__global__ __launch_bounds__(256) void sdg_cells(Cloud X, Cloud Y) {
   __shared__ Box s_box;
   const int b = blockIdx.y;
-  if (threadIdx.x == 0) s_box = sdg_box(part, b, nb, G);
+  const int xb = (X.n + 255) / 256;
+  const bool first = (int)blockIdx.x < xb;
+  const int n = first ? X.n : Y.n, G = first ? X.G : Y.G;
+  if (threadIdx.x == 0) s_box = sdg_box_decode((first ? X.box : Y.box) + (size_t)b * 8, G);
   __syncthreads();
-  const int mb = (M + 255) / 256;
-  const bool is_t = (int)blockIdx.x < mb;
-  const int n = is_t ? M : N;
-  const int i = (is_t ? blockIdx.x : blockIdx.x - mb) * 256 + threadIdx.x;
+  const int i = (first ? blockIdx.x : blockIdx.x - xb) * 256 + threadIdx.x;
   if (i >= n) return;
-  const float* P = (is_t ? p2 : p1) + ((size_t)b * n + i) * 3;
+  const float* P = (first ? X.pts : Y.pts) + ((size_t)b * n + i) * 3;
   const int cx = sdg_axis_cell(P[0], s_box.lo[0], s_box.inv[0], G);
   const int cy = sdg_axis_cell(P[1], s_box.lo[1], s_box.inv[1], G);
   const int cz = sdg_axis_cell(P[2], s_box.lo[2], s_box.inv[2], G);
   const int c = (cz * G + cy) * G + cx;
-  (is_t ? t_cell : q_cell)[(size_t)b * n + i] = c;
-  atomicAdd((is_t ? t_count : q_count) + (size_t)b * (G * G * G + 1) + c, 1);
+  const int rank = atomicAdd((first ? X.count : Y.count) + (size_t)b * (G * G * G) + c, 1);
+  (first ? X.cellrank : Y.cellrank)[(size_t)b * n + i] = make_int2(c, rank);
 }
 
-// ---- 4. counting-sort scatter (targets and queries in one launch) --------------------------------------------------
-__global__ __launch_bounds__(256) void sdg_scatter(int M, int N, int NC, const float* __restrict__ p2,
-                                                   const int* __restrict__ t_cell, const int* __restrict__ q_cell,
-                                                   const int* __restrict__ t_start, const int* __restrict__ q_start,
-                                                   int* __restrict__ t_fill, int* __restrict__ q_fill,
-                                                   float4* __restrict__ t_sorted, int* __restrict__ q_sorted) {
+// ---- 3. exclusive scan of the counts: start[c] = points in cells < c, start[NC] = n ---------------------------------
+// one launch: a block owns 1024 cells and first adds up every count before them (<= 2M ints = 8 MB from L2 at the
+// largest grid, ~50k ints at 100k points), so there is no second pass and no inter-block dependency
+__global__ __launch_bounds__(1024) void sdg_scan(Cloud X, Cloud Y) {
+  __shared__ int s_wave[16];
+  __shared__ int s_off;
+  const bool first = blockIdx.z == 0;
+  const int G = first ? X.G : Y.G, NC = G * G * G;
+  const int base = blockIdx.x * 1024;
+  if (base >= NC || (first ? X.n : Y.n) == 0) return;
+  const int* cnt = (first ? X.count : Y.count) + (size_t)blockIdx.y * NC;
+  int* start = (first ? X.start : Y.start) + (size_t)blockIdx.y * (NC + 1);
+  int part = 0;
+  for (int k = threadIdx.x; k < base; k += 1024) part += cnt[k];
+  const int before = sdg_block_inclusive(part, s_wave);
+  if (threadIdx.x == 1023) s_off = before;
+  __syncthreads();
+  const int off = s_off;
+  __syncthreads();
+  const int i = base + threadIdx.x;
+  const int v = i < NC ? cnt[i] : 0;
+  const int inc = sdg_block_inclusive(v, s_wave);
+  if (i < NC) start[i] = off + inc - v;
+  if (i == NC - 1) start[NC] = off + inc;
+}
+
+// ---- 4. counting-sort scatter (both clouds in one launch) -------------------------------------------------------------
+__global__ __launch_bounds__(256) void sdg_scatter(Cloud X, Cloud Y) {
   const int b = blockIdx.y;
-  const int mb = (M + 255) / 256;
-  if ((int)blockIdx.x < mb) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= M) return;
-    const int c = t_cell[(size_t)b * M + i];
-    const int pos = t_start[(size_t)b * (NC + 1) + c] + atomicAdd(t_fill + (size_t)b * NC + c, 1);
-    const float* P = p2 + ((size_t)b * M + i) * 3;
-    t_sorted[(size_t)b * M + pos] = make_float4(P[0], P[1], P[2], __int_as_float(i));
-  } else {
-    const int i = (blockIdx.x - mb) * 256 + threadIdx.x;
-    if (i >= N) return;
-    const int c = q_cell[(size_t)b * N + i];
-    const int pos = q_start[(size_t)b * (NC + 1) + c] + atomicAdd(q_fill + (size_t)b * NC + c, 1);
-    q_sorted[(size_t)b * N + pos] = i;
-  }
+  const int xb = (X.n + 255) / 256;
+  const bool first = (int)blockIdx.x < xb;
+  const int n = first ? X.n : Y.n, G = first ? X.G : Y.G;
+  const int i = (first ? blockIdx.x : blockIdx.x - xb) * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int2 cr = (first ? X.cellrank : Y.cellrank)[(size_t)b * n + i];
+  const int pos = (first ? X.start : Y.start)[(size_t)b * (G * G * G + 1) + cr.x] + cr.y;
+  const float* P = (first ? X.pts : Y.pts) + ((size_t)b * n + i) * 3;
+  (first ? X.sorted : Y.sorted)[(size_t)b * n + pos] = make_float4(P[0], P[1], P[2], __int_as_float(i));
 }
 
 // ---- 5. query ----------------------------------------------------------------------------------------------------------
@@ -134,34 +232,16 @@ __device__ __forceinline__ float sdg_dist(float tx, float ty, float tz, float qx
 
 constexpr int SDG_GROUP = 8;  // lanes cooperating on one query (rows of the cell cube are dealt round-robin)
 
-__global__ __launch_bounds__(256) void sdg_query(int N, int M, int nb, int G, const float* __restrict__ p1,
-                                                 const float* __restrict__ p2, const float* __restrict__ part,
-                                                 const int* __restrict__ q_sorted, const int* __restrict__ q_cell,
-                                                 const int* __restrict__ t_start, const float4* __restrict__ t_sorted,
-                                                 float* __restrict__ dist, int64_t* __restrict__ idx) {
-  __shared__ Box s_box;
-  const int b = blockIdx.y;
-  if (threadIdx.x == 0) s_box = sdg_box(part, b, nb, G);
-  __syncthreads();
-  // 100k queries are only ~1.5 wavefronts per SIMD and every query is a chain of dependent loads (cell range ->
-  // targets): 8 lanes share a query so that 8x more loads are in flight; the lanes' (dist, idx) are merged with a
-  // 3-step butterfly after every ring
-  const int sub = threadIdx.x % SDG_GROUP;
-  const int slot = (blockIdx.x * 256 + threadIdx.x) / SDG_GROUP;
-  const bool live = slot < N;
-  const int NC = G * G * G;
-  const int qi = live ? q_sorted[(size_t)b * N + slot] : 0;
-  const float* Q = p1 + ((size_t)b * N + qi) * 3;
-  const float qx = Q[0], qy = Q[1], qz = Q[2];
-  const float* T0 = p2 + (size_t)b * M * 3;
+// the search for one query, shared by the one-direction and the two-direction kernels.  All SDG_GROUP lanes of a query
+// call it with the same (qx, qy, qz, c); on return every lane holds the query's (best, best_i).
+__device__ __forceinline__ void sdg_search(const Box& s_box, int G, float qx, float qy, float qz, int c,
+                                           const float* __restrict__ T0, const int* __restrict__ start,
+                                           const float4* __restrict__ TS, int sub, float& best, int& best_i) {
   // the reference's seed: target 0 unconditionally (a NaN distance sticks)
-  float best = sdg_dist(T0[0], T0[1], T0[2], qx, qy, qz);
-  int best_i = 0;
+  best = sdg_dist(T0[0], T0[1], T0[2], qx, qy, qz);
+  best_i = 0;
   if (best == best) {  // uniform within the group (same query)
-    const int c = q_cell[(size_t)b * N + qi];
     const int cx = c % G, cy = (c / G) % G, cz = c / (G * G);
-    const int* start = t_start + (size_t)b * (NC + 1);
-    const float4* TS = t_sorted + (size_t)b * M;
     // rounding head-room of the geometric bound: cell membership is decided by a rounded (v - lo) * inv
     const float q[3] = {qx, qy, qz};
     float slack[3];
@@ -235,44 +315,91 @@ __global__ __launch_bounds__(256) void sdg_query(int N, int M, int nb, int G, co
       if (bound > 0.f && best < bound * bound * 0.99999f) break;
     }
   }
+}
+
+
+// blockIdx.z = direction: 0 answers the queries A against the targets T (dist1 / idx1), 1 the reverse (dist2 / idx2).
+// The search runs on the TARGETS' grid; the queries only have to arrive in a spatially coherent order, which their own
+// sorted copy provides whichever grid it was sorted on.
+__global__ __launch_bounds__(256) void sdg_query(Cloud A, Cloud T, float* __restrict__ dist1, int64_t* __restrict__ idx1,
+                                                 float* __restrict__ dist2, int64_t* __restrict__ idx2) {
+  __shared__ Box s_box;
+  const int b = blockIdx.y;
+  const bool fwd = blockIdx.z == 0;
+  const int nq = fwd ? A.n : T.n, nt = fwd ? T.n : A.n, G = fwd ? T.G : A.G;
+  if ((long long)blockIdx.x * 256 >= (long long)nq * SDG_GROUP) return;  // the launch is sized for the larger cloud
+  if (threadIdx.x == 0) s_box = sdg_box_decode((fwd ? T.box : A.box) + (size_t)b * 8, G);
+  __syncthreads();
+  // 100k queries are only ~1.5 wavefronts per SIMD and every query is a chain of dependent loads (cell range ->
+  // targets): 8 lanes share a query so that 8x more loads are in flight; the lanes' (dist, idx) are merged with a
+  // 3-step butterfly after every ring
+  const int sub = threadIdx.x % SDG_GROUP;
+  const int slot = (blockIdx.x * 256 + threadIdx.x) / SDG_GROUP;
+  const bool live = slot < nq;
+  const int NC = G * G * G;
+  const float4 q = (fwd ? A.sorted : T.sorted)[(size_t)b * nq + (live ? slot : 0)];
+  const int cx = sdg_axis_cell(q.x, s_box.lo[0], s_box.inv[0], G);
+  const int cy = sdg_axis_cell(q.y, s_box.lo[1], s_box.inv[1], G);
+  const int cz = sdg_axis_cell(q.z, s_box.lo[2], s_box.inv[2], G);
+  float best;
+  int best_i;
+  sdg_search(s_box, G, q.x, q.y, q.z, (cz * G + cy) * G + cx, (fwd ? T.pts : A.pts) + (size_t)b * nt * 3,
+             (fwd ? T.start : A.start) + (size_t)b * (NC + 1), (fwd ? T.sorted : A.sorted) + (size_t)b * nt, sub, best,
+             best_i);
   if (live && sub == 0) {
-    dist[(size_t)b * N + qi] = best;
-    idx[(size_t)b * N + qi] = best_i;
+    const size_t o = (size_t)b * nq + __float_as_int(q.w);
+    (fwd ? dist1 : dist2)[o] = best;
+    (fwd ? idx1 : idx2)[o] = best_i;
   }
+}
+
+int sdg_run(hipStream_t st, int B, int N, int M, const float* p1, const float* p2, float* dist1, int64_t* idx1,
+            float* dist2, int64_t* idx2, void* workspace, bool pair) {
+  const SdgWs w = sdg_layout(workspace, B, N, M, p1, p2, pair);
+  const Cloud none = {0, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  auto blocks = [](int n) { return kamd_cdiv(n, 2048) < 128 ? kamd_cdiv(n, 2048) : 128; };
+  KAMD_CHECK(kamd_zero_async(workspace, w.zero_bytes, st));
+  {
+    ProfScope p(K_SDG_BUILD, st);
+    if (pair)
+      hipLaunchKernelGGL(sdg_bbox_atomic, dim3(blocks(M) + blocks(N), B), dim3(256), 0, st, w.b, w.a, blocks(M));
+    else  // the queries are binned on the targets' box
+      hipLaunchKernelGGL(sdg_bbox_atomic, dim3(blocks(M), B), dim3(256), 0, st, w.b, none, blocks(M));
+    hipLaunchKernelGGL(sdg_cells, dim3(kamd_cdiv(M, 256) + kamd_cdiv(N, 256), B), dim3(256), 0, st, w.b, w.a);
+    const int ncmax = (w.a.G > w.b.G ? w.a.G : w.b.G) * (w.a.G > w.b.G ? w.a.G : w.b.G) * (w.a.G > w.b.G ? w.a.G : w.b.G);
+    hipLaunchKernelGGL(sdg_scan, dim3(kamd_cdiv(ncmax, 1024), B, 2), dim3(1024), 0, st, w.b, w.a);
+    hipLaunchKernelGGL(sdg_scatter, dim3(kamd_cdiv(M, 256) + kamd_cdiv(N, 256), B), dim3(256), 0, st, w.b, w.a);
+  }
+  KAMD_CHECK(hipGetLastError());
+  {
+    ProfScope p(K_SDG_QUERY, st);
+    const int big = (pair && M > N) ? M : N;
+    hipLaunchKernelGGL(sdg_query, dim3(kamd_cdiv((long long)big * SDG_GROUP, 256), B, pair ? 2 : 1), dim3(256), 0, st, w.a,
+                       w.b, dist1, idx1, dist2, idx2);
+  }
+  KAMD_RETURN_LAST_ERROR();
 }
 
 }  // namespace
 
 bool sdgrid_applicable(int B, int N, int M) {
-  // below this the brute-force kernels are as fast as the seven launches of the grid pipeline
+  // below this the brute-force kernels are as fast as the launches of the grid pipeline
   return B >= 1 && M >= 8192 && N >= 2048 && (long long)B * (long long)(M > N ? M : N) < (1ll << 30);
 }
-size_t sdgrid_workspace_bytes(int B, int N, int M) { return sdg_layout(nullptr, B, N, M).total; }
+size_t sdgrid_workspace_bytes(int B, int N, int M) { return sdg_layout(nullptr, B, N, M, nullptr, nullptr, false).total; }
 
 int sdgrid_forward_f32(hipStream_t st, int B, int N, int M, const float* p1, const float* p2, float* dist, int64_t* idx,
                        void* workspace) {
-  const SdgGeom g = sdg_geom(M);
-  const SdgWs w = sdg_layout(workspace, B, N, M);
-  const int nb = kamd_cdiv(M, 4096) < SDG_NB ? kamd_cdiv(M, 4096) : SDG_NB;
-  KAMD_CHECK(hipMemsetAsync(workspace, 0, w.zero_bytes, st));
-  {
-    ProfScope p(K_SDG_BUILD, st);
-    hipLaunchKernelGGL(sdg_bbox, dim3(nb, B), dim3(256), 0, st, M, p2, w.bbox_part);
-    hipLaunchKernelGGL(sdg_cells, dim3(kamd_cdiv(M, 256) + kamd_cdiv(N, 256), B), dim3(256), 0, st, M, N, nb, g.G, p2, p1,
-                       w.bbox_part, w.t_cell, w.q_cell, w.t_count, w.q_count);
-    const int nblk = kamd_cdiv(g.NC, 1024);
-    hipLaunchKernelGGL(sdg_scan_sums, dim3(nblk, B, 2), dim3(1024), 0, st, g.NC, nblk, w.t_count, w.q_count, w.scan_sums);
-    hipLaunchKernelGGL(sdg_scan_apply, dim3(nblk, B, 2), dim3(1024), 0, st, g.NC, nblk, w.t_count, w.q_count, w.scan_sums);
-    hipLaunchKernelGGL(sdg_scatter, dim3(kamd_cdiv(M, 256) + kamd_cdiv(N, 256), B), dim3(256), 0, st, M, N, g.NC, p2,
-                       w.t_cell, w.q_cell, w.t_count, w.q_count, w.t_fill, w.q_fill, w.t_sorted, w.q_sorted);
-  }
-  KAMD_CHECK(hipGetLastError());
-  {
-    ProfScope p(K_SDG_QUERY, st);
-    hipLaunchKernelGGL(sdg_query, dim3(kamd_cdiv((long long)N * SDG_GROUP, 256), B), dim3(256), 0, st, N, M, nb, g.G, p1, p2, w.bbox_part, w.q_sorted,
-                       w.q_cell, w.t_count, w.t_sorted, dist, idx);
-  }
-  KAMD_RETURN_LAST_ERROR();
+  return sdg_run(st, B, N, M, p1, p2, dist, idx, nullptr, nullptr, workspace, false);
+}
+
+bool sdgrid_pair_applicable(int B, int N, int M) { return sdgrid_applicable(B, N, M) && sdgrid_applicable(B, M, N); }
+size_t sdgrid_pair_workspace_bytes(int B, int N, int M) {
+  return sdg_layout(nullptr, B, N, M, nullptr, nullptr, true).total;
+}
+int sdgrid_pair_forward_f32(hipStream_t st, int B, int N, int M, const float* p1, const float* p2, float* dist1,
+                            int64_t* idx1, float* dist2, int64_t* idx2, void* workspace) {
+  return sdg_run(st, B, N, M, p1, p2, dist1, idx1, dist2, idx2, workspace, true);
 }
 
 }  // namespace kamd

@@ -47,9 +47,77 @@ def sided_distance(p1, p2):
     return _SidedDistanceFunction.apply(p1, p2)
 
 
-def _mean_nearest(src, dst, squared):
-    d = sided_distance(src, dst)[0]
-    return (d if squared else d.sqrt()).mean(dim=-1)
+class _SidedDistancePairFunction(torch.autograd.Function):
+    """``sided_distance(p1, p2)[0]`` and ``sided_distance(p2, p1)[0]`` from one binning pass over both clouds (``_C.metrics.sided_distance_pair_forward``); the gradients are the two reference backward calls."""
+
+    @staticmethod
+    def forward(ctx, p1, p2):
+        a, b = p1.contiguous(), p2.contiguous()
+        both = _C.metrics.sided_distance_pair_forward(a, b)
+        if both is None:
+            dist1, near1 = _C.metrics.sided_distance_forward_cuda(a, b)
+            dist2, near2 = _C.metrics.sided_distance_forward_cuda(b, a)
+        else:
+            dist1, near1, dist2, near2 = both
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(a, b, near1, near2)
+        return dist1, dist2
+
+    @staticmethod
+    def backward(ctx, grad1, grad2):
+        a, b, near1, near2 = ctx.saved_tensors
+        grad_a = grad_b = None
+        if grad1 is not None:
+            grad_a, grad_b = _C.metrics.sided_distance_backward_cuda(grad1.contiguous(), a, b, near1)
+        if grad2 is not None:
+            more_b, more_a = _C.metrics.sided_distance_backward_cuda(grad2.contiguous(), b, a, near2)
+            grad_a = more_a if grad_a is None else grad_a.add_(more_a)
+            grad_b = more_b if grad_b is None else grad_b.add_(more_b)
+        return grad_a, grad_b
+
+
+class _ChamferDistanceFunction(torch.autograd.Function):
+    """The whole of ``chamfer_distance`` as one autograd node for fp32 clouds on the GPU: one search pipeline for both
+    directions, the reference's expression for the value, and one kernel for the gradient of both clouds
+    (``_C.metrics.chamfer_distance_backward``) instead of a chain of ~10 small autograd nodes."""
+
+    @staticmethod
+    def forward(ctx, p1, p2, w1, w2, squared):
+        a, b = p1.contiguous(), p2.contiguous()
+        both = _C.metrics.sided_distance_pair_forward(a, b)
+        if both is None:
+            dist1, near1 = _C.metrics.sided_distance_forward_cuda(a, b)
+            dist2, near2 = _C.metrics.sided_distance_forward_cuda(b, a)
+        else:
+            dist1, near1, dist2, near2 = both
+        ctx.save_for_backward(a, b, near1, near2, dist1, dist2)
+        ctx.weights, ctx.squared = (w1, w2), squared
+        ctx.set_materialize_grads(False)
+        return _chamfer_value(dist1, dist2, w1, w2, squared)
+
+    @staticmethod
+    def backward(ctx, grad):
+        if grad is None:
+            return None, None, None, None, None
+        a, b, near1, near2, dist1, dist2 = ctx.saved_tensors
+        grad_a, grad_b = _C.metrics.chamfer_distance_backward(grad.contiguous(), ctx.weights[0], ctx.weights[1],
+                                                              ctx.squared, a, b, near1, near2, dist1, dist2)
+        return grad_a, grad_b, None, None, None
+
+
+def _chamfer_value(to_p2, to_p1, w1, w2, squared):
+    forward_term = (to_p2 if squared else to_p2.sqrt()).mean(dim=-1)
+    backward_term = (to_p1 if squared else to_p1.sqrt()).mean(dim=-1)
+    if w1 == 1 and w2 == 1:
+        return forward_term + backward_term
+    return w1 * forward_term + w2 * backward_term
+
+
+def _nearest_both_ways(p1, p2):
+    """(distances p1 -> p2, distances p2 -> p1).  Large fp32 clouds on the GPU are binned once for both searches."""
+    if p1.is_cuda and p1.dtype == torch.float32 and p2.dtype == torch.float32 and p1.dim() == 3 and p2.dim() == 3:
+        return _SidedDistancePairFunction.apply(p1, p2)
+    return sided_distance(p1, p2)[0], sided_distance(p2, p1)[0]
 
 
 def chamfer_distance(p1, p2, w1=1., w2=1., squared=True):
@@ -64,11 +132,12 @@ def chamfer_distance(p1, p2, w1=1., w2=1., squared=True):
     Returns:
         (torch.Tensor): :math:`(B)`.
     """
-    forward_term = _mean_nearest(p1, p2, squared)
-    backward_term = _mean_nearest(p2, p1, squared)
-    if w1 == 1 and w2 == 1:
-        return forward_term + backward_term
-    return w1 * forward_term + w2 * backward_term
+    if (p1.is_cuda and p1.dtype == torch.float32 and p2.dtype == torch.float32 and p1.dim() == 3 and p2.dim() == 3
+            and p1.size(1) > 0 and p2.size(1) > 0
+            and isinstance(w1, (int, float)) and isinstance(w2, (int, float))):
+        return _ChamferDistanceFunction.apply(p1, p2, w1, w2, squared)
+    to_p2, to_p1 = _nearest_both_ways(p1, p2)
+    return _chamfer_value(to_p2, to_p1, w1, w2, squared)
 
 
 def f_score(gt_points, pred_points, radius=0.01, eps=1e-8):
@@ -80,8 +149,7 @@ def f_score(gt_points, pred_points, radius=0.01, eps=1e-8):
         (torch.Tensor): :math:`(B)`.
     """
     dtype = gt_points.dtype
-    gt_to_pred = sided_distance(gt_points, pred_points)[0].sqrt()
-    pred_to_gt = sided_distance(pred_points, gt_points)[0].sqrt()
+    gt_to_pred, pred_to_gt = (d.sqrt() for d in _nearest_both_ways(gt_points, pred_points))
     missed = (gt_to_pred > radius).sum(dim=1).type(dtype)          # false negatives
     spurious = (pred_to_gt > radius).sum(dim=1).type(dtype)        # false positives
     hits = (pred_to_gt.shape[1] - spurious).type(dtype)            # true positives

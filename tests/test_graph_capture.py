@@ -1,0 +1,141 @@
+"""Two properties a production step needs beyond parity on clean inputs (GPU only):
+(i) a whole forward + backward step is capturable into a HIP graph (torch.cuda.graph) and replays to the eager result
+    on NEW input values -- every operator is a sequence of kernel nodes on torch's current stream, with scratch from
+    torch's allocator; (ii) results do not depend on what a recycled scratch / output block held before."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def kal():
+    import kaolin_amd
+    return kaolin_amd
+
+
+def rel_close(a, b, tol):
+    scale = max(float(b.abs().max()), 1e-30)
+    return float((a.double() - b.double()).abs().max()) <= tol * scale
+
+
+def _capture(step):
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    return graph
+
+
+def _poison_allocator():
+    """Leaves torch's cached free blocks full of 0xFF (NaN as float, -1 as int): the next torch.empty gets them."""
+    junk = [torch.full((1 << 28,), -1, dtype=torch.int32, device='cuda')]          # 1 GiB, split for large requests
+    junk += [torch.full((n,), -1, dtype=torch.int32, device='cuda') for n in (64, 1024, 16384, 131072) for _ in range(8)]
+    del junk
+
+
+def test_chamfer_step_graph_replay():
+    pc = kal().metrics.pointcloud
+    B, N, M = 2, 9000, 10000
+    g = torch.Generator().manual_seed(0)
+    a = torch.rand(B, N, 3, generator=g).cuda().requires_grad_()
+    b = torch.rand(B, M, 3, generator=g).cuda().requires_grad_()
+    out = {'v': torch.zeros(B, device='cuda'), 'ga': torch.zeros_like(a), 'gb': torch.zeros_like(b)}
+
+    def step():
+        v = pc.chamfer_distance(a, b, w1=0.5, w2=2.)
+        ga, gb = torch.autograd.grad(v.sum(), [a, b])
+        out['v'].copy_(v)
+        out['ga'].copy_(ga)
+        out['gb'].copy_(gb)
+    graph = _capture(step)
+    for seed in (1, 2):
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            a.copy_(torch.rand(B, N, 3, generator=g) * (1 + seed))
+            b.copy_(torch.rand(B, M, 3, generator=g) * (1 + seed) + 0.1)
+        graph.replay()
+        got = {k: t.clone() for k, t in out.items()}
+        step()
+        assert torch.equal(got['v'], out['v'])
+        assert rel_close(got['ga'], out['ga'], 1e-5) and rel_close(got['gb'], out['gb'], 1e-5)
+
+
+def _dibr_inputs(level, views):
+    from kaolin_amd.utils import testing as T
+    fz, fimg, feats, nz = T.sphere_scene(level=level, num_views=views, dtype=torch.float, seed=3)
+    return fz.cuda(), fimg.cuda(), torch.cat(feats, -1).cuda(), nz.cuda()
+
+
+def test_dibr_step_graph_replay():
+    """dibr_rasterization forward + backward (side-stream fork / join included) captured once, replayed on moved
+    geometry: index output bit-exact, floats and gradients as close as two eager runs are to each other."""
+    H, W = 160, 128
+    fz, fimg, feat, nz = _dibr_inputs(12, 2)
+    img = fimg.clone().requires_grad_()
+    G1 = torch.rand(2, H, W, feat.shape[-1], device='cuda')
+    G2 = torch.rand(2, H, W, device='cuda')
+    out = {}
+
+    def step():
+        f, soft, idx = kal().render.mesh.dibr_rasterization(H, W, fz, img, feat, nz)
+        (g,) = torch.autograd.grad((f * G1).sum() + (soft * G2).sum(), [img])
+        for k, t in (('f', f), ('soft', soft), ('idx', idx), ('g', g)):
+            if k in out:
+                out[k].copy_(t)
+            else:
+                out[k] = t.detach().clone()
+    step()
+    graph = _capture(step)
+    for shift in (0.03, -0.05):
+        with torch.no_grad():
+            img.copy_(fimg * (1 + shift) + shift)
+        graph.replay()
+        got = {k: t.clone() for k, t in out.items()}
+        step()
+        assert torch.equal(got['idx'], out['idx'])
+        assert rel_close(got['f'], out['f'], 1e-6) and rel_close(got['soft'], out['soft'], 1e-5)
+        assert rel_close(got['g'], out['g'], 1e-4)
+
+
+def test_results_do_not_depend_on_recycled_memory():
+    """Every scratch and output buffer comes from torch.empty: run each operator, fill the allocator's free blocks
+    with 0xFF, run it again -- same results."""
+    k = kal()
+    H, W = 96, 128
+    fz, fimg, feat, nz = _dibr_inputs(10, 2)
+    g = torch.Generator().manual_seed(7)
+    p1, p2 = torch.rand(1, 9000, 3, generator=g).cuda(), torch.rand(1, 12000, 3, generator=g).cuda()
+    from kaolin_amd.utils import testing as T
+    verts, faces = T.geodesic_sphere(16)
+    verts, faces = verts.float().cuda(), faces.cuda()
+    fv = verts[faces].contiguous()
+    pts = (torch.rand(70000, 3, generator=g) - 0.5).cuda()
+
+    def everything():
+        img = fimg.clone().requires_grad_()
+        f, soft, idx = k.render.mesh.dibr_rasterization(H, W, fz, img, feat, nz)
+        (gi,) = torch.autograd.grad(f.sum() + soft.sum(), [img])
+        a = p1.clone().requires_grad_()
+        cd = k.metrics.pointcloud.chamfer_distance(a, p2)
+        (ga,) = torch.autograd.grad(cd.sum(), [a])
+        d, fi, ty = k.metrics.trianglemesh.point_to_mesh_distance(pts[None], fv[None])
+        vox = k.ops.conversions.trianglemeshes_to_voxelgrids(verts[None], faces, 64)
+        sign = k.ops.mesh.check_sign(verts[None], faces, pts[None, :5000])
+        return [f, soft, idx, gi, cd, ga, d, fi, ty, vox, sign]
+    first = everything()
+    _poison_allocator()
+    second = everything()
+    names = ['features', 'soft_mask', 'face_idx', 'grad_image_vertices', 'chamfer', 'grad_p1', 'distance', 'face', 'type',
+             'voxelgrid', 'sign']
+    for name, x, y in zip(names, first, second):
+        if name.startswith('grad'):
+            assert rel_close(x, y, 1e-4), name          # float atomics: summation order
+        elif x.dtype.is_floating_point:
+            assert rel_close(x, y, 1e-5), name
+        else:
+            assert torch.equal(x, y), name

@@ -296,3 +296,106 @@ def test_grid_search_nonfinite_and_brute_force_switch():
     finally:
         del os.environ['KAMD_SIDED_DISTANCE']
     assert torch.equal(i2, i) and torch.equal(torch.nan_to_num(d2), torch.nan_to_num(d))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['uniform', 'clustered', 'surface', 'flat'])
+@pytest.mark.parametrize('shape', [(1, 20000, 30010), (3, 8192, 8192), (2, 9001, 40000)])
+def test_pair_search_bit_exact_vs_oracle(kind, shape):
+    """chamfer_distance's two searches share one binning pass (kamd_sided_distance_pair_forward_f32): both directions must be
+    bit-identical to the all-pairs oracle, and the chamfer value / gradients identical to composing two
+    sided_distance calls."""
+    from kaolin_amd import _C
+    pc = _pc()
+    B, N, M = shape
+    p1, p2 = _clouds(kind, B, N, M, seed=N + M + 1)
+    both = _C.metrics.sided_distance_pair_forward(p1.cuda(), p2.cuda())
+    assert both is not None, 'these shapes must take the shared-grid path'
+    d1_ref, i1_ref = oracle.sided_distance_forward(p1, p2, omp=True)
+    d2_ref, i2_ref = oracle.sided_distance_forward(p2, p1, omp=True)
+    assert torch.equal(both[1].cpu(), i1_ref) and torch.equal(both[0].cpu(), d1_ref)
+    assert torch.equal(both[3].cpu(), i2_ref) and torch.equal(both[2].cpu(), d2_ref)
+    a = p1.cuda().requires_grad_(True)
+    b = p2.cuda().requires_grad_(True)
+    w = torch.rand(B, generator=torch.Generator().manual_seed(1)).cuda()
+    (pc.chamfer_distance(a, b, w1=0.7, w2=1.3) * w).sum().backward()
+    a2 = p1.cuda().requires_grad_(True)
+    b2 = p2.cuda().requires_grad_(True)
+    two = 0.7 * pc.sided_distance(a2, b2)[0].mean(-1) + 1.3 * pc.sided_distance(b2, a2)[0].mean(-1)
+    (two * w).sum().backward()
+    assert torch.equal(pc.chamfer_distance(a, b, w1=0.7, w2=1.3), two)
+    # the scatter side of the backward adds with float atomics: equal up to the summation order
+    assert torch.allclose(a.grad, a2.grad, rtol=1e-5, atol=1e-9)
+    assert torch.allclose(b.grad, b2.grad, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_pair_search_nonfinite_fallback_and_one_sided_grad():
+    """NaN / inf points through the two-direction search; shapes that do not qualify return None (chamfer_distance then makes the
+    two calls); a gradient that reaches only one of the two outputs leaves the other backward call out."""
+    from kaolin_amd import _C
+    pc = _pc()
+    torch.manual_seed(6)
+    p1, p2 = torch.rand(2, 9000, 3), torch.rand(2, 12000, 3)
+    p2[0, 0, 1] = float('nan')
+    p2[1, 17, 0] = float('nan')
+    p2[1, 23, 2] = float('inf')
+    p1[1, 5, 0] = float('nan')
+    p1[1, 0, 2] = float('-inf')
+    both = _C.metrics.sided_distance_pair_forward(p1.cuda(), p2.cuda())
+    for (q, t), (d, i) in zip([(p1, p2), (p2, p1)], [both[:2], both[2:]]):
+        d_ref, i_ref = oracle.sided_distance_forward(q, t, omp=True)
+        assert torch.equal(i.cpu(), i_ref)
+        assert torch.equal(torch.isnan(d.cpu()), torch.isnan(d_ref))
+        assert torch.equal(torch.nan_to_num(d.cpu()), torch.nan_to_num(d_ref))
+    assert _C.metrics.sided_distance_pair_forward(p1[:, :100].cuda().contiguous(), p2.cuda()) is None
+    assert _C.metrics.sided_distance_pair_forward(p1.double().cuda(), p2.double().cuda()) is None
+    small = pc.chamfer_distance(p1[:1, 1:200].cuda(), p2[:1, 1:300].cuda())
+    ref = oracle.sided_distance_forward(p1[:1, 1:200], p2[:1, 1:300])[0].mean(-1) + \
+        oracle.sided_distance_forward(p2[:1, 1:300], p1[:1, 1:200])[0].mean(-1)
+    assert torch.allclose(small.cpu(), ref, rtol=1e-6)
+    a = torch.rand(1, 9000, 3, device='cuda', requires_grad=True)
+    b = torch.rand(1, 9000, 3, device='cuda', requires_grad=True)
+    to_b, to_a = pc._nearest_both_ways(a, b)
+    to_b.sum().backward()
+    a2 = a.detach().clone().requires_grad_(True)
+    b2 = b.detach().clone().requires_grad_(True)
+    pc.sided_distance(a2, b2)[0].sum().backward()
+    assert torch.equal(a.grad, a2.grad) and torch.allclose(b.grad, b2.grad, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 9000, 9000), (2, 300, 500)])
+@pytest.mark.parametrize('squared', [True, False])
+def test_chamfer_single_node_equals_composition(shape, squared):
+    """fp32 chamfer_distance on the GPU is one autograd node (value: the reference's expression on the searched
+    distances; gradient: kamd_chamfer_distance_backward_f32).  It must reproduce the reference's composition
+    weight * mean([sqrt](sided_distance)) of kaolin/metrics/pointcloud.py:120-136, value bit for bit and gradients up
+    to the order of the atomic float additions."""
+    pc = _pc()
+    B, N, M = shape
+    g = torch.Generator().manual_seed(N)
+    p1, p2 = torch.rand(B, N, 3, generator=g), torch.rand(B, M, 3, generator=g)
+    up = torch.rand(B, generator=g).cuda()
+    for w1, w2 in [(1., 1.), (0.25, 3)]:
+        a, b = p1.cuda().requires_grad_(True), p2.cuda().requires_grad_(True)
+        out = pc.chamfer_distance(a, b, w1, w2, squared=squared)
+        assert type(out.grad_fn).__name__.startswith('_ChamferDistanceFunction')
+        out.backward(up)
+        a2, b2 = p1.cuda().requires_grad_(True), p2.cuda().requires_grad_(True)
+        d1, d2 = pc.sided_distance(a2, b2)[0], pc.sided_distance(b2, a2)[0]
+        if not squared:
+            d1, d2 = d1.sqrt(), d2.sqrt()
+        ref = d1.mean(-1) + d2.mean(-1) if (w1 == 1 and w2 == 1) else w1 * d1.mean(-1) + w2 * d2.mean(-1)
+        ref.backward(up)
+        assert torch.equal(out, ref)
+        assert torch.allclose(a.grad, a2.grad, rtol=1e-5, atol=1e-10)
+        assert torch.allclose(b.grad, b2.grad, rtol=1e-5, atol=1e-10)
+    # the oracle's gradient (CPU, float64 accumulation of the same formula) at the small shape
+    if N < 1000 and squared:
+        d1r, i1r = oracle.sided_distance_forward(p1, p2)
+        d2r, i2r = oracle.sided_distance_forward(p2, p1)
+        g1a, g1b = oracle.sided_distance_backward((up.cpu() * 0.25 / N)[:, None].expand(B, N).contiguous(), p1, p2, i1r)
+        g2b, g2a = oracle.sided_distance_backward((up.cpu() * 3 / M)[:, None].expand(B, M).contiguous(), p2, p1, i2r)
+        assert torch.allclose(a.grad.cpu(), g1a + g2a, rtol=1e-5, atol=1e-9)
+        assert torch.allclose(b.grad.cpu(), g1b + g2b, rtol=1e-5, atol=1e-9)
