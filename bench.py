@@ -15,7 +15,8 @@ resident in HBM when the timed region starts.  The same run also times chamfer_d
 100k x 100k (config C3, one batch item per GPU) and reports it under "chamfer".
 
 Rank 0 prints ONE JSON line.  "roofline" describes the kernel with the largest share of the DIB-R step, timed
-live with HIP events on the launch stream (libkaolin_amd's kamd_profile_* hooks); "cpu_baseline" is the CPU
+live with HIP events on the launch stream inside the timed region (libkaolin_amd's kamd_profile_* hooks; the table
+of every kernel comes from a separate, fully instrumented pass of the same step before it); "cpu_baseline" is the CPU
 oracle (OpenMP) timed on a bounded sample on this box's host cores (rank 0, N = 1 only).
 """
 import argparse
@@ -148,8 +149,13 @@ def main():
         kernels[name] = {'avg_us': round(avg_us, 2), 'launches_per_step': round(n / args.steps, 2),
                          'share_of_instrumented_step': round(ms / args.steps / inst_ms_per_step, 4),
                          'algorithmic_GBps': None if ab is None else round(ab / (avg_us * 1e-6) / 1e9, 1)}
-    dom = max((k for k in kernels if kernels[k]['algorithmic_GBps'] is not None),
-              key=lambda k: kernels[k]['share_of_instrumented_step'] * 1.0, default=None)
+    # the dominant kernel; shares within 5 % of each other (raster_tile and soft_search tie) are resolved towards a
+    # kernel that runs alone on the stream in the timed region, so that its event pair times that kernel only
+    overlapped = {'raster_tile_kernel', 'bin_faces_kernel', 'raster_backward_kernel', 'soft_mask_backward_list_kernel'}
+    ranked = sorted((k for k in kernels if kernels[k]['algorithmic_GBps'] is not None),
+                    key=lambda k: -kernels[k]['share_of_instrumented_step'])
+    near = [k for k in ranked if kernels[k]['share_of_instrumented_step'] >= 0.95 * kernels[ranked[0]]['share_of_instrumented_step']]
+    dom = next((k for k in near if k not in overlapped), ranked[0] if ranked else None)
 
     lib.kamd_profile_reset()
     lib.kamd_profile_select(kernel_ids.get(dom, -1) if dom else -1)

@@ -14,6 +14,7 @@ def kal():
 
 
 def rel_close(a, b, tol):
+    a, b = a.detach(), b.detach()
     scale = max(float(b.abs().max()), 1e-30)
     return float((a.double() - b.double()).abs().max()) <= tol * scale
 

@@ -298,6 +298,13 @@ def test_grid_search_nonfinite_and_brute_force_switch():
     assert torch.equal(i2, i) and torch.equal(torch.nan_to_num(d2), torch.nan_to_num(d))
 
 
+def _scale_close(got, want, tol=1e-5):
+    """Gradients that are sums of float atomics: the order of the additions differs between runs and paths, so entries
+    are compared relative to the largest entry (1e-5, the tolerance of BASELINE.json's north_star)."""
+    scale = max(float(want.abs().max()), 1e-30)
+    return float((got.double() - want.double()).abs().max()) <= tol * scale
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('kind', ['uniform', 'clustered', 'surface', 'flat'])
 @pytest.mark.parametrize('shape', [(1, 20000, 30010), (3, 8192, 8192), (2, 9001, 40000)])
@@ -325,8 +332,8 @@ def test_pair_search_bit_exact_vs_oracle(kind, shape):
     (two * w).sum().backward()
     assert torch.equal(pc.chamfer_distance(a, b, w1=0.7, w2=1.3), two)
     # the scatter side of the backward adds with float atomics: equal up to the summation order
-    assert torch.allclose(a.grad, a2.grad, rtol=1e-5, atol=1e-9)
-    assert torch.allclose(b.grad, b2.grad, rtol=1e-5, atol=1e-9)
+    assert _scale_close(a.grad, a2.grad)
+    assert _scale_close(b.grad, b2.grad)
 
 
 @pytest.mark.gpu
@@ -361,7 +368,7 @@ def test_pair_search_nonfinite_fallback_and_one_sided_grad():
     a2 = a.detach().clone().requires_grad_(True)
     b2 = b.detach().clone().requires_grad_(True)
     pc.sided_distance(a2, b2)[0].sum().backward()
-    assert torch.equal(a.grad, a2.grad) and torch.allclose(b.grad, b2.grad, rtol=1e-5, atol=1e-9)
+    assert torch.equal(a.grad, a2.grad) and _scale_close(b.grad, b2.grad)
 
 
 @pytest.mark.gpu
@@ -389,13 +396,13 @@ def test_chamfer_single_node_equals_composition(shape, squared):
         ref = d1.mean(-1) + d2.mean(-1) if (w1 == 1 and w2 == 1) else w1 * d1.mean(-1) + w2 * d2.mean(-1)
         ref.backward(up)
         assert torch.equal(out, ref)
-        assert torch.allclose(a.grad, a2.grad, rtol=1e-5, atol=1e-10)
-        assert torch.allclose(b.grad, b2.grad, rtol=1e-5, atol=1e-10)
+        assert _scale_close(a.grad, a2.grad)
+        assert _scale_close(b.grad, b2.grad)
     # the oracle's gradient (CPU, float64 accumulation of the same formula) at the small shape
     if N < 1000 and squared:
         d1r, i1r = oracle.sided_distance_forward(p1, p2)
         d2r, i2r = oracle.sided_distance_forward(p2, p1)
         g1a, g1b = oracle.sided_distance_backward((up.cpu() * 0.25 / N)[:, None].expand(B, N).contiguous(), p1, p2, i1r)
         g2b, g2a = oracle.sided_distance_backward((up.cpu() * 3 / M)[:, None].expand(B, M).contiguous(), p2, p1, i2r)
-        assert torch.allclose(a.grad.cpu(), g1a + g2a, rtol=1e-5, atol=1e-9)
-        assert torch.allclose(b.grad.cpu(), g1b + g2b, rtol=1e-5, atol=1e-9)
+        assert _scale_close(a.grad.cpu(), g1a + g2a)
+        assert _scale_close(b.grad.cpu(), g1b + g2b)
