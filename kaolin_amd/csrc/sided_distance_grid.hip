@@ -384,7 +384,7 @@ int sdg_run(hipStream_t st, int B, int N, int M, const float* p1, const float* p
 
 bool sdgrid_applicable(int B, int N, int M) {
   // below this the brute-force kernels are as fast as the launches of the grid pipeline
-  return B >= 1 && M >= 8192 && N >= 2048 && (long long)B * (long long)(M > N ? M : N) < (1ll << 30);
+  return B >= 1 && B <= 65535 && M >= 8192 && N >= 2048 && (long long)B * (long long)(M > N ? M : N) < (1ll << 30);
 }
 size_t sdgrid_workspace_bytes(int B, int N, int M) { return sdg_layout(nullptr, B, N, M, nullptr, nullptr, false).total; }
 
