@@ -173,7 +173,7 @@ def main():
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
     if dom and os.path.exists(tpath):
         # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, calibrated on launches of
-        # known size: tools/pmc_traffic.py, tools/parse_traffic.py, raw tables in profiles/r01h_pmc_*.txt)
+        # known size: tools/pmc_traffic.py, tools/parse_traffic.py, raw tables in profiles/r01i_pmc_*.txt)
         traffic = (json.load(open(tpath)).get(dom) or {}).get('hbm_bytes')
     roofline = None
     if dom and dom_n:
