@@ -9,7 +9,8 @@
 //   1. sdg_bbox      bounding box of the finite targets (per batch item): block minima / maxima merged with integer
 //                    atomicMax on an order-preserving encoding, so that consumers read six words;
 //   2. sdg_cells     cell id of every point and its rank inside the cell (the value the counting atomicAdd returns);
-//   3. sdg_scan      exclusive scan of the cell counts, one launch (every 1024-cell block sums the counts before it);
+//   3. sdg_scan      exclusive scan of the cell counts: one launch (every 1024-cell block sums the counts before it),
+//                    two on grids of more than 160 blocks;
 //   4. sdg_scatter   counting sort without further atomics: point -> start[cell] + rank, stored as float4
 //                    {x, y, z, original index};
 //   5. sdg_query     per query: seed with target 0 exactly as the reference does, then visit the cube of cells around
@@ -56,6 +57,8 @@ struct Cloud {
 
 struct SdgWs {
   Cloud a, b;           // a = p1 (N points), b = p2 (M points)
+  int* scan_sums;       // (2, B, blocks of 1024 cells): per-block totals, large grids only
+  int scan_blocks;
   size_t zero_bytes;    // prefix of the workspace that must be zeroed (counts + boxes)
   size_t total;
 };
@@ -87,6 +90,8 @@ inline SdgWs sdg_layout(void* base, int B, int N, int M, const float* p1, const 
   w.a.cellrank = (int2*)take((size_t)B * N * 8);
   w.b.sorted = (float4*)take((size_t)B * M * 16);
   w.a.sorted = (float4*)take((size_t)B * N * 16);
+  w.scan_blocks = (int)(((nca > ncb ? nca : ncb) + 1023) / 1024);
+  w.scan_sums = (int*)take((size_t)2 * B * w.scan_blocks * 4);
   w.total = off;
   return w;
 }
@@ -185,9 +190,25 @@ __global__ __launch_bounds__(256) void sdg_cells(Cloud X, Cloud Y) {
 }
 
 // ---- 3. exclusive scan of the counts: start[c] = points in cells < c, start[NC] = n ---------------------------------
-// one launch: a block owns 1024 cells and first adds up every count before them (<= 2M ints = 8 MB from L2 at the
-// largest grid, ~50k ints at 100k points), so there is no second pass and no inter-block dependency
-__global__ __launch_bounds__(1024) void sdg_scan(Cloud X, Cloud Y) {
+// a block owns 1024 cells and first needs the number of points before them.  Small grids (<= SDG_SCAN_DIRECT blocks,
+// i.e. clouds up to ~330k points): one launch, every block adds up the raw counts before it (block k reads k * 4 KB from
+// L2: 5 MB in total at 100k points) -- no second pass, no inter-block dependency.  Larger grids would make that
+// quadratic read matter (8 GB at the 128^3 grid), so a first launch leaves per-block totals and blocks add up those.
+constexpr int SDG_SCAN_DIRECT = 160;
+
+__global__ __launch_bounds__(1024) void sdg_scan_sums(Cloud X, Cloud Y, int* __restrict__ sums, int nblk) {
+  __shared__ int s_wave[16];
+  const bool first = blockIdx.z == 0;
+  const int G = first ? X.G : Y.G, NC = G * G * G;
+  const int base = blockIdx.x * 1024;
+  if (base >= NC || (first ? X.n : Y.n) == 0) return;
+  const int* cnt = (first ? X.count : Y.count) + (size_t)blockIdx.y * NC;
+  const int i = base + threadIdx.x;
+  const int tot = sdg_block_inclusive(i < NC ? cnt[i] : 0, s_wave);
+  if (threadIdx.x == 1023) sums[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * nblk + blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(1024) void sdg_scan(Cloud X, Cloud Y, const int* __restrict__ sums, int nblk) {
   __shared__ int s_wave[16];
   __shared__ int s_off;
   const bool first = blockIdx.z == 0;
@@ -197,7 +218,12 @@ __global__ __launch_bounds__(1024) void sdg_scan(Cloud X, Cloud Y) {
   const int* cnt = (first ? X.count : Y.count) + (size_t)blockIdx.y * NC;
   int* start = (first ? X.start : Y.start) + (size_t)blockIdx.y * (NC + 1);
   int part = 0;
-  for (int k = threadIdx.x; k < base; k += 1024) part += cnt[k];
+  if (sums != nullptr) {
+    const int* my = sums + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * nblk;
+    for (int k = threadIdx.x; k < (int)blockIdx.x; k += 1024) part += my[k];
+  } else {
+    for (int k = threadIdx.x; k < base; k += 1024) part += cnt[k];
+  }
   const int before = sdg_block_inclusive(part, s_wave);
   if (threadIdx.x == 1023) s_off = before;
   __syncthreads();
@@ -366,8 +392,13 @@ int sdg_run(hipStream_t st, int B, int N, int M, const float* p1, const float* p
     else  // the queries are binned on the targets' box
       hipLaunchKernelGGL(sdg_bbox_atomic, dim3(blocks(M), B), dim3(256), 0, st, w.b, none, blocks(M));
     hipLaunchKernelGGL(sdg_cells, dim3(kamd_cdiv(M, 256) + kamd_cdiv(N, 256), B), dim3(256), 0, st, w.b, w.a);
-    const int ncmax = (w.a.G > w.b.G ? w.a.G : w.b.G) * (w.a.G > w.b.G ? w.a.G : w.b.G) * (w.a.G > w.b.G ? w.a.G : w.b.G);
-    hipLaunchKernelGGL(sdg_scan, dim3(kamd_cdiv(ncmax, 1024), B, 2), dim3(1024), 0, st, w.b, w.a);
+    const dim3 scan_grid(w.scan_blocks, B, 2);
+    const int* sums = nullptr;
+    if (w.scan_blocks > SDG_SCAN_DIRECT) {
+      hipLaunchKernelGGL(sdg_scan_sums, scan_grid, dim3(1024), 0, st, w.b, w.a, w.scan_sums, w.scan_blocks);
+      sums = w.scan_sums;
+    }
+    hipLaunchKernelGGL(sdg_scan, scan_grid, dim3(1024), 0, st, w.b, w.a, sums, w.scan_blocks);
     hipLaunchKernelGGL(sdg_scatter, dim3(kamd_cdiv(M, 256) + kamd_cdiv(N, 256), B), dim3(256), 0, st, w.b, w.a);
   }
   KAMD_CHECK(hipGetLastError());

@@ -406,3 +406,24 @@ def test_chamfer_single_node_equals_composition(shape, squared):
         g2b, g2a = oracle.sided_distance_backward((up.cpu() * 3 / M)[:, None].expand(B, M).contiguous(), p2, p1, i2r)
         assert _scale_close(a.grad.cpu(), g1a + g2a)
         assert _scale_close(b.grad.cpu(), g1b + g2b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['uniform', 'surface'])
+def test_grid_search_large_clouds(kind):
+    """Clouds above ~330k points use the two-launch cell scan (more than 160 blocks of 1024 cells).  One direction
+    against the oracle; both directions from the single binning pass against the oracle on a slice of the queries and
+    against the one-direction path on all of them."""
+    from kaolin_amd import _C
+    pc = _pc()
+    p1, p2 = _clouds(kind, 1, 350000, 400000, seed=11)
+    d_ref, i_ref = oracle.sided_distance_forward(p1[:, :3000].contiguous(), p2, omp=True)
+    d, i = pc.sided_distance(p1[:, :3000].contiguous().cuda(), p2.cuda())
+    assert torch.equal(i.cpu(), i_ref) and torch.equal(d.cpu(), d_ref)
+    d1, i1, d2, i2 = _C.metrics.sided_distance_pair_forward(p1.cuda(), p2.cuda())
+    assert torch.equal(i1[:, :3000].cpu(), i_ref) and torch.equal(d1[:, :3000].cpu(), d_ref)
+    d_ref2, i_ref2 = oracle.sided_distance_forward(p2[:, -3000:].contiguous(), p1, omp=True)
+    assert torch.equal(i2[:, -3000:].cpu(), i_ref2) and torch.equal(d2[:, -3000:].cpu(), d_ref2)
+    s1, j1 = pc.sided_distance(p1.cuda(), p2.cuda())
+    s2, j2 = pc.sided_distance(p2.cuda(), p1.cuda())
+    assert torch.equal(j1, i1) and torch.equal(s1, d1) and torch.equal(j2, i2) and torch.equal(s2, d2)
