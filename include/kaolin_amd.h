@@ -127,6 +127,8 @@ int kamd_packed_rasterize_forward_f64(void* stream, int B, int H, int W, int D,
 /* img (B,F,3,2) UNSCALED, feat (B,F,3,D), face_idx (B,H,W) mesh-relative.    */
 /* g_img (B,F,3,2), g_feat (B,F,3,D) are accumulated (caller zeroes them).    */
 /* Works for any B*H*W >= 1 (the reference launches 0 blocks below 512 px).   */
+/* g_feat may be NULL when the caller does not need the feature gradient      */
+/* (autograd's needs_input_grad): it is then not computed.                     */
 int kamd_rasterize_backward_f32(void* stream, int B, int H, int W, int F, int D,
                                 const float* grad, const int64_t* face_idx,
                                 const float* weights, const float* img, const float* feat,
@@ -268,7 +270,8 @@ int kamd_dibr_soft_mask_forward_fused_f64(void* stream, int B, int H, int W, int
 /* other (soft-mask binning vs. rasterizer; the two backward kernels) are     */
 /* enqueued on an internal side stream forked from / joined to `stream` with  */
 /* events, so the call is still stream-ordered for the caller.  g_img         */
-/* (zeroed by the caller) receives BOTH gradient contributions.               */
+/* (zeroed by the caller) receives BOTH gradient contributions; g_feat may be  */
+/* NULL (feature gradient not needed: not computed).                          */
 /* ------------------------------------------------------------------------- */
 int kamd_dibr_rasterization_forward_f32(void* stream, int B, int H, int W, int F, int D, int K,
                                         const float* z, int64_t z_face_stride, int64_t z_vertex_stride,

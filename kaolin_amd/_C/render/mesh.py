@@ -50,8 +50,9 @@ def packed_rasterize_forward_cuda(height, width, face_vertices_z, face_vertices_
 
 
 def rasterize_backward_cuda(grad_interpolated_features, interpolated_features, selected_face_idx, output_weights,
-                            face_vertices_image, face_features, eps):
-    """reference: rasterization.cpp:106-168 -> [grad_face_vertices_image (B,F,3,2), grad_face_features (B,F,3,D)]"""
+                            face_vertices_image, face_features, eps, need_feature_grad=True):
+    """reference: rasterization.cpp:106-168 -> [grad_face_vertices_image (B,F,3,2), grad_face_features (B,F,3,D)].
+    ``need_feature_grad=False`` (not in the reference; autograd's ``needs_input_grad``) skips the second one -> None."""
     fn = 'rasterize_backward_cuda'
     args = [Arg(grad_interpolated_features, 'grad_interpolated_features', 1),
             Arg(interpolated_features, 'interpolated_features', 2),
@@ -73,7 +74,7 @@ def rasterize_backward_cuda(grad_interpolated_features, interpolated_features, s
     lib = _lib.load()
     with torch.cuda.device(device):
         g_img = torch.zeros_like(face_vertices_image)
-        g_feat = torch.zeros_like(face_features)
+        g_feat = torch.zeros_like(face_features) if need_feature_grad else None
         st = getattr(lib, f'kamd_rasterize_backward_{sfx}')(
             _lib.stream_ptr(device), batch_size, height, width, num_faces, feat_dim,
             _lib.ptr(grad_interpolated_features), _lib.ptr(selected_face_idx), _lib.ptr(output_weights),
@@ -386,9 +387,11 @@ def dibr_rasterization_forward_fused(height, width, face_vertices_z, face_vertic
 
 
 def dibr_rasterization_backward_fused(grad_features, grad_soft_mask, face_idx, output_weights, soft_mask, hits,
-                                      face_vertices_image, face_features, sigmainv, knum, multiplier, eps):
+                                      face_vertices_image, face_features, sigmainv, knum, multiplier, eps,
+                                      need_feature_grad=True):
     """Backward of :func:`dibr_rasterization_forward_fused`: the rasterizer's and the soft mask's backward kernels run
-    concurrently and accumulate into ONE grad_face_vertices_image. -> (grad_face_vertices_image, grad_face_features)"""
+    concurrently and accumulate into ONE grad_face_vertices_image. -> (grad_face_vertices_image, grad_face_features);
+    ``need_feature_grad=False`` (static features: autograd's ``needs_input_grad``) skips the second one -> None."""
     fn = 'dibr_rasterization_backward_fused'
     args = [Arg(grad_features, 'grad_features', 1), Arg(grad_soft_mask, 'grad_soft_mask', 2), Arg(face_idx, 'face_idx', 3),
             Arg(output_weights, 'output_weights', 4), Arg(soft_mask, 'soft_mask', 5),
@@ -407,7 +410,7 @@ def dibr_rasterization_backward_fused(grad_features, grad_soft_mask, face_idx, o
     lib = _lib.load()
     with torch.cuda.device(device):
         g_img = torch.zeros_like(face_vertices_image)
-        g_feat = torch.zeros_like(face_features)
+        g_feat = torch.zeros_like(face_features) if need_feature_grad else None
         st = getattr(lib, f'kamd_dibr_rasterization_backward_{sfx}')(
             _lib.stream_ptr(device), batch_size, height, width, num_faces, feat_dim, int(knum),
             _lib.ptr(grad_features), _lib.ptr(grad_soft_mask), _lib.ptr(face_idx), _lib.ptr(output_weights),

@@ -88,7 +88,8 @@ class DibrRasterizationCuda(torch.autograd.Function):
             grad_soft_mask = torch.zeros_like(soft_mask)
         g_img, g_feat = _C.render.mesh.dibr_rasterization_backward_fused(
             grad_feats.contiguous(), grad_soft_mask.contiguous(), face_idx, weights, soft_mask, ctx.saved_tensors[5:],
-            face_vertices_image, face_features, sigmainv, knum, multiplier, eps)
+            face_vertices_image, face_features, sigmainv, knum, multiplier, eps,
+            need_feature_grad=ctx.needs_input_grad[4])
         return None, None, None, g_img, g_feat, None, None, None, None, None, None
 
 

@@ -39,7 +39,7 @@ class RasterizeCuda(torch.autograd.Function):
         interpolated_features, face_idx, output_weights, face_vertices_image, face_features = ctx.saved_tensors
         grad_img, grad_feat = _C.render.mesh.rasterize_backward_cuda(
             grad_interpolated_features.contiguous(), interpolated_features, face_idx, output_weights,
-            face_vertices_image, face_features, ctx.eps)
+            face_vertices_image, face_features, ctx.eps, need_feature_grad=ctx.needs_input_grad[4])
         return None, None, None, grad_img, grad_feat, None, None, None
 
 

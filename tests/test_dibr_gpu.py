@@ -384,3 +384,30 @@ def test_dibr_rasterization_reads_views_in_place(dtype):
         assert torch.equal(x, y)
     assert torch.equal(a[2], idx) and torch.equal(a[0], feats) and torch.equal(a[1], soft)
     assert int((idx >= 0).sum()) > 0
+
+
+@pytest.mark.parametrize('D', [3, 5])
+def test_static_features_skip_their_gradient(D):
+    """autograd's needs_input_grad: with face_features that do not require grad (static texture coordinates) the
+    backward kernels merge only the image-coordinate terms (g_feat = NULL at the C ABI).  The vertex gradient must be
+    the one obtained when the features do require grad, through `rasterize` and through `dibr_rasterization`."""
+    fz, fimg, feats, nz = _scene(10, 2, torch.float)
+    torch.manual_seed(D)
+    feat = torch.rand(feats[0].shape[:-1] + (D,))
+    H, W = 96, 80
+    up = torch.rand(2, H, W, D).cuda()
+    up_soft = torch.rand(2, H, W).cuda()
+    for name in ('rasterize', 'dibr_rasterization'):
+        grads = []
+        for needs in (True, False):
+            a = fimg.cuda().requires_grad_()
+            f = feat.cuda().requires_grad_(needs)
+            if name == 'rasterize':
+                out, _ = kal().render.mesh.rasterize(H, W, fz.cuda(), a, f, (nz >= 0).cuda())
+                out.backward(up)
+            else:
+                out, soft, _ = kal().render.mesh.dibr_rasterization(H, W, fz.cuda(), a, f, nz.cuda())
+                ((out * up).sum() + (soft * up_soft).sum()).backward()
+            assert (f.grad is not None) == needs
+            grads.append(a.grad.clone())
+        assert rel_close(grads[1], grads[0], 1e-5), name
