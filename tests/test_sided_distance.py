@@ -196,6 +196,15 @@ def test_empty_target_keeps_zeros():
     assert float(d.abs().max()) == 0. and int(i.abs().max()) == 0
 
 
+def test_argument_errors_of_the_pair_search_read_as_the_reference_operator():
+    """chamfer_distance's fused search checks its arguments before touching the library (runs without a GPU); the
+    messages name the operator the reference's chamfer_distance fails in (sided_distance_forward_cuda)."""
+    from kaolin_amd import _C
+    with pytest.raises(RuntimeError, match=r"Tensor for argument #1 'p1' is on CPU, Tensor for argument #2 'p2' is on CPU, "
+                                           r"but expected it to be on GPU \(while checking arguments for sided_distance_forward_cuda\)"):
+        _C.metrics.sided_distance_pair_forward(torch.rand(1, 4, 3), torch.rand(1, 5, 3))
+
+
 @pytest.mark.gpu
 def test_error_strings():
     """ATen checkSize/checkSameGPU/checkSameType texts the reference's tests regex-match
