@@ -320,7 +320,8 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'C4: dibr_rasterization fwd+bwd, {V} views/GPU at {H}x{W} of a {F}-triangle geodesic '
-                                   f'sphere (shared vertices), D=3 features, knum=30, sigmainv=7000, boxlen=0.02, '
+                                   f'sphere (shared vertices), D=3 static face features (uv + mask channel; gradient w.r.t. the vertices only), '
+                                   f'knum=30, sigmainv=7000, boxlen=0.02, '
                                    f'prepare_vertices + vertex-gradient all-reduce inside the step',
                        'views_per_gpu': V, 'global_views': V * world, 'height': H, 'width': W, 'faces': F,
                        'covered_pixel_fraction': round(covered, 4), 'parallelism': f'views sharded {world}-way'},
