@@ -68,6 +68,23 @@ def algorithmic_bytes(kernel, B, P, F, Fv, D, K, esz=4):
     return B * per[kernel] if kernel in per else None
 
 
+# kernels of the fused DIB-R operator that share the GPU with a concurrent launch in the timed region
+OVERLAPPED = {'raster_tile_kernel', 'bin_faces_kernel', 'raster_backward_kernel', 'soft_mask_backward_list_kernel'}
+
+
+def pick_dominant(kernels):
+    """Name of the kernel the roofline line describes: the largest share of the instrumented step among the kernels with
+    an algorithmic byte count; shares within 5 % of each other (raster_tile and soft_search tie) are resolved towards a
+    kernel that runs alone on the stream in the timed region, so that its event pair times that kernel only."""
+    ranked = sorted((k for k in kernels if kernels[k]['algorithmic_GBps'] is not None),
+                    key=lambda k: -kernels[k]['share_of_instrumented_step'])
+    if not ranked:
+        return None
+    top = kernels[ranked[0]]['share_of_instrumented_step']
+    near = [k for k in ranked if kernels[k]['share_of_instrumented_step'] >= 0.95 * top]
+    return next((k for k in near if k not in OVERLAPPED), ranked[0])
+
+
 def main():
     args = parse()
     D.init_from_env()
@@ -149,13 +166,7 @@ def main():
         kernels[name] = {'avg_us': round(avg_us, 2), 'launches_per_step': round(n / args.steps, 2),
                          'share_of_instrumented_step': round(ms / args.steps / inst_ms_per_step, 4),
                          'algorithmic_GBps': None if ab is None else round(ab / (avg_us * 1e-6) / 1e9, 1)}
-    # the dominant kernel; shares within 5 % of each other (raster_tile and soft_search tie) are resolved towards a
-    # kernel that runs alone on the stream in the timed region, so that its event pair times that kernel only
-    overlapped = {'raster_tile_kernel', 'bin_faces_kernel', 'raster_backward_kernel', 'soft_mask_backward_list_kernel'}
-    ranked = sorted((k for k in kernels if kernels[k]['algorithmic_GBps'] is not None),
-                    key=lambda k: -kernels[k]['share_of_instrumented_step'])
-    near = [k for k in ranked if kernels[k]['share_of_instrumented_step'] >= 0.95 * kernels[ranked[0]]['share_of_instrumented_step']]
-    dom = next((k for k in near if k not in overlapped), ranked[0] if ranked else None)
+    dom = pick_dominant(kernels)
 
     lib.kamd_profile_reset()
     lib.kamd_profile_select(kernel_ids.get(dom, -1) if dom else -1)

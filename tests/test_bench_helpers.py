@@ -1,0 +1,37 @@
+"""Host-side helpers of bench.py that decide what the one JSON line reports (no GPU needed)."""
+import importlib.util
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location('bench', os.path.join(ROOT, 'bench.py'))
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
+
+
+def _k(share, gbps=100.0):
+    return {'share_of_instrumented_step': share, 'algorithmic_GBps': gbps}
+
+
+def test_dominant_kernel_is_the_largest_share_with_a_byte_count():
+    kernels = {'raster_backward_kernel': _k(0.30), 'soft_search_kernel': _k(0.16), 'pv_forward_kernel': _k(0.5, None)}
+    assert bench.pick_dominant(kernels) == 'raster_backward_kernel'
+    assert bench.pick_dominant({'pv_forward_kernel': _k(0.5, None)}) is None
+    assert bench.pick_dominant({}) is None
+
+
+def test_near_ties_go_to_a_kernel_that_is_alone_on_the_stream():
+    kernels = {'raster_tile_kernel': _k(0.1567), 'soft_search_kernel': _k(0.1547), 'soft_classify_kernel': _k(0.07)}
+    assert bench.pick_dominant(kernels) == 'soft_search_kernel'
+    kernels['soft_search_kernel'] = _k(0.14)                     # more than 5 % behind: no tie any more
+    assert bench.pick_dominant(kernels) == 'raster_tile_kernel'
+    only_overlapped = {'raster_tile_kernel': _k(0.2), 'raster_backward_kernel': _k(0.199)}
+    assert bench.pick_dominant(only_overlapped) == 'raster_tile_kernel'
+
+
+def test_algorithmic_bytes_follow_the_survey_per_unit_figures():
+    """SURVEY 8(d) per-unit figures x the units one launch processes: spot values at C4."""
+    B, P, F, Fv = 8, 1024 * 1024, 50000, 25000
+    assert bench.algorithmic_bytes('soft_search_kernel', B, P, F, Fv, 3, 30) == B * (P * 12 + F * 40)
+    assert bench.algorithmic_bytes('soft_classify_kernel', B, P, F, Fv, 3, 30) == B * P * 12
+    assert bench.algorithmic_bytes('fill_regions_kernel', B, P, F, Fv, 3, 30) == B * P * 30 * 13
+    assert bench.algorithmic_bytes('pv_forward_kernel', B, P, F, Fv, 3, 30) is None
