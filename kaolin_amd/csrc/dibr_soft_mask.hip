@@ -776,7 +776,10 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
     KAMD_CHECK(hipGetLastError());
     if (total_faces > 0) {
       kamd::ProfScope prof_(kamd::K_SOFT_TILE, st);
-      const dim3 grid((unsigned)(n_sub < KAMD_NUM_CU * 16 ? n_sub : KAMD_NUM_CU * 16));
+      static const int per_cu_lean = kamd_resident_blocks_per_cu(soft_search_kernel<T, true>, 64, 8, 16);
+      static const int per_cu_full = kamd_resident_blocks_per_cu(soft_search_kernel<T, false>, 64, 8, 16);
+      const int resident = KAMD_NUM_CU * (lean ? per_cu_lean : per_cu_full);
+      const dim3 grid((unsigned)(n_sub < resident ? n_sub : resident));
       if (lean)
         hipLaunchKernelGGL((soft_search_kernel<T, true>), grid, dim3(64), 0, st, B, F, g, K, sigmainv, multiplier, rec,
                            masks, worklist, work, cand, cand_count, sel_idx, soft_mask, (T*)nullptr, (int64_t*)nullptr,
@@ -797,7 +800,8 @@ int soft_mask_backward_list_launch(hipStream_t st, int B, int H, int W, int F, i
   if ((long long)B * H * W <= 0 || F <= 0) return 0;
   {
     kamd::ProfScope prof_(kamd::K_SOFT_BACKWARD_LIST, st);
-    hipLaunchKernelGGL(soft_mask_backward_list_kernel<T>, dim3(KAMD_NUM_CU * 10), dim3(SL_THREADS), 0, st, H, W, F, K, grad,
+    static const int per_cu = kamd_resident_blocks_per_cu(soft_mask_backward_list_kernel<T>, SL_THREADS, 5, 10);
+    hipLaunchKernelGGL(soft_mask_backward_list_kernel<T>, dim3(KAMD_NUM_CU * per_cu), dim3(SL_THREADS), 0, st, H, W, F, K, grad,
                        soft_mask, list, img, (T)img_scale, sigmainv, multiplier, g_img);
   }
   KAMD_RETURN_LAST_ERROR();
