@@ -55,3 +55,25 @@ def test_no_product_import_of_oracle():
             if f.endswith('.py') and re.search(r'^\s*(import|from)\s+oracle\b', open(os.path.join(d, f)).read(), re.M):
                 bad.append(f)
     assert not bad
+
+
+def test_workspace_queries_are_host_only_and_shape_driven():
+    """The *_workspace entry points are pure host arithmetic (callable without a GPU): sizes grow with the problem, and
+    0 tells the shim that a path does not apply (it then takes the other one)."""
+    from kaolin_amd import _lib
+    lib = _lib.load()
+    sd = lib.kamd_sided_distance_forward_workspace
+    pair = lib.kamd_sided_distance_pair_forward_workspace
+    assert sd(1, 100000, 100000, 4) > 0 and sd(2, 100000, 100000, 4) > sd(1, 100000, 100000, 4)
+    assert sd(1, 100000, 100000, 8) == 0                          # fp64: the generic kernel needs no scratch
+    assert sd(0, 10, 10, 4) == 0 and sd(1, 0, 10, 4) == 0
+    # both directions from one binning pass: both clouds must be large enough for the grid search, fp32 only
+    assert pair(1, 100000, 100000, 4) > 0
+    assert pair(1, 100, 100000, 4) == 0 and pair(1, 100000, 100, 4) == 0 and pair(1, 100000, 100000, 8) == 0
+    assert pair(70000, 8192, 8192, 4) == 0                        # batch beyond the launch grid's y extent
+    assert pair(1, 8192, 4000000, 4) > pair(1, 8192, 400000, 4)
+    assert lib.kamd_rasterize_forward_workspace(8, 1024, 1024, 400000, 4) > \
+        lib.kamd_rasterize_forward_workspace(1, 1024, 1024, 50000, 4) > 0
+    assert lib.kamd_rasterize_forward_workspace(1, 0, 1024, 50000, 4) == 0
+    assert lib.kamd_trianglemeshes_to_voxelgrids_workspace(1, 30000, 4) > 0
+    assert lib.kamd_deftet_forward_workspace(1, 50000, 4096, 4) > 0
