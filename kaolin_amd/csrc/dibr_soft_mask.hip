@@ -800,8 +800,9 @@ int soft_mask_backward_list_launch(hipStream_t st, int B, int H, int W, int F, i
   if ((long long)B * H * W <= 0 || F <= 0) return 0;
   {
     kamd::ProfScope prof_(kamd::K_SOFT_BACKWARD_LIST, st);
-    static const int per_cu = kamd_resident_blocks_per_cu(soft_mask_backward_list_kernel<T>, SL_THREADS, 5, 10);
-    hipLaunchKernelGGL(soft_mask_backward_list_kernel<T>, dim3(KAMD_NUM_CU * per_cu), dim3(SL_THREADS), 0, st, H, W, F, K, grad,
+    // (10 per CU although 6 fit: in the fused backward this kernel shares the GPU with raster_backward, whose one-shot
+    // workgroups need the slots the surplus leaves free at the start; a one-resident-set grid is unmeasured there)
+    hipLaunchKernelGGL(soft_mask_backward_list_kernel<T>, dim3(KAMD_NUM_CU * 10), dim3(SL_THREADS), 0, st, H, W, F, K, grad,
                        soft_mask, list, img, (T)img_scale, sigmainv, multiplier, g_img);
   }
   KAMD_RETURN_LAST_ERROR();
