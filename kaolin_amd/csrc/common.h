@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <math.h>
+#include <stdlib.h>
 
 #define KAMD_WAVE 64
 #define KAMD_NUM_CU 256
@@ -67,6 +68,13 @@ static inline int kamd_resident_blocks_per_cu(Kernel kernel, int threads, int lo
     nb = hi;
   }
   return nb < lo ? lo : (nb > hi ? hi : nb);
+}
+// measurement knob: an integer from the environment (grid sweeps on the GPU box), `dflt` when unset or not positive
+static inline int kamd_env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  if (v == nullptr || *v == 0) return dflt;
+  const int x = atoi(v);
+  return x > 0 ? x : dflt;
 }
 
 // ---- fills -------------------------------------------------------------------------------------------------------------

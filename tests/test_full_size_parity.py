@@ -1,0 +1,101 @@
+"""Oracle parity AT the headline shapes of BASELINE.json:
+
+* C4: one 1024x1024 view of the 50 000-triangle geodesic sphere through ``dibr_rasterization`` -- ``face_idx``
+  bit-exact, interpolated features bit-exact (same IEEE operations in the same order), ``soft_mask`` and both
+  gradients within 1e-5 relative (reference tests: tests/python/kaolin/render/mesh/test_rasterization.py:146-158,
+  test_dibr.py:495-529).  The OpenMP oracle needs a few seconds per view on the GPU box's host cores.
+* C3: chamfer / sided distance at exactly 100 000 x 100 000 points -- a 4 096-query slice of either direction
+  bit-exact against the all-pairs oracle (distance and index), and the gradient of ``chamfer_distance`` against the
+  oracle's backward on the full clouds (the nearest indices come from the GPU forward, themselves checked on the slices).
+"""
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def kal():
+    import kaolin_amd
+    return kaolin_amd
+
+
+def rel_close(a, b, tol=1e-5):
+    a, b = a.double().cpu(), b.double().cpu()
+    scale = max(float(b.abs().max()), 1e-30)
+    return float((a - b).abs().max()) <= tol * scale
+
+
+@pytest.mark.parametrize('view', [0, 5])
+def test_c4_one_view_1024_vs_oracle(view):
+    from kaolin_amd.utils import testing as T
+    H = W = 1024
+    fz, fimg, feats, nz = T.sphere_scene(level=50, num_views=8, device='cpu')
+    fz, fimg, nz = fz[view:view + 1].contiguous(), fimg[view:view + 1].contiguous(), nz[view:view + 1].contiguous()
+    feat = torch.cat([f[view:view + 1] for f in feats], -1).contiguous()
+    ref = oracle.dibr_rasterization(H, W, fz, fimg, feat, nz, omp=True)
+    a = fimg.cuda().requires_grad_()
+    f = feat.cuda().requires_grad_()
+    out, soft, face_idx = kal().render.mesh.dibr_rasterization(H, W, fz.cuda(), a, f, nz.cuda())
+    assert torch.equal(face_idx.cpu(), ref['face_idx'])
+    assert 0.15 < float((face_idx >= 0).float().mean()) < 0.25
+    assert torch.equal(out.detach().cpu(), ref['features'])
+    assert rel_close(soft.detach(), ref['soft_mask'], 1e-5)
+    # the silhouette band is where the soft mask is neither 0 nor 1: it must exist and agree pixel for pixel
+    band = (ref['soft_mask'] > 0) & (ref['soft_mask'] < 1)
+    assert int(band.sum()) > 10000
+    assert torch.equal((soft.detach().cpu() > 0) & (soft.detach().cpu() < 1), band)
+    g = torch.Generator().manual_seed(7)
+    g_feat_out = torch.rand(out.shape, generator=g)
+    g_soft_out = torch.rand(soft.shape, generator=g)
+    ((out * g_feat_out.cuda()).sum() + (soft * g_soft_out.cuda()).sum()).backward()
+    r_img, r_feat = oracle.rasterize_backward(g_feat_out, ref['face_idx'], ref['weights'], fimg, feat, 1e-8)
+    r_soft = oracle.dibr_soft_mask_backward(g_soft_out, ref['soft_mask'], ref['face_idx'], ref['close_face_prob'],
+                                            ref['close_face_idx'], ref['close_face_dist_type'], ref['scaled_vertices'],
+                                            7000, 1000.)
+    assert rel_close(f.grad, r_feat, 1e-5)
+    assert rel_close(a.grad, r_img + r_soft, 1e-5)
+
+
+def test_c4_kbuffer_operator_1024_vs_oracle():
+    """The reference-contract soft-mask operator (K-buffers) at 1024^2 / 50k faces: idx and type bit-exact, prob 1e-5."""
+    from kaolin_amd.utils import testing as T
+    H = W = 1024
+    fz, fimg, feats, nz = T.sphere_scene(level=50, num_views=8, device='cpu')
+    v = 2
+    fz, fimg, nz = fz[v:v + 1].contiguous(), fimg[v:v + 1].contiguous(), nz[v:v + 1].contiguous()
+    feat = torch.cat([f[v:v + 1] for f in feats], -1).contiguous()
+    ref = oracle.dibr_rasterization(H, W, fz, fimg, feat, nz, omp=True)
+    m = kal()._C.render.mesh
+    scaled = ref['scaled_vertices'].cuda()
+    bbox = torch.cat([scaled.min(dim=-2)[0] - 0.02 * 1000., scaled.max(dim=-2)[0] + 0.02 * 1000.], -1)
+    soft, prob, idx, typ = m.dibr_soft_mask_forward_cuda(scaled, bbox, ref['face_idx'].cuda(), 7000., 30, 1000.)
+    assert torch.equal(idx.cpu(), ref['close_face_idx'])
+    assert torch.equal(typ.cpu(), ref['close_face_dist_type'])
+    assert rel_close(prob, ref['close_face_prob'], 1e-5) and rel_close(soft, ref['soft_mask'], 1e-5)
+
+
+def test_c3_chamfer_100k_x_100k_vs_oracle():
+    pc = kal().metrics.pointcloud
+    n = 100000
+    g = torch.Generator().manual_seed(0)            # config C3, batch item 0
+    p1 = torch.rand((1, n, 3), generator=g)
+    p2 = torch.rand((1, n, 3), generator=g)
+    a, b = p1.cuda().requires_grad_(), p2.cuda().requires_grad_()
+    d12, i12 = pc.sided_distance(a, b)
+    d21, i21 = pc.sided_distance(b, a)
+    sl = torch.randperm(n, generator=g)[:4096]
+    r_d, r_i = oracle.sided_distance_forward(p1[:, sl], p2, omp=True)
+    assert torch.equal(i12[:, sl.cuda()].cpu(), r_i) and torch.equal(d12[:, sl.cuda()].detach().cpu(), r_d)
+    r_d, r_i = oracle.sided_distance_forward(p2[:, sl], p1, omp=True)
+    assert torch.equal(i21[:, sl.cuda()].cpu(), r_i) and torch.equal(d21[:, sl.cuda()].detach().cpu(), r_d)
+    # chamfer_distance = mean(d12) + mean(d21) (reference: kaolin/metrics/pointcloud.py:89-136) and its gradient
+    loss = pc.chamfer_distance(a, b)
+    ref_loss = d12.detach().double().mean() + d21.detach().double().mean()
+    assert abs(float(loss) - float(ref_loss)) <= 1e-5 * float(ref_loss)
+    loss.sum().backward()
+    w = torch.full((1, n), 1.0 / n)
+    g1a, g2a = oracle.sided_distance_backward(w, p1, p2, i12.cpu())
+    g2b, g1b = oracle.sided_distance_backward(w, p2, p1, i21.cpu())
+    assert rel_close(a.grad, g1a + g1b, 1e-5) and rel_close(b.grad, g2a + g2b, 1e-5)
