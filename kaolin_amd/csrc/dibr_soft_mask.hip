@@ -777,8 +777,8 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
     KAMD_CHECK(hipGetLastError());
     if (total_faces > 0) {
       kamd::ProfScope prof_(kamd::K_SOFT_TILE, st);
-      static const int per_cu_lean = kamd_env_int("KAMD_SOFT_SEARCH_PER_CU", kamd_resident_blocks_per_cu(soft_search_kernel<T, true>, 64, 8, 16));
-      static const int per_cu_full = kamd_env_int("KAMD_SOFT_SEARCH_PER_CU", kamd_resident_blocks_per_cu(soft_search_kernel<T, false>, 64, 8, 16));
+      static const int per_cu_lean = kamd_env_int("KAMD_SOFT_SEARCH_PER_CU", 24);
+      static const int per_cu_full = kamd_env_int("KAMD_SOFT_SEARCH_PER_CU", 24);
       if (getenv("KAMD_VERBOSE")) fprintf(stderr, "[kamd] soft_search per CU: lean %d full %d\n", per_cu_lean, per_cu_full);
       const int resident = KAMD_NUM_CU * (lean ? per_cu_lean : per_cu_full);
       const dim3 grid((unsigned)(n_sub < resident ? n_sub : resident));
@@ -804,7 +804,7 @@ int soft_mask_backward_list_launch(hipStream_t st, int B, int H, int W, int F, i
     kamd::ProfScope prof_(kamd::K_SOFT_BACKWARD_LIST, st);
     // (10 per CU although 6 fit: in the fused backward this kernel shares the GPU with raster_backward, whose one-shot
     // workgroups need the slots the surplus leaves free at the start; a one-resident-set grid is unmeasured there)
-    hipLaunchKernelGGL(soft_mask_backward_list_kernel<T>, dim3(KAMD_NUM_CU * kamd_env_int("KAMD_SOFT_BWD_PER_CU", 10)), dim3(SL_THREADS), 0, st, H, W, F, K, grad,
+    hipLaunchKernelGGL(soft_mask_backward_list_kernel<T>, dim3(KAMD_NUM_CU * kamd_env_int("KAMD_SOFT_BWD_PER_CU", 16)), dim3(SL_THREADS), 0, st, H, W, F, K, grad,
                        soft_mask, list, img, (T)img_scale, sigmainv, multiplier, g_img);
   }
   KAMD_RETURN_LAST_ERROR();
