@@ -149,18 +149,20 @@ int kamd_rasterize_backward_f64(void* stream, int B, int H, int W, int F, int D,
 /* hit_count (B,H,W) uint8 is OPTIONAL (NULL = not produced; not part of the  */
 /* reference's interface): number of K-buffer entries written per pixel,      */
 /* saturated at 255; the backward uses it to skip pixels without hits.        */
+/* work: kamd_dibr_soft_mask_work_words(B,H,W) 32-bit words receiving the      */
+/* search's worklist (scratch for this operator).                             */
 /* ------------------------------------------------------------------------- */
 size_t kamd_dibr_soft_mask_forward_workspace(int B, int H, int W, int F, int elem_size);
 int kamd_dibr_soft_mask_forward_f32(void* stream, int B, int H, int W, int F, int K,
                                     const float* img, const float* large_bbox,
                                     const int64_t* sel_idx, float sigmainv, float multiplier,
                                     float* soft_mask, float* prob, int64_t* idx, uint8_t* type,
-                                    void* workspace, uint8_t* hit_count);
+                                    void* workspace, uint8_t* hit_count, uint32_t* work);
 int kamd_dibr_soft_mask_forward_f64(void* stream, int B, int H, int W, int F, int K,
                                     const double* img, const double* large_bbox,
                                     const int64_t* sel_idx, float sigmainv, float multiplier,
                                     double* soft_mask, double* prob, int64_t* idx, uint8_t* type,
-                                    void* workspace, uint8_t* hit_count);
+                                    void* workspace, uint8_t* hit_count, uint32_t* work);
 
 /* render.mesh.dibr_soft_mask_backward_cuda(grad, soft_mask, sel_idx, prob,   */
 /*     idx, type, img*mult, sigmainv, multiplier) -> g_img                    */
@@ -182,30 +184,35 @@ int kamd_dibr_soft_mask_backward_f64(void* stream, int B, int H, int W, int F, i
 /* Compact-list variant used by this package's own autograd Function (not part  */
 /* of the reference's interface): same search, same soft_mask, but instead of   */
 /* the (B,H,W,K) K-buffers every accepted (pixel, face) hit is appended to four */
-/* parallel arrays (capacity B*H*W*K entries).  The list is SEGMENTED: work item */
-/* i (a 16x4-pixel sub-tile that has hits to search) owns the records            */
-/* [i*64*K, i*64*K + item_count[i]); *n_items receives the number of work items. */
-/* item_count holds ceil(W/32)*ceil(H/32)*16*B ints.  No shared append counter:  */
-/* ~20k same-address atomics per step would serialise.  Requires B*H*W < 2^31.   */
-/* Records each of the four hit arrays must hold (64*K per 16x4-pixel sub-tile). */
+/* parallel arrays.  The list is SEGMENTED: a work item (a 16x4-pixel sub-tile    */
+/* that has hits to search), identified by item = (32x32 tile * B + b) * 16 +    */
+/* sub-tile, owns the records [item*64*K, item*64*K + item_count[item]), stored  */
+/* FACE-MAJOR (the pixels of one face are consecutive).  item_count holds        */
+/* ceil(W/32)*ceil(H/32)*16*B ints.  `work` (kamd_dibr_soft_mask_work_words      */
+/* 32-bit words) receives the worklist: 8 sharded item counters, then the items  */
+/* {item, uncovered-pixel mask}; the backward walks it.  No shared append        */
+/* counter for the hits: ~20k same-address atomics per step would serialise.     */
+/* Requires B*H*W < 2^31.                                                        */
+/* Records each of the four hit arrays must hold (64*K per sub-tile slot).       */
 size_t kamd_dibr_soft_mask_lean_capacity(int B, int H, int W, int K);
+size_t kamd_dibr_soft_mask_work_words(int B, int H, int W);
 int kamd_dibr_soft_mask_forward_lean_f32(void* stream, int B, int H, int W, int F, int K,
                                          const float* img, const float* large_bbox,
                                          const int64_t* sel_idx, float sigmainv, float multiplier,
                                          float* soft_mask, int32_t* hit_pix, int32_t* hit_face,
                                          float* hit_prob, uint8_t* hit_type, int32_t* item_count,
-                                         uint32_t* n_items, void* workspace);
+                                         uint32_t* work, void* workspace);
 int kamd_dibr_soft_mask_forward_lean_f64(void* stream, int B, int H, int W, int F, int K,
                                          const double* img, const double* large_bbox,
                                          const int64_t* sel_idx, float sigmainv, float multiplier,
                                          double* soft_mask, int32_t* hit_pix, int32_t* hit_face,
                                          double* hit_prob, uint8_t* hit_type, int32_t* item_count,
-                                         uint32_t* n_items, void* workspace);
+                                         uint32_t* work, void* workspace);
 int kamd_dibr_soft_mask_backward_lean_f32(void* stream, int B, int H, int W, int F, int K,
                                           const float* grad, const float* soft_mask,
                                           const int32_t* hit_pix, const int32_t* hit_face,
                                           const float* hit_prob, const uint8_t* hit_type,
-                                          const int32_t* item_count, const uint32_t* n_items,
+                                          const int32_t* item_count, const uint32_t* work,
                                           const float* img,
                                           double img_scale, float sigmainv, float multiplier,
                                           float* g_img);
@@ -213,7 +220,7 @@ int kamd_dibr_soft_mask_backward_lean_f64(void* stream, int B, int H, int W, int
                                           const double* grad, const double* soft_mask,
                                           const int32_t* hit_pix, const int32_t* hit_face,
                                           const double* hit_prob, const uint8_t* hit_type,
-                                          const int32_t* item_count, const uint32_t* n_items,
+                                          const int32_t* item_count, const uint32_t* work,
                                           const double* img,
                                           double img_scale, float sigmainv, float multiplier,
                                           double* g_img);
@@ -255,24 +262,27 @@ int kamd_dibr_soft_mask_forward_fused_f32(void* stream, int B, int H, int W, int
                                           const int64_t* sel_idx, float sigmainv,
                                           float* soft_mask, int32_t* hit_pix, int32_t* hit_face,
                                           float* hit_prob, uint8_t* hit_type, int32_t* item_count,
-                                          uint32_t* n_items, void* workspace);
+                                          uint32_t* work, void* workspace);
 int kamd_dibr_soft_mask_forward_fused_f64(void* stream, int B, int H, int W, int F, int K,
                                           const double* img, double multiplier, double margin,
                                           const int64_t* sel_idx, float sigmainv,
                                           double* soft_mask, int32_t* hit_pix, int32_t* hit_face,
                                           double* hit_prob, uint8_t* hit_type, int32_t* item_count,
-                                          uint32_t* n_items, void* workspace);
+                                          uint32_t* work, void* workspace);
 
 /* ------------------------------------------------------------------------- */
 /* dibr_rasterization in one call (ours; kaolin/render/mesh/dibr.py:119-209   */
 /* = rasterize with valid faces + dibr_soft_mask over all faces).  Same       */
-/* kernels as the separate entry points; kernels that do not depend on each   */
-/* other (soft-mask binning vs. rasterizer; the two backward kernels) are     */
-/* enqueued on an internal side stream forked from / joined to `stream` with  */
-/* events, so the call is still stream-ordered for the caller.  g_img         */
-/* (zeroed by the caller) receives BOTH gradient contributions; g_feat may be  */
-/* NULL (feature gradient not needed: not computed).                          */
+/* kernels as the separate entry points, sharing one binning pass: the faces  */
+/* are binned for both operators in one launch per phase, and the rasterizer's */
+/* tile kernel classifies the pixels for the soft mask.  The two backward      */
+/* kernels do not depend on each other: the soft mask's is enqueued on an      */
+/* internal side stream forked from / joined to `stream` with events, so the   */
+/* call is still stream-ordered for the caller.  g_img (zeroed by the caller)  */
+/* receives BOTH gradient contributions; g_feat may be NULL (feature gradient  */
+/* not needed: not computed).  workspace: kamd_dibr_rasterization_workspace.   */
 /* ------------------------------------------------------------------------- */
+size_t kamd_dibr_rasterization_workspace(int B, int H, int W, int F, int elem_size);
 int kamd_dibr_rasterization_forward_f32(void* stream, int B, int H, int W, int F, int D, int K,
                                         const float* z, int64_t z_face_stride, int64_t z_vertex_stride,
                                         const float* img, const float* feat, const uint8_t* valid,
@@ -280,8 +290,8 @@ int kamd_dibr_rasterization_forward_f32(void* stream, int B, int H, int W, int F
                                         float eps, float sigmainv, double margin, float* interp,
                                         int64_t* face_idx, float* weights, float* soft_mask,
                                         int32_t* hit_pix, int32_t* hit_face, float* hit_prob,
-                                        uint8_t* hit_type, int32_t* item_count, uint32_t* n_items,
-                                        void* ws_raster, void* ws_soft);
+                                        uint8_t* hit_type, int32_t* item_count, uint32_t* work,
+                                        void* workspace);
 int kamd_dibr_rasterization_forward_f64(void* stream, int B, int H, int W, int F, int D, int K,
                                         const double* z, int64_t z_face_stride, int64_t z_vertex_stride,
                                         const double* img, const double* feat, const uint8_t* valid,
@@ -289,15 +299,15 @@ int kamd_dibr_rasterization_forward_f64(void* stream, int B, int H, int W, int F
                                         float eps, float sigmainv, double margin, double* interp,
                                         int64_t* face_idx, double* weights, double* soft_mask,
                                         int32_t* hit_pix, int32_t* hit_face, double* hit_prob,
-                                        uint8_t* hit_type, int32_t* item_count, uint32_t* n_items,
-                                        void* ws_raster, void* ws_soft);
+                                        uint8_t* hit_type, int32_t* item_count, uint32_t* work,
+                                        void* workspace);
 int kamd_dibr_rasterization_backward_f32(void* stream, int B, int H, int W, int F, int D, int K,
                                          const float* grad_feat, const float* grad_soft,
                                          const int64_t* face_idx, const float* weights,
                                          const float* soft_mask, const int32_t* hit_pix,
                                          const int32_t* hit_face, const float* hit_prob,
                                          const uint8_t* hit_type, const int32_t* item_count,
-                                         const uint32_t* n_items, const float* img, const float* feat,
+                                         const uint32_t* work, const float* img, const float* feat,
                                          double multiplier, float eps, float sigmainv,
                                          float* g_img, float* g_feat);
 int kamd_dibr_rasterization_backward_f64(void* stream, int B, int H, int W, int F, int D, int K,
@@ -306,7 +316,7 @@ int kamd_dibr_rasterization_backward_f64(void* stream, int B, int H, int W, int 
                                          const double* soft_mask, const int32_t* hit_pix,
                                          const int32_t* hit_face, const double* hit_prob,
                                          const uint8_t* hit_type, const int32_t* item_count,
-                                         const uint32_t* n_items, const double* img, const double* feat,
+                                         const uint32_t* work, const double* img, const double* feat,
                                          double multiplier, float eps, float sigmainv,
                                          double* g_img, double* g_feat);
 

@@ -113,11 +113,12 @@ def dibr_soft_mask_forward_cuda(face_vertices_image, face_large_bboxes, selected
         hits = torch.empty((batch_size, height, width), dtype=torch.uint8, device=device) if _with_hit_count else None
         ws = _lib.workspace(lib.kamd_dibr_soft_mask_forward_workspace(batch_size, height, width, num_faces,
                                                                       face_vertices_image.element_size()), device)
+        work = _work_buffer(batch_size, height, width, device)
         st = getattr(lib, f'kamd_dibr_soft_mask_forward_{sfx}')(
             _lib.stream_ptr(device), batch_size, height, width, num_faces, knum,
             _lib.ptr(face_vertices_image), _lib.ptr(face_large_bboxes), _lib.ptr(selected_face_idx),
             float(sigmainv), float(multiplier), _lib.ptr(soft_mask), _lib.ptr(prob), _lib.ptr(idx), _lib.ptr(typ),
-            _lib.ptr(ws), _lib.ptr(hits))
+            _lib.ptr(ws), _lib.ptr(hits), _lib.ptr(work))
     _lib.check(st, fn)
     return [soft_mask, prob, idx, typ, hits] if _with_hit_count else [soft_mask, prob, idx, typ]
 
@@ -193,7 +194,7 @@ def dibr_soft_mask_backward_lean(grad_soft_mask, soft_mask, hits, face_vertices_
     """Backward of :func:`dibr_soft_mask_forward_lean` / ``_fused`` -> grad_face_vertices_image (B,F,3,2), w.r.t. the
     unscaled input.  ``face_vertices_image * img_scale`` must be the scaled vertices the forward searched with."""
     fn = 'dibr_soft_mask_backward_lean'
-    hit_pix, hit_face, hit_prob, hit_type, item_count, n_items = hits
+    hit_pix, hit_face, hit_prob, hit_type, item_count, work = hits
     knum = int(knum)
     args = [Arg(grad_soft_mask, 'grad_soft_mask', 1), Arg(soft_mask, 'soft_mask', 2),
             Arg(face_vertices_image, 'face_vertices_image', 4)]
@@ -210,31 +211,44 @@ def dibr_soft_mask_backward_lean(grad_soft_mask, soft_mask, hits, face_vertices_
         st = getattr(lib, f'kamd_dibr_soft_mask_backward_lean_{sfx}')(
             _lib.stream_ptr(device), batch_size, height, width, num_faces, knum,
             _lib.ptr(grad_soft_mask), _lib.ptr(soft_mask), _lib.ptr(hit_pix), _lib.ptr(hit_face), _lib.ptr(hit_prob),
-            _lib.ptr(hit_type), _lib.ptr(item_count), _lib.ptr(n_items), _lib.ptr(face_vertices_image), float(img_scale), float(sigmainv),
+            _lib.ptr(hit_type), _lib.ptr(item_count), _lib.ptr(work), _lib.ptr(face_vertices_image), float(img_scale), float(sigmainv),
             float(multiplier), _lib.ptr(g_img))
     _lib.check(st, fn)
     return g_img
 
 
+def _work_buffer(batch_size, height, width, device):
+    """The search's worklist: 8 sharded item counters (16-word header), then the items {item id, uncovered-pixel mask}."""
+    n = max(int(_lib.load().kamd_dibr_soft_mask_work_words(batch_size, height, width)), 16)
+    return torch.empty(n, dtype=torch.int32, device=device)
+
+
 def _hit_list(batch_size, height, width, knum, dtype, device, num_faces=0):
-    """Storage of the segmented hit list: capacity B*H*W*K records (just the used parts are ever touched), one count
-    per potential work item (16x4-pixel sub-tile), and the number of work items."""
+    """Storage of the segmented hit list: 64*K record slots per 16x4-pixel sub-tile slot (just the used parts are ever
+    touched), one count per sub-tile slot, and the worklist of the sub-tiles that were searched."""
     cap = max(int(_lib.load().kamd_dibr_soft_mask_lean_capacity(batch_size, height, width, int(knum))), 1)
     n_sub = ((width + 31) // 32) * ((height + 31) // 32) * 16 * batch_size
     return (torch.empty(cap, dtype=torch.int32, device=device), torch.empty(cap, dtype=torch.int32, device=device),
             torch.empty(cap, dtype=dtype, device=device), torch.empty(cap, dtype=torch.uint8, device=device),
             torch.empty(max(n_sub, 1), dtype=torch.int32, device=device),
-            # the search kernel writes the number of work items whenever it runs, i.e. whenever there are faces
-            (torch.empty if num_faces > 0 else torch.zeros)(1, dtype=torch.int32, device=device))
+            _work_buffer(batch_size, height, width, device))
+
+
+def work_items(work):
+    """Item ids (int64, 1-D) recorded in a worklist buffer (tests / debugging; synchronises)."""
+    counts = work[:8].tolist()
+    shard_cap = (work.numel() - 16) // (8 * 4)
+    items = work[16:].view(8, shard_cap, 4)
+    return torch.cat([items[s, :min(c, shard_cap), 0] for s, c in enumerate(counts)]).long()
 
 
 def hit_list_entries(hits, knum):
     """Flattens a segmented hit list -> (pix, face, prob, type) 1-D tensors of the recorded hits (tests / debugging)."""
-    hit_pix, hit_face, hit_prob, hit_type, item_count, n_items = hits
-    n = int(n_items.item())
-    counts = item_count[:n].long()
-    stride = 64 * int(knum)
-    starts = torch.arange(n, device=counts.device) * stride
+    hit_pix, hit_face, hit_prob, hit_type, item_count, work = hits
+    items = work_items(work)
+    n = items.numel()
+    counts = item_count[items].long()
+    starts = items * (64 * int(knum))
     total = int(counts.sum())
     seg = torch.repeat_interleave(torch.arange(n, device=counts.device), counts)
     within = torch.arange(total, device=counts.device) - torch.repeat_interleave(torch.cumsum(counts, 0) - counts, counts)
@@ -328,8 +342,8 @@ def _face_strides(t, inner):
 
 def dibr_rasterization_forward_fused(height, width, face_vertices_z, face_vertices_image, face_features, valid_faces,
                                      sigmainv, boxlen, knum, multiplier, eps):
-    """``rasterize_forward_fused`` + ``dibr_soft_mask_forward_fused`` in one library call (ours): the same kernels,
-    with the soft mask's binning enqueued on an internal side stream next to the rasterizer.  ``valid_faces`` is either
+    """``rasterize_forward_fused`` + ``dibr_soft_mask_forward_fused`` in one library call (ours): the same kernels
+    sharing one binning pass, the rasterizer's tile kernel classifying the pixels for the soft mask.  ``valid_faces`` is either
     the bool mask of the faces to rasterize or a FLOAT (B, F) tensor ``n`` standing for the mask ``n >= 0`` (the face
     normals' z of ``dibr_rasterization``): that one, and ``face_vertices_z``, may be last-index views and are read in
     place.  -> (interpolated_features, face_idx, output_weights, soft_mask, hits)"""
@@ -368,8 +382,7 @@ def dibr_rasterization_forward_fused(height, width, face_vertices_z, face_vertic
         interp = torch.empty((batch_size, height, width, feat_dim), dtype=dtype, device=device)
         soft_mask = torch.empty((batch_size, height, width), dtype=dtype, device=device)
         hits = _hit_list(batch_size, height, width, knum, dtype, device, num_faces)
-        ws_r = _lib.workspace(lib.kamd_rasterize_forward_workspace(batch_size, height, width, batch_size * num_faces, esz), device)
-        ws_s = _lib.workspace(lib.kamd_dibr_soft_mask_forward_workspace(batch_size, height, width, num_faces, esz), device)
+        ws = _lib.workspace(lib.kamd_dibr_rasterization_workspace(batch_size, height, width, num_faces, esz), device)
         st = getattr(lib, f'kamd_dibr_rasterization_forward_{sfx}')(
             _lib.stream_ptr(device), batch_size, height, width, num_faces, feat_dim, int(knum),
             _lib.ptr(z), int(z_face), int(z_vertex), _lib.ptr(face_vertices_image), _lib.ptr(face_features),
@@ -377,11 +390,7 @@ def dibr_rasterization_forward_fused(height, width, face_vertices_z, face_vertic
             float(multiplier), float(eps), float(sigmainv), float(boxlen * multiplier),
             _lib.ptr(interp), _lib.ptr(face_idx), _lib.ptr(wts), _lib.ptr(soft_mask),
             _lib.ptr(hits[0]), _lib.ptr(hits[1]), _lib.ptr(hits[2]), _lib.ptr(hits[3]), _lib.ptr(hits[4]), _lib.ptr(hits[5]),
-            _lib.ptr(ws_r), _lib.ptr(ws_s))
-        # the side stream reads / writes these buffers: keep torch's allocator from recycling them under it
-        for t in (ws_s, face_vertices_image) + tuple(hits):
-            if t is not None:
-                t.record_stream(torch.cuda.current_stream(device))
+            _lib.ptr(ws))
     _lib.check(st, fn)
     return interp, face_idx, wts, soft_mask, hits
 

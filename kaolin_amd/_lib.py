@@ -33,6 +33,8 @@ SIGNATURES = {
     'kamd_dibr_soft_mask_forward_workspace': (_sz, [_i, _i, _i, _i, _i]),
     'kamd_triangle_distance_forward_workspace': (_sz, [_i, _i, _i]),
     'kamd_dibr_soft_mask_lean_capacity': (_sz, [_i, _i, _i, _i]),
+    'kamd_dibr_soft_mask_work_words': (_sz, [_i, _i, _i]),
+    'kamd_dibr_rasterization_workspace': (_sz, [_i, _i, _i, _i, _i]),
     'kamd_trianglemeshes_to_voxelgrids_workspace': (_sz, [_i, _i, _i]),
     'kamd_deftet_forward_workspace': (_sz, [_i, _i, _i, _i]),
     'kamd_mesh_to_spc_stage_levels': (_i, []),
@@ -58,7 +60,7 @@ for _t in ('f32', 'f64'):
     SIGNATURES[f'kamd_rasterize_backward_{_t}'] = (
         _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp])
     SIGNATURES[f'kamd_dibr_soft_mask_forward_{_t}'] = (
-        _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp])
+        _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_dibr_soft_mask_backward_{_t}'] = (
         _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp])
     SIGNATURES[f'kamd_dibr_soft_mask_forward_lean_{_t}'] = (
@@ -70,7 +72,7 @@ for _t in ('f32', 'f64'):
     SIGNATURES[f'kamd_dibr_soft_mask_forward_fused_{_t}'] = (
         _i, [_vp, _i, _i, _i, _i, _i, _vp, _dbl, _dbl, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_dibr_rasterization_forward_{_t}'] = (
-        _i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _dbl, _f, _f, _dbl] + [_vp] * 12)
+        _i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _dbl, _f, _f, _dbl] + [_vp] * 11)
     SIGNATURES[f'kamd_rasterize_forward_fused_strided_{_t}'] = (
         _i, [_vp, _i, _i, _i, _i, _i, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _dbl, _f, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_dibr_rasterization_backward_{_t}'] = (

@@ -10,154 +10,21 @@
 // Arithmetic: compiled with -ffp-contract=off, every expression in the reference's operand order and
 // types, so face_idx is bit-exact against the oracle.
 //
-// MI355X design: see tile_bins.h.  K1 is two launches, bin_faces_kernel + raster_tile_kernel; every
-// output element is written by raster_tile_kernel (uncovered pixels get -1 / 0), so no pre-fill pass over
-// the G-buffer is needed.  A 16x4-pixel sub-tile per wavefront makes each row of the G-buffer a 128-B
-// (idx), 192-B (weights) or 64*D/4-B (features) contiguous store per wavefront.
+// MI355X design: see tile_lists.h / raster2.inc.  K1 = face binning into per-tile lists (count, scan, emit) + raster_tile_kernel2;
+// every output element is written by the tile kernel (uncovered pixels get -1 / 0), so no pre-fill pass over the G-buffer
+// is needed.  A 16x4-pixel sub-tile per wavefront makes each row of the G-buffer a 128-B (idx), 192-B (weights) or
+// 64*D/4-B (features) contiguous store per wavefront.
 #include "common.h"
 #include "profile.h"
 #include "tile_bins.h"
+#include "tile_lists.h"
+#include "dibr_internal.h"
 #include "../../include/kaolin_amd.h"
 
 namespace {
 using namespace kamd;
 
-template <typename T> struct RasterCap;  // faces staged in LDS per round (32 KiB of records)
-template <> struct RasterCap<float> { static constexpr int value = 512; };
-template <> struct RasterCap<double> { static constexpr int value = 256; };
-
-template <typename T>
-__global__ __launch_bounds__(TILE_THREADS) void raster_tile_kernel(
-    int B, int F_dense, const int64_t* __restrict__ first, TileGeom g, int D, float multiplier, float eps,
-    const T* __restrict__ rec, const unsigned int* __restrict__ masks, const unsigned int* __restrict__ tile_flags,
-    const T* __restrict__ feat, T* __restrict__ interp, int64_t* __restrict__ sel_idx, T* __restrict__ weights) {
-  constexpr int CAP = RasterCap<T>::value;
-  __shared__ __attribute__((aligned(16))) T s_bbox[CAP * 4];
-  __shared__ __attribute__((aligned(16))) T s_rest[CAP * 12];  // a.xy b.xy c.xy z.abc pad3
-  __shared__ int s_ids[CAP];
-  __shared__ int s_scan[TILE_THREADS / 64 + 1];
-
-  const int b = blockIdx.x % B;  // consecutive workgroups -> consecutive XCDs: with B % 8 == 0 a view stays on one XCD's L2
-  const int tile = blockIdx.x / B;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t first_b = first ? first[b] : (int64_t)b * F_dense;
-  const int n_b = first ? (int)(first[b + 1] - first_b) : F_dense;
-  const int stride_b = (n_b + 31) / 32;
-  const unsigned int* tmask = masks + mask_base(g.ntiles, first_b, b, tile, stride_b);
-
-  const int tile_x = (tile % g.tiles_x) * TILE_W, tile_y = (tile / g.tiles_x) * TILE_H;
-  const int sub_x = tile_x + (wave & 1) * SUB_W, sub_y = tile_y + (wave >> 1) * SUB_H;
-  const int col = sub_x + (lane & 15), row = sub_y + (lane >> 4);
-  const bool in_image = col < g.W && row < g.H;
-  const T x0 = pixel_x(multiplier, g.W, col);
-  const T y0 = pixel_y(multiplier, g.H, row);
-  // sub-tile extent in pixel-centre coordinates (clamped to the image); x grows with col, y falls with row
-  const T sx_min = pixel_x(multiplier, g.W, sub_x), sx_max = pixel_x(multiplier, g.W, min(sub_x + SUB_W, g.W) - 1);
-  const T sy_max = pixel_y(multiplier, g.H, sub_y), sy_min = pixel_y(multiplier, g.H, min(sub_y + SUB_H, g.H) - 1);
-  const bool sub_in_image = sub_x < g.W && sub_y < g.H;
-
-  T best_z = -INFINITY, bw0 = 0, bw1 = 0, bw2 = 0;
-  int best = -1;
-  const int nwords = (tile_flags != nullptr && tile_flags[(size_t)b * g.ntiles + tile]) ? stride_b : 0;  // untouched tile: background only
-
-  for (int seg0 = 0; seg0 < nwords; seg0 += TILE_THREADS) {
-    const int wi = seg0 + tid;
-    unsigned int word = wi < nwords ? tmask[wi] : 0u;
-    int total;
-    const int excl = block_exclusive_scan(__popc(word), s_scan, &total);
-    for (int c0 = 0; c0 < total; c0 += CAP) {
-      __syncthreads();  // previous round's readers are done with the LDS lists
-      {
-        unsigned int wv = word;
-        int pos = excl;
-        while (wv) {
-          const int bit = __ffs(wv) - 1;
-          wv &= wv - 1;
-          if (pos >= c0 && pos < c0 + CAP) s_ids[pos - c0] = wi * 32 + bit;
-          ++pos;
-        }
-      }
-      __syncthreads();
-      const int n = min(CAP, total - c0);
-      // a record is four 16-byte quads: box | a.xy b.xy | c.xy z.ab | z.c pad -- copied as such (4 lanes per record)
-      for (int i = tid; i < n * 4; i += TILE_THREADS) {
-        const int k = i >> 2, q = i & 3;
-        const Rec4<T> v = reinterpret_cast<const Rec4<T>*>(rec + ((size_t)first_b + s_ids[k]) * REC_STRIDE)[q];
-        if (q == 0)
-          reinterpret_cast<Rec4<T>*>(s_bbox)[k] = v;
-        else
-          reinterpret_cast<Rec4<T>*>(s_rest)[k * 3 + (q - 1)] = v;
-      }
-      __syncthreads();
-      if (sub_in_image) {
-        for (int k0 = 0; k0 < n; k0 += 64) {
-          const int k = k0 + lane;
-          bool keep = false;
-          Box4<T> fb = {0, 0, 0, 0};
-          if (k < n) {
-            fb = reinterpret_cast<const Box4<T>*>(s_bbox)[k];
-            // a face is dropped only if NO pixel centre of the sub-tile can pass the reference's reject test
-            keep = !((sx_max < fb.x0) | (sx_min >= fb.x1) | (sy_max < fb.y0) | (sy_min >= fb.y1));
-          }
-          const unsigned long long m = __ballot(keep);
-          if (m == 0ull) continue;
-          // (1) lane = pixel: which of the kept faces have this pixel inside their box?  The boxes sit in the registers
-          // of the lanes that tested them; a readlane per limit broadcasts them (no LDS round trip, no divergence).
-          unsigned long long hm = 0ull;
-          for (unsigned long long mm = m; mm != 0ull; mm &= mm - 1ull) {
-            const int j = __ffsll((long long)mm) - 1;
-            Box4<T> bb;
-            bb.x0 = wave_bcast<T>(fb.x0, j);
-            bb.y0 = wave_bcast<T>(fb.y0, j);
-            bb.x1 = wave_bcast<T>(fb.x1, j);
-            bb.y1 = wave_bcast<T>(fb.y1, j);
-            hm |= box_rejects<T>(bb, x0, y0) ? 0ull : (1ull << j);
-          }
-          if (!in_image) hm = 0ull;
-          // (2) every lane walks ITS OWN boxes in ascending (= mesh) order: the edge functions run on full lanes
-          while (__any(hm != 0ull)) {
-            if (hm == 0ull) continue;
-            const int kk = k0 + (__ffsll((long long)hm) - 1);
-            hm &= hm - 1ull;
-            const T* v = s_rest + kk * 12;
-            const T aex = v[0] - x0, aey = v[1] - y0;
-            const T bex = v[2] - x0, bey = v[3] - y0;
-            const T cex = v[4] - x0, cey = v[5] - y0;
-            T w0 = bex * cey - bey * cex;
-            T w1 = cex * aey - cey * aex;
-            T w2 = aex * bey - aey * bex;
-            T norm = w0 + w1 + w2;
-            norm = (T)((double)norm + copysign((double)eps, (double)norm));
-            w0 /= norm;
-            w1 /= norm;
-            w2 /= norm;
-            if (w0 < 0. || w1 < 0. || w2 < 0.) continue;
-            const T z0 = w0 * v[6] + w1 * v[7] + w2 * v[8];
-            if (z0 <= best_z) continue;
-            best_z = z0;
-            best = s_ids[kk];
-            bw0 = w0;
-            bw1 = w1;
-            bw2 = w2;
-          }
-        }
-      }
-    }
-  }
-
-  if (!in_image) return;
-  const size_t p = ((size_t)b * g.H + row) * g.W + col;
-  sel_idx[p] = best;  // relative to the mesh's first packed face, -1 = no face
-  weights[p * 3 + 0] = bw0;
-  weights[p * 3 + 1] = bw1;
-  weights[p * 3 + 2] = bw2;
-  if (best >= 0) {
-    const T* ff = feat + ((size_t)first_b + best) * 3 * D;
-    for (int d = 0; d < D; ++d) interp[p * D + d] = bw0 * ff[d] + bw1 * ff[D + d] + bw2 * ff[2 * D + d];
-  } else {
-    for (int d = 0; d < D; ++d) interp[p * D + d] = 0;
-  }
-}
+#include "raster2.inc"
 
 // ---- K2 -------------------------------------------------------------------------------------------------
 // Per covered pixel the reference issues 3*D + 6*D float atomics on addresses shared by every pixel of the same
@@ -200,19 +67,6 @@ __device__ __forceinline__ T barycentric_jacobian(const T* v, T aw, T bw, T cw, 
   dw2[4] = dw2dn;
   dw2[5] = dw2dq;
   return k3;
-}
-
-// value of the lane N places to the left / right inside the same row of 16 lanes (DPP row_shr / row_shl: a register
-// move, no LDS crossbar); lanes without a source read 0
-template <int N>
-__device__ __forceinline__ int row_shr(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + N, 0xF, 0xF, true); }
-template <int N>
-__device__ __forceinline__ int row_shl(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x100 + N, 0xF, 0xF, true); }
-template <int N>
-__device__ __forceinline__ float row_shr(float v) { return __int_as_float(row_shr<N>(__float_as_int(v))); }
-template <int N>
-__device__ __forceinline__ double row_shr(double v) {
-  return __hiloint2double(row_shr<N>(__double2hiint(v)), row_shr<N>(__double2loint(v)));
 }
 
 // DT > 0: feature count known at compile time (block-merged through LDS); DT == 0: any D, per-lane global atomics.
@@ -343,55 +197,50 @@ int rasterize_forward_launch(hipStream_t st, int B, int H, int W, int D, int64_t
                              const T* bbox, const T* feat, const int64_t* first_idx, float multiplier, float eps,
                              T* interp, int64_t* sel_idx, T* weights, void* workspace) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
-  const TileGeom g = tile_geom(H, W);
   if (total_faces > 0 && workspace == nullptr) return (int)hipErrorInvalidValue;
-  T* rec = (T*)workspace;
-  unsigned int* masks = (unsigned int*)((char*)workspace + align256((size_t)total_faces * REC_STRIDE * sizeof(T)));
-  unsigned int* flags = total_faces > 0 ? masks + mask_words(g.ntiles, B, total_faces) : nullptr;
-  if (total_faces > 0) {
-    KAMD_CHECK(kamd_zero_async(masks, ((mask_words(g.ntiles, B, total_faces) + flag_words(g.ntiles, B)) * 4 + 15) & ~(size_t)15, st));  // inside the 256-byte padding
-    {
-      kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
-      hipLaunchKernelGGL(bin_faces_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, 0,
-                       (long long)total_faces, first_idx, bbox, img, z, g, multiplier, rec, masks, flags, (uint8_t*)nullptr);
-    }
-    KAMD_CHECK(hipGetLastError());
-  }
-  {
-    kamd::ProfScope prof_(kamd::K_RASTER_TILE, st);
-    hipLaunchKernelGGL(raster_tile_kernel<T>, dim3(g.ntiles * B), dim3(TILE_THREADS), 0, st, B, 0, first_idx, g, D,
-                     multiplier, eps, rec, masks, flags, feat, interp, sel_idx, weights);
-  }
-  KAMD_RETURN_LAST_ERROR();
+  tl::BinIn<T> in{};
+  in.B = B;
+  in.F = 0;
+  in.total_faces = total_faces;
+  in.first = first_idx;
+  in.img = img;      // already scaled by the caller (rasterization.py:320)
+  in.z = z;
+  in.lay = FaceLayout{3, 1, 1};
+  in.bbox_r = bbox;  // given (rasterization.py:325-327)
+  in.mult = (T)1;
+  in.margin = (T)0;
+  in.multiplier = multiplier;
+  in.H = H;
+  in.W = W;
+  return raster2_bin_and_draw<T>(st, B, H, W, D, 0, (long long)total_faces, first_idx, in, feat, multiplier, eps, interp,
+                                 sel_idx, weights, workspace);
 }
 
-// fused front door: raw (B,F,...) inputs + optional valid mask; scaling, bounding boxes and packing happen in
-// bin_faces_raw_kernel; sel_idx comes out as the mesh-relative face index (what the Python layer returns)
+// fused front door: raw (B,F,...) inputs + optional valid mask; scaling, bounding boxes and packing happen in the bin
+// kernel; sel_idx comes out as the mesh-relative face index (what the Python layer returns)
 template <typename T>
 int rasterize_forward_fused_launch(hipStream_t st, int B, int H, int W, int F, int D, const T* z, FaceLayout lay, const T* img,
                                    const T* feat, const uint8_t* valid, const T* front, double multiplier, float eps,
                                    T* interp, int64_t* face_idx, T* weights, void* workspace) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
-  const TileGeom g = tile_geom(H, W);
   const long long total_faces = (long long)B * F;
   if (total_faces > 0 && workspace == nullptr) return (int)hipErrorInvalidValue;
-  T* rec = (T*)workspace;
-  unsigned int* masks = (unsigned int*)((char*)workspace + align256((size_t)total_faces * REC_STRIDE * sizeof(T)));
-  unsigned int* flags = total_faces > 0 ? masks + mask_words(g.ntiles, B, total_faces) : nullptr;
-  if (total_faces > 0) {
-    KAMD_CHECK(kamd_zero_async(masks, ((mask_words(g.ntiles, B, total_faces) + flag_words(g.ntiles, B)) * 4 + 15) & ~(size_t)15, st));  // inside the 256-byte padding
-    kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
-    hipLaunchKernelGGL(bin_faces_raw_kernel<T>, dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, B, F, img, z, lay, valid,
-                       front, (T)multiplier, (T)0, g, (float)multiplier, rec, masks, flags, (uint8_t*)nullptr);
-  }
-  KAMD_CHECK(hipGetLastError());
-  {
-    kamd::ProfScope prof_(kamd::K_RASTER_TILE, st);
-    hipLaunchKernelGGL(raster_tile_kernel<T>, dim3(g.ntiles * B), dim3(TILE_THREADS), 0, st, B, F,
-                       (const int64_t*)nullptr, g, D, (float)multiplier, eps, rec, masks, flags, feat, interp, face_idx,
-                       weights);
-  }
-  KAMD_RETURN_LAST_ERROR();
+  tl::BinIn<T> in{};
+  in.B = B;
+  in.F = F;
+  in.total_faces = total_faces;
+  in.img = img;
+  in.z = z;
+  in.lay = lay;
+  in.valid = valid;
+  in.front = front;
+  in.mult = (T)multiplier;
+  in.margin = (T)0;
+  in.multiplier = (float)multiplier;
+  in.H = H;
+  in.W = W;
+  return raster2_bin_and_draw<T>(st, B, H, W, D, F, total_faces, (const int64_t*)nullptr, in, feat, (float)multiplier, eps,
+                                 interp, face_idx, weights, workspace);
 }
 
 template <typename T>
@@ -421,11 +270,26 @@ int rasterize_backward_launch(hipStream_t st, int B, int H, int W, int F, int D,
 
 }  // namespace
 
+namespace kamd {
+template <typename T>
+int raster2_draw(hipStream_t st, int B, int H, int W, int D, int F_dense, float multiplier, float eps, const T* rec,
+                 const tl::Lists& LR, const T* feat, T* interp, int64_t* sel_idx, T* weights, const tl::ClassifyOut& co) {
+  kamd::ProfScope prof_(kamd::K_RASTER_TILE, st);
+  hipLaunchKernelGGL((raster_tile_kernel2<T, true>), dim3(LR.ntiles * B), dim3(256), 0, st, B, F_dense,
+                     (const int64_t*)nullptr, H, W, D, multiplier, eps, rec, LR, feat, interp, sel_idx, weights, co);
+  return (int)hipGetLastError();
+}
+template int raster2_draw<float>(hipStream_t, int, int, int, int, int, float, float, const float*, const tl::Lists&, const float*,
+                                 float*, int64_t*, float*, const tl::ClassifyOut&);
+template int raster2_draw<double>(hipStream_t, int, int, int, int, int, float, float, const double*, const tl::Lists&,
+                                  const double*, double*, int64_t*, double*, const tl::ClassifyOut&);
+}  // namespace kamd
+
 extern "C" {
 
 size_t kamd_rasterize_forward_workspace(int B, int H, int W, int64_t total_faces, int elem_size) {
   if (B <= 0 || H <= 0 || W <= 0 || total_faces <= 0) return 0;
-  return kamd::bins_workspace_bytes(B, H, W, total_faces, elem_size);
+  return kamd::tl::make_layout(B, H, W, total_faces, elem_size, true, false).total;
 }
 
 int kamd_packed_rasterize_forward_f32(void* stream, int B, int H, int W, int D, int64_t total_faces, const float* z,

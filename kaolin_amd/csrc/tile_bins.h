@@ -351,6 +351,19 @@ __global__ __launch_bounds__(256) void bin_faces_raw_kernel(
   bin_emit_wave(active, b, j, tx0, tx1, ty0, ty1, F, g, masks, tile_flags);
 }
 
+// value of the lane N places to the left / right inside the same row of 16 lanes (DPP row_shr / row_shl: a register
+// move, no LDS crossbar); lanes without a source read 0
+template <int N>
+__device__ __forceinline__ int row_shr(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x110 + N, 0xF, 0xF, true); }
+template <int N>
+__device__ __forceinline__ int row_shl(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x100 + N, 0xF, 0xF, true); }
+template <int N>
+__device__ __forceinline__ float row_shr(float v) { return __int_as_float(row_shr<N>(__float_as_int(v))); }
+template <int N>
+__device__ __forceinline__ double row_shr(double v) {
+  return __hiloint2double(row_shr<N>(__double2hiint(v)), row_shr<N>(__double2loint(v)));
+}
+
 // ---- block-wide exclusive scan over 1024 threads (16 wavefronts) -------------------------------------
 __device__ __forceinline__ int wave_inclusive_scan(int v) {
   const int lane = threadIdx.x & 63;

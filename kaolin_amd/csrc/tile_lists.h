@@ -1,0 +1,531 @@
+// Screen-tile face lists shared by the DIB-R rasterizer and the soft-mask kernels (gfx950), second generation.
+//
+// The reference tests every pixel against every face (rasterization_cuda.cu:88-170, dibr_soft_mask_cuda.cu:80-172).
+// A face only ever acts on a pixel whose centre lies inside the face's (possibly enlarged) bounding box, so the search
+// is made sub-linear by binning the boxes into screen tiles.  The first generation (tile_bins.h) kept one BIT per
+// (tile, face): a workspace of ntiles x F bits that had to be cleared and scanned on every call (51 MB at 8 views x
+// 1024^2 x 50k faces, O(tiles x F) in general).  Here a tile owns a compact LIST of entries
+//
+//        entry = { block : the index of 64 consecutive faces of the packed face list,
+//                  mask  : which of those 64 faces may touch the tile }            (16 bytes)
+//
+// produced by one ballot of the wavefront that holds those 64 faces -- consecutive faces of a mesh are usually
+// neighbours on screen, so an entry carries many faces, and inside an entry the ascending face order the reference's
+// loops rely on is simply the bit order.  Lists are sized exactly by a count pass + scan + emit pass (no fixed
+// per-tile capacity); only the TOTAL number of entries is bounded by the workspace (shape-only: no host sync), and a
+// tile whose list does not fit falls back to scanning every block of its mesh (slow, still exact).  Faces whose box
+// spans more than 8 x 8 tiles (or is NaN) go to a per-mesh "big face" list that every tile tests directly.
+//
+// Work per call: O(faces + entries) for the binning, nothing proportional to tiles x faces, and the only memory that
+// must be cleared is one counter per tile.
+#pragma once
+#include "common.h"
+#include "tile_bins.h"  // Box4 / Rec4 / pixel_x / pixel_y / FaceLayout / wave helpers
+
+namespace kamd {
+namespace tl {
+
+constexpr int R_TILE = 16;            // rasterizer tile: 16 x 16 pixels = one 256-thread workgroup (4 sub-tiles of 16 x 4)
+constexpr int S_TILE = 32;            // soft-mask tile: 32 x 32 pixels = 16 sub-tiles of 16 x 4 (work items of the search)
+constexpr int S_SUBS = (S_TILE / SUB_W) * (S_TILE / SUB_H);  // 16
+constexpr int REC_R = 16;             // raster record scalars: box[4] a.xy b.xy c.xy z[3] flag pad2
+constexpr int REC_S = 12;             // soft record scalars:   large box[4] a.xy b.xy c.xy pad2
+constexpr int WORK_SHARDS = 8;        // worklist shards (one append counter each; workgroup id & 7 picks the shard)
+
+struct PassGeom {
+  int tile, tiles_x, tiles_y, ntiles;
+};
+__host__ __device__ inline PassGeom pass_geom(int H, int W, int tile) {
+  PassGeom g;
+  g.tile = tile;
+  g.tiles_x = (W + tile - 1) / tile;
+  g.tiles_y = (H + tile - 1) / tile;
+  g.ntiles = g.tiles_x * g.tiles_y;
+  return g;
+}
+
+// device view of one pass' lists
+struct Lists {
+  unsigned int* count;        // [B * ntiles]      zeroed; count pass: entries per tile; after the scan: 0 again (emit cursor)
+  unsigned int* base;         // [B * ntiles + 1]  exclusive scan of count (written by the scan kernel)
+  uint4* entries;             // [cap]             {block, 0, mask.lo, mask.hi}
+  unsigned int cap;
+  unsigned int* big_count;    // [B]               zeroed; faces of mesh b in the big list
+  unsigned int* big_list;     // [total_faces]     mesh b's segment starts at its first packed face
+  unsigned int* sub_touched;  // [B * ntiles]      zeroed; soft pass only: bit s = some enlarged box reaches sub-tile s
+  int tiles_x, ntiles;
+};
+
+inline size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline unsigned int entry_capacity(long long total_faces, long long n_tiles_total) {
+  long long c = total_faces / 2 + 2 * n_tiles_total + 64;
+  const long long worst = ((total_faces + 63) / 64 + 1) * n_tiles_total;  // every block in every tile
+  if (c > worst) c = worst;
+  if (c > 0x7fffffffll) c = 0x7fffffffll;
+  return (unsigned int)c;
+}
+
+// Host-side layout of one pass inside a workspace.  All `zero_*` arrays of both passes are placed in ONE contiguous
+// region at the start of the workspace so that a single fill kernel clears them.
+struct PassLayout {
+  size_t count, big_count, sub_touched;  // inside the zero region
+  size_t base, entries, big_list, rec;   // after it
+  unsigned int cap;
+  PassGeom g;
+};
+struct Layout {
+  size_t zero_bytes;      // [0, zero_bytes) is cleared on every call
+  PassLayout r, s;        // raster / soft (either may be absent: offsets 0, cap 0)
+  size_t total;
+};
+inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, bool with_r, bool with_s) {
+  Layout L{};
+  size_t off = 0;
+  L.r.g = pass_geom(H, W, R_TILE);
+  L.s.g = pass_geom(H, W, S_TILE);
+  const size_t ntr = (size_t)B * L.r.g.ntiles, nts = (size_t)B * L.s.g.ntiles;
+  if (with_r) {
+    L.r.count = off; off += a256(ntr * 4);
+    L.r.big_count = off; off += a256((size_t)B * 4);
+  }
+  if (with_s) {
+    L.s.count = off; off += a256(nts * 4);
+    L.s.big_count = off; off += a256((size_t)B * 4);
+    L.s.sub_touched = off; off += a256(nts * 4);
+  }
+  L.zero_bytes = off;
+  if (with_r) {
+    L.r.cap = entry_capacity(total_faces, (long long)ntr);
+    L.r.base = off; off += a256((ntr + 1) * 4);
+    L.r.entries = off; off += a256((size_t)L.r.cap * 16);
+    L.r.big_list = off; off += a256((size_t)total_faces * 4);
+    L.r.rec = off; off += a256((size_t)total_faces * REC_R * esz);
+  }
+  if (with_s) {
+    L.s.cap = entry_capacity(total_faces, (long long)nts);
+    L.s.base = off; off += a256((nts + 1) * 4);
+    L.s.entries = off; off += a256((size_t)L.s.cap * 16);
+    L.s.big_list = off; off += a256((size_t)total_faces * 4);
+    L.s.rec = off; off += a256((size_t)total_faces * REC_S * esz);
+  }
+  L.total = off + 256;
+  return L;
+}
+// the worklist lives in its own buffer (the autograd path keeps it for the backward pass): WORK_HEADER words of counters,
+// then WORK_SHARDS x shard_cap items of 16 bytes.  One 256-thread workgroup per 16 x 16 pixels appends at most 4 items.
+constexpr int WORK_HEADER = 16;
+inline unsigned int work_shard_cap(int B, int H, int W) {
+  const PassGeom g = pass_geom(H, W, R_TILE);
+  const size_t n_groups = (size_t)B * g.ntiles;
+  return (unsigned int)(4 * ((n_groups + WORK_SHARDS - 1) / WORK_SHARDS));
+}
+inline size_t work_words(int B, int H, int W) { return WORK_HEADER + (size_t)WORK_SHARDS * work_shard_cap(B, H, W) * 4; }
+
+inline Lists lists_of(void* ws, const PassLayout& p, int B, bool soft) {
+  char* c = (char*)ws;
+  Lists l;
+  l.count = (unsigned int*)(c + p.count);
+  l.base = (unsigned int*)(c + p.base);
+  l.entries = (uint4*)(c + p.entries);
+  l.cap = p.cap;
+  l.big_count = (unsigned int*)(c + p.big_count);
+  l.big_list = (unsigned int*)(c + p.big_list);
+  l.sub_touched = soft ? (unsigned int*)(c + p.sub_touched) : nullptr;
+  l.tiles_x = p.g.tiles_x;
+  l.ntiles = p.g.ntiles;
+  return l;
+}
+
+// ---- conservative pixel range of a half-open box -----------------------------------------------------------------------
+// col(x) = (x*W/mult + W - 1)/2 increasing in x, row(y) = (H - 1 - y*H/mult)/2 decreasing in y; +-1 pixel of slack covers
+// the rounding of the float pixel-centre expressions.  Returns false when the box misses the image.  NaN limits (or a
+// non-positive multiplier) make the box "everywhere", as in the reference where NaN comparisons never reject.
+struct PixRange {
+  int c_lo, c_hi, r_lo, r_hi;
+  bool everywhere;
+};
+template <typename T>
+__device__ __forceinline__ bool pixel_range(T xmin, T ymin, T xmax, T ymax, int H, int W, float multiplier, PixRange* out) {
+  out->c_lo = 0;
+  out->c_hi = W - 1;
+  out->r_lo = 0;
+  out->r_hi = H - 1;
+  const double dxmin = (double)xmin, dxmax = (double)xmax, dymin = (double)ymin, dymax = (double)ymax;
+  out->everywhere = !(multiplier > 0.f) || !(dxmin == dxmin) || !(dxmax == dxmax) || !(dymin == dymin) || !(dymax == dymax);
+  if (out->everywhere) return true;
+  const double sx = (double)W / (double)multiplier, sy = (double)H / (double)multiplier;
+  const double cl = floor((dxmin * sx + W - 1) * 0.5) - 1.0, ch = ceil((dxmax * sx + W - 1) * 0.5) + 1.0;
+  const double rl = floor((H - 1 - dymax * sy) * 0.5) - 1.0, rh = ceil((H - 1 - dymin * sy) * 0.5) + 1.0;
+  if (ch < 0.0 || cl > (double)(W - 1) || rh < 0.0 || rl > (double)(H - 1)) return false;
+  out->c_lo = (int)fmax(cl, 0.0);
+  out->c_hi = (int)fmin(ch, (double)(W - 1));
+  out->r_lo = (int)fmax(rl, 0.0);
+  out->r_hi = (int)fmin(rh, (double)(H - 1));
+  return true;
+}
+
+// torch.min / torch.max semantics (NaN propagates), as the reference's Python glue computes the boxes (rasterization.py:325-327)
+template <typename T>
+__device__ __forceinline__ T nan_min(T a, T b) { return (a != a || b != b) ? (T)NAN : (a < b ? a : b); }
+template <typename T>
+__device__ __forceinline__ T nan_max(T a, T b) { return (a != a || b != b) ? (T)NAN : (a > b ? a : b); }
+
+__device__ __forceinline__ unsigned int wave_or_u32(unsigned int v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v |= (unsigned int)__shfl_xor((int)v, d, 64);
+  return v;
+}
+
+// ---- one wavefront bins its 64 faces into one pass' lists ---------------------------------------------------------------
+// `active`: the lane's face takes part; (b, first_b): its mesh and the mesh's first packed face; tile rectangle
+// [tx0,tx1] x [ty0,ty1]; `big`: the rectangle exceeds 8 x 8 tiles (or the box is NaN).  `block` = packed face index >> 6
+// (the same for the whole wavefront).  EMIT == false: count pass (one atomicAdd per distinct (mesh, tile) the wavefront
+// touches); EMIT == true: the entries are written at base[tile] + cursor++.
+// Distinct tiles are enumerated without walking the union rectangle: every lane keeps the not-yet-emitted tiles of its
+// own rectangle as a 64-bit mask over an 8 x 8 local grid; each step takes the first pending tile of the first pending
+// lane, ballots the lanes whose rectangle holds it and clears it everywhere.  Steps = distinct tiles.  The results are
+// parked one per lane and flushed with ONE vector atomic per 64 tiles (a returning atomic per step would serialise the
+// loop on L2 latency).
+template <bool EMIT, bool SOFT>
+__device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long first_b, long long f, int tx0, int tx1,
+                                         int ty0, int ty1, int c_lo, int c_hi, int r_lo, int r_hi, const Lists& L) {
+  const int lane = threadIdx.x & 63;
+  const unsigned int block = (unsigned int)(f >> 6);
+  unsigned long long remaining = __ballot(active);
+  while (remaining != 0ull) {
+    const int leader = __ffsll((long long)remaining) - 1;
+    const int bL = __builtin_amdgcn_readlane(b, leader);
+    const bool mine = active && b == bL;
+    remaining &= ~__ballot(mine);
+    // big faces: appended to the mesh's big list (emit pass only)
+    const unsigned long long bigm = __ballot(mine && big);
+    if (EMIT && bigm != 0ull) {
+      unsigned int start = 0;
+      if (lane == leader) start = atomicAdd(L.big_count + bL, (unsigned int)__popcll(bigm));
+      start = (unsigned int)__builtin_amdgcn_readlane((int)start, leader);
+      if (mine && big) L.big_list[first_b + start + __popcll(bigm & ((1ull << lane) - 1ull))] = (unsigned int)f;
+    }
+    const bool small = mine && !big;
+    unsigned long long pending = 0ull;
+    if (small) {
+      const int w = tx1 - tx0 + 1, h = ty1 - ty0 + 1;  // 1..8 each
+      const unsigned long long rowm = (1ull << w) - 1ull;
+      const unsigned long long rows = h >= 8 ? ~0ull : ((1ull << (8 * h)) - 1ull);
+      pending = (rowm * 0x0101010101010101ull) & rows;
+    }
+    int my_t = -1, k = 0;
+    unsigned long long my_bal = 0ull;
+    unsigned int my_sub = 0u;
+    auto flush = [&]() {
+      if (my_t >= 0) {
+        const size_t ti = (size_t)bL * L.ntiles + my_t;
+        if (!EMIT) {
+          atomicAdd(L.count + ti, 1u);
+        } else {
+          const unsigned int pos = L.base[ti] + atomicAdd(L.count + ti, 1u);
+          if (pos < L.cap) L.entries[pos] = make_uint4(block, 0u, (unsigned int)my_bal, (unsigned int)(my_bal >> 32));
+          if (SOFT && my_sub != 0u) atomicOr(L.sub_touched + ti, my_sub);
+        }
+      }
+      my_t = -1;
+      k = 0;
+    };
+    for (;;) {
+      const unsigned long long todo = __ballot(pending != 0ull);
+      if (todo == 0ull) break;
+      const int l2 = __ffsll((long long)todo) - 1;
+      const int i = pending != 0ull ? __ffsll((long long)pending) - 1 : 0;
+      const int tx = __builtin_amdgcn_readlane(tx0 + (i & 7), l2);
+      const int ty = __builtin_amdgcn_readlane(ty0 + (i >> 3), l2);
+      const bool inr = small && tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1;
+      const unsigned long long bal = __ballot(inr);
+      if (inr) pending &= ~(1ull << ((ty - ty0) * 8 + (tx - tx0)));
+      unsigned int sub = 0u;
+      if (SOFT && EMIT) {
+        // the 16 x 4-pixel sub-tiles of tile (tx, ty) the lane's pixel range reaches: bit = sy * 2 + sx
+        unsigned int m16 = 0u;
+        if (inr) {
+          const int px0 = tx * S_TILE, py0 = ty * S_TILE;
+          const int sx0 = max(c_lo - px0, 0) / SUB_W, sx1 = min(c_hi - px0, S_TILE - 1) / SUB_W;
+          const int sy0 = max(r_lo - py0, 0) / SUB_H, sy1 = min(r_hi - py0, S_TILE - 1) / SUB_H;
+          const unsigned int colbits = (sx0 == 0 ? 1u : 0u) | (sx1 >= 1 ? 2u : 0u);
+          const unsigned int rowsel = ((1u << (2 * (sy1 + 1))) - 1u) & ~((1u << (2 * sy0)) - 1u) & 0x5555u;
+          m16 = colbits * rowsel;
+        }
+        sub = wave_or_u32(m16);
+      }
+      if (lane == k) {
+        my_t = ty * L.tiles_x + tx;
+        my_bal = bal;
+        my_sub = sub;
+      }
+      if (++k == 64) flush();
+    }
+    flush();
+  }
+}
+
+// ---- the bin kernel -------------------------------------------------------------------------------------------------------
+// One thread per face of the packed face list, in two passes over the same code: count (EMIT = false) and emit (true).
+// Inputs come in two flavours:
+//   raw     the Python layer's (B, F, ...) tensors: vertices scaled by `mult` here, boxes = min / max over the three
+//           vertices (-+ margin for the soft pass), faces with valid[f] == 0 or front[f] < 0 skipped by the rasterizer
+//           pass -- the torch glue of rasterization.py:292-327 / dibr.py:31-39 (incl. its torch.where host sync);
+//   packed  the reference operators' own inputs: scaled vertices, boxes given, `first` (B+1) face ranges (rasterizer) or
+//           a dense batch (soft mask).
+template <typename T>
+struct BinIn {
+  int B, F;                  // dense batch: mesh b owns faces [b*F, (b+1)*F); with `first`: F unused
+  long long total_faces;
+  const int64_t* first;      // (B+1) packed face ranges, or nullptr
+  const T* img;              // (total, 3, 2)
+  const T* z;                // raster: (total, 3) through `lay`; may be nullptr
+  FaceLayout lay;
+  const uint8_t* valid;      // raster, raw: optional
+  const T* front;            // raster, raw: optional (kept when >= 0)
+  const T* bbox_r;           // raster, packed: given boxes (total, 4); nullptr -> from the vertices
+  const T* bbox_s;           // soft, packed: given large boxes (total, 4); nullptr -> from the vertices -+ margin
+  T mult;                    // raw: scale applied to img (1 when already scaled)
+  T margin;                  // soft, raw: boxlen * multiplier
+  float multiplier;          // the operator's float multiplier (pixel-centre arithmetic)
+  int H, W;
+  T* rec_r;
+  T* rec_s;
+};
+
+template <typename T, bool DO_R, bool DO_S, bool EMIT>
+__global__ __launch_bounds__(256) void bin_faces_kernel2(BinIn<T> in, Lists LR, Lists LS) {
+  const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+  bool live = f < in.total_faces;
+  int b = 0;
+  long long first_b = 0;
+  if (live) {
+    if (in.first == nullptr) {
+      b = (int)(f / in.F);
+      first_b = (long long)b * in.F;
+    } else {
+      while (b + 1 < in.B && in.first[b + 1] <= f) ++b;
+      first_b = in.first[b];
+      if (f >= in.first[in.B]) live = false;
+    }
+  }
+  bool act_r = false, act_s = false, big_r = false, big_s = false;
+  int rx0 = 0, rx1 = 0, ry0 = 0, ry1 = 0, sx0 = 0, sx1 = 0, sy0 = 0, sy1 = 0;
+  PixRange pr_s{0, 0, 0, 0, false};
+  if (live) {
+    T v[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = in.img[f * 6 + i] * in.mult;
+    T xmin = nan_min<T>(nan_min<T>(v[0], v[2]), v[4]), xmax = nan_max<T>(nan_max<T>(v[0], v[2]), v[4]);
+    T ymin = nan_min<T>(nan_min<T>(v[1], v[3]), v[5]), ymax = nan_max<T>(nan_max<T>(v[1], v[3]), v[5]);
+    if (DO_R) {
+      bool keep = true;
+      if (in.valid != nullptr && in.valid[f] == 0) keep = false;
+      if (keep && in.front != nullptr && !(in.front[f * in.lay.front_stride] >= (T)0)) keep = false;
+      T bx0 = xmin, by0 = ymin, bx1 = xmax, by1 = ymax;
+      if (in.bbox_r != nullptr) {
+        bx0 = in.bbox_r[f * 4 + 0];
+        by0 = in.bbox_r[f * 4 + 1];
+        bx1 = in.bbox_r[f * 4 + 2];
+        by1 = in.bbox_r[f * 4 + 3];
+      }
+      if (EMIT) {
+        T z0 = 0, z1 = 0, z2 = 0;
+        if (in.z != nullptr) {
+          z0 = in.z[f * in.lay.z_face + 0 * in.lay.z_vertex];
+          z1 = in.z[f * in.lay.z_face + 1 * in.lay.z_vertex];
+          z2 = in.z[f * in.lay.z_face + 2 * in.lay.z_vertex];
+        }
+        Rec4<T>* r = reinterpret_cast<Rec4<T>*>(in.rec_r + (size_t)f * REC_R);
+        r[0] = Rec4<T>{bx0, by0, bx1, by1};
+        r[1] = Rec4<T>{v[0], v[1], v[2], v[3]};
+        r[2] = Rec4<T>{v[4], v[5], z0, z1};
+        r[3] = Rec4<T>{z2, keep ? (T)1 : (T)0, 0, 0};
+      }
+      PixRange pr;
+      if (keep && pixel_range<T>(bx0, by0, bx1, by1, in.H, in.W, in.multiplier, &pr)) {
+        act_r = true;
+        rx0 = pr.c_lo / R_TILE;
+        rx1 = pr.c_hi / R_TILE;
+        ry0 = pr.r_lo / R_TILE;
+        ry1 = pr.r_hi / R_TILE;
+        big_r = pr.everywhere || rx1 - rx0 >= 8 || ry1 - ry0 >= 8;
+      }
+    }
+    if (DO_S) {
+      T bx0, by0, bx1, by1;
+      if (in.bbox_s != nullptr) {
+        bx0 = in.bbox_s[f * 4 + 0];
+        by0 = in.bbox_s[f * 4 + 1];
+        bx1 = in.bbox_s[f * 4 + 2];
+        by1 = in.bbox_s[f * 4 + 3];
+      } else {
+        bx0 = xmin - in.margin;
+        by0 = ymin - in.margin;
+        bx1 = xmax + in.margin;
+        by1 = ymax + in.margin;
+      }
+      if (EMIT) {
+        Rec4<T>* r = reinterpret_cast<Rec4<T>*>(in.rec_s + (size_t)f * REC_S);
+        r[0] = Rec4<T>{bx0, by0, bx1, by1};
+        r[1] = Rec4<T>{v[0], v[1], v[2], v[3]};
+        r[2] = Rec4<T>{v[4], v[5], 0, 0};
+      }
+      if (pixel_range<T>(bx0, by0, bx1, by1, in.H, in.W, in.multiplier, &pr_s)) {
+        act_s = true;
+        sx0 = pr_s.c_lo / S_TILE;
+        sx1 = pr_s.c_hi / S_TILE;
+        sy0 = pr_s.r_lo / S_TILE;
+        sy1 = pr_s.r_hi / S_TILE;
+        big_s = pr_s.everywhere || sx1 - sx0 >= 8 || sy1 - sy0 >= 8;
+      }
+    }
+  }
+  if (DO_R) wave_bin<EMIT, false>(act_r, big_r, b, first_b, f, rx0, rx1, ry0, ry1, 0, 0, 0, 0, LR);
+  if (DO_S) wave_bin<EMIT, true>(act_s, big_s, b, first_b, f, sx0, sx1, sy0, sy1, pr_s.c_lo, pr_s.c_hi, pr_s.r_lo, pr_s.r_hi, LS);
+}
+
+// ---- scan: count -> base (exclusive), count reset to 0 (it becomes the emit pass' cursor) --------------------------------
+// One 1024-thread workgroup walks the counters in slabs of 4096 (one 16-byte load per thread: coalesced), block-scans a
+// slab and carries the running total into the next.  Up to two arrays in one launch.
+static __global__ __launch_bounds__(1024) void bin_scan_kernel(unsigned int* cnt_a, unsigned int* base_a, int n_a,
+                                                        unsigned int* cnt_b, unsigned int* base_b, int n_b) {
+  __shared__ unsigned int s_wave[17];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int arr = 0; arr < 2; ++arr) {
+    unsigned int* cnt = arr == 0 ? cnt_a : cnt_b;
+    unsigned int* base = arr == 0 ? base_a : base_b;
+    const int n = arr == 0 ? n_a : n_b;
+    if (cnt == nullptr || n <= 0) continue;
+    unsigned int carry = 0;
+    for (int s0 = 0; s0 < n; s0 += 4096) {
+      const int i = s0 + tid * 4;
+      uint4 c = make_uint4(0u, 0u, 0u, 0u);
+      if (i + 3 < n) {
+        c = *reinterpret_cast<const uint4*>(cnt + i);
+      } else {
+        if (i < n) c.x = cnt[i];
+        if (i + 1 < n) c.y = cnt[i + 1];
+        if (i + 2 < n) c.z = cnt[i + 2];
+      }
+      const unsigned int sum = c.x + c.y + c.z + c.w;
+      unsigned int inc = sum;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned int o = (unsigned int)__shfl_up((int)inc, d, 64);
+        if (lane >= d) inc += o;
+      }
+      __syncthreads();  // s_wave may still be read by the previous slab
+      if (lane == 63) s_wave[wave] = inc;
+      __syncthreads();
+      if (tid == 0) {
+        unsigned int run = 0;
+        for (int w = 0; w < 16; ++w) {
+          const unsigned int t = s_wave[w];
+          s_wave[w] = run;
+          run += t;
+        }
+        s_wave[16] = run;
+      }
+      __syncthreads();
+      const unsigned int e0 = carry + s_wave[wave] + inc - sum;
+      const uint4 bs = make_uint4(e0, e0 + c.x, e0 + c.x + c.y, e0 + c.x + c.y + c.z);
+      if (i + 3 < n) {
+        *reinterpret_cast<uint4*>(base + i) = bs;
+        *reinterpret_cast<uint4*>(cnt + i) = make_uint4(0u, 0u, 0u, 0u);
+      } else {
+        if (i < n) { base[i] = bs.x; cnt[i] = 0u; }
+        if (i + 1 < n) { base[i + 1] = bs.y; cnt[i + 1] = 0u; }
+        if (i + 2 < n) { base[i + 2] = bs.z; cnt[i + 2] = 0u; }
+      }
+      carry += s_wave[16];
+    }
+    if (tid == 0) base[n] = carry;
+    __syncthreads();
+  }
+}
+
+// ---- consumers: the candidate faces of a tile ------------------------------------------------------------------------------
+// A tile's candidates are (a) its entries, (b) the faces of its mesh's big list; a tile whose entries did not fit into the
+// pool (base + n > cap) takes every block of its mesh instead.  `TileSrc` describes which.
+struct TileSrc {
+  unsigned int base, n;     // entries [base, base + n)
+  bool brute;               // list overflowed: every face of the mesh is a candidate
+};
+__device__ __forceinline__ TileSrc tile_src(const Lists& L, int b, int tile) {
+  const size_t ti = (size_t)b * L.ntiles + tile;
+  TileSrc s;
+  s.base = L.base[ti];
+  s.n = L.base[ti + 1] - s.base;
+  s.brute = (unsigned long long)s.base + s.n > (unsigned long long)L.cap;
+  return s;
+}
+
+// what the rasterizer's tile kernel needs to settle the soft mask's trivial pixels and queue the search's work items
+struct ClassifyOut {
+  void* soft_mask;                  // T* (B, H, W)
+  const unsigned int* sub_touched;  // soft pass: [B * ntiles_s]
+  const unsigned int* big_count_s;  // soft pass: [B]
+  int tiles_x_s, ntiles_s;
+  uint4* work_items;
+  unsigned int* work_counts;
+  unsigned int shard_cap;
+};
+
+// exclusive prefix over the 256 threads of a workgroup; *total = sum.  `scratch`: 4 ints of LDS.
+__device__ __forceinline__ int block_scan_256(int v, int* scratch, int* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int inc = wave_inclusive_scan(v);
+  __syncthreads();  // scratch may still be read by the previous round
+  if (lane == 63) scratch[wave] = inc;
+  __syncthreads();
+  const int s0 = scratch[0], s1 = scratch[1], s2 = scratch[2], s3 = scratch[3];
+  *total = s0 + s1 + s2 + s3;
+  const int before = wave == 0 ? 0 : (wave == 1 ? s0 : (wave == 2 ? s0 + s1 : s0 + s1 + s2));
+  return before + inc - v;
+}
+
+// ---- the soft-mask search's worklist ----------------------------------------------------------------------------------------
+// A 256-thread workgroup covers 16 x 16 pixels = four 16 x 4 sub-tiles (one per wavefront).  Wavefront `wave` hands in
+// the bit mask `unc` of its uncovered pixels; the sub-tile becomes a work item {item id, unc} when some enlarged face box
+// reaches it (the soft pass' sub_touched bits; a mesh with big faces reaches everything).  One append per workgroup;
+// the counter is sharded WORK_SHARDS ways by workgroup id.  item id = (soft tile * B + b) * 16 + sub-tile of the tile.
+__device__ __forceinline__ void queue_items(unsigned long long unc, bool has_faces, int B, int b, int tile_x, int tile_y,
+                                            int wave, int lane, const unsigned int* __restrict__ sub_touched,
+                                            const unsigned int* __restrict__ big_count_s, int tiles_x_s, int ntiles_s,
+                                            uint4* __restrict__ work_items, unsigned int* __restrict__ work_counts,
+                                            unsigned int shard_cap, unsigned long long* s_item_unc) {
+  bool item = false;
+  if (unc != 0ull && has_faces) {
+    const int sy = tile_y + wave * SUB_H;
+    const int st = (sy / S_TILE) * tiles_x_s + tile_x / S_TILE;
+    const int ss = ((sy % S_TILE) / SUB_H) * (S_TILE / SUB_W) + (tile_x % S_TILE) / SUB_W;
+    item = ((sub_touched[(size_t)b * ntiles_s + st] >> ss) & 1u) != 0u || big_count_s[b] != 0u;
+  }
+  if (lane == 0) s_item_unc[wave] = item ? unc : 0ull;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int n = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) n += s_item_unc[w] != 0ull ? 1 : 0;
+    if (n > 0) {
+      const unsigned int shard = blockIdx.x & (WORK_SHARDS - 1);
+      unsigned int pos = atomicAdd(work_counts + shard, (unsigned int)n);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const unsigned long long u = s_item_unc[w];
+        if (u == 0ull) continue;
+        const int sy = tile_y + w * SUB_H;
+        const int st = (sy / S_TILE) * tiles_x_s + tile_x / S_TILE;
+        const int ss = ((sy % S_TILE) / SUB_H) * (S_TILE / SUB_W) + (tile_x % S_TILE) / SUB_W;
+        const unsigned int item_id = (unsigned int)((st * B + b) * S_SUBS + ss);
+        if (pos < shard_cap)
+          work_items[(size_t)shard * shard_cap + pos] = make_uint4(item_id, (unsigned int)u, (unsigned int)(u >> 32), 0u);
+        ++pos;
+      }
+    }
+  }
+}
+
+}  // namespace tl
+}  // namespace kamd
