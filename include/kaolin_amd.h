@@ -152,7 +152,7 @@ int kamd_rasterize_backward_f64(void* stream, int B, int H, int W, int F, int D,
 /* work: kamd_dibr_soft_mask_work_words(B,H,W) 32-bit words receiving the      */
 /* search's worklist (scratch for this operator).                             */
 /* ------------------------------------------------------------------------- */
-size_t kamd_dibr_soft_mask_forward_workspace(int B, int H, int W, int F, int elem_size);
+size_t kamd_dibr_soft_mask_forward_workspace(int B, int H, int W, int F, int K, int elem_size);
 int kamd_dibr_soft_mask_forward_f32(void* stream, int B, int H, int W, int F, int K,
                                     const float* img, const float* large_bbox,
                                     const int64_t* sel_idx, float sigmainv, float multiplier,
@@ -183,8 +183,10 @@ int kamd_dibr_soft_mask_backward_f64(void* stream, int B, int H, int W, int F, i
 
 /* Compact-list variant used by this package's own autograd Function (not part  */
 /* of the reference's interface): same search, same soft_mask, but instead of   */
-/* the (B,H,W,K) K-buffers every accepted (pixel, face) hit is appended to four */
-/* parallel arrays.  The list is SEGMENTED: a work item (a 16x4-pixel sub-tile    */
+/* the (B,H,W,K) K-buffers every accepted (pixel, face) hit is appended to     */
+/* three parallel arrays: hit_pair (two int32 per record: the mesh-relative     */
+/* face, and (pixel of the sub-tile 0..63) << 16 | rank of the hit among the    */
+/* pixel's hits), hit_prob, hit_type.  The list is SEGMENTED: a work item (a 16x4-pixel sub-tile    */
 /* that has hits to search), identified by item = (32x32 tile * B + b) * 16 +    */
 /* sub-tile, owns the records [item*64*K, item*64*K + item_count[item]), stored  */
 /* FACE-MAJOR (the pixels of one face are consecutive).  item_count holds        */
@@ -199,18 +201,18 @@ size_t kamd_dibr_soft_mask_work_words(int B, int H, int W);
 int kamd_dibr_soft_mask_forward_lean_f32(void* stream, int B, int H, int W, int F, int K,
                                          const float* img, const float* large_bbox,
                                          const int64_t* sel_idx, float sigmainv, float multiplier,
-                                         float* soft_mask, int32_t* hit_pix, int32_t* hit_face,
+                                         float* soft_mask, int32_t* hit_pair,
                                          float* hit_prob, uint8_t* hit_type, int32_t* item_count,
                                          uint32_t* work, void* workspace);
 int kamd_dibr_soft_mask_forward_lean_f64(void* stream, int B, int H, int W, int F, int K,
                                          const double* img, const double* large_bbox,
                                          const int64_t* sel_idx, float sigmainv, float multiplier,
-                                         double* soft_mask, int32_t* hit_pix, int32_t* hit_face,
+                                         double* soft_mask, int32_t* hit_pair,
                                          double* hit_prob, uint8_t* hit_type, int32_t* item_count,
                                          uint32_t* work, void* workspace);
 int kamd_dibr_soft_mask_backward_lean_f32(void* stream, int B, int H, int W, int F, int K,
                                           const float* grad, const float* soft_mask,
-                                          const int32_t* hit_pix, const int32_t* hit_face,
+                                          const int32_t* hit_pair,
                                           const float* hit_prob, const uint8_t* hit_type,
                                           const int32_t* item_count, const uint32_t* work,
                                           const float* img,
@@ -218,7 +220,7 @@ int kamd_dibr_soft_mask_backward_lean_f32(void* stream, int B, int H, int W, int
                                           float* g_img);
 int kamd_dibr_soft_mask_backward_lean_f64(void* stream, int B, int H, int W, int F, int K,
                                           const double* grad, const double* soft_mask,
-                                          const int32_t* hit_pix, const int32_t* hit_face,
+                                          const int32_t* hit_pair,
                                           const double* hit_prob, const uint8_t* hit_type,
                                           const int32_t* item_count, const uint32_t* work,
                                           const double* img,
@@ -260,13 +262,13 @@ int kamd_rasterize_forward_fused_strided_f64(void* stream, int B, int H, int W, 
 int kamd_dibr_soft_mask_forward_fused_f32(void* stream, int B, int H, int W, int F, int K,
                                           const float* img, double multiplier, double margin,
                                           const int64_t* sel_idx, float sigmainv,
-                                          float* soft_mask, int32_t* hit_pix, int32_t* hit_face,
+                                          float* soft_mask, int32_t* hit_pair,
                                           float* hit_prob, uint8_t* hit_type, int32_t* item_count,
                                           uint32_t* work, void* workspace);
 int kamd_dibr_soft_mask_forward_fused_f64(void* stream, int B, int H, int W, int F, int K,
                                           const double* img, double multiplier, double margin,
                                           const int64_t* sel_idx, float sigmainv,
-                                          double* soft_mask, int32_t* hit_pix, int32_t* hit_face,
+                                          double* soft_mask, int32_t* hit_pair,
                                           double* hit_prob, uint8_t* hit_type, int32_t* item_count,
                                           uint32_t* work, void* workspace);
 
@@ -282,14 +284,14 @@ int kamd_dibr_soft_mask_forward_fused_f64(void* stream, int B, int H, int W, int
 /* receives BOTH gradient contributions; g_feat may be NULL (feature gradient  */
 /* not needed: not computed).  workspace: kamd_dibr_rasterization_workspace.   */
 /* ------------------------------------------------------------------------- */
-size_t kamd_dibr_rasterization_workspace(int B, int H, int W, int F, int elem_size);
+size_t kamd_dibr_rasterization_workspace(int B, int H, int W, int F, int K, int elem_size);
 int kamd_dibr_rasterization_forward_f32(void* stream, int B, int H, int W, int F, int D, int K,
                                         const float* z, int64_t z_face_stride, int64_t z_vertex_stride,
                                         const float* img, const float* feat, const uint8_t* valid,
                                         const float* front, int64_t front_stride, double multiplier,
                                         float eps, float sigmainv, double margin, float* interp,
                                         int64_t* face_idx, float* weights, float* soft_mask,
-                                        int32_t* hit_pix, int32_t* hit_face, float* hit_prob,
+                                        int32_t* hit_pair, float* hit_prob,
                                         uint8_t* hit_type, int32_t* item_count, uint32_t* work,
                                         void* workspace);
 int kamd_dibr_rasterization_forward_f64(void* stream, int B, int H, int W, int F, int D, int K,
@@ -298,14 +300,14 @@ int kamd_dibr_rasterization_forward_f64(void* stream, int B, int H, int W, int F
                                         const double* front, int64_t front_stride, double multiplier,
                                         float eps, float sigmainv, double margin, double* interp,
                                         int64_t* face_idx, double* weights, double* soft_mask,
-                                        int32_t* hit_pix, int32_t* hit_face, double* hit_prob,
+                                        int32_t* hit_pair, double* hit_prob,
                                         uint8_t* hit_type, int32_t* item_count, uint32_t* work,
                                         void* workspace);
 int kamd_dibr_rasterization_backward_f32(void* stream, int B, int H, int W, int F, int D, int K,
                                          const float* grad_feat, const float* grad_soft,
                                          const int64_t* face_idx, const float* weights,
-                                         const float* soft_mask, const int32_t* hit_pix,
-                                         const int32_t* hit_face, const float* hit_prob,
+                                         const float* soft_mask, const int32_t* hit_pair,
+                                         const float* hit_prob,
                                          const uint8_t* hit_type, const int32_t* item_count,
                                          const uint32_t* work, const float* img, const float* feat,
                                          double multiplier, float eps, float sigmainv,
@@ -313,8 +315,8 @@ int kamd_dibr_rasterization_backward_f32(void* stream, int B, int H, int W, int 
 int kamd_dibr_rasterization_backward_f64(void* stream, int B, int H, int W, int F, int D, int K,
                                          const double* grad_feat, const double* grad_soft,
                                          const int64_t* face_idx, const double* weights,
-                                         const double* soft_mask, const int32_t* hit_pix,
-                                         const int32_t* hit_face, const double* hit_prob,
+                                         const double* soft_mask, const int32_t* hit_pair,
+                                         const double* hit_prob,
                                          const uint8_t* hit_type, const int32_t* item_count,
                                          const uint32_t* work, const double* img, const double* feat,
                                          double multiplier, float eps, float sigmainv,

@@ -111,7 +111,7 @@ def dibr_soft_mask_forward_cuda(face_vertices_image, face_large_bboxes, selected
         idx = torch.empty((batch_size, height, width, knum), dtype=torch.long, device=device)
         typ = torch.empty((batch_size, height, width, knum), dtype=torch.uint8, device=device)
         hits = torch.empty((batch_size, height, width), dtype=torch.uint8, device=device) if _with_hit_count else None
-        ws = _lib.workspace(lib.kamd_dibr_soft_mask_forward_workspace(batch_size, height, width, num_faces,
+        ws = _lib.workspace(lib.kamd_dibr_soft_mask_forward_workspace(batch_size, height, width, num_faces, knum,
                                                                       face_vertices_image.element_size()), device)
         work = _work_buffer(batch_size, height, width, device)
         st = getattr(lib, f'kamd_dibr_soft_mask_forward_{sfx}')(
@@ -178,13 +178,13 @@ def dibr_soft_mask_forward_lean(face_vertices_image, face_large_bboxes, selected
     with torch.cuda.device(device):
         soft_mask = torch.empty((batch_size, height, width), dtype=dtype, device=device)
         hits = _hit_list(batch_size, height, width, knum, dtype, device, num_faces)
-        ws = _lib.workspace(lib.kamd_dibr_soft_mask_forward_workspace(batch_size, height, width, num_faces,
+        ws = _lib.workspace(lib.kamd_dibr_soft_mask_forward_workspace(batch_size, height, width, num_faces, int(knum),
                                                                       face_vertices_image.element_size()), device)
         st = getattr(lib, f'kamd_dibr_soft_mask_forward_lean_{sfx}')(
             _lib.stream_ptr(device), batch_size, height, width, num_faces, int(knum),
             _lib.ptr(face_vertices_image), _lib.ptr(face_large_bboxes), _lib.ptr(selected_face_idx),
             float(sigmainv), float(multiplier), _lib.ptr(soft_mask), _lib.ptr(hits[0]), _lib.ptr(hits[1]),
-            _lib.ptr(hits[2]), _lib.ptr(hits[3]), _lib.ptr(hits[4]), _lib.ptr(hits[5]), _lib.ptr(ws))
+            _lib.ptr(hits[2]), _lib.ptr(hits[3]), _lib.ptr(hits[4]), _lib.ptr(ws))
     _lib.check(st, fn)
     return soft_mask, hits
 
@@ -194,7 +194,7 @@ def dibr_soft_mask_backward_lean(grad_soft_mask, soft_mask, hits, face_vertices_
     """Backward of :func:`dibr_soft_mask_forward_lean` / ``_fused`` -> grad_face_vertices_image (B,F,3,2), w.r.t. the
     unscaled input.  ``face_vertices_image * img_scale`` must be the scaled vertices the forward searched with."""
     fn = 'dibr_soft_mask_backward_lean'
-    hit_pix, hit_face, hit_prob, hit_type, item_count, work = hits
+    hit_pair, hit_prob, hit_type, item_count, work = hits
     knum = int(knum)
     args = [Arg(grad_soft_mask, 'grad_soft_mask', 1), Arg(soft_mask, 'soft_mask', 2),
             Arg(face_vertices_image, 'face_vertices_image', 4)]
@@ -210,7 +210,7 @@ def dibr_soft_mask_backward_lean(grad_soft_mask, soft_mask, hits, face_vertices_
         g_img = torch.zeros_like(face_vertices_image)
         st = getattr(lib, f'kamd_dibr_soft_mask_backward_lean_{sfx}')(
             _lib.stream_ptr(device), batch_size, height, width, num_faces, knum,
-            _lib.ptr(grad_soft_mask), _lib.ptr(soft_mask), _lib.ptr(hit_pix), _lib.ptr(hit_face), _lib.ptr(hit_prob),
+            _lib.ptr(grad_soft_mask), _lib.ptr(soft_mask), _lib.ptr(hit_pair), _lib.ptr(hit_prob),
             _lib.ptr(hit_type), _lib.ptr(item_count), _lib.ptr(work), _lib.ptr(face_vertices_image), float(img_scale), float(sigmainv),
             float(multiplier), _lib.ptr(g_img))
     _lib.check(st, fn)
@@ -225,10 +225,11 @@ def _work_buffer(batch_size, height, width, device):
 
 def _hit_list(batch_size, height, width, knum, dtype, device, num_faces=0):
     """Storage of the segmented hit list: 64*K record slots per 16x4-pixel sub-tile slot (just the used parts are ever
-    touched), one count per sub-tile slot, and the worklist of the sub-tiles that were searched."""
+    touched) -- pair records {face, pixel << 16 | rank} as (cap, 2) int32, probabilities, types --, one count per
+    sub-tile slot, and the worklist of the sub-tiles that were searched."""
     cap = max(int(_lib.load().kamd_dibr_soft_mask_lean_capacity(batch_size, height, width, int(knum))), 1)
     n_sub = ((width + 31) // 32) * ((height + 31) // 32) * 16 * batch_size
-    return (torch.empty(cap, dtype=torch.int32, device=device), torch.empty(cap, dtype=torch.int32, device=device),
+    return (torch.empty((cap, 2), dtype=torch.int32, device=device),
             torch.empty(cap, dtype=dtype, device=device), torch.empty(cap, dtype=torch.uint8, device=device),
             torch.empty(max(n_sub, 1), dtype=torch.int32, device=device),
             _work_buffer(batch_size, height, width, device))
@@ -242,9 +243,10 @@ def work_items(work):
     return torch.cat([items[s, :min(c, shard_cap), 0] for s, c in enumerate(counts)]).long()
 
 
-def hit_list_entries(hits, knum):
-    """Flattens a segmented hit list -> (pix, face, prob, type) 1-D tensors of the recorded hits (tests / debugging)."""
-    hit_pix, hit_face, hit_prob, hit_type, item_count, work = hits
+def hit_list_entries(hits, knum, batch_size, height, width):
+    """Flattens a segmented hit list -> (pix, face, prob, type) 1-D tensors of the recorded hits, pix = flat (b, row, col)
+    index (tests / debugging)."""
+    hit_pair, hit_prob, hit_type, item_count, work = hits
     items = work_items(work)
     n = items.numel()
     counts = item_count[items].long()
@@ -253,7 +255,15 @@ def hit_list_entries(hits, knum):
     seg = torch.repeat_interleave(torch.arange(n, device=counts.device), counts)
     within = torch.arange(total, device=counts.device) - torch.repeat_interleave(torch.cumsum(counts, 0) - counts, counts)
     pos = starts[seg] + within
-    return hit_pix[pos], hit_face[pos], hit_prob[pos], hit_type[pos]
+    # item = (tile * B + b) * 16 + sub; tile = 32x32 pixels, sub-tile = 16x4 pixels, 2 sub-tiles across
+    it = items[seg]
+    sub, b, tile = it % 16, (it // 16) % batch_size, it // (16 * batch_size)
+    tiles_x = (width + 31) // 32
+    u = (hit_pair[pos, 1] >> 16).long()
+    col = (tile % tiles_x) * 32 + (sub % 2) * 16 + (u % 16)
+    row = (tile // tiles_x) * 32 + (sub // 2) * 4 + (u // 16)
+    pix = (b * height + row) * width + col
+    return pix, hit_pair[pos, 0], hit_prob[pos], hit_type[pos]
 
 
 def dibr_soft_mask_forward_fused(face_vertices_image, selected_face_idx, sigmainv, boxlen, knum, multiplier):
@@ -274,13 +284,13 @@ def dibr_soft_mask_forward_fused(face_vertices_image, selected_face_idx, sigmain
     with torch.cuda.device(device):
         soft_mask = torch.empty((batch_size, height, width), dtype=dtype, device=device)
         hits = _hit_list(batch_size, height, width, knum, dtype, device, num_faces)
-        ws = _lib.workspace(lib.kamd_dibr_soft_mask_forward_workspace(batch_size, height, width, num_faces,
+        ws = _lib.workspace(lib.kamd_dibr_soft_mask_forward_workspace(batch_size, height, width, num_faces, int(knum),
                                                                       face_vertices_image.element_size()), device)
         st = getattr(lib, f'kamd_dibr_soft_mask_forward_fused_{sfx}')(
             _lib.stream_ptr(device), batch_size, height, width, num_faces, int(knum), _lib.ptr(face_vertices_image),
             float(multiplier), float(boxlen * multiplier), _lib.ptr(selected_face_idx), float(sigmainv),
             _lib.ptr(soft_mask), _lib.ptr(hits[0]), _lib.ptr(hits[1]), _lib.ptr(hits[2]), _lib.ptr(hits[3]),
-            _lib.ptr(hits[4]), _lib.ptr(hits[5]), _lib.ptr(ws))
+            _lib.ptr(hits[4]), _lib.ptr(ws))
     _lib.check(st, fn)
     return soft_mask, hits
 
@@ -382,14 +392,14 @@ def dibr_rasterization_forward_fused(height, width, face_vertices_z, face_vertic
         interp = torch.empty((batch_size, height, width, feat_dim), dtype=dtype, device=device)
         soft_mask = torch.empty((batch_size, height, width), dtype=dtype, device=device)
         hits = _hit_list(batch_size, height, width, knum, dtype, device, num_faces)
-        ws = _lib.workspace(lib.kamd_dibr_rasterization_workspace(batch_size, height, width, num_faces, esz), device)
+        ws = _lib.workspace(lib.kamd_dibr_rasterization_workspace(batch_size, height, width, num_faces, int(knum), esz), device)
         st = getattr(lib, f'kamd_dibr_rasterization_forward_{sfx}')(
             _lib.stream_ptr(device), batch_size, height, width, num_faces, feat_dim, int(knum),
             _lib.ptr(z), int(z_face), int(z_vertex), _lib.ptr(face_vertices_image), _lib.ptr(face_features),
             _lib.ptr(valid_faces), _lib.ptr(front), int(front_stride),
             float(multiplier), float(eps), float(sigmainv), float(boxlen * multiplier),
             _lib.ptr(interp), _lib.ptr(face_idx), _lib.ptr(wts), _lib.ptr(soft_mask),
-            _lib.ptr(hits[0]), _lib.ptr(hits[1]), _lib.ptr(hits[2]), _lib.ptr(hits[3]), _lib.ptr(hits[4]), _lib.ptr(hits[5]),
+            _lib.ptr(hits[0]), _lib.ptr(hits[1]), _lib.ptr(hits[2]), _lib.ptr(hits[3]), _lib.ptr(hits[4]),
             _lib.ptr(ws))
     _lib.check(st, fn)
     return interp, face_idx, wts, soft_mask, hits
@@ -424,7 +434,7 @@ def dibr_rasterization_backward_fused(grad_features, grad_soft_mask, face_idx, o
             _lib.stream_ptr(device), batch_size, height, width, num_faces, feat_dim, int(knum),
             _lib.ptr(grad_features), _lib.ptr(grad_soft_mask), _lib.ptr(face_idx), _lib.ptr(output_weights),
             _lib.ptr(soft_mask), _lib.ptr(hits[0]), _lib.ptr(hits[1]), _lib.ptr(hits[2]), _lib.ptr(hits[3]),
-            _lib.ptr(hits[4]), _lib.ptr(hits[5]), _lib.ptr(face_vertices_image), _lib.ptr(face_features),
+            _lib.ptr(hits[4]), _lib.ptr(face_vertices_image), _lib.ptr(face_features),
             float(multiplier), float(eps), float(sigmainv), _lib.ptr(g_img), _lib.ptr(g_feat))
     _lib.check(st, fn)
     return g_img, g_feat

@@ -30,11 +30,11 @@ SIGNATURES = {
     'kamd_chamfer_distance_backward_f32': (_i, [_vp, _i, _i, _i, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'kamd_sided_distance_pair_forward_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'kamd_rasterize_forward_workspace': (_sz, [_i, _i, _i, _i64, _i]),
-    'kamd_dibr_soft_mask_forward_workspace': (_sz, [_i, _i, _i, _i, _i]),
+    'kamd_dibr_soft_mask_forward_workspace': (_sz, [_i, _i, _i, _i, _i, _i]),
     'kamd_triangle_distance_forward_workspace': (_sz, [_i, _i, _i]),
     'kamd_dibr_soft_mask_lean_capacity': (_sz, [_i, _i, _i, _i]),
     'kamd_dibr_soft_mask_work_words': (_sz, [_i, _i, _i]),
-    'kamd_dibr_rasterization_workspace': (_sz, [_i, _i, _i, _i, _i]),
+    'kamd_dibr_rasterization_workspace': (_sz, [_i, _i, _i, _i, _i, _i]),
     'kamd_trianglemeshes_to_voxelgrids_workspace': (_sz, [_i, _i, _i]),
     'kamd_deftet_forward_workspace': (_sz, [_i, _i, _i, _i]),
     'kamd_mesh_to_spc_stage_levels': (_i, []),
@@ -64,19 +64,19 @@ for _t in ('f32', 'f64'):
     SIGNATURES[f'kamd_dibr_soft_mask_backward_{_t}'] = (
         _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp])
     SIGNATURES[f'kamd_dibr_soft_mask_forward_lean_{_t}'] = (
-        _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+        _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_dibr_soft_mask_backward_lean_{_t}'] = (
-        _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _f, _f, _vp])
+        _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _f, _f, _vp])
     SIGNATURES[f'kamd_rasterize_forward_fused_{_t}'] = (
         _i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _dbl, _f, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_dibr_soft_mask_forward_fused_{_t}'] = (
-        _i, [_vp, _i, _i, _i, _i, _i, _vp, _dbl, _dbl, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+        _i, [_vp, _i, _i, _i, _i, _i, _vp, _dbl, _dbl, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_dibr_rasterization_forward_{_t}'] = (
-        _i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _dbl, _f, _f, _dbl] + [_vp] * 11)
+        _i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _dbl, _f, _f, _dbl] + [_vp] * 10)
     SIGNATURES[f'kamd_rasterize_forward_fused_strided_{_t}'] = (
         _i, [_vp, _i, _i, _i, _i, _i, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _dbl, _f, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_dibr_rasterization_backward_{_t}'] = (
-        _i, [_vp, _i, _i, _i, _i, _i, _i] + [_vp] * 13 + [_dbl, _f, _f, _vp, _vp])
+        _i, [_vp, _i, _i, _i, _i, _i, _i] + [_vp] * 12 + [_dbl, _f, _f, _vp, _vp])
     SIGNATURES[f'kamd_prepare_vertices_forward_{_t}'] = (
         _i, [_vp, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_prepare_vertices_backward_{_t}'] = (

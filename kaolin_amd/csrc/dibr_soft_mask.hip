@@ -243,34 +243,81 @@ __global__ __launch_bounds__(64) void soft_mask_backward_kernel(
 template <typename T>
 int soft2_search_launch(hipStream_t st, int B, int H, int W, int F, int K, float sigmainv, float multiplier, const T* rec,
                         const tl::Lists& LS, const unsigned int* work, T* soft_mask, T* prob, int64_t* idx, uint8_t* type,
-                        uint8_t* hit_count, const HitList2<T>* lean) {
-  Search2Args<T> a{};
-  a.B = B;
-  a.F = F;
-  a.H = H;
-  a.W = W;
-  a.K = K;
-  a.sigmainv = sigmainv;
-  a.multiplier = multiplier;
-  a.rec = rec;
-  a.L = LS;
-  a.work = work;
-  a.shard_cap = tl::work_shard_cap(B, H, W);
-  a.soft_mask = soft_mask;
-  a.prob_out = prob;
-  a.idx_out = idx;
-  a.type_out = type;
-  a.hit_count = hit_count;
-  if (lean) a.list = *lean;
+                        uint8_t* hit_count, const HitList2<T>* lean, unsigned short* pixcnt, T* prob_pm) {
+  const unsigned int shard_cap = tl::work_shard_cap(B, H, W);
   const long long n_sub = (long long)B * LS.ntiles * tl::S_SUBS;
-  static const int per_cu = kamd_env_int("KAMD_SOFT_SEARCH_PER_CU", 8);
-  const long long want = (long long)KAMD_NUM_CU * per_cu;
-  const dim3 grid((unsigned)(n_sub < want ? (n_sub > 0 ? n_sub : 1) : want));
-  kamd::ProfScope prof_(kamd::K_SOFT_TILE, st);
-  if (lean)
-    hipLaunchKernelGGL((soft_search_kernel2<T, true>), grid, dim3(S2_THREADS), 0, st, a);
-  else
-    hipLaunchKernelGGL((soft_search_kernel2<T, false>), grid, dim3(S2_THREADS), 0, st, a);
+  Select2Args<T> sa{};
+  sa.B = B;
+  sa.F = F;
+  sa.H = H;
+  sa.W = W;
+  sa.K = K;
+  sa.multiplier = multiplier;
+  sa.rec = rec;
+  sa.L = LS;
+  sa.work = work;
+  sa.shard_cap = shard_cap;
+  sa.pixcnt = pixcnt;
+  if (lean) sa.list = *lean;
+  sa.idx_out = idx;
+  sa.hit_count = hit_count;
+  Eval2Args<T> ea{};
+  ea.B = B;
+  ea.F = F;
+  ea.H = H;
+  ea.W = W;
+  ea.K = K;
+  ea.sigmainv = sigmainv;
+  ea.multiplier = multiplier;
+  ea.rec = rec;
+  ea.tiles_x_s = LS.tiles_x;
+  ea.work = work;
+  ea.shard_cap = shard_cap;
+  ea.pixcnt = pixcnt;
+  ea.soft_mask = soft_mask;
+  if (lean) ea.list = *lean;
+  ea.prob_out = prob;
+  ea.idx_out = idx;
+  ea.type_out = type;
+  ea.prob_pm = prob_pm;
+  // one wavefront (select) / workgroup (eval) per work item; the number of items is known on the device only, so the
+  // grids cover the worklist round-robin
+  static const int sel_per_cu = kamd_env_int("KAMD_SOFT_SELECT_PER_CU", 32);
+  static const int eval_per_cu = kamd_env_int("KAMD_SOFT_EVAL_PER_CU", 32);
+  const long long sel_want = (long long)KAMD_NUM_CU * sel_per_cu, eval_want = (long long)KAMD_NUM_CU * eval_per_cu;
+  const dim3 sel_grid((unsigned)(n_sub < sel_want ? (n_sub > 0 ? n_sub : 1) : sel_want));
+  const dim3 eval_grid((unsigned)(n_sub < eval_want ? (n_sub > 0 ? n_sub : 1) : eval_want));
+  {
+    kamd::ProfScope prof_(kamd::K_SOFT_SELECT, st);
+    if (lean)
+      hipLaunchKernelGGL((soft_select_kernel<T, true>), sel_grid, dim3(64), 0, st, sa);
+    else
+      hipLaunchKernelGGL((soft_select_kernel<T, false>), sel_grid, dim3(64), 0, st, sa);
+  }
+  KAMD_CHECK(hipGetLastError());
+  const bool lds_fold = K <= S2_LDS_KMAX;
+  const size_t shmem = lds_fold ? (size_t)64 * (K > 0 ? K : 1) * sizeof(T) : 0;
+  {
+    kamd::ProfScope prof_(kamd::K_SOFT_TILE, st);
+    if (lean) {
+      if (lds_fold)
+        hipLaunchKernelGGL((soft_eval_kernel<T, true, true>), eval_grid, dim3(S2_EVAL_THREADS), shmem, st, ea);
+      else
+        hipLaunchKernelGGL((soft_eval_kernel<T, true, false>), eval_grid, dim3(S2_EVAL_THREADS), 0, st, ea);
+    } else {
+      if (lds_fold)
+        hipLaunchKernelGGL((soft_eval_kernel<T, false, true>), eval_grid, dim3(S2_EVAL_THREADS), shmem, st, ea);
+      else
+        hipLaunchKernelGGL((soft_eval_kernel<T, false, false>), eval_grid, dim3(S2_EVAL_THREADS), 0, st, ea);
+    }
+  }
+  KAMD_CHECK(hipGetLastError());
+  if (!lds_fold) {
+    if (lean)
+      hipLaunchKernelGGL((soft_fold_kernel<T, true>), sel_grid, dim3(64), 0, st, ea);
+    else
+      hipLaunchKernelGGL((soft_fold_kernel<T, false>), sel_grid, dim3(64), 0, st, ea);
+  }
   return (int)hipGetLastError();
 }
 
@@ -285,7 +332,7 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
   const long long total_faces = (long long)B * F;
   if (workspace == nullptr || work == nullptr) return (int)hipErrorInvalidValue;
   if (lean != nullptr && (long long)B * H * W >= (1ll << 31)) return (int)hipErrorInvalidValue;
-  const tl::Layout lay = tl::make_layout(B, H, W, total_faces, (int)sizeof(T), false, true);
+  const tl::Layout lay = tl::make_layout(B, H, W, total_faces, (int)sizeof(T), false, true, K);
   tl::Lists LS = tl::lists_of(workspace, lay.s, B, true);
   tl::Lists none{};
   T* rec = (T*)((char*)workspace + lay.s.rec);
@@ -337,7 +384,8 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
   KAMD_CHECK(hipGetLastError());
   if (total_faces > 0)
     KAMD_CHECK(soft2_search_launch<T>(st, B, H, W, F, K, sigmainv, multiplier, rec, LS, work, soft_mask, prob, idx, type,
-                                      hit_count, lean));
+                                      hit_count, lean, (unsigned short*)((char*)workspace + lay.s.pixcnt),
+                                      (T*)((char*)workspace + lay.s.prob_pm)));
   KAMD_RETURN_LAST_ERROR();
 }
 
@@ -350,7 +398,8 @@ int soft_mask_backward_list_launch(hipStream_t st, int B, int H, int W, int F, i
     kamd::ProfScope prof_(kamd::K_SOFT_BACKWARD_LIST, st);
     static const int per_cu = kamd_env_int("KAMD_SOFT_BWD_PER_CU", 8);
     hipLaunchKernelGGL(soft_mask_backward_list_kernel2<T>, dim3(KAMD_NUM_CU * per_cu), dim3(256), 0, st, B, H, W, F, K, grad,
-                       soft_mask, list, work, tl::work_shard_cap(B, H, W), img, (T)img_scale, sigmainv, multiplier, g_img);
+                       soft_mask, list, work, tl::work_shard_cap(B, H, W), tl::pass_geom(H, W, tl::S_TILE).tiles_x, img,
+                       (T)img_scale, sigmainv, multiplier, g_img);
   }
   KAMD_RETURN_LAST_ERROR();
 }
@@ -384,7 +433,7 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
   const long long total_faces = (long long)B * F;
   if (workspace == nullptr || work == nullptr) return (int)hipErrorInvalidValue;
   if ((long long)B * H * W >= (1ll << 31)) return (int)hipErrorInvalidValue;
-  const tl::Layout lay = tl::make_layout(B, H, W, total_faces, (int)sizeof(T), true, true);
+  const tl::Layout lay = tl::make_layout(B, H, W, total_faces, (int)sizeof(T), true, true, K);
   tl::Lists LR = tl::lists_of(workspace, lay.r, B, false);
   tl::Lists LS = tl::lists_of(workspace, lay.s, B, true);
   T* rec_r = (T*)((char*)workspace + lay.r.rec);
@@ -428,7 +477,9 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
   KAMD_CHECK(kamd::raster2_draw<T>(st, B, H, W, D, F, (float)multiplier, eps, rec_r, LR, feat, interp, face_idx, weights, co));
   if (total_faces > 0)
     KAMD_CHECK(soft2_search_launch<T>(st, B, H, W, F, K, sigmainv, (float)multiplier, rec_s, LS, work, soft_mask, (T*)nullptr,
-                                      (int64_t*)nullptr, (uint8_t*)nullptr, (uint8_t*)nullptr, &list));
+                                      (int64_t*)nullptr, (uint8_t*)nullptr, (uint8_t*)nullptr, &list,
+                                      (unsigned short*)((char*)workspace + lay.s.pixcnt),
+                                      (T*)((char*)workspace + lay.s.prob_pm)));
   KAMD_RETURN_LAST_ERROR();
 }
 
@@ -498,13 +549,13 @@ size_t kamd_dibr_soft_mask_work_words(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
   return kamd::tl::work_words(B, H, W);
 }
-size_t kamd_dibr_soft_mask_forward_workspace(int B, int H, int W, int F, int elem_size) {
+size_t kamd_dibr_soft_mask_forward_workspace(int B, int H, int W, int F, int K, int elem_size) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
-  return kamd::tl::make_layout(B, H, W, (long long)B * (F > 0 ? F : 0), elem_size, false, true).total;
+  return kamd::tl::make_layout(B, H, W, (long long)B * (F > 0 ? F : 0), elem_size, false, true, K).total;
 }
-size_t kamd_dibr_rasterization_workspace(int B, int H, int W, int F, int elem_size) {
+size_t kamd_dibr_rasterization_workspace(int B, int H, int W, int F, int K, int elem_size) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
-  return kamd::tl::make_layout(B, H, W, (long long)B * (F > 0 ? F : 0), elem_size, true, true).total;
+  return kamd::tl::make_layout(B, H, W, (long long)B * (F > 0 ? F : 0), elem_size, true, true, K).total;
 }
 
 #define KAMD_SOFT_ENTRY(SFX, T)                                                                                       \
@@ -524,29 +575,29 @@ size_t kamd_dibr_rasterization_workspace(int B, int H, int W, int F, int elem_si
   }                                                                                                                   \
   int kamd_dibr_soft_mask_forward_lean_##SFX(void* stream, int B, int H, int W, int F, int K, const T* img,          \
                                              const T* large_bbox, const int64_t* sel_idx, float sigmainv,            \
-                                             float multiplier, T* soft_mask, int32_t* hit_pix, int32_t* hit_face,    \
-                                             T* hit_prob, uint8_t* hit_type, int32_t* item_count, uint32_t* work,    \
+                                             float multiplier, T* soft_mask, int32_t* hit_pair, T* hit_prob,         \
+                                             uint8_t* hit_type, int32_t* item_count, uint32_t* work,                 \
                                              void* workspace) {                                                       \
-    HitList2<T> l{hit_pix, hit_face, hit_prob, hit_type, item_count};                                                \
+    HitList2<T> l{(int2*)hit_pair, hit_prob, hit_type, item_count};                                                  \
     return soft_mask_forward_launch<T>((hipStream_t)stream, B, H, W, F, K, img, large_bbox, sel_idx, sigmainv,       \
                                        multiplier, soft_mask, nullptr, nullptr, nullptr, workspace, nullptr, &l,     \
                                        work);                                                                         \
   }                                                                                                                   \
   int kamd_dibr_soft_mask_backward_lean_##SFX(void* stream, int B, int H, int W, int F, int K, const T* grad,        \
-                                              const T* soft_mask, const int32_t* hit_pix, const int32_t* hit_face,   \
-                                              const T* hit_prob, const uint8_t* hit_type, const int32_t* item_count,  \
+                                              const T* soft_mask, const int32_t* hit_pair, const T* hit_prob,        \
+                                              const uint8_t* hit_type, const int32_t* item_count,                    \
                                               const uint32_t* work, const T* img, double img_scale, float sigmainv,   \
                                               float multiplier, T* g_img) {                                           \
-    HitList2<T> l{(int*)hit_pix, (int*)hit_face, (T*)hit_prob, (uint8_t*)hit_type, (int*)item_count};                \
+    HitList2<T> l{(int2*)hit_pair, (T*)hit_prob, (uint8_t*)hit_type, (int*)item_count};                              \
     return soft_mask_backward_list_launch<T>((hipStream_t)stream, B, H, W, F, K, grad, soft_mask, l, work, img,      \
                                              img_scale, sigmainv, multiplier, g_img);                                 \
   }                                                                                                                   \
   int kamd_dibr_soft_mask_forward_fused_##SFX(void* stream, int B, int H, int W, int F, int K, const T* img,         \
                                               double multiplier, double margin, const int64_t* sel_idx,              \
-                                              float sigmainv, T* soft_mask, int32_t* hit_pix, int32_t* hit_face,     \
-                                              T* hit_prob, uint8_t* hit_type, int32_t* item_count, uint32_t* work,   \
+                                              float sigmainv, T* soft_mask, int32_t* hit_pair, T* hit_prob,          \
+                                              uint8_t* hit_type, int32_t* item_count, uint32_t* work,                \
                                               void* workspace) {                                                      \
-    HitList2<T> l{hit_pix, hit_face, hit_prob, hit_type, item_count};                                                \
+    HitList2<T> l{(int2*)hit_pair, hit_prob, hit_type, item_count};                                                  \
     return soft_mask_forward_launch<T>((hipStream_t)stream, B, H, W, F, K, img, nullptr, sel_idx, sigmainv,          \
                                        (float)multiplier, soft_mask, nullptr, nullptr, nullptr, workspace, nullptr,  \
                                        &l, work, true, multiplier, margin);                                           \
@@ -555,19 +606,19 @@ size_t kamd_dibr_rasterization_workspace(int B, int H, int W, int F, int elem_si
       void* stream, int B, int H, int W, int F, int D, int K, const T* z, int64_t z_face_stride,                      \
       int64_t z_vertex_stride, const T* img, const T* feat, const uint8_t* valid, const T* front,                     \
       int64_t front_stride, double multiplier, float eps, float sigmainv, double margin, T* interp, int64_t* face_idx, \
-      T* weights, T* soft_mask, int32_t* hit_pix, int32_t* hit_face, T* hit_prob, uint8_t* hit_type,                  \
-      int32_t* item_count, uint32_t* work, void* workspace) {                                                         \
-    HitList2<T> l{hit_pix, hit_face, hit_prob, hit_type, item_count};                                                 \
+      T* weights, T* soft_mask, int32_t* hit_pair, T* hit_prob, uint8_t* hit_type, int32_t* item_count,               \
+      uint32_t* work, void* workspace) {                                                                              \
+    HitList2<T> l{(int2*)hit_pair, hit_prob, hit_type, item_count};                                                   \
     return dibr_forward_fused<T>((hipStream_t)stream, B, H, W, F, D, K, z, z_face_stride, z_vertex_stride, img, feat,  \
                                  valid, front, front_stride, multiplier, eps, sigmainv, margin, interp, face_idx,     \
                                  weights, soft_mask, l, work, workspace);                                             \
   }                                                                                                                   \
   int kamd_dibr_rasterization_backward_##SFX(                                                                         \
       void* stream, int B, int H, int W, int F, int D, int K, const T* grad_feat, const T* grad_soft,                 \
-      const int64_t* face_idx, const T* weights, const T* soft_mask, const int32_t* hit_pix, const int32_t* hit_face,  \
-      const T* hit_prob, const uint8_t* hit_type, const int32_t* item_count, const uint32_t* work, const T* img,      \
-      const T* feat, double multiplier, float eps, float sigmainv, T* g_img, T* g_feat) {                             \
-    HitList2<T> l{(int*)hit_pix, (int*)hit_face, (T*)hit_prob, (uint8_t*)hit_type, (int*)item_count};                 \
+      const int64_t* face_idx, const T* weights, const T* soft_mask, const int32_t* hit_pair, const T* hit_prob,      \
+      const uint8_t* hit_type, const int32_t* item_count, const uint32_t* work, const T* img, const T* feat,          \
+      double multiplier, float eps, float sigmainv, T* g_img, T* g_feat) {                                            \
+    HitList2<T> l{(int2*)hit_pair, (T*)hit_prob, (uint8_t*)hit_type, (int*)item_count};                               \
     return dibr_backward_fused<T>((hipStream_t)stream, B, H, W, F, D, K, grad_feat, grad_soft, face_idx, weights,     \
                                   soft_mask, l, work, img, feat, multiplier, eps, sigmainv, g_img, g_feat);           \
   }

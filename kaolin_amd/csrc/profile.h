@@ -11,7 +11,7 @@ namespace kamd {
 enum KernelId {
   K_SD_MAIN = 0, K_SD_FINAL, K_SD_GENERIC, K_SD_BACKWARD, K_SDG_BUILD, K_SDG_QUERY,
   K_BIN_FACES, K_RASTER_TILE, K_RASTER_BACKWARD,
-  K_SOFT_FILL, K_SOFT_CLASSIFY, K_SOFT_TILE, K_SOFT_BACKWARD, K_SOFT_BACKWARD_LIST,
+  K_SOFT_FILL, K_SOFT_CLASSIFY, K_SOFT_SELECT, K_SOFT_TILE, K_SOFT_BACKWARD, K_SOFT_BACKWARD_LIST,
   K_TD_PREP, K_TD_MAIN, K_TD_FINAL, K_TD_BACKWARD,
   K_VOX_VERTICES, K_VOX_FACES, K_MEMSET, K_PV_FORWARD, K_PV_BACKWARD, K_MESH_INTERSECTION,
   K_DEFTET_FORWARD, K_DEFTET_SORT, K_DEFTET_BACKWARD, K_SPC_STAGE, K_SPC_BUILD,

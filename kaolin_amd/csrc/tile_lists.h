@@ -29,7 +29,10 @@ constexpr int R_TILE = 16;            // rasterizer tile: 16 x 16 pixels = one 2
 constexpr int S_TILE = 32;            // soft-mask tile: 32 x 32 pixels = 16 sub-tiles of 16 x 4 (work items of the search)
 constexpr int S_SUBS = (S_TILE / SUB_W) * (S_TILE / SUB_H);  // 16
 constexpr int REC_R = 16;             // raster record scalars: box[4] a.xy b.xy c.xy z[3] flag pad2
-constexpr int REC_S = 12;             // soft record scalars:   large box[4] a.xy b.xy c.xy pad2
+// soft record: large box[4] a.xy b.xy c.xy pad2, then the three edges' reciprocals 1 / (|edge|^2 + EPS) as doubles
+// (dibr_soft_mask_cuda.cu:128-139 divides by that sum for every (pixel, face) pair; the divisor depends on the face only)
+constexpr int rec_s_scalars(int elem_size) { return elem_size == 4 ? 20 : 16; }
+constexpr double SOFT_EPS = 1e-7;     // the reference's literal EPS (dibr_soft_mask_cuda.cu:23), a double
 constexpr int WORK_SHARDS = 8;        // worklist shards (one append counter each; workgroup id & 7 picks the shard)
 
 struct PassGeom {
@@ -70,6 +73,7 @@ inline unsigned int entry_capacity(long long total_faces, long long n_tiles_tota
 struct PassLayout {
   size_t count, big_count, sub_touched;  // inside the zero region
   size_t base, entries, big_list, rec;   // after it
+  size_t pixcnt, prob_pm;                // soft pass: hits per (item, pixel) (u16); pixel-major probabilities (knum > 128 only)
   unsigned int cap;
   PassGeom g;
 };
@@ -78,7 +82,7 @@ struct Layout {
   PassLayout r, s;        // raster / soft (either may be absent: offsets 0, cap 0)
   size_t total;
 };
-inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, bool with_r, bool with_s) {
+inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, bool with_r, bool with_s, int K = 0) {
   Layout L{};
   size_t off = 0;
   L.r.g = pass_geom(H, W, R_TILE);
@@ -106,7 +110,10 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
     L.s.base = off; off += a256((nts + 1) * 4);
     L.s.entries = off; off += a256((size_t)L.s.cap * 16);
     L.s.big_list = off; off += a256((size_t)total_faces * 4);
-    L.s.rec = off; off += a256((size_t)total_faces * REC_S * esz);
+    L.s.rec = off; off += a256((size_t)total_faces * rec_s_scalars(esz) * esz);
+    const size_t item_pixels = nts * S_SUBS * 64;
+    L.s.pixcnt = off; off += a256(item_pixels * 2);
+    L.s.prob_pm = off; off += K > 128 ? a256(item_pixels * (size_t)K * esz) : 0;
   }
   L.total = off + 256;
   return L;
@@ -366,10 +373,19 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(BinIn<T> in, Lists LR, 
         by1 = ymax + in.margin;
       }
       if (EMIT) {
-        Rec4<T>* r = reinterpret_cast<Rec4<T>*>(in.rec_s + (size_t)f * REC_S);
+        constexpr int RS = rec_s_scalars((int)sizeof(T));
+        Rec4<T>* r = reinterpret_cast<Rec4<T>*>(in.rec_s + (size_t)f * RS);
         r[0] = Rec4<T>{bx0, by0, bx1, by1};
         r[1] = Rec4<T>{v[0], v[1], v[2], v[3]};
         r[2] = Rec4<T>{v[4], v[5], 0, 0};
+        double* rc = reinterpret_cast<double*>(in.rec_s + (size_t)f * RS + 12);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const T x1 = v[k * 2], y1 = v[k * 2 + 1], x2 = v[((k + 1) % 3) * 2], y2 = v[((k + 1) % 3) * 2 + 1];
+          const T A = y2 - y1, Bc = x1 - x2;
+          const T down = A * A + Bc * Bc;
+          rc[k] = 1.0 / ((double)down + SOFT_EPS);
+        }
       }
       if (pixel_range<T>(bx0, by0, bx1, by1, in.H, in.W, in.multiplier, &pr_s)) {
         act_s = true;

@@ -315,7 +315,7 @@ def test_kbuffer_operators_match_lean_autograd_path(dtype):
     soft, prob, idx, typ = m.dibr_soft_mask_forward_cuda(scaled, bbox, face_idx, 7000., 30, 1000.)
     soft2, hits = m.dibr_soft_mask_forward_lean(scaled, bbox, face_idx, 7000., 30, 1000.)
     assert torch.equal(soft, soft2)
-    l_pix, l_face, l_prob, l_type = m.hit_list_entries(hits, 30)
+    l_pix, l_face, l_prob, l_type = m.hit_list_entries(hits, 30, 2, H, W)
     assert l_pix.numel() == int((idx >= 0).sum())
     # same multiset of (pixel, face, type, prob)
     pix = torch.nonzero(idx >= 0)
@@ -350,8 +350,8 @@ def test_fused_front_door_equals_reference_glue_plus_contract_operator(dtype, wi
     bbox = torch.cat([scaled.min(dim=-2)[0] - 0.02 * 1000., scaled.max(dim=-2)[0] + 0.02 * 1000.], -1)
     s1, h1 = m.dibr_soft_mask_forward_lean(scaled, bbox, y, 7000, 30, 1000.)
     s2, h2 = m.dibr_soft_mask_forward_fused(fimg.cuda(), y, 7000, 0.02, 30, 1000.)
-    i1, i2 = m.work_items(h1[5]).sort()[0], m.work_items(h2[5]).sort()[0]   # queued in a run-dependent order
-    assert torch.equal(s1, s2) and torch.equal(i1, i2) and torch.equal(h1[4][i1], h2[4][i2])
+    i1, i2 = m.work_items(h1[4]).sort()[0], m.work_items(h2[4]).sort()[0]   # queued in a run-dependent order
+    assert torch.equal(s1, s2) and torch.equal(i1, i2) and torch.equal(h1[3][i1], h2[3][i2])
     g = torch.rand(s1.shape, device='cuda', dtype=dtype)
     g1 = m.dibr_soft_mask_backward_lean(g, s1, h1, scaled, 7000, 30, 1000.)
     g2 = m.dibr_soft_mask_backward_lean(g, s2, h2, fimg.cuda(), 7000, 30, 1000., img_scale=1000.)
