@@ -12,7 +12,8 @@ import threading
 import torch  # noqa: F401  (must be imported first: we share torch's libamdhip64.so.7)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libkaolin_amd.so')
+# (KAMD_LIB_PATH: development builds of the same library, e.g. the phase-profiling variant `make -C kaolin_amd/csrc prof`)
+LIB_PATH = os.environ.get('KAMD_LIB_PATH') or os.path.join(_HERE, 'libkaolin_amd.so')
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int

@@ -22,6 +22,7 @@
 #include "tile_bins.h"
 #include "tile_lists.h"
 #include "dibr_internal.h"
+#include "phase_prof.h"
 #include "../../include/kaolin_amd.h"
 
 #define DIBR_EPS 1e-7
@@ -214,10 +215,13 @@ __global__ __launch_bounds__(64) void soft_mask_backward_kernel(
       const T A = y2 - y1, Bc = x1 - x2, C = x2 * y1 - x1 * y2;
       const T up = A * x0 + Bc * y0 + C;
       const T down = A * A + Bc * Bc;
-      const T d2 = up * up / (down + DIBR_EPS);
-      const T dzdA = 2 * (x0 * up - d2 * A) / (down + DIBR_EPS);
-      const T dzdB = 2 * (y0 * up - d2 * Bc) / (down + DIBR_EPS);
-      const T dzdC = 2 * up / (down + DIBR_EPS);
+      // the reference divides four times by the double (down + EPS) (dibr_soft_mask_cuda.cu:318-327); gradients are
+      // compared at 1e-5, not bit for bit: one double reciprocal, four double products (each rounded to T as before)
+      const double rden = 1.0 / ((double)down + DIBR_EPS);
+      const T d2 = (T)((double)(T)(up * up) * rden);
+      const T dzdA = (T)((double)(T)(2 * (x0 * up - d2 * A)) * rden);
+      const T dzdB = (T)((double)(T)(2 * (y0 * up - d2 * Bc)) * rden);
+      const T dzdC = (T)((double)(T)(2 * up) * rden);
       const T dLdx1 = dLdz * (dzdB - y2 * dzdC);
       const T dLdy1 = dLdz * (x2 * dzdC - dzdA);
       const T dLdx2 = dLdz * (y1 * dzdC - dzdB);
@@ -399,7 +403,7 @@ int soft_mask_backward_list_launch(hipStream_t st, int B, int H, int W, int F, i
     static const int per_cu = kamd_env_int("KAMD_SOFT_BWD_PER_CU", 8);
     hipLaunchKernelGGL(soft_mask_backward_list_kernel2<T>, dim3(KAMD_NUM_CU * per_cu), dim3(256), 0, st, B, H, W, F, K, grad,
                        soft_mask, list, work, tl::work_shard_cap(B, H, W), tl::pass_geom(H, W, tl::S_TILE).tiles_x, img,
-                       (T)img_scale, sigmainv, multiplier, g_img);
+                       (T)img_scale, sigmainv, multiplier, g_img, kamd_env_int("KAMD_BWD_MODE", 0));
   }
   KAMD_RETURN_LAST_ERROR();
 }
@@ -536,6 +540,17 @@ int dibr_backward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K
 }
 
 }  // namespace
+
+#ifdef KAMD_PHASE_PROF
+extern "C" int kamd_debug_phase_cycles(unsigned long long* out16, int reset) {
+  int rc = (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_select), 16 * sizeof(unsigned long long));
+  if (reset) {
+    unsigned long long z[16] = {0};
+    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_select), z, sizeof(z));
+  }
+  return rc;
+}
+#endif
 
 extern "C" {
 

@@ -19,6 +19,7 @@
 #include "tile_bins.h"
 #include "tile_lists.h"
 #include "dibr_internal.h"
+#include "phase_prof.h"
 #include "../../include/kaolin_amd.h"
 
 namespace {
@@ -276,7 +277,8 @@ int raster2_draw(hipStream_t st, int B, int H, int W, int D, int F_dense, float 
                  const tl::Lists& LR, const T* feat, T* interp, int64_t* sel_idx, T* weights, const tl::ClassifyOut& co) {
   kamd::ProfScope prof_(kamd::K_RASTER_TILE, st);
   hipLaunchKernelGGL((raster_tile_kernel2<T, true>), dim3(LR.ntiles * B), dim3(256), 0, st, B, F_dense,
-                     (const int64_t*)nullptr, H, W, D, multiplier, eps, rec, LR, feat, interp, sel_idx, weights, co);
+                     (const int64_t*)nullptr, H, W, D, pixel_scale(multiplier, H, W), eps,
+                     raster2_wide_ok(W, interp, sel_idx, weights, co.soft_mask), rec, LR, feat, interp, sel_idx, weights, co);
   return (int)hipGetLastError();
 }
 template int raster2_draw<float>(hipStream_t, int, int, int, int, int, float, float, const float*, const tl::Lists&, const float*,
@@ -284,6 +286,17 @@ template int raster2_draw<float>(hipStream_t, int, int, int, int, int, float, fl
 template int raster2_draw<double>(hipStream_t, int, int, int, int, int, float, float, const double*, const tl::Lists&,
                                   const double*, double*, int64_t*, double*, const tl::ClassifyOut&);
 }  // namespace kamd
+
+#ifdef KAMD_PHASE_PROF
+extern "C" int kamd_debug_phase_cycles_raster(unsigned long long* out16, int reset) {
+  int rc = (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_raster), 16 * sizeof(unsigned long long));
+  if (reset) {
+    unsigned long long z[16] = {0};
+    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_raster), z, sizeof(z));
+  }
+  return rc;
+}
+#endif
 
 extern "C" {
 

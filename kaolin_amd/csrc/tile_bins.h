@@ -80,6 +80,15 @@ inline size_t bins_workspace_bytes(int B, int H, int W, long long total_faces, i
 //   x0 = multiplier / width * (2*col + 1 - width),  y0 = multiplier / height * (height - 2*row - 1)
 __device__ __forceinline__ float pixel_x(float multiplier, int W, int col) { return multiplier / W * (2 * col + 1 - W); }
 __device__ __forceinline__ float pixel_y(float multiplier, int H, int row) { return multiplier / H * (H - 2 * row - 1); }
+// the same with the quotients `multiplier / W`, `multiplier / H` (one IEEE float division each, identical on host and
+// device) taken once per launch instead of once per evaluation
+struct PixelScale {
+  float mw, mh;
+  int W, H;
+};
+inline PixelScale pixel_scale(float multiplier, int H, int W) { return PixelScale{multiplier / W, multiplier / H, W, H}; }
+__device__ __forceinline__ float pixel_x(const PixelScale& ps, int col) { return ps.mw * (2 * col + 1 - ps.W); }
+__device__ __forceinline__ float pixel_y(const PixelScale& ps, int row) { return ps.mh * (ps.H - 2 * row - 1); }
 
 // word offset of (mesh b, tile t) in the mask area
 __device__ __forceinline__ size_t mask_base(int ntiles, long long first_b, int b, int t, int stride_b) {

@@ -100,14 +100,14 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
   L.zero_bytes = off;
   if (with_r) {
     L.r.cap = entry_capacity(total_faces, (long long)ntr);
-    L.r.base = off; off += a256((ntr + 1) * 4);
+    L.r.base = off; off += a256((ntr + 4) * 4);
     L.r.entries = off; off += a256((size_t)L.r.cap * 16);
     L.r.big_list = off; off += a256((size_t)total_faces * 4);
     L.r.rec = off; off += a256((size_t)total_faces * REC_R * esz);
   }
   if (with_s) {
     L.s.cap = entry_capacity(total_faces, (long long)nts);
-    L.s.base = off; off += a256((nts + 1) * 4);
+    L.s.base = off; off += a256((nts + 4) * 4);
     L.s.entries = off; off += a256((size_t)L.s.cap * 16);
     L.s.big_list = off; off += a256((size_t)total_faces * 4);
     L.s.rec = off; off += a256((size_t)total_faces * rec_s_scalars(esz) * esz);
@@ -157,17 +157,19 @@ __device__ __forceinline__ bool pixel_range(T xmin, T ymin, T xmax, T ymax, int 
   out->c_hi = W - 1;
   out->r_lo = 0;
   out->r_hi = H - 1;
-  const double dxmin = (double)xmin, dxmax = (double)xmax, dymin = (double)ymin, dymax = (double)ymax;
-  out->everywhere = !(multiplier > 0.f) || !(dxmin == dxmin) || !(dxmax == dxmax) || !(dymin == dymin) || !(dymax == dymax);
+  // float is enough: coordinates are O(multiplier), so the column / row estimates are off by ~1e-4 pixel at most, against
+  // one whole pixel of slack on either side (values beyond float range become +-inf and clamp)
+  const float fxmin = (float)xmin, fxmax = (float)xmax, fymin = (float)ymin, fymax = (float)ymax;
+  out->everywhere = !(multiplier > 0.f) || !(fxmin == fxmin) || !(fxmax == fxmax) || !(fymin == fymin) || !(fymax == fymax);
   if (out->everywhere) return true;
-  const double sx = (double)W / (double)multiplier, sy = (double)H / (double)multiplier;
-  const double cl = floor((dxmin * sx + W - 1) * 0.5) - 1.0, ch = ceil((dxmax * sx + W - 1) * 0.5) + 1.0;
-  const double rl = floor((H - 1 - dymax * sy) * 0.5) - 1.0, rh = ceil((H - 1 - dymin * sy) * 0.5) + 1.0;
-  if (ch < 0.0 || cl > (double)(W - 1) || rh < 0.0 || rl > (double)(H - 1)) return false;
-  out->c_lo = (int)fmax(cl, 0.0);
-  out->c_hi = (int)fmin(ch, (double)(W - 1));
-  out->r_lo = (int)fmax(rl, 0.0);
-  out->r_hi = (int)fmin(rh, (double)(H - 1));
+  const float sx = (float)W / multiplier, sy = (float)H / multiplier;
+  const float cl = floorf((fxmin * sx + (float)(W - 1)) * 0.5f) - 1.0f, ch = ceilf((fxmax * sx + (float)(W - 1)) * 0.5f) + 1.0f;
+  const float rl = floorf(((float)(H - 1) - fymax * sy) * 0.5f) - 1.0f, rh = ceilf(((float)(H - 1) - fymin * sy) * 0.5f) + 1.0f;
+  if (ch < 0.0f || cl > (float)(W - 1) || rh < 0.0f || rl > (float)(H - 1)) return false;
+  out->c_lo = (int)fmaxf(cl, 0.0f);
+  out->c_hi = (int)fminf(ch, (float)(W - 1));
+  out->r_lo = (int)fmaxf(rl, 0.0f);
+  out->r_hi = (int)fminf(rh, (float)(H - 1));
   return true;
 }
 
@@ -177,10 +179,16 @@ __device__ __forceinline__ T nan_min(T a, T b) { return (a != a || b != b) ? (T)
 template <typename T>
 __device__ __forceinline__ T nan_max(T a, T b) { return (a != a || b != b) ? (T)NAN : (a > b ? a : b); }
 
+// OR over the wavefront (result wave-uniform): row shifts inside the four rows of 16 lanes (DPP: register moves, no LDS
+// crossbar), then the last lane of every row
 __device__ __forceinline__ unsigned int wave_or_u32(unsigned int v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v |= (unsigned int)__shfl_xor((int)v, d, 64);
-  return v;
+  int x = (int)v;
+  x |= row_shr<1>(x);
+  x |= row_shr<2>(x);
+  x |= row_shr<4>(x);
+  x |= row_shr<8>(x);
+  return (unsigned int)(__builtin_amdgcn_readlane(x, 15) | __builtin_amdgcn_readlane(x, 31) | __builtin_amdgcn_readlane(x, 47) |
+                        __builtin_amdgcn_readlane(x, 63));
 }
 
 // ---- one wavefront bins its 64 faces into one pass' lists ---------------------------------------------------------------
@@ -402,10 +410,10 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(BinIn<T> in, Lists LR, 
 }
 
 // ---- scan: count -> base (exclusive), count reset to 0 (it becomes the emit pass' cursor) --------------------------------
-// One 1024-thread workgroup walks the counters in slabs of 4096 (one 16-byte load per thread: coalesced), block-scans a
-// slab and carries the running total into the next.  Up to two arrays in one launch.
+// One 1024-thread workgroup walks the counters in slabs of 8192 (two 16-byte loads per thread, both coalesced across the
+// workgroup), block-scans a slab and carries the running total into the next.  Up to two arrays in one launch.
 static __global__ __launch_bounds__(1024) void bin_scan_kernel(unsigned int* cnt_a, unsigned int* base_a, int n_a,
-                                                        unsigned int* cnt_b, unsigned int* base_b, int n_b) {
+                                                               unsigned int* cnt_b, unsigned int* base_b, int n_b) {
   __shared__ unsigned int s_wave[17];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int arr = 0; arr < 2; ++arr) {
@@ -413,18 +421,25 @@ static __global__ __launch_bounds__(1024) void bin_scan_kernel(unsigned int* cnt
     unsigned int* base = arr == 0 ? base_a : base_b;
     const int n = arr == 0 ? n_a : n_b;
     if (cnt == nullptr || n <= 0) continue;
+    const int groups = (n + 3) / 4;  // 16-byte groups (the arrays are padded: whole groups can be read and written)
     unsigned int carry = 0;
-    for (int s0 = 0; s0 < n; s0 += 4096) {
-      const int i = s0 + tid * 4;
-      uint4 c = make_uint4(0u, 0u, 0u, 0u);
-      if (i + 3 < n) {
-        c = *reinterpret_cast<const uint4*>(cnt + i);
-      } else {
-        if (i < n) c.x = cnt[i];
-        if (i + 1 < n) c.y = cnt[i + 1];
-        if (i + 2 < n) c.z = cnt[i + 2];
+    for (int s0 = 0; s0 < groups; s0 += 2048) {
+      // thread t owns groups s0 + 2t and s0 + 2t + 1 (32 contiguous bytes)
+      const int g = s0 + 2 * tid;
+      uint4 c0 = make_uint4(0u, 0u, 0u, 0u), c1 = c0;
+      if (g < groups) c0 = reinterpret_cast<const uint4*>(cnt)[g];
+      if (g + 1 < groups) c1 = reinterpret_cast<const uint4*>(cnt)[g + 1];
+      {
+        const int i = g * 4;
+        if (i + 1 >= n) c0.y = 0u;
+        if (i + 2 >= n) c0.z = 0u;
+        if (i + 3 >= n) c0.w = 0u;
+        if (i + 4 >= n) c1.x = 0u;
+        if (i + 5 >= n) c1.y = 0u;
+        if (i + 6 >= n) c1.z = 0u;
+        if (i + 7 >= n) c1.w = 0u;
       }
-      const unsigned int sum = c.x + c.y + c.z + c.w;
+      const unsigned int sum0 = c0.x + c0.y + c0.z + c0.w, sum = sum0 + c1.x + c1.y + c1.z + c1.w;
       unsigned int inc = sum;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
@@ -444,19 +459,19 @@ static __global__ __launch_bounds__(1024) void bin_scan_kernel(unsigned int* cnt
         s_wave[16] = run;
       }
       __syncthreads();
-      const unsigned int e0 = carry + s_wave[wave] + inc - sum;
-      const uint4 bs = make_uint4(e0, e0 + c.x, e0 + c.x + c.y, e0 + c.x + c.y + c.z);
-      if (i + 3 < n) {
-        *reinterpret_cast<uint4*>(base + i) = bs;
-        *reinterpret_cast<uint4*>(cnt + i) = make_uint4(0u, 0u, 0u, 0u);
-      } else {
-        if (i < n) { base[i] = bs.x; cnt[i] = 0u; }
-        if (i + 1 < n) { base[i + 1] = bs.y; cnt[i + 1] = 0u; }
-        if (i + 2 < n) { base[i + 2] = bs.z; cnt[i + 2] = 0u; }
+      const unsigned int e0 = carry + s_wave[wave] + inc - sum, e1 = e0 + sum0;
+      if (g < groups) {
+        reinterpret_cast<uint4*>(base)[g] = make_uint4(e0, e0 + c0.x, e0 + c0.x + c0.y, e0 + c0.x + c0.y + c0.z);
+        reinterpret_cast<uint4*>(cnt)[g] = make_uint4(0u, 0u, 0u, 0u);
+      }
+      if (g + 1 < groups) {
+        reinterpret_cast<uint4*>(base)[g + 1] = make_uint4(e1, e1 + c1.x, e1 + c1.x + c1.y, e1 + c1.x + c1.y + c1.z);
+        reinterpret_cast<uint4*>(cnt)[g + 1] = make_uint4(0u, 0u, 0u, 0u);
       }
       carry += s_wave[16];
     }
-    if (tid == 0) base[n] = carry;
+    __syncthreads();
+    if (tid == 0) base[n] = carry;  // (after the group stores: base[n] may share the last group)
     __syncthreads();
   }
 }

@@ -1,0 +1,33 @@
+"""Development probe: per-phase cycle sums of the instrumented soft-mask kernels (library built with `make prof`,
+selected through KAMD_LIB_PATH).  usage: KAMD_LIB_PATH=kaolin_amd/libkaolin_amd_prof.so python tools/phase_prof.py"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import kaolin_amd as kal
+from kaolin_amd import _lib
+from kaolin_amd.utils import testing as T
+lib = _lib.load()
+V, H, W = 8, 1024, 1024
+fz, fimg, feats, nz = T.sphere_scene(level=50, num_views=V, device='cuda')
+feat = torch.cat(feats, -1).contiguous()
+for _ in range(2):
+    kal.render.mesh.dibr_rasterization(H, W, fz, fimg, feat, nz)
+torch.cuda.synchronize()
+buf, buf2 = (ctypes.c_ulonglong * 16)(), (ctypes.c_ulonglong * 16)()
+raw = ctypes.CDLL(_lib.LIB_PATH)
+raw.kamd_debug_phase_cycles(buf, 1)
+raw.kamd_debug_phase_cycles_raster(buf2, 1)
+n = 5
+for _ in range(n):
+    kal.render.mesh.dibr_rasterization(H, W, fz, fimg, feat, nz)
+torch.cuda.synchronize()
+raw.kamd_debug_phase_cycles(buf, 0)
+raw.kamd_debug_phase_cycles_raster(buf2, 0)
+for title, b, names in (
+        ('soft_select', buf, ['setup', 'order entries', 'stream+cull', 'chunk masks', 'accept+transposes', 'pair write', 'tail']),
+        ('raster_tile', buf2, ['setup (touched)', 'entries load', 'scan+ids', 'stage+cull+readlane', 'mask (readlane)',
+                               'walk 1 (signs)', 'walk 2 (divisions)', 'tail of loops', 'output+classify', 'background tile'])):
+    tot = sum(b[:10]) or 1
+    print(title)
+    for i, nm in enumerate(names):
+        print(f'  {nm:22s} {b[i] / n / 1e6:10.2f} Mticks/step  {100.0 * b[i] / tot:5.1f} %')

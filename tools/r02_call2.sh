@@ -1,6 +1,6 @@
 set -u
 out=gpurun_out/r02b; mkdir -p $out
-timeout 600 python -m pytest tests/test_dibr_gpu.py tests/test_full_size_parity.py -q -x -m gpu > $out/pytest_dibr.log 2>&1; tail -15 $out/pytest_dibr.log
+timeout 600 python -m pytest tests/test_dibr_gpu.py tests/test_full_size_parity.py -q -x -m gpu > $out/pytest_dibr.log 2>&1; tail -3 $out/pytest_dibr.log
 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-chamfer --no-c5 2> $out/bench.err | tail -1 > $out/bench.json
 python - <<'PY'
 import json
@@ -10,3 +10,4 @@ try:
 except Exception as e:
     print('bench failed', e); print(open('gpurun_out/r02b/bench.err').read()[-2000:])
 PY
+if [ -f kaolin_amd/libkaolin_amd_prof.so ]; then KAMD_LIB_PATH=$PWD/kaolin_amd/libkaolin_amd_prof.so timeout 300 python tools/phase_prof.py 2>&1 | grep -v amdgpu.ids; fi
