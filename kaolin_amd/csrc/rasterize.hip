@@ -278,7 +278,7 @@ int raster2_draw(hipStream_t st, int B, int H, int W, int D, int F_dense, float 
   kamd::ProfScope prof_(kamd::K_RASTER_TILE, st);
   hipLaunchKernelGGL((raster_tile_kernel2<T, true>), dim3(LR.ntiles * B), dim3(256), 0, st, B, F_dense,
                      (const int64_t*)nullptr, H, W, D, pixel_scale(multiplier, H, W), eps,
-                     raster2_wide_ok(W, interp, sel_idx, weights, co.soft_mask), rec, LR, feat, interp, sel_idx, weights, co);
+                     raster2_wide_ok(W, interp, sel_idx, weights, co.soft_mask), kamd_env_int("KAMD_RASTER_MODE", 0), rec, LR, feat, interp, sel_idx, weights, co);
   return (int)hipGetLastError();
 }
 template int raster2_draw<float>(hipStream_t, int, int, int, int, int, float, float, const float*, const tl::Lists&, const float*,
