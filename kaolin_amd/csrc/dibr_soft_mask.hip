@@ -372,11 +372,7 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
     in.W = W;
     in.rec_s = rec;
     kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
-    const dim3 grid(kamd_cdiv(total_faces, 256));
-    hipLaunchKernelGGL((tl::bin_faces_kernel2<T, false, true, false>), grid, dim3(256), 0, st, in, none, LS);
-    hipLaunchKernelGGL(tl::bin_scan_kernel, dim3(1), dim3(1024), 0, st, LS.count, LS.base, B * LS.ntiles,
-                       (unsigned int*)nullptr, (unsigned int*)nullptr, 0);
-    hipLaunchKernelGGL((tl::bin_faces_kernel2<T, false, true, true>), grid, dim3(256), 0, st, in, none, LS);
+    hipLaunchKernelGGL((tl::bin_faces_kernel2<T, false, true>), dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, in, none, LS);
   }
   KAMD_CHECK(hipGetLastError());
   {
@@ -462,11 +458,7 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
     in.rec_r = rec_r;
     in.rec_s = rec_s;
     kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
-    const dim3 grid(kamd_cdiv(total_faces, 256));
-    hipLaunchKernelGGL((tl::bin_faces_kernel2<T, true, true, false>), grid, dim3(256), 0, st, in, LR, LS);
-    hipLaunchKernelGGL(tl::bin_scan_kernel, dim3(1), dim3(1024), 0, st, LR.count, LR.base, B * LR.ntiles, LS.count, LS.base,
-                       B * LS.ntiles);
-    hipLaunchKernelGGL((tl::bin_faces_kernel2<T, true, true, true>), grid, dim3(256), 0, st, in, LR, LS);
+    hipLaunchKernelGGL((tl::bin_faces_kernel2<T, true, true>), dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, in, LR, LS);
   }
   KAMD_CHECK(hipGetLastError());
   tl::ClassifyOut co{};

@@ -11,13 +11,15 @@
 //
 // produced by one ballot of the wavefront that holds those 64 faces -- consecutive faces of a mesh are usually
 // neighbours on screen, so an entry carries many faces, and inside an entry the ascending face order the reference's
-// loops rely on is simply the bit order.  Lists are sized exactly by a count pass + scan + emit pass (no fixed
-// per-tile capacity); only the TOTAL number of entries is bounded by the workspace (shape-only: no host sync), and a
-// tile whose list does not fit falls back to scanning every block of its mesh (slow, still exact).  Faces whose box
-// spans more than 8 x 8 tiles (or is NaN) go to a per-mesh "big face" list that every tile tests directly.
+// loops rely on is simply the bit order.  Lists are built in ONE pass over the faces: a tile owns INLINE slots for its
+// first entries (at an address known from the tile index: a consumer reads count and entries in one round trip) and, past
+// those, chunks of 31 entries taken from a pool and published in the tile's chunk table.  Nothing is sized by the data
+// (shape-only workspace, no host sync): a tile that outgrows its table, or finds the pool empty, is flagged and falls
+// back to scanning every block of its mesh (slow, still exact).  Faces whose box spans more than 8 x 8 tiles (or is NaN)
+// go to a per-mesh "big face" list that every tile tests directly.
 //
-// Work per call: O(faces + entries) for the binning, nothing proportional to tiles x faces, and the only memory that
-// must be cleared is one counter per tile.
+// Work per call: O(faces + entries), nothing proportional to tiles x faces, and the only memory that must be cleared is
+// one counter and one small chunk table per tile.
 #pragma once
 #include "common.h"
 #include "tile_bins.h"  // Box4 / Rec4 / pixel_x / pixel_y / FaceLayout / wave helpers
@@ -47,12 +49,19 @@ __host__ __device__ inline PassGeom pass_geom(int H, int W, int tile) {
   return g;
 }
 
+constexpr int OVC = 32;               // pool chunk: header {next free, -, -, -} is unused; slots 1..31 hold entries
+constexpr int OVC_PAYLOAD = OVC - 1;
+constexpr unsigned int BRUTE_BIT = 0x80000000u;  // set in a tile's counter when an entry could not be stored
+
 // device view of one pass' lists
 struct Lists {
-  unsigned int* count;        // [B * ntiles]      zeroed; count pass: entries per tile; after the scan: 0 again (emit cursor)
-  unsigned int* base;         // [B * ntiles + 1]  exclusive scan of count (written by the scan kernel)
-  uint4* entries;             // [cap]             {block, 0, mask.lo, mask.hi}
-  unsigned int cap;
+  unsigned int* count;        // [B * ntiles]         zeroed; entries appended to the tile (| BRUTE_BIT)
+  unsigned int* tab;          // [B * ntiles * maxc]  zeroed; chunk c of the tile lives at pool chunk tab[..] - 1
+  uint4* inl;                 // [B * ntiles * C]     the tile's first C entries {block, 0, mask.lo, mask.hi}
+  uint4* pool;                // [cap_chunks * OVC]
+  unsigned int* pool_top;     // zeroed
+  unsigned int cap_chunks;
+  int C, maxc;
   unsigned int* big_count;    // [B]               zeroed; faces of mesh b in the big list
   unsigned int* big_list;     // [total_faces]     mesh b's segment starts at its first packed face
   unsigned int* sub_touched;  // [B * ntiles]      zeroed; soft pass only: bit s = some enlarged box reaches sub-tile s
@@ -60,26 +69,26 @@ struct Lists {
 };
 
 inline size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
-inline unsigned int entry_capacity(long long total_faces, long long n_tiles_total) {
-  long long c = total_faces / 2 + 2 * n_tiles_total + 64;
-  const long long worst = ((total_faces + 63) / 64 + 1) * n_tiles_total;  // every block in every tile
-  if (c > worst) c = worst;
-  if (c > 0x7fffffffll) c = 0x7fffffffll;
+inline unsigned int pool_chunks(long long total_faces, long long n_tiles_total) {
+  long long e = total_faces / 2 + 2 * n_tiles_total + 64;  // entries the pool can take beyond the inline slots
+  long long c = e / OVC_PAYLOAD + 64;
+  if (c > 0x3fffffll) c = 0x3fffffll;
   return (unsigned int)c;
 }
 
-// Host-side layout of one pass inside a workspace.  All `zero_*` arrays of both passes are placed in ONE contiguous
-// region at the start of the workspace so that a single fill kernel clears them.
+// Host-side layout of one pass inside a workspace.  All zeroed arrays of both passes are placed in ONE contiguous region
+// at the start of the workspace so that a single fill kernel clears them.
 struct PassLayout {
-  size_t count, big_count, sub_touched;  // inside the zero region
-  size_t base, entries, big_list, rec;   // after it
+  size_t count, tab, pool_top, big_count, sub_touched;  // inside the zero region
+  size_t inl, pool, big_list, rec;                      // after it
   size_t pixcnt, prob_pm;                // soft pass: hits per (item, pixel) (u16); pixel-major probabilities (knum > 128 only)
-  unsigned int cap;
+  unsigned int cap_chunks;
+  int C, maxc;
   PassGeom g;
 };
 struct Layout {
   size_t zero_bytes;      // [0, zero_bytes) is cleared on every call
-  PassLayout r, s;        // raster / soft (either may be absent: offsets 0, cap 0)
+  PassLayout r, s;        // raster / soft (either may be absent: offsets 0)
   size_t total;
 };
 inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, bool with_r, bool with_s, int K = 0) {
@@ -87,28 +96,34 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
   size_t off = 0;
   L.r.g = pass_geom(H, W, R_TILE);
   L.s.g = pass_geom(H, W, S_TILE);
+  L.r.C = 16; L.r.maxc = 8;     // 16 + 8 * 31 = 264 entries per 16 x 16 tile before the fallback
+  L.s.C = 64; L.s.maxc = 32;    // 64 + 32 * 31 = 1056 entries per 32 x 32 tile
   const size_t ntr = (size_t)B * L.r.g.ntiles, nts = (size_t)B * L.s.g.ntiles;
   if (with_r) {
     L.r.count = off; off += a256(ntr * 4);
+    L.r.tab = off; off += a256(ntr * L.r.maxc * 4);
+    L.r.pool_top = off; off += 256;
     L.r.big_count = off; off += a256((size_t)B * 4);
   }
   if (with_s) {
     L.s.count = off; off += a256(nts * 4);
+    L.s.tab = off; off += a256(nts * L.s.maxc * 4);
+    L.s.pool_top = off; off += 256;
     L.s.big_count = off; off += a256((size_t)B * 4);
     L.s.sub_touched = off; off += a256(nts * 4);
   }
   L.zero_bytes = off;
   if (with_r) {
-    L.r.cap = entry_capacity(total_faces, (long long)ntr);
-    L.r.base = off; off += a256((ntr + 4) * 4);
-    L.r.entries = off; off += a256((size_t)L.r.cap * 16);
+    L.r.cap_chunks = pool_chunks(total_faces, (long long)ntr);
+    L.r.inl = off; off += a256(ntr * L.r.C * 16);
+    L.r.pool = off; off += a256((size_t)L.r.cap_chunks * OVC * 16);
     L.r.big_list = off; off += a256((size_t)total_faces * 4);
     L.r.rec = off; off += a256((size_t)total_faces * REC_R * esz);
   }
   if (with_s) {
-    L.s.cap = entry_capacity(total_faces, (long long)nts);
-    L.s.base = off; off += a256((nts + 4) * 4);
-    L.s.entries = off; off += a256((size_t)L.s.cap * 16);
+    L.s.cap_chunks = pool_chunks(total_faces, (long long)nts);
+    L.s.inl = off; off += a256(nts * L.s.C * 16);
+    L.s.pool = off; off += a256((size_t)L.s.cap_chunks * OVC * 16);
     L.s.big_list = off; off += a256((size_t)total_faces * 4);
     L.s.rec = off; off += a256((size_t)total_faces * rec_s_scalars(esz) * esz);
     const size_t item_pixels = nts * S_SUBS * 64;
@@ -132,9 +147,13 @@ inline Lists lists_of(void* ws, const PassLayout& p, int B, bool soft) {
   char* c = (char*)ws;
   Lists l;
   l.count = (unsigned int*)(c + p.count);
-  l.base = (unsigned int*)(c + p.base);
-  l.entries = (uint4*)(c + p.entries);
-  l.cap = p.cap;
+  l.tab = (unsigned int*)(c + p.tab);
+  l.inl = (uint4*)(c + p.inl);
+  l.pool = (uint4*)(c + p.pool);
+  l.pool_top = (unsigned int*)(c + p.pool_top);
+  l.cap_chunks = p.cap_chunks;
+  l.C = p.C;
+  l.maxc = p.maxc;
   l.big_count = (unsigned int*)(c + p.big_count);
   l.big_list = (unsigned int*)(c + p.big_list);
   l.sub_touched = soft ? (unsigned int*)(c + p.sub_touched) : nullptr;
@@ -191,17 +210,59 @@ __device__ __forceinline__ unsigned int wave_or_u32(unsigned int v) {
                         __builtin_amdgcn_readlane(x, 63));
 }
 
+// ---- appending one entry to a tile -----------------------------------------------------------------------------------------
+// slot = count++; the first C slots are inline.  Past them, slot o = slot - C lives in chunk c = o / 31 at position o % 31;
+// the lane that draws position 0 takes a chunk from the pool and publishes it in the tile's table, the others wait for
+// the table entry.  Allocation never waits for anything (it happens before any spinning of the same wavefront), so every
+// awaited publication is made by a lane that already holds its slot and is on its way: no cycle of waits.
+__device__ __forceinline__ void append_entry(bool on, const Lists& L, size_t ti, uint4 entry) {
+  // (called by whole wavefronts, `on` = the lane has an entry: the three steps below are separate, reconverging blocks, so
+  // that every allocating lane of a wavefront has published before any of its lanes starts to wait)
+  unsigned int slot = 0, c = 0, i = 0, v = 0;
+  bool pooled = false;
+  if (on) {
+    slot = atomicAdd(L.count + ti, 1u) & ~BRUTE_BIT;
+    if (slot < (unsigned int)L.C) {
+      L.inl[ti * L.C + slot] = entry;
+    } else {
+      const unsigned int o = slot - (unsigned int)L.C;
+      c = o / OVC_PAYLOAD;
+      i = o - c * OVC_PAYLOAD;
+      if (c >= (unsigned int)L.maxc)
+        atomicOr(L.count + ti, BRUTE_BIT);
+      else
+        pooled = true;
+    }
+  }
+  unsigned int* link = L.tab + ti * L.maxc + c;
+  if (pooled && i == 0) {  // step 1: allocate and publish (never waits)
+    const unsigned int p = atomicAdd(L.pool_top, 1u);
+    v = p < L.cap_chunks ? p + 1u : 0xFFFFFFFFu;
+    __hip_atomic_store(link, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (pooled && i != 0) {  // step 2: wait for the chunk's allocator (another wavefront, or an earlier append of this one)
+    do {
+      v = __hip_atomic_load(link, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v == 0u) __builtin_amdgcn_s_sleep(1);
+    } while (v == 0u);
+  }
+  if (pooled) {            // step 3
+    if (v == 0xFFFFFFFFu)
+      atomicOr(L.count + ti, BRUTE_BIT);
+    else
+      L.pool[(size_t)(v - 1u) * OVC + 1u + i] = entry;
+  }
+}
+
 // ---- one wavefront bins its 64 faces into one pass' lists ---------------------------------------------------------------
 // `active`: the lane's face takes part; (b, first_b): its mesh and the mesh's first packed face; tile rectangle
 // [tx0,tx1] x [ty0,ty1]; `big`: the rectangle exceeds 8 x 8 tiles (or the box is NaN).  `block` = packed face index >> 6
-// (the same for the whole wavefront).  EMIT == false: count pass (one atomicAdd per distinct (mesh, tile) the wavefront
-// touches); EMIT == true: the entries are written at base[tile] + cursor++.
+// (the same for the whole wavefront).
 // Distinct tiles are enumerated without walking the union rectangle: every lane keeps the not-yet-emitted tiles of its
 // own rectangle as a 64-bit mask over an 8 x 8 local grid; each step takes the first pending tile of the first pending
 // lane, ballots the lanes whose rectangle holds it and clears it everywhere.  Steps = distinct tiles.  The results are
-// parked one per lane and flushed with ONE vector atomic per 64 tiles (a returning atomic per step would serialise the
-// loop on L2 latency).
-template <bool EMIT, bool SOFT>
+// parked one per lane and appended 64 tiles at a time (a returning atomic per step would serialise the loop on L2 latency).
+template <bool SOFT>
 __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long first_b, long long f, int tx0, int tx1,
                                          int ty0, int ty1, int c_lo, int c_hi, int r_lo, int r_hi, const Lists& L) {
   const int lane = threadIdx.x & 63;
@@ -212,9 +273,9 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
     const int bL = __builtin_amdgcn_readlane(b, leader);
     const bool mine = active && b == bL;
     remaining &= ~__ballot(mine);
-    // big faces: appended to the mesh's big list (emit pass only)
+    // big faces: appended to the mesh's big list
     const unsigned long long bigm = __ballot(mine && big);
-    if (EMIT && bigm != 0ull) {
+    if (bigm != 0ull) {
       unsigned int start = 0;
       if (lane == leader) start = atomicAdd(L.big_count + bL, (unsigned int)__popcll(bigm));
       start = (unsigned int)__builtin_amdgcn_readlane((int)start, leader);
@@ -232,16 +293,9 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
     unsigned long long my_bal = 0ull;
     unsigned int my_sub = 0u;
     auto flush = [&]() {
-      if (my_t >= 0) {
-        const size_t ti = (size_t)bL * L.ntiles + my_t;
-        if (!EMIT) {
-          atomicAdd(L.count + ti, 1u);
-        } else {
-          const unsigned int pos = L.base[ti] + atomicAdd(L.count + ti, 1u);
-          if (pos < L.cap) L.entries[pos] = make_uint4(block, 0u, (unsigned int)my_bal, (unsigned int)(my_bal >> 32));
-          if (SOFT && my_sub != 0u) atomicOr(L.sub_touched + ti, my_sub);
-        }
-      }
+      const size_t ti = (size_t)bL * L.ntiles + (my_t >= 0 ? my_t : 0);
+      append_entry(my_t >= 0, L, ti, make_uint4(block, 0u, (unsigned int)my_bal, (unsigned int)(my_bal >> 32)));
+      if (SOFT && my_t >= 0 && my_sub != 0u) atomicOr(L.sub_touched + ti, my_sub);
       my_t = -1;
       k = 0;
     };
@@ -256,7 +310,7 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
       const unsigned long long bal = __ballot(inr);
       if (inr) pending &= ~(1ull << ((ty - ty0) * 8 + (tx - tx0)));
       unsigned int sub = 0u;
-      if (SOFT && EMIT) {
+      if (SOFT) {
         // the 16 x 4-pixel sub-tiles of tile (tx, ty) the lane's pixel range reaches: bit = sy * 2 + sx
         unsigned int m16 = 0u;
         if (inr) {
@@ -281,8 +335,7 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
 }
 
 // ---- the bin kernel -------------------------------------------------------------------------------------------------------
-// One thread per face of the packed face list, in two passes over the same code: count (EMIT = false) and emit (true).
-// Inputs come in two flavours:
+// One thread per face of the packed face list, ONE pass.  Inputs come in two flavours:
 //   raw     the Python layer's (B, F, ...) tensors: vertices scaled by `mult` here, boxes = min / max over the three
 //           vertices (-+ margin for the soft pass), faces with valid[f] == 0 or front[f] < 0 skipped by the rasterizer
 //           pass -- the torch glue of rasterization.py:292-327 / dibr.py:31-39 (incl. its torch.where host sync);
@@ -308,7 +361,7 @@ struct BinIn {
   T* rec_s;
 };
 
-template <typename T, bool DO_R, bool DO_S, bool EMIT>
+template <typename T, bool DO_R, bool DO_S>
 __global__ __launch_bounds__(256) void bin_faces_kernel2(BinIn<T> in, Lists LR, Lists LS) {
   const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
   bool live = f < in.total_faces;
@@ -344,7 +397,7 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(BinIn<T> in, Lists LR, 
         bx1 = in.bbox_r[f * 4 + 2];
         by1 = in.bbox_r[f * 4 + 3];
       }
-      if (EMIT) {
+      {
         T z0 = 0, z1 = 0, z2 = 0;
         if (in.z != nullptr) {
           z0 = in.z[f * in.lay.z_face + 0 * in.lay.z_vertex];
@@ -380,7 +433,7 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(BinIn<T> in, Lists LR, 
         bx1 = xmax + in.margin;
         by1 = ymax + in.margin;
       }
-      if (EMIT) {
+      {
         constexpr int RS = rec_s_scalars((int)sizeof(T));
         Rec4<T>* r = reinterpret_cast<Rec4<T>*>(in.rec_s + (size_t)f * RS);
         r[0] = Rec4<T>{bx0, by0, bx1, by1};
@@ -405,91 +458,32 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(BinIn<T> in, Lists LR, 
       }
     }
   }
-  if (DO_R) wave_bin<EMIT, false>(act_r, big_r, b, first_b, f, rx0, rx1, ry0, ry1, 0, 0, 0, 0, LR);
-  if (DO_S) wave_bin<EMIT, true>(act_s, big_s, b, first_b, f, sx0, sx1, sy0, sy1, pr_s.c_lo, pr_s.c_hi, pr_s.r_lo, pr_s.r_hi, LS);
-}
-
-// ---- scan: count -> base (exclusive), count reset to 0 (it becomes the emit pass' cursor) --------------------------------
-// One 1024-thread workgroup walks the counters in slabs of 8192 (two 16-byte loads per thread, both coalesced across the
-// workgroup), block-scans a slab and carries the running total into the next.  Up to two arrays in one launch.
-static __global__ __launch_bounds__(1024) void bin_scan_kernel(unsigned int* cnt_a, unsigned int* base_a, int n_a,
-                                                               unsigned int* cnt_b, unsigned int* base_b, int n_b) {
-  __shared__ unsigned int s_wave[17];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int arr = 0; arr < 2; ++arr) {
-    unsigned int* cnt = arr == 0 ? cnt_a : cnt_b;
-    unsigned int* base = arr == 0 ? base_a : base_b;
-    const int n = arr == 0 ? n_a : n_b;
-    if (cnt == nullptr || n <= 0) continue;
-    const int groups = (n + 3) / 4;  // 16-byte groups (the arrays are padded: whole groups can be read and written)
-    unsigned int carry = 0;
-    for (int s0 = 0; s0 < groups; s0 += 2048) {
-      // thread t owns groups s0 + 2t and s0 + 2t + 1 (32 contiguous bytes)
-      const int g = s0 + 2 * tid;
-      uint4 c0 = make_uint4(0u, 0u, 0u, 0u), c1 = c0;
-      if (g < groups) c0 = reinterpret_cast<const uint4*>(cnt)[g];
-      if (g + 1 < groups) c1 = reinterpret_cast<const uint4*>(cnt)[g + 1];
-      {
-        const int i = g * 4;
-        if (i + 1 >= n) c0.y = 0u;
-        if (i + 2 >= n) c0.z = 0u;
-        if (i + 3 >= n) c0.w = 0u;
-        if (i + 4 >= n) c1.x = 0u;
-        if (i + 5 >= n) c1.y = 0u;
-        if (i + 6 >= n) c1.z = 0u;
-        if (i + 7 >= n) c1.w = 0u;
-      }
-      const unsigned int sum0 = c0.x + c0.y + c0.z + c0.w, sum = sum0 + c1.x + c1.y + c1.z + c1.w;
-      unsigned int inc = sum;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const unsigned int o = (unsigned int)__shfl_up((int)inc, d, 64);
-        if (lane >= d) inc += o;
-      }
-      __syncthreads();  // s_wave may still be read by the previous slab
-      if (lane == 63) s_wave[wave] = inc;
-      __syncthreads();
-      if (tid == 0) {
-        unsigned int run = 0;
-        for (int w = 0; w < 16; ++w) {
-          const unsigned int t = s_wave[w];
-          s_wave[w] = run;
-          run += t;
-        }
-        s_wave[16] = run;
-      }
-      __syncthreads();
-      const unsigned int e0 = carry + s_wave[wave] + inc - sum, e1 = e0 + sum0;
-      if (g < groups) {
-        reinterpret_cast<uint4*>(base)[g] = make_uint4(e0, e0 + c0.x, e0 + c0.x + c0.y, e0 + c0.x + c0.y + c0.z);
-        reinterpret_cast<uint4*>(cnt)[g] = make_uint4(0u, 0u, 0u, 0u);
-      }
-      if (g + 1 < groups) {
-        reinterpret_cast<uint4*>(base)[g + 1] = make_uint4(e1, e1 + c1.x, e1 + c1.x + c1.y, e1 + c1.x + c1.y + c1.z);
-        reinterpret_cast<uint4*>(cnt)[g + 1] = make_uint4(0u, 0u, 0u, 0u);
-      }
-      carry += s_wave[16];
-    }
-    __syncthreads();
-    if (tid == 0) base[n] = carry;  // (after the group stores: base[n] may share the last group)
-    __syncthreads();
-  }
+  if (DO_R) wave_bin<false>(act_r, big_r, b, first_b, f, rx0, rx1, ry0, ry1, 0, 0, 0, 0, LR);
+  if (DO_S) wave_bin<true>(act_s, big_s, b, first_b, f, sx0, sx1, sy0, sy1, pr_s.c_lo, pr_s.c_hi, pr_s.r_lo, pr_s.r_hi, LS);
 }
 
 // ---- consumers: the candidate faces of a tile ------------------------------------------------------------------------------
-// A tile's candidates are (a) its entries, (b) the faces of its mesh's big list; a tile whose entries did not fit into the
-// pool (base + n > cap) takes every block of its mesh instead.  `TileSrc` describes which.
+// A tile's candidates are (a) its entries, (b) the faces of its mesh's big list; a tile flagged BRUTE (an entry could not
+// be stored) takes every block of its mesh instead.
 struct TileSrc {
-  unsigned int base, n;     // entries [base, base + n)
-  bool brute;               // list overflowed: every face of the mesh is a candidate
+  size_t ti;
+  unsigned int n;   // entries
+  bool brute;
 };
 __device__ __forceinline__ TileSrc tile_src(const Lists& L, int b, int tile) {
-  const size_t ti = (size_t)b * L.ntiles + tile;
   TileSrc s;
-  s.base = L.base[ti];
-  s.n = L.base[ti + 1] - s.base;
-  s.brute = (unsigned long long)s.base + s.n > (unsigned long long)L.cap;
+  s.ti = (size_t)b * L.ntiles + tile;
+  const unsigned int raw = L.count[s.ti];
+  s.brute = (raw & BRUTE_BIT) != 0u;
+  s.n = raw & ~BRUTE_BIT;
   return s;
+}
+// e-th entry of a tile (e < n; the tile is not BRUTE, so every chunk it needs was published)
+__device__ __forceinline__ uint4 tile_entry(const Lists& L, const TileSrc& s, unsigned int e) {
+  if (e < (unsigned int)L.C) return L.inl[s.ti * L.C + e];
+  const unsigned int o = e - (unsigned int)L.C, c = o / OVC_PAYLOAD, i = o - c * OVC_PAYLOAD;
+  const unsigned int chunk = L.tab[s.ti * L.maxc + c] - 1u;
+  return L.pool[(size_t)chunk * OVC + 1u + i];
 }
 
 // what the rasterizer's tile kernel needs to settle the soft mask's trivial pixels and queue the search's work items
