@@ -10,4 +10,3 @@ try:
 except Exception as e:
     print('bench failed', e); print(open('gpurun_out/r02b/bench.err').read()[-2000:])
 PY
-if [ -f kaolin_amd/libkaolin_amd_prof.so ]; then KAMD_LIB_PATH=$PWD/kaolin_amd/libkaolin_amd_prof.so timeout 300 python tools/phase_prof.py 2>&1 | grep -v amdgpu.ids; fi
