@@ -54,6 +54,17 @@ int kamd_sided_distance_forward_f64(void* stream, int B, int N, int M,
 int kamd_sided_distance_forward_f16(void* stream, int B, int N, int M,
                                     const uint16_t* p1, const uint16_t* p2,
                                     uint16_t* dist, int64_t* idx, void* workspace);
+/* integer clouds (the reference dispatches Byte / Short / Int / Long as well, */
+/* kaolin/csrc/utils.h:50-64): arithmetic in the element type, C promotions,   */
+/* truncation at every assignment as in sided_distance_cuda.cu:83-86           */
+int kamd_sided_distance_forward_u8(void* stream, int B, int N, int M, const uint8_t* p1, const uint8_t* p2,
+                                   uint8_t* dist, int64_t* idx, void* workspace);
+int kamd_sided_distance_forward_i16(void* stream, int B, int N, int M, const int16_t* p1, const int16_t* p2,
+                                    int16_t* dist, int64_t* idx, void* workspace);
+int kamd_sided_distance_forward_i32(void* stream, int B, int N, int M, const int32_t* p1, const int32_t* p2,
+                                    int32_t* dist, int64_t* idx, void* workspace);
+int kamd_sided_distance_forward_i64(void* stream, int B, int N, int M, const int64_t* p1, const int64_t* p2,
+                                    int64_t* dist, int64_t* idx, void* workspace);
 
 /* Both directions of chamfer_distance in one pass (kaolin/metrics/pointcloud.py */
 /* :89-136 calls sided_distance(p1, p2) and sided_distance(p2, p1)): both clouds */
@@ -92,6 +103,14 @@ int kamd_sided_distance_backward_f64(void* stream, int B, int N, int M,
 int kamd_sided_distance_backward_f16(void* stream, int B, int N, int M,
                                      const uint16_t* grad, const uint16_t* p1, const uint16_t* p2,
                                      const int64_t* idx, uint16_t* g1, uint16_t* g2);
+int kamd_sided_distance_backward_u8(void* stream, int B, int N, int M, const uint8_t* grad, const uint8_t* p1,
+                                    const uint8_t* p2, const int64_t* idx, uint8_t* g1, uint8_t* g2);
+int kamd_sided_distance_backward_i16(void* stream, int B, int N, int M, const int16_t* grad, const int16_t* p1,
+                                     const int16_t* p2, const int64_t* idx, int16_t* g1, int16_t* g2);
+int kamd_sided_distance_backward_i32(void* stream, int B, int N, int M, const int32_t* grad, const int32_t* p1,
+                                     const int32_t* p2, const int64_t* idx, int32_t* g1, int32_t* g2);
+int kamd_sided_distance_backward_i64(void* stream, int B, int N, int M, const int64_t* grad, const int64_t* p1,
+                                     const int64_t* p2, const int64_t* idx, int64_t* g1, int64_t* g2);
 
 /* ------------------------------------------------------------------------- */
 /* render.mesh.packed_rasterize_forward_cuda(H, W, z, img, bbox, feat,        */

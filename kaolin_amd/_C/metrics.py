@@ -5,6 +5,8 @@ from .. import _lib
 from .._checks import (Arg, check_same_gpu, check_all_same_gpu, check_all_contiguous, check_same_type,
                        check_size, check_same_size, torch_check)
 
+_SD_TYPES = ('f32', 'f64', 'f16', 'u8', 'i16', 'i32', 'i64')   # the reference's DISPATCH_NUM_TYPES (utils.h:50-64)
+
 
 def sided_distance_forward_cuda(p1, p2):
     """reference: kaolin/csrc/metrics/sided_distance.cpp:65-89 -> [dist, idx]"""
@@ -16,7 +18,7 @@ def sided_distance_forward_cuda(p1, p2):
     batch_size, num_p1, num_p2 = p1.size(0), p1.size(1), p2.size(1)
     check_size(fn, p1_arg, [batch_size, num_p1, 3])
     check_size(fn, p2_arg, [batch_size, num_p2, 3])
-    sfx = _lib.dtype_suffix(p1.dtype, fn, ('f32', 'f64', 'f16'))
+    sfx = _lib.dtype_suffix(p1.dtype, fn, _SD_TYPES)
     lib = _lib.load()
     with torch.cuda.device(p1.device):
         # the reference allocates zeros (sided_distance.cpp:80-81); every kernel path writes all B x N entries, so only
@@ -106,7 +108,7 @@ def sided_distance_backward_cuda(grad_output, p1, p2, idx):
     check_size(fn, p1_arg, [batch_size, num_p1, 3])
     check_size(fn, p2_arg, [batch_size, num_p2, 3])
     check_same_size(fn, idx_arg, g_arg)
-    sfx = _lib.dtype_suffix(p1.dtype, fn, ('f32', 'f64', 'f16'))
+    sfx = _lib.dtype_suffix(p1.dtype, fn, _SD_TYPES)
     lib = _lib.load()
     with torch.cuda.device(p1.device):
         g1 = torch.zeros_like(p1)

@@ -52,7 +52,7 @@ SIGNATURES = {
     'kamd_profile_kernel_name': (ctypes.c_char_p, [_i]),
     'kamd_profile_read': (_i, [_i, _vp, _vp]),
 }
-for _t in ('f32', 'f64', 'f16'):
+for _t in ('f32', 'f64', 'f16', 'u8', 'i16', 'i32', 'i64'):
     SIGNATURES[f'kamd_sided_distance_forward_{_t}'] = (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_sided_distance_backward_{_t}'] = (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp])
 for _t in ('f32', 'f64'):
@@ -131,7 +131,8 @@ _PRETTY = {torch.float16: 'Half', torch.float32: 'Float', torch.float64: 'Double
 
 
 def dtype_suffix(dtype, what, allowed=('f32', 'f64')):
-    s = {torch.float32: 'f32', torch.float64: 'f64', torch.float16: 'f16'}.get(dtype)
+    s = {torch.float32: 'f32', torch.float64: 'f64', torch.float16: 'f16', torch.uint8: 'u8', torch.int16: 'i16',
+         torch.int32: 'i32', torch.int64: 'i64'}.get(dtype)
     if s is None or s not in allowed:
         # reference: AT_ERROR(name, " not implemented for '", toString(TYPE), "'")
         raise RuntimeError(f'"{what}" not implemented for \'{_PRETTY.get(dtype, dtype)}\'')

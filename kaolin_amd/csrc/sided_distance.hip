@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include "profile.h"
 #include "sided_distance_grid.h"
+#include <type_traits>
 #include "../../include/kaolin_amd.h"
 
 namespace {
@@ -69,6 +70,45 @@ template <> struct SdArith<__half> {
     return kamd_hround(kamd_hround(2.f * kamd_hround(a - b)) * g);
   }
 };
+
+// Integer clouds (the reference dispatches Byte / Short / Int / Long too, kaolin/csrc/utils.h:50-64): its kernel spells
+// every intermediate as scalar_t, so differences, squares and sums are computed with C's usual promotions and TRUNCATED
+// to the element type at each assignment (sided_distance_cuda.cu:83-86,229-236) -- e.g. uint8 differences wrap mod 256.
+template <typename I, typename W>   // W: the type C promotes I's arithmetic to (made unsigned where overflow would be UB)
+struct SdIntArith {
+  using acc_t = I;
+  static __device__ __forceinline__ I load(const I* p) { return *p; }
+  static __device__ __forceinline__ void store(I* p, I v) { *p = v; }
+  static __device__ __forceinline__ I dist(I tx, I ty, I tz, I qx, I qy, I qz) {
+    const I dx = (I)((W)tx - (W)qx), dy = (I)((W)ty - (W)qy), dz = (I)((W)tz - (W)qz);
+    return (I)((W)dx * (W)dx + (W)dy * (W)dy + (W)dz * (W)dz);
+  }
+  static __device__ __forceinline__ I grad(I a, I b, I g) { return (I)((W)2 * ((W)a - (W)b) * (W)g); }
+};
+template <> struct SdArith<uint8_t> : SdIntArith<uint8_t, int> {};
+template <> struct SdArith<int16_t> : SdIntArith<int16_t, int> {};
+template <> struct SdArith<int32_t> : SdIntArith<int32_t, unsigned int> {};
+template <> struct SdArith<int64_t> : SdIntArith<int64_t, unsigned long long> {};
+
+// atomic adds for the integer gradients (sub-word types through a CAS on the containing 32-bit word)
+using ::kamd_atomic_add;
+__device__ __forceinline__ void kamd_atomic_add(int32_t* p, int32_t v) { atomicAdd(p, v); }
+__device__ __forceinline__ void kamd_atomic_add(int64_t* p, int64_t v) { atomicAdd((unsigned long long*)p, (unsigned long long)v); }
+template <typename I>
+__device__ __forceinline__ void kamd_atomic_add_subword(I* p, I v) {
+  const uintptr_t a = (uintptr_t)p;
+  unsigned int* w = (unsigned int*)(a & ~(uintptr_t)3);
+  const unsigned int shift = (unsigned int)(a & 3) * 8u, mask = (sizeof(I) == 1 ? 0xFFu : 0xFFFFu) << shift;
+  unsigned int old = *w, assumed;
+  do {
+    assumed = old;
+    const unsigned int cur = (assumed & mask) >> shift;
+    const unsigned int sum = ((cur + (unsigned int)(typename std::make_unsigned<I>::type)v) << shift) & mask;
+    old = atomicCAS(w, assumed, (assumed & ~mask) | sum);
+  } while (old != assumed);
+}
+__device__ __forceinline__ void kamd_atomic_add(uint8_t* p, uint8_t v) { kamd_atomic_add_subword<uint8_t>(p, v); }
+__device__ __forceinline__ void kamd_atomic_add(int16_t* p, int16_t v) { kamd_atomic_add_subword<int16_t>(p, v); }
 
 // ---- generic forward: one query per lane, exact reference semantics ---------
 constexpr int SDG_THREADS = 256;
@@ -263,10 +303,12 @@ inline SdPlan sd_plan(int B, int N, int M) {
 template <typename T>
 int sd_forward_generic_launch(hipStream_t st, int B, int N, int M, const T* p1, const T* p2, T* dist, int64_t* idx) {
   if (B <= 0 || N <= 0 || M <= 0) return 0;  // M == 0: outputs keep the caller's zeros
-  dim3 grid(kamd_cdiv(N, SDG_THREADS), B);
-  {
-    kamd::ProfScope prof_(kamd::K_SD_GENERIC, st);
-    hipLaunchKernelGGL(sd_forward_generic<T>, grid, dim3(SDG_THREADS), 0, st, N, M, p1, p2, dist, idx);
+  kamd::ProfScope prof_(kamd::K_SD_GENERIC, st);
+  for (int b0 = 0; b0 < B; b0 += 65535) {  // the batch rides on the grid's y extent: slabs of at most 65535 items
+    const int nb = B - b0 < 65535 ? B - b0 : 65535;
+    dim3 grid(kamd_cdiv(N, SDG_THREADS), nb);
+    hipLaunchKernelGGL(sd_forward_generic<T>, grid, dim3(SDG_THREADS), 0, st, N, M, p1 + (size_t)b0 * N * 3,
+                       p2 + (size_t)b0 * M * 3, dist + (size_t)b0 * N, idx + (size_t)b0 * N);
   }
   KAMD_RETURN_LAST_ERROR();
 }
@@ -302,10 +344,12 @@ template <typename T>
 int sd_backward_launch(hipStream_t st, int B, int N, int M, const T* grad, const T* p1, const T* p2,
                        const int64_t* idx, T* g1, T* g2) {
   if (B <= 0 || N <= 0 || M <= 0) return 0;
-  dim3 grid(kamd_cdiv(N, 256), B);
-  {
-    kamd::ProfScope prof_(kamd::K_SD_BACKWARD, st);
-    hipLaunchKernelGGL(sd_backward<T>, grid, dim3(256), 0, st, N, M, grad, p1, p2, idx, g1, g2);
+  kamd::ProfScope prof_(kamd::K_SD_BACKWARD, st);
+  for (int b0 = 0; b0 < B; b0 += 65535) {
+    const int nb = B - b0 < 65535 ? B - b0 : 65535;
+    dim3 grid(kamd_cdiv(N, 256), nb);
+    hipLaunchKernelGGL(sd_backward<T>, grid, dim3(256), 0, st, N, M, grad + (size_t)b0 * N, p1 + (size_t)b0 * N * 3,
+                       p2 + (size_t)b0 * M * 3, idx + (size_t)b0 * N, g1 + (size_t)b0 * N * 3, g2 + (size_t)b0 * M * 3);
   }
   KAMD_RETURN_LAST_ERROR();
 }
@@ -432,6 +476,22 @@ int kamd_sided_distance_forward_f16(void* stream, int B, int N, int M, const uin
   return sd_forward_generic_launch<__half>((hipStream_t)stream, B, N, M, (const __half*)p1, (const __half*)p2,
                                            (__half*)dist, idx);
 }
+
+#define KAMD_SD_INT_ENTRY(SFX, I)                                                                                       \
+  int kamd_sided_distance_forward_##SFX(void* stream, int B, int N, int M, const I* p1, const I* p2, I* dist,          \
+                                        int64_t* idx, void* workspace) {                                              \
+    (void)workspace;                                                                                                   \
+    return sd_forward_generic_launch<I>((hipStream_t)stream, B, N, M, p1, p2, dist, idx);                              \
+  }                                                                                                                    \
+  int kamd_sided_distance_backward_##SFX(void* stream, int B, int N, int M, const I* grad, const I* p1, const I* p2,  \
+                                         const int64_t* idx, I* g1, I* g2) {                                           \
+    return sd_backward_launch<I>((hipStream_t)stream, B, N, M, grad, p1, p2, idx, g1, g2);                             \
+  }
+KAMD_SD_INT_ENTRY(u8, uint8_t)
+KAMD_SD_INT_ENTRY(i16, int16_t)
+KAMD_SD_INT_ENTRY(i32, int32_t)
+KAMD_SD_INT_ENTRY(i64, int64_t)
+#undef KAMD_SD_INT_ENTRY
 
 int kamd_sided_distance_backward_f32(void* stream, int B, int N, int M, const float* grad, const float* p1,
                                      const float* p2, const int64_t* idx, float* g1, float* g2) {

@@ -155,3 +155,10 @@ def f_score(gt_points, pred_points, radius=0.01, eps=1e-8):
     hits = (pred_to_gt.shape[1] - spurious).type(dtype)            # true positives
     precision, recall = hits / (hits + spurious), hits / (hits + missed)
     return 2 * (precision * recall) / (precision + recall + eps)
+
+
+def _sided_distance(p1, p2):
+    """Dense torch formulation of :func:`sided_distance` (values only), any device: the oracle the reference's tests
+    compare the operator with (kaolin/metrics/pointcloud.py:186-197).  O(N1 * N2) memory per batch item."""
+    delta = p1.unsqueeze(2) - p2.unsqueeze(1)           # (B, N1, N2, 3)
+    return (delta * delta).sum(dim=-1).min(dim=-1).values

@@ -2,7 +2,7 @@
 subdivision the voxelizer's definition rests on."""
 import torch
 
-__all__ = ['index_vertices_by_faces', 'face_normals', 'check_sign']
+__all__ = ['index_vertices_by_faces', 'face_normals', 'check_sign', 'adjacency_matrix', 'uniform_laplacian']
 
 
 def index_vertices_by_faces(vertices_features, faces):
@@ -31,12 +31,101 @@ def face_normals(face_vertices, unit=False):
     return n
 
 
+def adjacency_matrix(num_vertices, faces, sparse=True):
+    """Vertex adjacency of a polygon mesh, (V, V), entries 1 between vertices that share a face edge (consecutive corners of
+    a face, cyclically).  Behaviour of kaolin/ops/mesh/mesh.py:77-114: COO tensor by default, dense with ``sparse=False``."""
+    k = faces.shape[1]
+    src = faces.reshape(-1)
+    dst = torch.roll(faces, -1, dims=1).reshape(-1)
+    pairs = torch.unique(torch.stack([torch.cat([src, dst]), torch.cat([dst, src])], dim=1), dim=0)
+    if k < 2:
+        pairs = pairs[:0]
+    if sparse:
+        return torch.sparse_coo_tensor(pairs.t(), torch.ones(pairs.shape[0], dtype=torch.float, device=faces.device),
+                                       (num_vertices, num_vertices))
+    dense = torch.zeros((num_vertices, num_vertices), dtype=torch.float, device=faces.device)
+    dense[pairs[:, 0], pairs[:, 1]] = 1.
+    return dense
+
+
+def uniform_laplacian(num_vertices, faces):
+    """Uniform Laplacian of a mesh, (V, V): 1 / #neighbours(i) between neighbours, -1 on the diagonal, rows of isolated
+    vertices are zero off the diagonal (behaviour of kaolin/ops/mesh/mesh.py:116-164)."""
+    adj = adjacency_matrix(num_vertices, faces, sparse=False)
+    degree = adj.sum(dim=1, keepdim=True)
+    lap = torch.where(degree > 0, adj / degree.clamp(min=1.), torch.zeros_like(adj))
+    lap.fill_diagonal_(-1.)
+    return lap
+
+
 def _unbatched_check_sign_cuda(verts, faces, points):
     """kaolin/ops/mesh/check_sign.py:45-54."""
     from ... import _C
     corners = [verts[faces[:, k]].contiguous() for k in range(3)]
     crossings = _C.ops.unbatched_mesh_intersection_cuda(points.contiguous(), *corners)
     return crossings % 2 == 1.
+
+
+def _unbatched_check_sign_torch(verts, faces, points):
+    """The ray-parity count of the GPU operator in plain torch, for CPU tensors (the reference's CPU path is a C++
+    ``TriangleHash``, kaolin/ops/mesh/check_sign.py:56-58; this follows the rules of its CUDA kernel,
+    mesh_intersection_cuda.cu:101-218, so that both devices answer alike): a +x ray per point; a face counts when the point's
+    (y, z) projection lies in the face's projected box and triangle and the ray's two ends lie on different sides of
+    its plane; a projection exactly on an edge / vertex is credited to one of the faces sharing it."""
+    p1, p2, p3 = (verts[faces[:, k]] for k in range(3))                          # (F, 3)
+
+    def signed_volume(q):                                                         # (c, 1, 3) -> (c, F)
+        n = torch.cross(p2 - p1, p3 - p1, dim=-1)
+        return (n.unsqueeze(0) * (p1.unsqueeze(0) - q)).sum(-1) * -1.
+
+    def signed_area(q, b, c):            # q (c, 1, 2); b, c (F, 2): side of q w.r.t. the edge, direction-normalised
+        swap = (c[:, 0] > b[:, 0]) | ((b[:, 0] == c[:, 0]) & (c[:, 1] < b[:, 1]))
+        lo = torch.where(swap.unsqueeze(-1), c, b)
+        hi = torch.where(swap.unsqueeze(-1), b, c)
+        val = (hi[:, 1] - lo[:, 1]) * (q[..., 0] - lo[:, 0]) + (lo[:, 0] - hi[:, 0]) * (q[..., 1] - lo[:, 1])
+        return torch.where(swap, -val, val)
+
+    def above(v, l, r):                  # v left of the directed line l -> r
+        return ((r[..., 0] - l[..., 0]) * (v[..., 1] - l[..., 1]) - (r[..., 1] - l[..., 1]) * (v[..., 0] - l[..., 0])) > 0.
+
+    a, b, c = p1[:, 1:], p2[:, 1:], p3[:, 1:]                                    # (y, z) projections
+    lo = torch.minimum(torch.minimum(a, b), c).float()
+    hi = torch.maximum(torch.maximum(a, b), c).float()
+    counts = torch.zeros(points.shape[0], dtype=points.dtype, device=points.device)
+    step = max(1, (1 << 21) // max(faces.shape[0], 1))
+    for s0 in range(0, points.shape[0], step):
+        pts = points[s0:s0 + step]
+        q = pts[:, None, 1:]                                                     # (c, 1, 2)
+        inbox = ((q.float() >= lo) & (q.float() <= hi)).all(-1) if pts.dtype != torch.double else \
+            ((q >= lo.double()) & (q <= hi.double())).all(-1)
+        far = pts + torch.tensor([10., 0., 0.], dtype=pts.dtype, device=pts.device)
+        crosses = (signed_volume(pts[:, None, :]) > 0.) != (signed_volume(far[:, None, :]) > 0.)
+        d1, d2, d3 = signed_area(q, a, b), signed_area(q, b, c), signed_area(q, c, a)
+        inside = (d1 * d2 >= 0) & (d3 * d1 >= 0) & (d2 * d3 >= 0)
+        hit = inbox & crosses & inside
+        at_a, at_b, at_c = ((q == x).all(-1) for x in (a, b, c))
+        on_vertex = at_a | at_b | at_c
+        on_e1 = ~on_vertex & (d1 == 0.)
+        on_e2 = ~on_vertex & ~on_e1 & (d2 == 0.)
+        on_e3 = ~on_vertex & ~on_e1 & ~on_e2 & (d3 == 0.)
+
+        def pick(m_a, m_b, m_c, xa, xb, xc):   # per-(point, face) 2-vectors chosen by exclusive masks
+            z = torch.zeros(hit.shape + (2,), dtype=pts.dtype, device=pts.device)
+            return torch.where(m_a.unsqueeze(-1), xa, torch.where(m_b.unsqueeze(-1), xb, torch.where(m_c.unsqueeze(-1), xc, z)))
+
+        A, Bv, C = (x.unsqueeze(0).expand(hit.shape + (2,)) for x in (a, b, c))
+        # the two ends of the edge the point lies on (or the two other vertices when it lies on a vertex), and the third vertex
+        e1 = torch.where(on_vertex.unsqueeze(-1), pick(at_a, at_b, at_c, Bv, A, A), pick(on_e1, on_e2, on_e3, A, Bv, C))
+        e2 = torch.where(on_vertex.unsqueeze(-1), pick(at_a, at_b, at_c, C, C, Bv), pick(on_e1, on_e2, on_e3, Bv, C, A))
+        other = pick(on_e1, on_e2, on_e3, C, A, Bv)
+        flip = (e1[..., 0] > e2[..., 0]) | ((e1[..., 0] == e2[..., 0]) & (e1[..., 1] > e2[..., 1]))
+        e1, e2 = torch.where(flip.unsqueeze(-1), e2, e1), torch.where(flip.unsqueeze(-1), e1, e2)
+        on_edge = on_e1 | on_e2 | on_e3
+        qq = q.expand(hit.shape + (2,))
+        drop = (on_edge & above(other, e1, e2)) | \
+               (on_vertex & ~(above(qq, e1, e2) & (e1[..., 0] < qq[..., 0]) & (e2[..., 0] >= qq[..., 0])))
+        counts[s0:s0 + step] = (hit & ~drop).sum(dim=1).to(points.dtype)
+    return counts % 2 == 1.
 
 
 def check_sign(verts, faces, points, hash_resolution=512):
@@ -72,11 +161,9 @@ def check_sign(verts, faces, points, hash_resolution=512):
     if points.shape[2] != 3:
         raise ValueError(f"Expected points to have 3 coordinates "
                          f"but got {points.shape[2]} coordinates.")
-    if points.device.type != 'cuda':
-        raise RuntimeError('check_sign: only the GPU path is implemented (the reference CPU path is a C++ TriangleHash, '
-                           'out of scope: SURVEY.md section 2)')
     # normalise by the largest extent of each mesh (check_sign.py:139-145): the ray's far end is then surely outside
     extent = verts.max(dim=1)[0] - verts.min(dim=1)[0]                      # (B, 3)
     scale = extent.max(dim=1)[0].view(-1, 1, 1)
     verts, points = verts / scale, points / scale
-    return torch.stack([_unbatched_check_sign_cuda(verts[i], faces, points[i]) for i in range(verts.shape[0])])
+    one = _unbatched_check_sign_cuda if points.is_cuda else _unbatched_check_sign_torch
+    return torch.stack([one(verts[i], faces, points[i]) for i in range(verts.shape[0])])

@@ -72,3 +72,69 @@ def deftet_sparse_render(pixel_coords, render_ranges, face_vertices_z, face_vert
         sizes = [f.shape[-1] for f in face_features]
         image_features = tuple(torch.split(image_features, sizes, dim=-1))
     return image_features, face_idx
+
+
+def _naive_deftet_sparse_render(pixel_coords, render_ranges, face_vertices_z, face_vertices_image, face_features, knum,
+                                valid_faces=None, eps=1e-8):
+    r"""Plain-torch rendition of :func:`deftet_sparse_render` on any device -- the oracle the reference's rasterizer and
+    DefTet tests are pinned to (kaolin/render/mesh/deftet.py:101-267).  Per pixel: the valid faces whose half-open
+    bounding box holds it, whose three normalised edge functions are >= 0 and whose interpolated depth lies strictly
+    inside the pixel's render range, nearest first (largest depth; equal depths keep mesh order), at most ``knum``.
+    Unlike the operator it keeps the NEAREST ``knum`` faces of a crowded pixel, not the first in mesh order.
+
+    Returns (features (B, P, knum, D) or a tuple of them for a list input, face_idx (B, P, knum) int64, -1 = void);
+    differentiable w.r.t. ``face_vertices_image`` and ``face_features``."""
+    as_list = isinstance(face_features, (list, tuple))
+    feats = torch.cat(face_features, dim=-1) if as_list else face_features
+    B, P = pixel_coords.shape[:2]
+    F, D = face_vertices_z.shape[1], feats.shape[-1]
+    dev = pixel_coords.device
+    assert pixel_coords.shape == (B, P, 2) and render_ranges.shape == (B, P, 2)
+    assert face_vertices_z.shape == (B, F, 3) and face_vertices_image.shape == (B, F, 3, 2) and feats.shape == (B, F, 3, D)
+    if valid_faces is None:
+        valid_faces = torch.ones((B, F), dtype=torch.bool, device=dev)
+    face_idx = torch.full((B, P, knum), -1, dtype=torch.long, device=dev)
+    with torch.no_grad():
+        img, z = face_vertices_image.detach(), face_vertices_z.detach()
+        lo, hi = img.min(dim=2)[0], img.max(dim=2)[0]                      # (B, F, 2)
+        step = max(1, (1 << 21) // max(F, 1))
+        for b in range(B):
+            for p0 in range(0, P, step):
+                px = pixel_coords[b, p0:p0 + step].detach().unsqueeze(1)    # (c, 1, 2)
+                rng = render_ranges[b, p0:p0 + step].detach()
+                inbox = ((px >= lo[b]) & (px < hi[b])).all(dim=-1) & valid_faces[b]
+                e = img[b].unsqueeze(0) - px.unsqueeze(2)                    # (c, F, 3, 2): vertex - pixel
+                w0 = e[:, :, 1, 0] * e[:, :, 2, 1] - e[:, :, 1, 1] * e[:, :, 2, 0]
+                w1 = e[:, :, 2, 0] * e[:, :, 0, 1] - e[:, :, 2, 1] * e[:, :, 0, 0]
+                w2 = e[:, :, 0, 0] * e[:, :, 1, 1] - e[:, :, 0, 1] * e[:, :, 1, 0]
+                total = w0 + w1 + w2
+                total = total + eps * torch.sign(total)
+                w0, w1, w2 = w0 / total, w1 / total, w2 / total
+                depth = w0 * z[b, :, 0] + w1 * z[b, :, 1] + w2 * z[b, :, 2]
+                hit = inbox & (w0 >= 0.) & (w1 >= 0.) & (w2 >= 0.) & (depth > rng[:, :1]) & (depth < rng[:, 1:])
+                key = torch.where(hit, depth, torch.full_like(depth, -float('inf')))
+                order = torch.argsort(key, dim=1, descending=True, stable=True)[:, :knum]
+                took = torch.gather(hit, 1, order)
+                n = order.shape[1]
+                face_idx[b, p0:p0 + step, :n] = torch.where(took, order, torch.full_like(order, -1))
+    # differentiable part: barycentric weights of every pixel in its selected faces, through the first vertex and the two
+    # edge vectors leaving it (void slots read a zero face with unit area)
+    safe = face_idx.clamp(min=0)
+    void = face_idx < 0
+    corners = torch.gather(face_vertices_image, 1, safe.reshape(B, -1, 1, 1).expand(-1, -1, 3, 2)).reshape(B, P, knum, 3, 2)
+    corners = torch.where(void[..., None, None], torch.zeros_like(corners), corners)
+    org, eb, ec = corners[..., 0, :], corners[..., 1, :] - corners[..., 0, :], corners[..., 2, :] - corners[..., 0, :]
+    rel = pixel_coords.unsqueeze(2) - org
+    area = eb[..., 0] * ec[..., 1] - ec[..., 0] * eb[..., 1]
+    area = torch.where(void, torch.ones_like(area), area)
+    denom = area + eps * torch.sign(area)
+    wb = (rel[..., 0] * ec[..., 1] - ec[..., 0] * rel[..., 1]) / denom
+    wc = (eb[..., 0] * rel[..., 1] - rel[..., 0] * eb[..., 1]) / denom
+    weights = torch.stack([1. - wb - wc, wb, wc], dim=-1)                  # (B, P, knum, 3)
+    picked = torch.gather(feats, 1, safe.reshape(B, -1, 1, 1).expand(-1, -1, 3, D)).reshape(B, P, knum, 3, D)
+    picked = torch.where(void[..., None, None], torch.zeros_like(picked), picked)
+    out = (picked * weights.unsqueeze(-1)).sum(dim=-2)
+    if as_list:
+        sizes = [f.shape[-1] for f in face_features]
+        out = tuple(torch.split(out, sizes, dim=-1))
+    return out, face_idx

@@ -33,6 +33,27 @@ def check_allclose(a, b, rtol=1e-5, atol=1e-8):
         raise AssertionError(f'max abs diff {(a - b).abs().max().item()}')
 
 
+def check_tensor(tensor, shape=None, dtype=None, device=None, throw=True):
+    """True when `tensor` has the given shape (None entries match anything), dtype and device; otherwise raises
+    (ValueError for the shape, TypeError for dtype / device) or, with throw=False, returns False
+    (behaviour of kaolin/utils/testing.py:73-111)."""
+    problem = None
+    if shape is not None:
+        if len(shape) != tensor.ndim:
+            problem = ValueError(f"tensor have {tensor.ndim} ndim, should have {len(shape)}")
+        elif any(want is not None and have != want for have, want in zip(tensor.shape, shape)):
+            problem = ValueError(f"tensor shape is {tensor.shape}, should be {shape}")
+    if problem is None and dtype is not None and tensor.dtype != dtype:
+        problem = TypeError(f"tensor dtype is {tensor.dtype}, should be {dtype}")
+    if problem is None and device is not None:
+        want = torch.device(device)
+        if want.type != tensor.device.type or (want.index is not None and want.index != tensor.device.index):
+            problem = TypeError(f"tensor device is {tensor.device}, should be {want}")
+    if problem is not None and throw:
+        raise problem
+    return problem is None
+
+
 def geodesic_sphere(frequency, radius=0.5):
     """Class-I geodesic icosphere: every icosahedron face split into frequency^2 triangles and pushed
     to the sphere: 20*f^2 faces, 10*f^2+2 vertices (f=16 -> 5120 faces, f=50 -> 50000 faces).
