@@ -14,7 +14,7 @@ existing notebooks/tests written against the reference import it unchanged.
 import sys
 
 from . import _C  # noqa: F401
-from . import metrics, ops, render, utils  # noqa: F401
+from . import io, metrics, ops, render, utils  # noqa: F401
 from . import distributed  # noqa: F401
 
 __version__ = '0.1.0'

@@ -11,7 +11,7 @@ for f in metrics/test_pointcloud.py metrics/test_trianglemesh.py metrics/test_re
          ops/conversions/test_trianglemesh.py; do
   mkdir -p "$dst/tests/python/kaolin/$(dirname $f)"; cp "$ref/tests/python/kaolin/$f" "$dst/tests/python/kaolin/$f"
 done
-cp "$ref/tests/samples/model.obj" "$ref/tests/samples/model.mtl" "$dst/tests/samples/" 2>/dev/null || true
+cp "$ref/tests/samples/model.obj" "$ref/tests/samples/model.mtl" "$ref/tests/samples/tex.png" "$dst/tests/samples/" 2>/dev/null || true
 cp -r "$ref/tests/samples/dibr" "$dst/tests/samples/"
 for d in rasterization ops render; do [ -d "$ref/tests/samples/$d" ] && cp -r "$ref/tests/samples/$d" "$dst/tests/samples/" || true; done
 cat > "$dst/conftest.py" <<'PY'
