@@ -292,6 +292,40 @@ int kamd_dibr_soft_mask_forward_fused_f64(void* stream, int B, int H, int W, int
                                           uint32_t* work, void* workspace);
 
 /* ------------------------------------------------------------------------- */
+/* kaolin.metrics.render.mask_iou(lhs, rhs) (kaolin/metrics/render.py:18-40),  */
+/* fused: forward = one pass over both (B, H, W) masks, P = H * W (+ a one-     */
+/* workgroup finish): sums (B, 2) doubles receive {sum(l*r), sum(l+r-l*r)} per  */
+/* item, loss the scalar 1 - mean(I / (U + 1e-10)); backward = one elementwise  */
+/* pass giving d loss / d(one mask) from the OTHER mask and the sums.           */
+/* workspace: kamd_mask_iou_workspace(B) bytes.                                 */
+/* ------------------------------------------------------------------------- */
+size_t kamd_mask_iou_workspace(int B);
+int kamd_mask_iou_forward_f32(void* stream, int B, int64_t P, const float* lhs, const float* rhs, void* workspace,
+                              double* sums, float* loss);
+int kamd_mask_iou_forward_f64(void* stream, int B, int64_t P, const double* lhs, const double* rhs, void* workspace,
+                              double* sums, double* loss);
+int kamd_mask_iou_backward_f32(void* stream, int B, int64_t P, const float* grad_loss, const float* other,
+                               const double* sums, float* grad);
+int kamd_mask_iou_backward_f64(void* stream, int B, int64_t P, const double* grad_loss, const double* other,
+                               const double* sums, double* grad);
+/* kaolin.render.mesh.texture_mapping (kaolin/render/mesh/utils.py:23-76), one  */
+/* gather kernel each way: uv (B, N, 2) OpenGL-style in [0, 1] (clamped), tex   */
+/* (B, C, TH, TW), out (B, N, C); grid_sample arithmetic (align_corners=False,  */
+/* border padding), bilinear != 0 or nearest.  Backward accumulates into the    */
+/* caller-zeroed g_tex (NULL: not needed) and writes g_uv (B, N, 2) (NULL: not  */
+/* needed; zero for nearest).                                                   */
+int kamd_texture_mapping_forward_f32(void* stream, int B, int64_t N, int C, int TH, int TW, int bilinear,
+                                     const float* uv, const float* tex, float* out);
+int kamd_texture_mapping_forward_f64(void* stream, int B, int64_t N, int C, int TH, int TW, int bilinear,
+                                     const double* uv, const double* tex, double* out);
+int kamd_texture_mapping_backward_f32(void* stream, int B, int64_t N, int C, int TH, int TW, int bilinear,
+                                      const float* uv, const float* tex, const float* grad_out, float* g_tex,
+                                      float* g_uv);
+int kamd_texture_mapping_backward_f64(void* stream, int B, int64_t N, int C, int TH, int TW, int bilinear,
+                                      const double* uv, const double* tex, const double* grad_out, double* g_tex,
+                                      double* g_uv);
+
+/* ------------------------------------------------------------------------- */
 /* dibr_rasterization in one call (ours; kaolin/render/mesh/dibr.py:119-209   */
 /* = rasterize with valid faces + dibr_soft_mask over all faces).  Same       */
 /* kernels as the separate entry points, sharing one binning pass: the faces  */

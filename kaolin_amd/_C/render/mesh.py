@@ -461,6 +461,22 @@ def vertex_face_adjacency(faces, num_vertices):
     return _ADJ_CACHE[key]
 
 
+_FACES_OK = {}
+
+
+def faces_in_range(faces, num_vertices):
+    """True when every index of `faces` addresses a vertex (the reference's index_select would raise otherwise; the fused
+    kernels read unchecked).  One host read per `faces` tensor, cached like the adjacency (mesh topology is static)."""
+    key = (faces.data_ptr(), tuple(faces.shape), faces._version, int(num_vertices), str(faces.device))
+    hit = _FACES_OK.get(key)
+    if hit is None:
+        hit = bool(faces.numel() == 0 or (int(faces.min()) >= 0 and int(faces.max()) < num_vertices))
+        if len(_FACES_OK) > 16:
+            _FACES_OK.clear()
+        _FACES_OK[key] = hit
+    return hit
+
+
 def _pv_common(vertices, faces, camera_proj, camera_rot, camera_trans, camera_transform):
     fn = 'prepare_vertices'
     batch_size = (camera_transform if camera_transform is not None else camera_rot).size(0)
@@ -625,3 +641,72 @@ def deftet_sparse_render_backward_cuda(grad_interpolated_features, face_idx, wei
             _lib.ptr(face_features), float(eps), _lib.ptr(g_img), _lib.ptr(g_feat))
     _lib.check(st, fn)
     return [g_img, g_feat]
+
+
+# ---- mask_iou / texture_mapping (the steps either side of DIB-R in the training loop) ----------------
+def mask_iou_forward_fused(lhs_mask, rhs_mask):
+    """``kaolin.metrics.render.mask_iou`` forward in one pass -> (loss (scalar), sums (B, 2) float64 {I_b, U_b})."""
+    fn = 'mask_iou'
+    sfx = _lib.dtype_suffix(lhs_mask.dtype, fn)
+    lib = _lib.load()
+    B, P = lhs_mask.shape[0], lhs_mask[0].numel() if lhs_mask.shape[0] else 0
+    device = lhs_mask.device
+    with torch.cuda.device(device):
+        loss = torch.empty((), dtype=lhs_mask.dtype, device=device)
+        sums = torch.empty((B, 2), dtype=torch.float64, device=device)
+        ws = _lib.workspace(lib.kamd_mask_iou_workspace(B), device)
+        st = getattr(lib, f'kamd_mask_iou_forward_{sfx}')(_lib.stream_ptr(device), B, P, _lib.ptr(lhs_mask), _lib.ptr(rhs_mask),
+                                                          _lib.ptr(ws), _lib.ptr(sums), _lib.ptr(loss))
+    _lib.check(st, fn)
+    return loss, sums
+
+
+def mask_iou_backward_fused(grad_loss, other_mask, sums):
+    """d loss / d(one mask) of :func:`mask_iou_forward_fused` from the OTHER mask and the forward's sums."""
+    fn = 'mask_iou'
+    sfx = _lib.dtype_suffix(other_mask.dtype, fn)
+    lib = _lib.load()
+    B, P = other_mask.shape[0], other_mask[0].numel() if other_mask.shape[0] else 0
+    device = other_mask.device
+    with torch.cuda.device(device):
+        grad = torch.empty_like(other_mask)
+        g = grad_loss.to(other_mask.dtype).reshape(1).contiguous()
+        st = getattr(lib, f'kamd_mask_iou_backward_{sfx}')(_lib.stream_ptr(device), B, P, _lib.ptr(g), _lib.ptr(other_mask),
+                                                           _lib.ptr(sums), _lib.ptr(grad))
+    _lib.check(st, fn)
+    return grad
+
+
+def texture_mapping_forward_fused(uv, texture_maps, bilinear):
+    """uv (B, N, 2), texture_maps (B, C, h, w) -> (B, N, C): clamp, OpenGL -> grid coordinates, sampling and the output layout
+    of kaolin/render/mesh/utils.py:23-76 in one gather kernel."""
+    fn = 'texture_mapping'
+    sfx = _lib.dtype_suffix(uv.dtype, fn)
+    lib = _lib.load()
+    B, N = uv.shape[0], uv.shape[1]
+    C, TH, TW = texture_maps.shape[1:]
+    device = uv.device
+    with torch.cuda.device(device):
+        out = torch.empty((B, N, C), dtype=uv.dtype, device=device)
+        st = getattr(lib, f'kamd_texture_mapping_forward_{sfx}')(_lib.stream_ptr(device), B, N, C, TH, TW, int(bool(bilinear)),
+                                                                 _lib.ptr(uv), _lib.ptr(texture_maps), _lib.ptr(out))
+    _lib.check(st, fn)
+    return out
+
+
+def texture_mapping_backward_fused(uv, texture_maps, grad_out, bilinear, need_tex, need_uv):
+    """-> (grad_texture_maps or None, grad_uv or None)."""
+    fn = 'texture_mapping'
+    sfx = _lib.dtype_suffix(uv.dtype, fn)
+    lib = _lib.load()
+    B, N = uv.shape[0], uv.shape[1]
+    C, TH, TW = texture_maps.shape[1:]
+    device = uv.device
+    with torch.cuda.device(device):
+        g_tex = torch.zeros_like(texture_maps) if need_tex else None
+        g_uv = torch.empty_like(uv) if need_uv else None
+        st = getattr(lib, f'kamd_texture_mapping_backward_{sfx}')(
+            _lib.stream_ptr(device), B, N, C, TH, TW, int(bool(bilinear)), _lib.ptr(uv), _lib.ptr(texture_maps),
+            _lib.ptr(grad_out), _lib.ptr(g_tex), _lib.ptr(g_uv))
+    _lib.check(st, fn)
+    return g_tex, g_uv

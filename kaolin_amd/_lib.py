@@ -37,6 +37,7 @@ SIGNATURES = {
     'kamd_dibr_soft_mask_work_words': (_sz, [_i, _i, _i]),
     'kamd_dibr_rasterization_workspace': (_sz, [_i, _i, _i, _i, _i, _i]),
     'kamd_trianglemeshes_to_voxelgrids_workspace': (_sz, [_i, _i, _i]),
+    'kamd_mask_iou_workspace': (_sz, [_i]),
     'kamd_deftet_forward_workspace': (_sz, [_i, _i, _i, _i]),
     'kamd_mesh_to_spc_stage_levels': (_i, []),
     'kamd_mesh_to_spc_scan_workspace': (_sz, [_i64]),
@@ -78,6 +79,10 @@ for _t in ('f32', 'f64'):
         _i, [_vp, _i, _i, _i, _i, _i, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _dbl, _f, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_dibr_rasterization_backward_{_t}'] = (
         _i, [_vp, _i, _i, _i, _i, _i, _i] + [_vp] * 12 + [_dbl, _f, _f, _vp, _vp])
+    SIGNATURES[f'kamd_mask_iou_forward_{_t}'] = (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _vp])
+    SIGNATURES[f'kamd_mask_iou_backward_{_t}'] = (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp])
+    SIGNATURES[f'kamd_texture_mapping_forward_{_t}'] = (_i, [_vp, _i, _i64, _i, _i, _i, _i, _vp, _vp, _vp])
+    SIGNATURES[f'kamd_texture_mapping_backward_{_t}'] = (_i, [_vp, _i, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_prepare_vertices_forward_{_t}'] = (
         _i, [_vp, _i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_prepare_vertices_backward_{_t}'] = (

@@ -14,7 +14,8 @@ const char* const kNames[K_NUM] = {
     "td_prep_kernel", "td_main_kernel", "td_final_kernel", "td_backward_kernel",
     "vox_vertices_kernel", "vox_faces_kernel", "zero_fill", "pv_forward_kernel", "pv_backward_kernel", "mesh_intersection_kernel",
     "deftet_forward(pixel sort + search)", "deftet_sort_interp_kernel", "deftet_backward_kernel",
-    "mesh_to_spc_stage(count|emit)", "mesh_to_spc_build(sort + unique + octree + results)"};
+    "mesh_to_spc_stage(count|emit)", "mesh_to_spc_build(sort + unique + octree + results)", "mask_iou_kernels",
+    "texture_mapping_kernel"};
 struct Pending {
   int id;
   hipEvent_t start, stop;

@@ -13,8 +13,8 @@ import os
 import torch
 import torch.distributed as dist
 
-__all__ = ['init_from_env', 'is_distributed', 'rank', 'world_size', 'shard_range', 'shard', 'all_reduce_gradients',
-           'all_gather_batch', 'barrier']
+__all__ = ['init_from_env', 'is_distributed', 'rank', 'world_size', 'shard_range', 'shard', 'shard_views',
+           'all_reduce_gradients', 'SharedGradientReducer', 'all_gather_batch', 'barrier']
 
 
 def init_from_env(backend=None):
@@ -58,6 +58,71 @@ def shard(tensor, dim=0):
     return tensor.narrow(dim, b, e - b)
 
 
+def shard_views(*tensors, dim=0):
+    """This rank's contiguous slice of per-view tensors (camera positions / rotations / translations, target images ...):
+    config C4 of SURVEY.md 8(e) -- the views of one mesh are split over the ranks, the mesh itself is replicated.
+    Returns one tensor, or a tuple in the order given; all of them must have the same number of views along `dim`."""
+    n = tensors[0].shape[dim]
+    if any(t.shape[dim] != n for t in tensors):
+        raise ValueError('shard_views: tensors disagree on the number of views')
+    out = tuple(shard(t, dim) for t in tensors)
+    return out[0] if len(out) == 1 else out
+
+
+def _all_reduce_tensor(t, async_op=False):
+    """SUM all-reduce of one tensor in place.  RCCL ("nccl") reduces device memory directly; the gloo backend of the CPU
+    tests takes GPU tensors through a host copy."""
+    if t.is_cuda and dist.get_backend() == 'gloo':
+        host = t.detach().cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        t.copy_(host)
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
+
+
+class SharedGradientReducer:
+    """Posts the all-reduce of every shared parameter's gradient from autograd itself, the moment that gradient has been
+    accumulated (``register_post_accumulate_grad_hook``), instead of after ``backward()`` returns: the collective of a
+    parameter whose gradient is ready early (a texture, a global offset) overlaps the rest of the backward pass, and the
+    last one overlaps the host's return from ``backward()`` and whatever the caller enqueues next.  ``wait()`` (before
+    the optimizer step) blocks until every posted collective has completed.  One small collective per parameter: the
+    payloads of this path are latency-bound on xGMI (300 KB of vertex gradient at C4), and posting early beats bucketing
+    late.  Single process: a no-op.
+
+        reducer = SharedGradientReducer([vertices, texture])
+        loss.backward(); reducer.wait(); optimizer.step()
+    """
+
+    def __init__(self, params, average=False):
+        self.params = [p for p in params if p.requires_grad]
+        self.average = average
+        self._pending = []
+        self.posted = 0
+        self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+
+    def _hook(self, p):
+        if not is_distributed() or p.grad is None:
+            return
+        g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+        self._pending.append((p, g, _all_reduce_tensor(g, async_op=True)))
+        self.posted += 1
+
+    def wait(self):
+        for p, g, work in self._pending:
+            if work is not None:
+                work.wait()
+            if self.average:
+                g /= world_size()
+            if g is not p.grad:
+                p.grad.copy_(g)
+        self._pending = []
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+
 def all_reduce_gradients(params, average=False):
     """Sums (or averages) the gradients of shared parameters over all ranks with a SINGLE all-reduce over one
     flat bucket (params whose .grad is None contribute zeros so that every rank posts the same size)."""
@@ -66,13 +131,13 @@ def all_reduce_gradients(params, average=False):
         return
     if len(params) == 1 and params[0].grad is not None and params[0].grad.is_contiguous():
         # one shared tensor (the usual case: the mesh vertices): reduce its gradient in place, no bucket copy
-        dist.all_reduce(params[0].grad, op=dist.ReduceOp.SUM)
+        _all_reduce_tensor(params[0].grad)
         if average:
             params[0].grad /= world_size()
         return
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(params[0].dtype)
                       for p in params])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    _all_reduce_tensor(flat)
     if average:
         flat /= world_size()
     off = 0

@@ -39,10 +39,23 @@ class _PrepareVerticesCuda(torch.autograd.Function):
 
 
 def _fusable(vertices, faces, camera_proj, camera_rot, camera_trans, camera_transform):
+    """The fused kernels read one camera per view at fixed strides and ONE projection: anything else (a batched
+    projection, a broadcast translation, a single camera for batched vertices, cameras that require grad, CPU tensors,
+    other dtypes) takes the torch op chain, which broadcasts like the reference's."""
     cams = [t for t in (camera_proj, camera_rot, camera_trans, camera_transform) if t is not None]
-    return (vertices.is_cuda and vertices.dtype in (torch.float32, torch.float64) and vertices.dim() == 3 and
-            faces.is_cuda and faces.dtype == torch.long and faces.dim() == 2 and faces.shape[1] == 3 and
-            all(t.is_cuda for t in cams) and not any(t.requires_grad for t in cams))
+    if not (vertices.is_cuda and vertices.dtype in (torch.float32, torch.float64) and vertices.dim() == 3 and
+            vertices.shape[-1] == 3 and faces.is_cuda and faces.dtype == torch.long and faces.dim() == 2 and
+            faces.shape[1] == 3 and all(t.is_cuda for t in cams) and not any(t.requires_grad for t in cams)):
+        return False
+    if camera_proj.numel() != 3:
+        return False
+    if camera_transform is not None:
+        batch = camera_transform.shape[0]
+        ok = tuple(camera_transform.shape) == (batch, 4, 3)
+    else:
+        batch = camera_rot.shape[0]
+        ok = tuple(camera_rot.shape) == (batch, 3, 3) and camera_trans.numel() == batch * 3 and camera_trans.shape[0] == batch
+    return ok and batch > 0 and vertices.shape[0] in (1, batch) and _C.render.mesh.faces_in_range(faces, vertices.shape[1])
 
 
 def prepare_vertices(vertices, faces, camera_proj, camera_rot=None, camera_trans=None, camera_transform=None):
@@ -76,11 +89,41 @@ def _prepare_vertices_torch(vertices, faces, camera_proj, camera_rot=None, camer
     return fv_cam, fv_img, _mesh.face_normals(fv_cam, unit=True)
 
 
-def texture_mapping(texture_coordinates, texture_maps, mode='nearest'):
-    """Samples texture_maps (B, C, h', w') at OpenGL-style coordinates in [0, 1] (y up), given densely
-    (B, h, w, 2) or sparsely (B, N, 2); returns (B, h, w, C) or (B, N, C)."""
+class _TextureMappingCuda(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, uv, texture_maps, bilinear):
+        uv, texture_maps = uv.contiguous(), texture_maps.contiguous()
+        out = _C.render.mesh.texture_mapping_forward_fused(uv, texture_maps, bilinear)
+        ctx.save_for_backward(uv, texture_maps)
+        ctx.bilinear = bilinear
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        uv, texture_maps = ctx.saved_tensors
+        g_tex, g_uv = _C.render.mesh.texture_mapping_backward_fused(
+            uv, texture_maps, grad_out.contiguous(), ctx.bilinear, ctx.needs_input_grad[1], ctx.needs_input_grad[0])
+        return g_uv, g_tex, None
+
+
+def _texture_mapping_torch(texture_coordinates, texture_maps, mode='nearest'):
+    """The reference's op chain (kaolin/render/mesh/utils.py:58-76)."""
     B, C = texture_coordinates.shape[0], texture_maps.shape[1]
     uv = torch.clamp(texture_coordinates.reshape(B, -1, 1, 2), 0., 1.) * 2 - 1
     grid = torch.stack([uv[..., 0], -uv[..., 1]], dim=-1)
     out = torch.nn.functional.grid_sample(texture_maps, grid, mode=mode, align_corners=False, padding_mode='border')
     return out.permute(0, 2, 3, 1).reshape(B, *texture_coordinates.shape[1:-1], C)
+
+
+def texture_mapping(texture_coordinates, texture_maps, mode='nearest'):
+    """Samples texture_maps (B, C, h', w') at OpenGL-style coordinates in [0, 1] (y up), given densely
+    (B, h, w, 2) or sparsely (B, N, 2); returns (B, h, w, C) or (B, N, C).  On the GPU (float / double, ``nearest`` or
+    ``bilinear``) this is one fused HIP gather each way; otherwise the torch chain, which also defines it."""
+    if (mode in ('nearest', 'bilinear') and texture_coordinates.is_cuda and texture_maps.is_cuda and
+            texture_coordinates.dtype == texture_maps.dtype and texture_coordinates.dtype in (torch.float32, torch.float64) and
+            texture_maps.dim() == 4 and texture_coordinates.shape[-1] == 2 and texture_coordinates.numel() > 0 and
+            texture_maps.shape[0] == texture_coordinates.shape[0] and texture_maps[0].numel() > 0):
+        B, C = texture_coordinates.shape[0], texture_maps.shape[1]
+        out = _TextureMappingCuda.apply(texture_coordinates.reshape(B, -1, 2), texture_maps, mode == 'bilinear')
+        return out.reshape(B, *texture_coordinates.shape[1:-1], C)
+    return _texture_mapping_torch(texture_coordinates, texture_maps, mode)

@@ -411,3 +411,20 @@ def test_static_features_skip_their_gradient(D):
             assert (f.grad is not None) == needs
             grads.append(a.grad.clone())
         assert rel_close(grads[1], grads[0], 1e-5), name
+
+
+def test_nan_vertex_matches_reference_glue():
+    """torch.min / torch.max propagate NaN, so a face with a NaN vertex has a NaN box that rejects no pixel; the
+    fused binning must give the reference glue's result (`_packed_forward`), not confine the face to its finite corners."""
+    from kaolin_amd.render.mesh.rasterization import _packed_forward
+    fz, fimg, feats, nz = _scene(6, 2, torch.float)
+    fimg = fimg.clone()
+    fimg[0, 5, 1, 0] = float('nan')
+    fimg[1, 17, 2, 1] = float('nan')
+    feat = torch.cat(feats, -1).cuda()
+    H, W = 48, 40
+    a, b_, c = _packed_forward(H, W, fz.cuda(), fimg.cuda(), feat, None, 1000, 1e-8)
+    x, y, w = kal()._C.render.mesh.rasterize_forward_fused(H, W, fz.cuda(), fimg.cuda(), feat, None, 1000, 1e-8)
+    assert torch.equal(b_, y)
+    assert torch.equal(torch.nan_to_num(a, nan=-7.), torch.nan_to_num(x, nan=-7.))
+    assert torch.equal(torch.nan_to_num(c, nan=-7.), torch.nan_to_num(w, nan=-7.))

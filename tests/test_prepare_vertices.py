@@ -76,3 +76,34 @@ def test_falls_back_when_camera_needs_grad():
     out = kal.render.mesh.prepare_vertices(verts.expand(2, -1, -1), f, proj, **kw)
     out[1].sum().backward()
     assert kw['camera_trans'].grad is not None
+
+
+def test_fused_path_only_for_shapes_it_reads():
+    """a batched projection (B, 3, 1), a broadcast (1, 3) translation, a single camera for batched vertices and
+    out-of-range face indices must not reach the fused kernels (fixed strides, unchecked gathers): they take the torch
+    chain, which broadcasts / raises like the reference."""
+    kal, verts, f, proj, kw = _setup(torch.float, 3, True, False)
+    from kaolin_amd.render.mesh.utils import _fusable, _prepare_vertices_torch, prepare_vertices
+    rot, trans = kw['camera_rot'], kw['camera_trans']
+    assert _fusable(verts, f, proj, rot, trans, None)
+    # batched projection: every view has its own focal terms
+    projs = torch.stack([proj.reshape(-1) * s for s in (1.0, 1.5, 2.0)]).reshape(3, 3, 1)
+    assert not _fusable(verts.expand(3, -1, -1), f, projs, rot, trans, None)
+    got = prepare_vertices(verts.expand(3, -1, -1), f, projs, camera_rot=rot, camera_trans=trans)
+    want = _prepare_vertices_torch(verts.expand(3, -1, -1), f, projs, camera_rot=rot, camera_trans=trans)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    assert not torch.allclose(got[1][0], got[1][1])
+    # broadcast translation
+    assert not _fusable(verts.expand(3, -1, -1), f, proj, rot, trans[:1], None)
+    got = prepare_vertices(verts.expand(3, -1, -1), f, proj, camera_rot=rot, camera_trans=trans[:1])
+    want = _prepare_vertices_torch(verts.expand(3, -1, -1), f, proj, camera_rot=rot, camera_trans=trans[:1])
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    # one camera, batched vertices
+    assert not _fusable(verts.repeat(2, 1, 1), f, proj, rot[:1], trans[:1], None)
+    # a face that points past the vertex list
+    bad = f.clone()
+    bad[0, 0] = verts.shape[1]
+    assert not _fusable(verts, bad, proj, rot, trans, None)
+    with pytest.raises((RuntimeError, IndexError)):
+        prepare_vertices(verts.expand(3, -1, -1), bad, proj, camera_rot=rot, camera_trans=trans)
+        torch.cuda.synchronize()

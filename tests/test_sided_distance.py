@@ -436,3 +436,38 @@ def test_grid_search_large_clouds(kind):
     s1, j1 = pc.sided_distance(p1.cuda(), p2.cuda())
     s2, j2 = pc.sided_distance(p2.cuda(), p1.cuda())
     assert torch.equal(j1, i1) and torch.equal(s1, d1) and torch.equal(j2, i2) and torch.equal(s2, d2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.uint8, torch.int16, torch.int32, torch.int64])
+def test_integer_clouds_follow_c_semantics(dtype):
+    """The reference dispatches its kernels on Byte / Short / Int / Long too (kaolin/csrc/utils.h:50-64): every
+    intermediate is the element type, so differences and sums wrap like C assignments (sided_distance_cuda.cu:83-86).
+    Checked against a numpy restatement: promote, operate, truncate at each assignment; lowest index on ties."""
+    import numpy as np
+    from kaolin_amd import _C
+    npdt = {torch.uint8: np.uint8, torch.int16: np.int16, torch.int32: np.int32, torch.int64: np.int64}[dtype]
+    wide = np.int64
+    g = torch.Generator().manual_seed(11)
+    hi = 200 if dtype == torch.uint8 else 300
+    p1 = torch.randint(0, hi, (2, 37, 3), generator=g).to(dtype)
+    p2 = torch.randint(0, hi, (2, 1100, 3), generator=g).to(dtype)
+    d, i = _C.metrics.sided_distance_forward_cuda(p1.cuda(), p2.cuda())
+    a, b = p1.numpy().astype(wide), p2.numpy().astype(wide)
+    with np.errstate(over='ignore'):
+        diff = (b[:, None, :, :] - a[:, :, None, :]).astype(npdt).astype(wide)          # scalar_t x2 = buf - x1
+        dist = (diff * diff).sum(-1).astype(npdt)                                        # scalar_t d = x2*x2 + ...
+    want_i = dist.argmin(-1)
+    assert np.array_equal(i.cpu().numpy(), want_i)
+    assert np.array_equal(d.cpu().numpy(), np.take_along_axis(dist, want_i[..., None], -1)[..., 0])
+    # backward operator: g1 = 2 * (p1 - p2[idx]) * g in the element type, g2 accumulates the opposite sign
+    grad = torch.randint(0, 3, (2, 37), generator=g).to(dtype)
+    g1, g2 = _C.metrics.sided_distance_backward_cuda(grad.cuda(), p1.cuda(), p2.cuda(), i)
+    sel = np.take_along_axis(b, want_i[..., None].repeat(3, -1), 1)
+    with np.errstate(over='ignore'):
+        want_g1 = (2 * (a - sel) * grad.numpy().astype(wide)[..., None]).astype(npdt)
+        want_g2 = np.zeros(b.shape, dtype=wide)
+        for bb in range(2):
+            np.add.at(want_g2[bb], want_i[bb], (2 * (sel[bb] - a[bb]) * grad.numpy().astype(wide)[bb][:, None]).astype(npdt).astype(wide))
+    assert np.array_equal(g1.cpu().numpy(), want_g1)
+    assert np.array_equal(g2.cpu().numpy(), want_g2.astype(npdt))
