@@ -54,22 +54,27 @@ def parse():
 
 
 def algorithmic_bytes(kernel, B, P, F, Fv, D, K, esz=4):
-    """Contract bytes per launch: every operator input read once, every output written once."""
+    """Contract bytes per launch: every operator input the kernel consumes read once, every operator
+    output it produces written once (intermediate records / lists are NOT counted: they are this design's own traffic)."""
     per = {
+        # face_idx (i64) + 3 weights + D features out; the front faces' 13 scalars + 3*D feature scalars in
         'raster_tile_kernel': P * (8 + 3 * esz + D * esz) + Fv * (13 * esz + 3 * D * esz),
         'raster_backward_kernel': P * (8 + 3 * esz + D * esz) + F * (6 * esz * 2 + 3 * D * esz * 2),
         'fill_regions_kernel': P * K * (esz + 8 + 1),
-        'soft_search_kernel': P * (8 + esz) + F * 10 * esz,
-        'soft_classify_kernel': P * (8 + esz),
+        # select reads face_idx of the uncovered pixels' tiles and the faces' 6 coordinates + 4 box scalars
+        'soft_select_kernel': P * 8 + F * 10 * esz,
+        # eval writes the soft mask
+        'soft_eval_kernel': P * esz,
         'soft_mask_backward_kernel': P * (8 + 2 * esz) + F * 6 * esz * 2,
         'soft_mask_backward_list_kernel': P * (2 * esz) + F * 6 * esz * 2,
-        'bin_faces_kernel': F * (13 * esz + 16 * esz),
+        'bin_faces_kernel': F * (13 * esz),
     }
     return B * per[kernel] if kernel in per else None
 
 
-# kernels of the fused DIB-R operator that share the GPU with a concurrent launch in the timed region
-OVERLAPPED = {'raster_tile_kernel', 'bin_faces_kernel', 'raster_backward_kernel', 'soft_mask_backward_list_kernel'}
+# kernels of the fused DIB-R operator that share the GPU with a concurrent launch in the timed region (backward: the
+# soft-mask list kernel runs on a side stream beside raster_backward)
+OVERLAPPED = {'raster_backward_kernel', 'soft_mask_backward_list_kernel'}
 
 
 def pick_dominant(kernels):
@@ -100,8 +105,7 @@ def main():
     verts = verts.float().to(dev).requires_grad_()
     faces = faces.to(dev)
     F = faces.shape[0]
-    cams_all = T.fibonacci_cameras(V * world, 2.5)
-    cams = cams_all[rank * V:(rank + 1) * V].to(dev)
+    cams = D.shard_views(T.fibonacci_cameras(V * world, 2.5)).to(dev)     # this rank's views of the shared mesh
     look_at = torch.zeros((V, 3), device=dev)
     up = torch.tensor([[0., 1., 0.]], device=dev).repeat(V, 1)
     rot, trans = kal.render.camera.generate_rotate_translate_matrices(cams, look_at, up)
@@ -113,18 +117,40 @@ def main():
     G1 = torch.rand((V, H, W, 3), generator=g).to(dev)
     G2 = torch.rand((V, H, W), generator=g).to(dev)
     G1f, G2f = G1.reshape(-1), G2.reshape(-1)
+    feats3_grad = feats3.clone().requires_grad_()          # variant: learnable per-face features (a texture atlas per view)
+    # The vertex gradient is shared by every view: its all-reduce is posted from autograd's accumulate hook and awaited
+    # before the step ends; with one process this is a no-op.
+    reducer = D.SharedGradientReducer([verts])
 
-    def dibr_step():
-        verts.grad = None
-        fv_cam, fv_img, normals = kal.render.mesh.prepare_vertices(
-            verts.unsqueeze(0).expand(V, -1, -1), faces, proj, camera_rot=rot, camera_trans=trans)
-        feat, soft, face_idx = kal.render.mesh.dibr_rasterization(
-            H, W, fv_cam[..., 2], fv_img, feats3, normals[..., 2])
-        # (features * G1).sum() + (soft_mask * G2).sum(), written as two dot products (one pass each way)
-        loss = torch.dot(feat.reshape(-1), G1f) + torch.dot(soft.reshape(-1), G2f)
-        loss.backward()
-        D.all_reduce_gradients([verts])
-        return face_idx
+    def make_step(features):
+        def step():
+            verts.grad = None
+            features.grad = None
+            fv_cam, fv_img, normals = kal.render.mesh.prepare_vertices(
+                verts.unsqueeze(0).expand(V, -1, -1), faces, proj, camera_rot=rot, camera_trans=trans)
+            feat, soft, face_idx = kal.render.mesh.dibr_rasterization(
+                H, W, fv_cam[..., 2], fv_img, features, normals[..., 2])
+            # (features * G1).sum() + (soft_mask * G2).sum(), written as two dot products (one pass each way)
+            loss = torch.dot(feat.reshape(-1), G1f) + torch.dot(soft.reshape(-1), G2f)
+            loss.backward()
+            reducer.wait()
+            return face_idx
+        return step
+    dibr_step = make_step(feats3)
+    dibr_step_feature_grad = make_step(feats3_grad)
+
+    def per_step_ms(fn, steps):
+        """Duration of every step of one more pass (events between steps on the launch stream, no host sync inside)."""
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        torch.cuda.synchronize()
+        ev[0].record()
+        for i in range(steps):
+            fn()
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        d = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+        return {'median': round(d[len(d) // 2], 4), 'min': round(d[0], 4), 'p90': round(d[min(len(d) - 1, int(0.9 * len(d)))], 4),
+                'max': round(d[-1], 4), 'steps': steps}
 
     def timed(fn, steps, warmup):
         for _ in range(warmup):
@@ -179,13 +205,31 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     mpix = world * V * H * W * args.steps / dt / 1e6
 
+    step_stats = per_step_ms(dibr_step, max(args.steps, 20))
+    # variant with gradients w.r.t. the face features as well (raster_backward adds its feature-gradient atomics)
+    fg_dt = timed(dibr_step_feature_grad, args.steps, args.warmup)
+    fg_stats = per_step_ms(dibr_step_feature_grad, max(args.steps, 20))
+    feature_grad = {'ms_per_step': round(fg_dt / args.steps * 1e3, 4), 'per_step_ms': fg_stats,
+                    'value': round(world * V * H * W * args.steps / fg_dt / 1e6, 2), 'unit': 'Mpixels/s',
+                    'note': 'same step with face_features.requires_grad (gradients to vertices AND features)'}
+
     covered = float((face_idx >= 0).float().mean())
-    traffic = None
+    traffic, step_traffic = None, None
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
     if dom and os.path.exists(tpath):
         # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, calibrated on launches of
-        # known size: tools/pmc_traffic.py, tools/parse_traffic.py, raw tables in profiles/r01i_pmc_*.txt)
-        traffic = (json.load(open(tpath)).get(dom) or {}).get('hbm_bytes')
+        # known size: tools/pmc_traffic.py, tools/parse_traffic.py, raw tables in profiles/r02*_pmc_*.txt)
+        tj = json.load(open(tpath))
+        traffic = (tj.get(dom) or {}).get('hbm_bytes')
+        per_kernel = {k: round(v['hbm_bytes']) for k, v in tj.items() if k in kernels and v.get('hbm_bytes')}
+        if per_kernel:
+            st = tj.get('_step') or {}
+            step_traffic = {'hbm_bytes_per_step': int(st.get('hbm_bytes') or
+                                                      sum(per_kernel[k] * kernels[k]['launches_per_step'] for k in per_kernel)),
+                            'of_which_other_kernels(torch dot / memset)': int(st.get('other_kernels_hbm_bytes') or 0),
+                            'per_kernel_hbm_bytes_per_launch': per_kernel,
+                            'kernels_without_counters': sorted(k for k in kernels if k not in per_kernel),
+                            'source': tj.get('_source', 'profiles/traffic.json')}
     roofline = None
     if dom and dom_n:
         dom_us = dom_ms / dom_n * 1e3                        # measured inside the timed region
@@ -201,6 +245,8 @@ def main():
     step_roofline = {'contract_bytes_per_step': contract, 'contract_GBps': round(contract / (ms_per_step * 1e-3) / 1e9, 1),
                      'contract_frac_of_8TBps': round(contract / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      'lean_bytes_per_step': lean}
+    if step_traffic:
+        step_roofline['measured_hbm_GBps'] = round(step_traffic['hbm_bytes_per_step'] / (ms_per_step * 1e-3) / 1e9, 1)
 
     # ---------------- chamfer 100k x 100k fwd+bwd (config C3: one batch item per rank + shared offset)
     chamfer = None
@@ -211,11 +257,13 @@ def main():
         p2 = torch.rand((1, n, 3), generator=gen).to(dev).requires_grad_()
         offset = torch.zeros(3, device=dev, requires_grad=True)
 
+        creducer = D.SharedGradientReducer([offset])
+
         def chamfer_step():
             offset.grad = None
             p2.grad = None
             kal.metrics.pointcloud.chamfer_distance(base + offset, p2).sum().backward()
-            D.all_reduce_gradients([offset])
+            creducer.wait()
 
         cdt = timed(chamfer_step, args.steps, args.warmup)
         chamfer_enqueue_ms = timed.enqueue_ms
@@ -333,10 +381,11 @@ def main():
             'config': {'workload': f'C4: dibr_rasterization fwd+bwd, {V} views/GPU at {H}x{W} of a {F}-triangle geodesic '
                                    f'sphere (shared vertices), D=3 static face features (uv + mask channel; gradient w.r.t. the vertices only), '
                                    f'knum=30, sigmainv=7000, boxlen=0.02, '
-                                   f'prepare_vertices + vertex-gradient all-reduce inside the step',
+                                   f'prepare_vertices + vertex-gradient all-reduce (posted from the autograd hook) inside the step',
                        'views_per_gpu': V, 'global_views': V * world, 'height': H, 'width': W, 'faces': F,
                        'covered_pixel_fraction': round(covered, 4), 'parallelism': f'views sharded {world}-way'},
-            'roofline': roofline, 'step_roofline': step_roofline, 'kernels': kernels,
+            'per_step_ms': step_stats, 'feature_grad_variant': feature_grad,
+            'roofline': roofline, 'step_roofline': step_roofline, 'step_traffic': step_traffic, 'kernels': kernels,
             'kernels_note': f'per-kernel table: separate pass of {args.steps} steps with HIP events around every launch '
                             f'({inst_ms_per_step:.4f} ms/step: the events and the single-stream order they need cost the '
                             f'difference); the timed region brackets the roofline kernel only',

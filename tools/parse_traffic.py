@@ -1,47 +1,62 @@
-"""usage: python tools/parse_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>
+"""usage: python tools/parse_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [source tag]
 Calibrates FETCH_SIZE / WRITE_SIZE on launches of known size (see tools/pmc_traffic.py), then reports per-launch HBM
-bytes of our kernels (MI355X_MICROARCH.md: gfx950 FETCH_SIZE counts 16-B/lane streaming reads at half their size;
-other widths uncalibrated -> we calibrate both counters on our own access patterns and say so)."""
+bytes of our kernels and the total of one DIB-R step (MI355X_MICROARCH.md: gfx950 FETCH_SIZE counts 16-B/lane streaming
+reads at half their size; other widths uncalibrated -> we calibrate both counters on our own access patterns and say so)."""
 import collections, csv, json, re, sys
 
-
-def per_kernel(path, counter):
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(path)):
-        if r['Counter_Name'] != counter:
-            continue
-        agg[r['Kernel_Name']].append(float(r['Counter_Value']))
-    return agg
+STEPS = 3
+# profile-table name (bench.py's "kernels" keys) -> pattern of the device symbol
+OURS = {'bin_faces_kernel': r'bin_faces_kernel2', 'raster_tile_kernel': r'raster_tile_kernel2', 'raster_backward_kernel': r'raster_backward_kernel',
+        'soft_items_kernel': r'soft_items_kernel', 'soft_select_kernel': r'soft_select_kernel', 'soft_eval_kernel': r'soft_eval_kernel',
+        'soft_mask_backward_list_kernel': r'soft_mask_backward_list_kernel2', 'pv_forward_kernel': r'pv_forward_kernel',
+        'pv_backward_kernel': r'pv_backward_kernel', 'fill_regions_kernel': r'fill_regions_kernel'}
 
 
-fetch, write = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'WRITE_SIZE')
+def rows(path, counter):
+    out = [(int(r['Dispatch_Id']), r['Kernel_Name'], float(r['Counter_Value'])) for r in csv.DictReader(open(path))
+           if r['Counter_Name'] == counter]
+    return sorted(out)
 
 
-def find(agg, pat):
-    return [(k, v) for k, v in agg.items() if re.search(pat, k)]
+def analyse(path, counter):
+    rs = rows(path, counter)
+    marker = max((d for d, k, v in rs if 'fill_regions_kernel' in k), default=-1)
+    clone = max((v for d, k, v in rs if '__amd_rocclr_copyBuffer' in k and d < marker), default=None)
+    fill = [v for d, k, v in rs if 'fill_regions_kernel' in k]
+    step = collections.defaultdict(list)
+    for d, k, v in rs:
+        if d > marker:
+            step[k].append(v)
+    return clone, (sum(fill) / len(fill) if fill else None), step
 
 
 GiB = float(1 << 30)
-# calibration 1: torch clone of 1 GiB (runs as __amd_rocclr_copyBuffer, 16 B/lane): reads 1 GiB, writes 1 GiB.
-# calibration 2: fill_regions_kernel writes exactly B*H*W*K*13 bytes; soft_classify_kernel reads exactly 8 B/pixel.
-clone_f = max((max(v) for k, v in find(fetch, '__amd_rocclr_copyBuffer')), default=None)
-clone_w = max((max(v) for k, v in find(write, '__amd_rocclr_copyBuffer')), default=None)
-fill_w = [sum(v) / len(v) for k, v in find(write, 'fill_regions_kernel')]
-out = {'_calibration': {'clone_1GiB_FETCH_SIZE_raw': clone_f, 'clone_1GiB_WRITE_SIZE_raw': clone_w,
-                        'fill_regions_WRITE_SIZE_raw': fill_w[0] if fill_w else None,
-                        'fill_regions_bytes': 8 * 1024 * 1024 * 30 * 13}}
+clone_f, _, step_f = analyse(sys.argv[1], 'FETCH_SIZE')
+clone_w, fill_w, step_w = analyse(sys.argv[2], 'WRITE_SIZE')
 f_scale = GiB / clone_f if clone_f else None      # bytes per raw unit, streaming 16-B reads
 w_scale = GiB / clone_w if clone_w else None
-out['_calibration']['bytes_per_FETCH_SIZE_unit'] = f_scale
-out['_calibration']['bytes_per_WRITE_SIZE_unit'] = w_scale
-for name in ('raster_tile_kernel', 'raster_backward_kernel', 'bin_faces_raw_kernel', 'bin_faces_kernel', 'soft_classify_kernel',
-             'soft_search_kernel', 'soft_mask_backward_list_kernel', 'fill_regions_kernel'):
-    f = [sum(v) / len(v) for k, v in find(fetch, name + r'\b|' + name + '<')]
-    w = [sum(v) / len(v) for k, v in find(write, name + r'\b|' + name + '<')]
-    if not f and not w:
+out = {'_source': sys.argv[4] if len(sys.argv) > 4 else 'tools/pmc_traffic.py',
+       '_calibration': {'clone_1GiB_FETCH_SIZE_raw': clone_f, 'clone_1GiB_WRITE_SIZE_raw': clone_w,
+                        'fill_regions_WRITE_SIZE_raw': fill_w, 'fill_regions_bytes': 8 * 1024 * 1024 * 30 * 13,
+                        'bytes_per_FETCH_SIZE_unit': f_scale, 'bytes_per_WRITE_SIZE_unit': w_scale}}
+claimed = set()
+for name, pat in OURS.items():
+    fk = [k for k in step_f if re.search(pat, k)]
+    wk = [k for k in step_w if re.search(pat, k)]
+    if not fk and not wk:
         continue
-    fb = f[0] * f_scale if f and f_scale else None
-    wb = w[0] * w_scale if w and w_scale else None
-    out[name] = {'fetch_bytes': fb, 'write_bytes': wb, 'hbm_bytes': (fb or 0) + (wb or 0)}
+    claimed.update(fk + wk)
+    fv = [v for k in fk for v in step_f[k]]
+    wv = [v for k in wk for v in step_w[k]]
+    fb = sum(fv) / len(fv) * f_scale if fv and f_scale else None
+    wb = sum(wv) / len(wv) * w_scale if wv and w_scale else None
+    out[name] = {'fetch_bytes': fb, 'write_bytes': wb, 'hbm_bytes': (fb or 0) + (wb or 0), 'launches_per_step': len(fv or wv) / STEPS}
+# everything else dispatched inside the steps (torch's dot / fill / cat kernels, memsets)
+other_f = sum(v for k, vs in step_f.items() if k not in claimed for v in vs) * (f_scale or 0) / STEPS
+other_w = sum(v for k, vs in step_w.items() if k not in claimed for v in vs) * (w_scale or 0) / STEPS
+ours = sum(v['hbm_bytes'] * v['launches_per_step'] for k, v in out.items() if not k.startswith('_') and k != 'fill_regions_kernel')
+out['_step'] = {'our_kernels_hbm_bytes': ours, 'other_kernels_hbm_bytes': other_f + other_w,
+                'hbm_bytes': ours + other_f + other_w,
+                'other_kernels': sorted({re.sub(r'\(.*', '', k)[:80] for k in list(step_f) + list(step_w) if k not in claimed})}
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
 print(json.dumps(out, indent=1))

@@ -1,7 +1,7 @@
 """usage: python tools/pmc_summary.py <counter_collection.csv> [kernel regex ...]
 Per-kernel means of every counter in a rocprofv3 --pmc pass (kernels matching the given patterns)."""
 import collections, csv, re, sys
-pats = sys.argv[2:] or ['raster_tile', 'raster_backward', 'soft_search', 'soft_classify', 'soft_mask_backward_list', 'bin_faces_raw']
+pats = sys.argv[2:] or ['bin_faces_kernel2', 'raster_tile_kernel2', 'raster_backward', 'soft_select', 'soft_eval', 'soft_mask_backward_list', 'pv_forward', 'pv_backward']
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     for p in pats:

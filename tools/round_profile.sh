@@ -6,7 +6,7 @@
 set -u
 tag=${1:-r01x}; pmc=${2:-}
 repo=$(pwd); out=$repo/gpurun_out/$tag; mkdir -p $out
-timeout 900 python -m pytest tests -m gpu -q -x > $out/pytest_gpu.log 2>&1; tail -2 $out/pytest_gpu.log
+timeout 1200 python -m pytest tests -m gpu -q -x --durations=15 > $out/pytest_gpu.log 2>&1; tail -2 $out/pytest_gpu.log
 timeout 600 python bench.py 2> $out/bench.err | tail -1 > $out/bench.json
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 cd /tmp && export TMPDIR=/tmp
@@ -18,6 +18,12 @@ if [ -n "$pmc" ]; then
   find $out/pmc_f -name '*counter_collection.csv' -exec cp {} $out/pmc_fetch.csv \;
   find $out/pmc_w -name '*counter_collection.csv' -exec cp {} $out/pmc_write.csv \;
   rm -rf $out/pmc_f $out/pmc_w
+  # SQ counters quoted in DESIGN (wave occupancy, VALU / SALU / LDS instruction and wait counts), two passes of 8 counters
+  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $out/pmc1 -- python $repo/tools/pmc_traffic.py > /dev/null 2>&1
+  find $out/pmc1 -name '*counter_collection.csv' -exec cp {} $out/pmc_sq1.csv \;
+  timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM --output-format csv -d $out/pmc2 -- python $repo/tools/pmc_traffic.py > /dev/null 2>&1
+  find $out/pmc2 -name '*counter_collection.csv' -exec cp {} $out/pmc_sq2.csv \;
+  rm -rf $out/pmc1 $out/pmc2
 fi
 rm -rf $out/prof
 cd $repo; ls -la $out; cat $out/bench.json | cut -c1-400
