@@ -68,6 +68,10 @@ def prepare_vertices(vertices, faces, camera_proj, camera_rot=None, camera_trans
             raise AssertionError('camera_transform or camera_trans and camera_rot must be defined')
     elif camera_rot is not None or camera_trans is not None:
         raise AssertionError('camera_trans and camera_rot must be None when camera_transform is defined')
+    if (faces.is_cuda and faces.dtype == torch.long and vertices.dim() == 3 and
+            not _C.render.mesh.faces_in_range(faces, vertices.shape[1])):
+        # the reference's index_select trips a device-side assert here (on ROCm that aborts the process): raise instead
+        raise IndexError('prepare_vertices: faces hold an index outside [0, num_vertices)')
     if _fusable(vertices, faces, camera_proj, camera_rot, camera_trans, camera_transform):
         return _PrepareVerticesCuda.apply(vertices, faces, camera_proj, camera_rot, camera_trans, camera_transform)
     return _prepare_vertices_torch(vertices, faces, camera_proj, camera_rot, camera_trans, camera_transform)

@@ -20,8 +20,10 @@ def rows(path, counter):
 
 def analyse(path, counter):
     rs = rows(path, counter)
-    marker = max((d for d, k, v in rs if 'fill_regions_kernel' in k), default=-1)
-    clone = max((v for d, k, v in rs if '__amd_rocclr_copyBuffer' in k and d < marker), default=None)
+    last_fill = max((d for d, k, v in rs if 'fill_regions_kernel' in k), default=-1)
+    # the steps begin with prepare_vertices: everything from the first pv_forward_kernel after the calibration on
+    marker = min((d for d, k, v in rs if 'pv_forward_kernel' in k and d > last_fill), default=last_fill + 1) - 1
+    clone = max((v for d, k, v in rs if '__amd_rocclr_copyBuffer' in k and d < last_fill), default=None)
     fill = [v for d, k, v in rs if 'fill_regions_kernel' in k]
     step = collections.defaultdict(list)
     for d, k, v in rs:
