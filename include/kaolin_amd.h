@@ -91,6 +91,24 @@ int kamd_chamfer_distance_backward_f32(void* stream, int B, int N, int M,
                                        const float* dist1, const float* dist2,
                                        float* g1, float* g2);
 
+/* chamfer_distance as ONE operator (kaolin/metrics/pointcloud.py:89-136, fp32):  */
+/* out (B) = w1 * mean_i f(dist1_i) + w2 * mean_j f(dist2_j), f = identity        */
+/* (squared != 0) or sqrt, from workspace fill + build + search = 3 launches; the */
+/* means are accumulated in double inside the search launch.  dist1/idx1/dist2/  */
+/* idx2 are optional outputs (NULL = not wanted).  with_grad != 0: the search     */
+/* also leaves d out / d p (per unit of upstream gradient) in the workspace,      */
+/* which the caller then keeps alive until kamd_chamfer_distance_backward_fused   */
+/* (one launch: g1 (B,N,3), g2 (B,M,3) = grad[b] * those, overwritten).           */
+/* ..._workspace returns 0 when the shapes do not qualify (see pair_forward).     */
+size_t kamd_chamfer_distance_forward_workspace(int B, int N, int M, int with_grad);
+int kamd_chamfer_distance_forward_f32(void* stream, int B, int N, int M,
+                                      const float* p1, const float* p2, float w1, float w2,
+                                      int squared, int with_grad, float* out,
+                                      float* dist1, int64_t* idx1, float* dist2, int64_t* idx2,
+                                      void* workspace);
+int kamd_chamfer_distance_backward_fused_f32(void* stream, int B, int N, int M, const float* grad,
+                                             void* workspace, float* g1, float* g2);
+
 /* metrics.sided_distance_backward_cuda(grad, p1, p2, idx) -> [g1, g2]        */
 /* reference: sided_distance.cpp:91-122, sided_distance_cuda.cu:203-242       */
 /* g1 (B,N,3) is overwritten; g2 (B,M,3) is accumulated (caller zeroes it).   */

@@ -25,6 +25,10 @@ def trianglemeshes_to_voxelgrids_cuda(vertices, faces, resolution, origin=None, 
     if scale is not None:
         torch_check(scale.is_cuda and scale.numel() == B, 'scale must be a CUDA tensor of size {batch_size}')
         scale = scale.to(v.dtype).reshape(B).contiguous()
+    from .render.mesh import faces_in_range
+    if not faces_in_range(f, V):
+        # the kernels gather vertices unchecked; the reference's indexing raises (a device assert) on such a mesh
+        raise IndexError(f'{fn}: faces hold an index outside [0, num_vertices)')
     lib = _lib.load()
     with torch.cuda.device(v.device):
         grid = torch.empty((B, R, R, R), dtype=v.dtype, device=v.device)

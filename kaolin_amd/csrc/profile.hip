@@ -12,7 +12,7 @@ const char* const kNames[K_NUM] = {
     "bin_faces_kernel", "raster_tile_kernel", "raster_backward_kernel",
     "fill_regions_kernel", "soft_items_kernel", "soft_select_kernel", "soft_eval_kernel", "soft_mask_backward_kernel", "soft_mask_backward_list_kernel",
     "td_prep_kernel", "td_main_kernel", "td_final_kernel", "td_backward_kernel",
-    "vox_vertices_kernel", "vox_faces_kernel", "zero_fill", "pv_forward_kernel", "pv_backward_kernel", "mesh_intersection_kernel",
+    "vox_clear_extent_kernel", "vox_mark_kernel", "zero_fill", "pv_forward_kernel", "pv_backward_kernel", "mesh_intersection_kernel",
     "deftet_forward(pixel sort + search)", "deftet_sort_interp_kernel", "deftet_backward_kernel",
     "mesh_to_spc_stage(count|emit)", "mesh_to_spc_build(sort + unique + octree + results)", "mask_iou_kernels",
     "texture_mapping_kernel"};

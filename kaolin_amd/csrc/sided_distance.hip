@@ -464,6 +464,25 @@ int kamd_chamfer_distance_backward_f32(void* stream, int B, int N, int M, const 
   KAMD_RETURN_LAST_ERROR();
 }
 
+size_t kamd_chamfer_distance_forward_workspace(int B, int N, int M, int with_grad) {
+  if (B <= 0 || N <= 0 || M <= 0 || !kamd::sdgrid_pair_applicable(B, N, M) || sd_force_brute()) return 0;
+  return kamd::sdgrid_chamfer_workspace_bytes(B, N, M, with_grad != 0);
+}
+
+int kamd_chamfer_distance_forward_f32(void* stream, int B, int N, int M, const float* p1, const float* p2, float w1,
+                                      float w2, int squared, int with_grad, float* out, float* dist1, int64_t* idx1,
+                                      float* dist2, int64_t* idx2, void* workspace) {
+  if (workspace == nullptr || out == nullptr || !kamd::sdgrid_pair_applicable(B, N, M)) return (int)hipErrorInvalidValue;
+  return kamd::sdgrid_chamfer_forward_f32((hipStream_t)stream, B, N, M, p1, p2, w1, w2, squared, with_grad != 0, out, dist1,
+                                          idx1, dist2, idx2, workspace);
+}
+
+int kamd_chamfer_distance_backward_fused_f32(void* stream, int B, int N, int M, const float* grad, void* workspace,
+                                             float* g1, float* g2) {
+  if (workspace == nullptr || !kamd::sdgrid_pair_applicable(B, N, M)) return (int)hipErrorInvalidValue;
+  return kamd::sdgrid_chamfer_backward_f32((hipStream_t)stream, B, N, M, grad, workspace, g1, g2);
+}
+
 int kamd_sided_distance_forward_f64(void* stream, int B, int N, int M, const double* p1, const double* p2,
                                     double* dist, int64_t* idx, void* workspace) {
   (void)workspace;

@@ -14,4 +14,12 @@ bool sdgrid_pair_applicable(int B, int N, int M);
 size_t sdgrid_pair_workspace_bytes(int B, int N, int M);
 int sdgrid_pair_forward_f32(hipStream_t st, int B, int N, int M, const float* p1, const float* p2, float* dist1,
                             int64_t* idx1, float* dist2, int64_t* idx2, void* workspace);
+// chamfer_distance as a whole: the query launch also produces the value and, with_grad, the gradient pieces kept in the
+// workspace (which the caller holds on to until sdgrid_chamfer_backward_f32); dist / idx outputs may be null
+size_t sdgrid_chamfer_workspace_bytes(int B, int N, int M, bool with_grad);
+int sdgrid_chamfer_forward_f32(hipStream_t st, int B, int N, int M, const float* p1, const float* p2, float w1, float w2,
+                               int squared, bool with_grad, float* out, float* dist1, int64_t* idx1, float* dist2,
+                               int64_t* idx2, void* workspace);
+int sdgrid_chamfer_backward_f32(hipStream_t st, int B, int N, int M, const float* grad, void* workspace, float* g1,
+                                float* g2);
 }  // namespace kamd

@@ -6,14 +6,14 @@
 // pairs while returning the SAME answer: dist = min_j d(p1_i, p2_j) with the identical fp32 expression
 // d = fma(dz,dz, fma(dy,dy, dx*dx)), idx = the lowest j attaining it, and a NaN distance to target 0 sticking
 // (the reference's `k == 0 ||` seed).  A uniform grid over the targets does that:
-//   1. sdg_bbox      bounding box of the finite targets (per batch item): block minima / maxima merged with integer
-//                    atomicMax on an order-preserving encoding, so that consumers read six words;
-//   2. sdg_cells     cell id of every point and its rank inside the cell (the value the counting atomicAdd returns);
-//   3. sdg_scan      exclusive scan of the cell counts: one launch (every 1024-cell block sums the counts before it),
-//                    two on grids of more than 160 blocks;
-//   4. sdg_scatter   counting sort without further atomics: point -> start[cell] + rank, stored as float4
-//                    {x, y, z, original index};
-//   5. sdg_query     per query: seed with target 0 exactly as the reference does, then visit the cube of cells around
+//   sdg_build (ONE persistent launch, phases separated by grid barriers):
+//     1. bounding box of the finite targets (per batch item): workgroup minima / maxima merged with integer atomicMax on
+//        an order-preserving encoding, so that consumers read six words;
+//     2. cell id of every point and its rank inside the cell (the value the counting atomicAdd returns);
+//     3. exclusive scan of the cell counts (every 512-cell block sums the counts before it; a per-block-totals phase
+//        first on grids of more than 320 blocks);
+//     4. counting sort without further atomics: point -> start[cell] + rank, stored as float4 {x, y, z, original index};
+//   sdg_query  per query: seed with target 0 exactly as the reference does, then visit the cube of cells around
 //                    the query ring by ring; after each ring every unvisited target is provably farther than the
 //                    distance from the query to the cube's faces (minus a rounding margin), so the search stops as soon
 //                    as the best distance is below that bound.  Ties are resolved towards the lower original index
@@ -49,21 +49,40 @@ struct Cloud {
   int n, G;             // points per batch item; cells per axis of the grid it is binned on
   const float* pts;     // (B, n, 3)
   unsigned int* box;    // (B, 8) encoded {lo[3], hi[3]} of the grid's box, 0 = no finite point yet
-  int* count;           // (B, G^3) zero before sdg_cells
+  int* count;           // (B, G^3) zero before the build
   int* start;           // (B, G^3 + 1)
   int2* cellrank;       // (B, n) {cell, rank inside the cell}
   float4* sorted;       // (B, n) {x, y, z, original index} in cell order
 };
 
+// what chamfer_distance adds to the search (SDG_VALUE / SDG_GRAD): everything the value and the gradient need is
+// produced by the query launch itself
+struct Fuse {
+  double* sums;         // (B, 2) sum_i f(dist1_i), sum_j f(dist2_j); zero before the query
+  unsigned int* done;   // query workgroups finished; zero before the query
+  float* out;           // (B) chamfer value, written by the last workgroup
+  float* own_a;         // (B, N, 3) d value / d p1_i through p1_i's own nearest-point term (plain stores)
+  float* own_b;         // (B, M, 3)
+  float* scat_a;        // (B, N, 3) ... through the terms of the p2 points whose nearest point is p1_i (atomics); zero before
+  float* scat_b;        // (B, M, 3)
+  float w1, w2, c1, c2; // weights; w1 / N and w2 / M
+  int squared;
+};
+enum { SDG_PLAIN = 0, SDG_VALUE = 1, SDG_GRAD = 2 };
+
 struct SdgWs {
   Cloud a, b;           // a = p1 (N points), b = p2 (M points)
-  int* scan_sums;       // (2, B, blocks of 1024 cells): per-block totals, large grids only
+  int* scan_sums;       // (2, B, scan blocks): per-block totals, large grids only
   int scan_blocks;
-  size_t zero_bytes;    // prefix of the workspace that must be zeroed (counts + boxes)
+  unsigned int* barrier;  // grid-barrier arrival counter of the build kernel; zero before it
+  Fuse fuse;
+  size_t zero_bytes;    // prefix of the workspace that must be zeroed (counts, boxes, barrier, sums, scatter sides)
   size_t total;
 };
+constexpr int SDG_BUILD_THREADS = 512;  // workgroup of the build kernel = cells per scan block
+
 // pair = false: sided_distance(p1, p2): both clouds on p2's grid.  pair = true: each cloud on its own grid.
-inline SdgWs sdg_layout(void* base, int B, int N, int M, const float* p1, const float* p2, bool pair) {
+inline SdgWs sdg_layout(void* base, int B, int N, int M, const float* p1, const float* p2, bool pair, int mode) {
   SdgWs w;
   w.b.n = M;
   w.b.G = sdg_cells_per_axis(M);
@@ -83,22 +102,44 @@ inline SdgWs sdg_layout(void* base, int B, int N, int M, const float* p1, const 
   w.a.count = (int*)take((size_t)B * nca * 4);
   w.b.box = (unsigned int*)take((size_t)B * 8 * 4);
   w.a.box = pair ? (unsigned int*)take((size_t)B * 8 * 4) : w.b.box;
+  w.barrier = (unsigned int*)take(64);
+  w.fuse = Fuse{};
+  if (mode >= SDG_VALUE) {
+    w.fuse.sums = (double*)take((size_t)B * 2 * 8);
+    w.fuse.done = (unsigned int*)take(64);
+  }
+  if (mode >= SDG_GRAD) {
+    w.fuse.scat_a = (float*)take((size_t)B * N * 12);
+    w.fuse.scat_b = (float*)take((size_t)B * M * 12);
+  }
   w.zero_bytes = off;
+  if (mode >= SDG_GRAD) {
+    w.fuse.own_a = (float*)take((size_t)B * N * 12);
+    w.fuse.own_b = (float*)take((size_t)B * M * 12);
+  }
   w.b.start = (int*)take((size_t)B * (ncb + 1) * 4);
   w.a.start = (int*)take((size_t)B * (nca + 1) * 4);
   w.b.cellrank = (int2*)take((size_t)B * M * 8);
   w.a.cellrank = (int2*)take((size_t)B * N * 8);
   w.b.sorted = (float4*)take((size_t)B * M * 16);
   w.a.sorted = (float4*)take((size_t)B * N * 16);
-  w.scan_blocks = (int)(((nca > ncb ? nca : ncb) + 1023) / 1024);
+  w.scan_blocks = (int)(((nca > ncb ? nca : ncb) + SDG_BUILD_THREADS - 1) / SDG_BUILD_THREADS);
   w.scan_sums = (int*)take((size_t)2 * B * w.scan_blocks * 4);
   w.total = off;
   return w;
 }
 
-// ---- 1. bounding box ---------------------------------------------------------------------------------------------------
+// ---- the build: ONE persistent launch -----------------------------------------------------------------------------------
+// bounding box -> cell id + rank -> scan of the cell counts -> counting-sort scatter are four dependent passes over at most
+// a few hundred thousand points: as four launches they cost more in launch gaps and host time than in work (36 us for
+// ~10 us of memory traffic at 100k + 100k points).  They are phases of one kernel whose workgroups are all resident
+// (grid <= the CU count, 512 threads each: a quarter of a CU's wave slots, so several such kernels can share the GPU
+// without starving each other) and meet at a grid barrier between phases: every thread publishes its stores
+// (__threadfence = release at agent scope: L2 write-back across XCDs), thread 0 of each workgroup arrives on one counter
+// and spins until all have, then acquires.
+
 // order-preserving float -> uint (negative values reversed below the positives); atomicMax on it is a float max, on
-// its complement a float min, and the all-zero word the workspace memset leaves is below every encoded value
+// its complement a float min, and the all-zero word the workspace fill leaves is below every encoded value
 __device__ __forceinline__ unsigned int sdg_ord(float v) {
   const unsigned int u = __float_as_uint(v);
   return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
@@ -107,46 +148,15 @@ __device__ __forceinline__ float sdg_unord(unsigned int o) {
   return __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 }
 
-// blocks [0, nbx) reduce cloud X into X.box, blocks [nbx, gridDim.x) cloud Y into Y.box (Y.n = 0: one cloud only)
-__global__ __launch_bounds__(256) void sdg_bbox_atomic(Cloud X, Cloud Y, int nbx) {
-  __shared__ float s[6][256];
-  const int b = blockIdx.y;
-  const bool first = (int)blockIdx.x < nbx;
-  const int n = first ? X.n : Y.n;
-  const int blk = first ? blockIdx.x : blockIdx.x - nbx, nblk = first ? nbx : gridDim.x - nbx;
-  const float* P = (first ? X.pts : Y.pts) + (size_t)b * n * 3;
-  unsigned int* box = (first ? X.box : Y.box) + (size_t)b * 8;
-  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int i = blk * 256 + threadIdx.x; i < n; i += nblk * 256) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float v = P[(size_t)i * 3 + a];
-      if (isfinite(v)) {
-        lo[a] = fminf(lo[a], v);
-        hi[a] = fmaxf(hi[a], v);
-      }
-    }
-  }
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    s[a][threadIdx.x] = lo[a];
-    s[3 + a][threadIdx.x] = hi[a];
+__device__ __forceinline__ void sdg_grid_barrier(unsigned int* counter, unsigned int target) {
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+    __threadfence();
   }
   __syncthreads();
-  for (int d = 128; d >= 1; d >>= 1) {
-    if (threadIdx.x < d) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        s[a][threadIdx.x] = fminf(s[a][threadIdx.x], s[a][threadIdx.x + d]);
-        s[3 + a][threadIdx.x] = fmaxf(s[3 + a][threadIdx.x], s[3 + a][threadIdx.x + d]);
-      }
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x < 3 && s[threadIdx.x][0] <= s[3 + threadIdx.x][0]) {  // this block saw a finite value on the axis
-    atomicMax(box + threadIdx.x, ~sdg_ord(s[threadIdx.x][0]));
-    atomicMax(box + 3 + threadIdx.x, sdg_ord(s[3 + threadIdx.x][0]));
-  }
 }
 
 // the grid geometry every consumer derives from the six words (same rules as grid_common.h's sdg_box)
@@ -169,85 +179,155 @@ __device__ __forceinline__ Box sdg_box_decode(const unsigned int* __restrict__ w
   return bx;
 }
 
-// ---- 2. cell id + rank inside the cell (both clouds in one launch) ------------------------------------------------
-__global__ __launch_bounds__(256) void sdg_cells(Cloud X, Cloud Y) {
-  __shared__ Box s_box;
-  const int b = blockIdx.y;
-  const int xb = (X.n + 255) / 256;
-  const bool first = (int)blockIdx.x < xb;
-  const int n = first ? X.n : Y.n, G = first ? X.G : Y.G;
-  if (threadIdx.x == 0) s_box = sdg_box_decode((first ? X.box : Y.box) + (size_t)b * 8, G);
-  __syncthreads();
-  const int i = (first ? blockIdx.x : blockIdx.x - xb) * 256 + threadIdx.x;
-  if (i >= n) return;
-  const float* P = (first ? X.pts : Y.pts) + ((size_t)b * n + i) * 3;
-  const int cx = sdg_axis_cell(P[0], s_box.lo[0], s_box.inv[0], G);
-  const int cy = sdg_axis_cell(P[1], s_box.lo[1], s_box.inv[1], G);
-  const int cz = sdg_axis_cell(P[2], s_box.lo[2], s_box.inv[2], G);
-  const int c = (cz * G + cy) * G + cx;
-  const int rank = atomicAdd((first ? X.count : Y.count) + (size_t)b * (G * G * G) + c, 1);
-  (first ? X.cellrank : Y.cellrank)[(size_t)b * n + i] = make_int2(c, rank);
-}
-
-// ---- 3. exclusive scan of the counts: start[c] = points in cells < c, start[NC] = n ---------------------------------
-// a block owns 1024 cells and first needs the number of points before them.  Small grids (<= SDG_SCAN_DIRECT blocks,
-// i.e. clouds up to ~330k points): one launch, every block adds up the raw counts before it (block k reads k * 4 KB from
-// L2: 5 MB in total at 100k points) -- no second pass, no inter-block dependency.  Larger grids would make that
-// quadratic read matter (8 GB at the 128^3 grid), so a first launch leaves per-block totals and blocks add up those.
-constexpr int SDG_SCAN_DIRECT = 160;
-
-__global__ __launch_bounds__(1024) void sdg_scan_sums(Cloud X, Cloud Y, int* __restrict__ sums, int nblk) {
-  __shared__ int s_wave[16];
-  const bool first = blockIdx.z == 0;
-  const int G = first ? X.G : Y.G, NC = G * G * G;
-  const int base = blockIdx.x * 1024;
-  if (base >= NC || (first ? X.n : Y.n) == 0) return;
-  const int* cnt = (first ? X.count : Y.count) + (size_t)blockIdx.y * NC;
-  const int i = base + threadIdx.x;
-  const int tot = sdg_block_inclusive(i < NC ? cnt[i] : 0, s_wave);
-  if (threadIdx.x == 1023) sums[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * nblk + blockIdx.x] = tot;
-}
-
-__global__ __launch_bounds__(1024) void sdg_scan(Cloud X, Cloud Y, const int* __restrict__ sums, int nblk) {
-  __shared__ int s_wave[16];
+// X = the targets' cloud, Y = the other one; own_box_y: Y is binned on its own box (chamfer), else on X's (sided_distance)
+__global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(Cloud X, Cloud Y, int B, int own_box_y, int* __restrict__ sums,
+                                                               int scan_blocks, int two_level,
+                                                               unsigned int* __restrict__ barrier) {
+  __shared__ float s_red[6][SDG_BUILD_THREADS / 64];
+  __shared__ int s_wave[SDG_BUILD_THREADS / 64];
   __shared__ int s_off;
-  const bool first = blockIdx.z == 0;
-  const int G = first ? X.G : Y.G, NC = G * G * G;
-  const int base = blockIdx.x * 1024;
-  if (base >= NC || (first ? X.n : Y.n) == 0) return;
-  const int* cnt = (first ? X.count : Y.count) + (size_t)blockIdx.y * NC;
-  int* start = (first ? X.start : Y.start) + (size_t)blockIdx.y * (NC + 1);
-  int part = 0;
-  if (sums != nullptr) {
-    const int* my = sums + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * nblk;
-    for (int k = threadIdx.x; k < (int)blockIdx.x; k += 1024) part += my[k];
-  } else {
-    for (int k = threadIdx.x; k < base; k += 1024) part += cnt[k];
-  }
-  const int before = sdg_block_inclusive(part, s_wave);
-  if (threadIdx.x == 1023) s_off = before;
-  __syncthreads();
-  const int off = s_off;
-  __syncthreads();
-  const int i = base + threadIdx.x;
-  const int v = i < NC ? cnt[i] : 0;
-  const int inc = sdg_block_inclusive(v, s_wave);
-  if (i < NC) start[i] = off + inc - v;
-  if (i == NC - 1) start[NC] = off + inc;
-}
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nwg = gridDim.x, wg = blockIdx.x;
+  unsigned int arrivals = 0;
 
-// ---- 4. counting-sort scatter (both clouds in one launch) -------------------------------------------------------------
-__global__ __launch_bounds__(256) void sdg_scatter(Cloud X, Cloud Y) {
-  const int b = blockIdx.y;
-  const int xb = (X.n + 255) / 256;
-  const bool first = (int)blockIdx.x < xb;
-  const int n = first ? X.n : Y.n, G = first ? X.G : Y.G;
-  const int i = (first ? blockIdx.x : blockIdx.x - xb) * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int2 cr = (first ? X.cellrank : Y.cellrank)[(size_t)b * n + i];
-  const int pos = (first ? X.start : Y.start)[(size_t)b * (G * G * G + 1) + cr.x] + cr.y;
-  const float* P = (first ? X.pts : Y.pts) + ((size_t)b * n + i) * 3;
-  (first ? X.sorted : Y.sorted)[(size_t)b * n + pos] = make_float4(P[0], P[1], P[2], __int_as_float(i));
+  // ---- phase 1: bounding boxes.  Units = (cloud, batch item); a unit is shared by P workgroups
+  {
+    const int U = (own_box_y ? 2 : 1) * B;
+    const int P = nwg / U > 0 ? nwg / U : 1, step = nwg / P;
+    for (int u = wg / P; u < U; u += step) {
+      const int part = wg % P;
+      const bool first = u < B;
+      const int b = first ? u : u - B;
+      const int n = first ? X.n : Y.n;
+      const float* Pt = (first ? X.pts : Y.pts) + (size_t)b * n * 3;
+      float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      for (int i = part * SDG_BUILD_THREADS + tid; i < n; i += P * SDG_BUILD_THREADS) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const float v = Pt[(size_t)i * 3 + a];
+          if (isfinite(v)) {
+            lo[a] = fminf(lo[a], v);
+            hi[a] = fmaxf(hi[a], v);
+          }
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+          lo[a] = fminf(lo[a], __shfl_xor(lo[a], d, 64));
+          hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], d, 64));
+        }
+      }
+      __syncthreads();  // s_red of the previous unit has been read
+      if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          s_red[a][wave] = lo[a];
+          s_red[3 + a][wave] = hi[a];
+        }
+      }
+      __syncthreads();
+      if (tid < 3) {
+        float l = INFINITY, h = -INFINITY;
+        for (int w = 0; w < SDG_BUILD_THREADS / 64; ++w) {
+          l = fminf(l, s_red[tid][w]);
+          h = fmaxf(h, s_red[3 + tid][w]);
+        }
+        unsigned int* box = (first ? X.box : Y.box) + (size_t)b * 8;
+        if (l <= h) {  // this workgroup saw a finite value on the axis
+          atomicMax(box + tid, ~sdg_ord(l));
+          atomicMax(box + 3 + tid, sdg_ord(h));
+        }
+      }
+    }
+  }
+  arrivals += nwg;
+  sdg_grid_barrier(barrier, arrivals);
+
+  // ---- phase 2: cell id + rank inside the cell (the value the counting atomicAdd returns)
+  const long long per_b = (long long)X.n + Y.n, total = per_b * B;
+  for (long long t = (long long)wg * SDG_BUILD_THREADS + tid; t < total; t += (long long)nwg * SDG_BUILD_THREADS) {
+    const int b = (int)(t / per_b);
+    int i = (int)(t - (long long)b * per_b);
+    const bool first = i < X.n;
+    if (!first) i -= X.n;
+    const int n = first ? X.n : Y.n, G = first ? X.G : Y.G;
+    const Box bx = sdg_box_decode((first ? X.box : Y.box) + (size_t)b * 8, G);
+    const float* Pt = (first ? X.pts : Y.pts) + ((size_t)b * n + i) * 3;
+    const int cx = sdg_axis_cell(Pt[0], bx.lo[0], bx.inv[0], G);
+    const int cy = sdg_axis_cell(Pt[1], bx.lo[1], bx.inv[1], G);
+    const int cz = sdg_axis_cell(Pt[2], bx.lo[2], bx.inv[2], G);
+    const int c = (cz * G + cy) * G + cx;
+    const int rank = atomicAdd((first ? X.count : Y.count) + (size_t)b * ((size_t)G * G * G) + c, 1);
+    (first ? X.cellrank : Y.cellrank)[(size_t)b * n + i] = make_int2(c, rank);
+  }
+  arrivals += nwg;
+  sdg_grid_barrier(barrier, arrivals);
+
+  // ---- phase 3: exclusive scan of the counts: start[c] = points in cells < c, start[NC] = n.  A unit = (cloud, batch
+  // item, block of SDG_BUILD_THREADS cells); it first needs the number of points before its block.  Small grids: it adds
+  // up the raw counts before it (block k reads k * 2 KB from L2) -- no inter-block dependency.  Large grids would make
+  // that quadratic read matter, so a first phase leaves per-block totals and the blocks add up those.
+  const int units3 = 2 * B * scan_blocks;
+  if (two_level) {
+    for (int u = wg; u < units3; u += nwg) {
+      const int z = u / (B * scan_blocks), b = (u / scan_blocks) % B, blk = u % scan_blocks;
+      const bool first = z == 0;
+      const int G = first ? X.G : Y.G, NC = G * G * G;
+      const int base = blk * SDG_BUILD_THREADS;
+      if (base >= NC || (first ? X.n : Y.n) == 0) continue;
+      const int* cnt = (first ? X.count : Y.count) + (size_t)b * NC;
+      const int i = base + tid;
+      __syncthreads();
+      const int tot = sdg_block_inclusive(i < NC ? cnt[i] : 0, s_wave);
+      if (tid == SDG_BUILD_THREADS - 1) sums[((size_t)z * B + b) * scan_blocks + blk] = tot;
+    }
+    arrivals += nwg;
+    sdg_grid_barrier(barrier, arrivals);
+  }
+  for (int u = wg; u < units3; u += nwg) {
+    const int z = u / (B * scan_blocks), b = (u / scan_blocks) % B, blk = u % scan_blocks;
+    const bool first = z == 0;
+    const int G = first ? X.G : Y.G, NC = G * G * G;
+    const int base = blk * SDG_BUILD_THREADS;
+    if (base >= NC || (first ? X.n : Y.n) == 0) continue;
+    const int* cnt = (first ? X.count : Y.count) + (size_t)b * NC;
+    int* start = (first ? X.start : Y.start) + (size_t)b * (NC + 1);
+    int part = 0;
+    if (two_level) {
+      const int* my = sums + ((size_t)z * B + b) * scan_blocks;
+      for (int k = tid; k < blk; k += SDG_BUILD_THREADS) part += my[k];
+    } else {
+      for (int k = tid; k < base; k += SDG_BUILD_THREADS) part += cnt[k];
+    }
+    __syncthreads();  // s_wave / s_off of the previous unit have been read
+    const int before = sdg_block_inclusive(part, s_wave);
+    if (tid == SDG_BUILD_THREADS - 1) s_off = before;
+    __syncthreads();
+    const int off = s_off;
+    const int i = base + tid;
+    const int v = i < NC ? cnt[i] : 0;
+    __syncthreads();
+    const int inc = sdg_block_inclusive(v, s_wave);
+    if (i < NC) start[i] = off + inc - v;
+    if (i == NC - 1) start[NC] = off + inc;
+  }
+  arrivals += nwg;
+  sdg_grid_barrier(barrier, arrivals);
+
+  // ---- phase 4: counting-sort scatter without further atomics: point -> start[cell] + rank, as float4 {xyz, index}
+  for (long long t = (long long)wg * SDG_BUILD_THREADS + tid; t < total; t += (long long)nwg * SDG_BUILD_THREADS) {
+    const int b = (int)(t / per_b);
+    int i = (int)(t - (long long)b * per_b);
+    const bool first = i < X.n;
+    if (!first) i -= X.n;
+    const int n = first ? X.n : Y.n, G = first ? X.G : Y.G;
+    const int2 cr = (first ? X.cellrank : Y.cellrank)[(size_t)b * n + i];
+    const int pos = (first ? X.start : Y.start)[(size_t)b * ((size_t)G * G * G + 1) + cr.x] + cr.y;
+    const float* Pt = (first ? X.pts : Y.pts) + ((size_t)b * n + i) * 3;
+    (first ? X.sorted : Y.sorted)[(size_t)b * n + pos] = make_float4(Pt[0], Pt[1], Pt[2], __int_as_float(i));
+  }
 }
 
 // ---- 5. query ----------------------------------------------------------------------------------------------------------
@@ -347,66 +427,154 @@ __device__ __forceinline__ void sdg_search(const Box& s_box, int G, float qx, fl
 // blockIdx.z = direction: 0 answers the queries A against the targets T (dist1 / idx1), 1 the reverse (dist2 / idx2).
 // The search runs on the TARGETS' grid; the queries only have to arrive in a spatially coherent order, which their own
 // sorted copy provides whichever grid it was sorted on.
+// MODE >= SDG_VALUE (chamfer_distance, kaolin/metrics/pointcloud.py:120-136): the launch also reduces f(dist) (f = identity
+// or sqrt) per direction -- wave shuffle, LDS, one double atomicAdd per workgroup -- and its last workgroup writes
+// w1 * mean1 + w2 * mean2.  MODE == SDG_GRAD: every query also leaves d value / d (its own point) and adds
+// d value / d (its nearest point) with float atomics, both already scaled by w / n [/ (2 sqrt(dist))]: the atomics ride in
+// a kernel that waits on dependent loads anyway, and the backward pass is one multiply by the upstream gradient.
+template <int MODE>
 __global__ __launch_bounds__(256) void sdg_query(Cloud A, Cloud T, float* __restrict__ dist1, int64_t* __restrict__ idx1,
-                                                 float* __restrict__ dist2, int64_t* __restrict__ idx2) {
+                                                 float* __restrict__ dist2, int64_t* __restrict__ idx2, Fuse fz) {
   __shared__ Box s_box;
+  __shared__ double s_sum[4];
+  __shared__ bool s_last;
   const int b = blockIdx.y;
   const bool fwd = blockIdx.z == 0;
   const int nq = fwd ? A.n : T.n, nt = fwd ? T.n : A.n, G = fwd ? T.G : A.G;
-  if ((long long)blockIdx.x * 256 >= (long long)nq * SDG_GROUP) return;  // the launch is sized for the larger cloud
-  if (threadIdx.x == 0) s_box = sdg_box_decode((fwd ? T.box : A.box) + (size_t)b * 8, G);
-  __syncthreads();
-  // 100k queries are only ~1.5 wavefronts per SIMD and every query is a chain of dependent loads (cell range ->
-  // targets): 8 lanes share a query so that 8x more loads are in flight; the lanes' (dist, idx) are merged with a
-  // 3-step butterfly after every ring
-  const int sub = threadIdx.x % SDG_GROUP;
-  const int slot = (blockIdx.x * 256 + threadIdx.x) / SDG_GROUP;
-  const bool live = slot < nq;
-  const int NC = G * G * G;
-  const float4 q = (fwd ? A.sorted : T.sorted)[(size_t)b * nq + (live ? slot : 0)];
-  const int cx = sdg_axis_cell(q.x, s_box.lo[0], s_box.inv[0], G);
-  const int cy = sdg_axis_cell(q.y, s_box.lo[1], s_box.inv[1], G);
-  const int cz = sdg_axis_cell(q.z, s_box.lo[2], s_box.inv[2], G);
-  float best;
-  int best_i;
-  sdg_search(s_box, G, q.x, q.y, q.z, (cz * G + cy) * G + cx, (fwd ? T.pts : A.pts) + (size_t)b * nt * 3,
-             (fwd ? T.start : A.start) + (size_t)b * (NC + 1), (fwd ? T.sorted : A.sorted) + (size_t)b * nt, sub, best,
-             best_i);
-  if (live && sub == 0) {
-    const size_t o = (size_t)b * nq + __float_as_int(q.w);
-    (fwd ? dist1 : dist2)[o] = best;
-    (fwd ? idx1 : idx2)[o] = best_i;
+  // the launch is sized for the larger cloud
+  const bool idle = (long long)blockIdx.x * 256 >= (long long)nq * SDG_GROUP;
+  if (MODE == SDG_PLAIN && idle) return;
+  double term = 0.0;
+  if (!idle) {
+    if (threadIdx.x == 0) s_box = sdg_box_decode((fwd ? T.box : A.box) + (size_t)b * 8, G);
+    __syncthreads();
+    // 100k queries are only ~1.5 wavefronts per SIMD and every query is a chain of dependent loads (cell range ->
+    // targets): 8 lanes share a query so that 8x more loads are in flight; the lanes' (dist, idx) are merged with a
+    // 3-step butterfly after every ring
+    const int sub = threadIdx.x % SDG_GROUP;
+    const int slot = (blockIdx.x * 256 + threadIdx.x) / SDG_GROUP;
+    const bool live = slot < nq;
+    const int NC = G * G * G;
+    const float4 q = (fwd ? A.sorted : T.sorted)[(size_t)b * nq + (live ? slot : 0)];
+    const int cx = sdg_axis_cell(q.x, s_box.lo[0], s_box.inv[0], G);
+    const int cy = sdg_axis_cell(q.y, s_box.lo[1], s_box.inv[1], G);
+    const int cz = sdg_axis_cell(q.z, s_box.lo[2], s_box.inv[2], G);
+    float best;
+    int best_i;
+    const float* Tp = (fwd ? T.pts : A.pts) + (size_t)b * nt * 3;
+    sdg_search(s_box, G, q.x, q.y, q.z, (cz * G + cy) * G + cx, Tp, (fwd ? T.start : A.start) + (size_t)b * (NC + 1),
+               (fwd ? T.sorted : A.sorted) + (size_t)b * nt, sub, best, best_i);
+    if (live && sub == 0) {
+      const size_t o = (size_t)b * nq + __float_as_int(q.w);
+      float* dist = fwd ? dist1 : dist2;
+      int64_t* idx = fwd ? idx1 : idx2;
+      if (dist != nullptr) dist[o] = best;
+      if (idx != nullptr) idx[o] = best_i;
+      if (MODE >= SDG_VALUE) {
+        const float root = fz.squared ? best : sqrtf(best);
+        term = (double)root;
+        if (MODE == SDG_GRAD) {
+          // value = sum_b up_b * (w1 / N * sum_i f(dist1_i) + w2 / M * sum_j f(dist2_j)); d dist / d q = 2 (q - t)
+          float k = fwd ? fz.c1 : fz.c2;
+          if (!fz.squared) k = k / (2.f * root);
+          float* own = (fwd ? fz.own_a : fz.own_b) + o * 3;
+          float* scat = (fwd ? fz.scat_b : fz.scat_a) + ((size_t)b * nt + best_i) * 3;
+          const float qv[3] = {q.x, q.y, q.z};
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            const float x = Tp[(size_t)best_i * 3 + a];
+            own[a] = 2.f * (qv[a] - x) * k;
+            kamd_atomic_add(scat + a, 2.f * (x - qv[a]) * k);
+          }
+        }
+      }
+    }
+  }
+  if (MODE >= SDG_VALUE) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) term += __shfl_xor(term, d, 64);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = term;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (!idle) kamd_atomic_add(fz.sums + (size_t)b * 2 + (fwd ? 0 : 1), (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]));
+      __threadfence();
+      const unsigned int total = gridDim.x * gridDim.y * gridDim.z;
+      s_last = __hip_atomic_fetch_add(fz.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == total - 1;
+    }
+    __syncthreads();
+    if (s_last) {
+      __threadfence();
+      for (int i = threadIdx.x; i < (int)gridDim.y; i += 256) {
+        const double s1 = __hip_atomic_load(fz.sums + (size_t)i * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double s2 = __hip_atomic_load(fz.sums + (size_t)i * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float m1 = (float)(s1 / (double)A.n), m2 = (float)(s2 / (double)T.n);
+        fz.out[i] = (fz.w1 == 1.f && fz.w2 == 1.f) ? m1 + m2 : fz.w1 * m1 + fz.w2 * m2;
+      }
+    }
   }
 }
 
+// chamfer backward after a SDG_GRAD forward: grad_p = upstream[b] * (own + scattered)
+__global__ __launch_bounds__(256) void sdg_chamfer_apply(int B, long long na, long long nb, const float* __restrict__ grad,
+                                                         const float* __restrict__ own_a, const float* __restrict__ scat_a,
+                                                         const float* __restrict__ own_b, const float* __restrict__ scat_b,
+                                                         float* __restrict__ g1, float* __restrict__ g2) {
+  const long long total = (long long)B * (na + nb);
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const bool first = t < (long long)B * na;
+    const long long k = first ? t : t - (long long)B * na;
+    const int b = (int)(k / (first ? na : nb));
+    const float g = grad[b];
+    if (first)
+      g1[k] = g * (own_a[k] + scat_a[k]);
+    else
+      g2[k] = g * (own_b[k] + scat_b[k]);
+  }
+}
+
+inline int sdg_num_cus() {
+  static int cached[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 64;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 64;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
 int sdg_run(hipStream_t st, int B, int N, int M, const float* p1, const float* p2, float* dist1, int64_t* idx1,
-            float* dist2, int64_t* idx2, void* workspace, bool pair) {
-  const SdgWs w = sdg_layout(workspace, B, N, M, p1, p2, pair);
-  const Cloud none = {0, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  auto blocks = [](int n) { return kamd_cdiv(n, 2048) < 128 ? kamd_cdiv(n, 2048) : 128; };
+            float* dist2, int64_t* idx2, void* workspace, bool pair, int mode, float w1, float w2, int squared, float* out) {
+  SdgWs w = sdg_layout(workspace, B, N, M, p1, p2, pair, mode);
   KAMD_CHECK(kamd_zero_async(workspace, w.zero_bytes, st));
   {
     ProfScope p(K_SDG_BUILD, st);
-    if (pair)
-      hipLaunchKernelGGL(sdg_bbox_atomic, dim3(blocks(M) + blocks(N), B), dim3(256), 0, st, w.b, w.a, blocks(M));
-    else  // the queries are binned on the targets' box
-      hipLaunchKernelGGL(sdg_bbox_atomic, dim3(blocks(M), B), dim3(256), 0, st, w.b, none, blocks(M));
-    hipLaunchKernelGGL(sdg_cells, dim3(kamd_cdiv(M, 256) + kamd_cdiv(N, 256), B), dim3(256), 0, st, w.b, w.a);
-    const dim3 scan_grid(w.scan_blocks, B, 2);
-    const int* sums = nullptr;
-    if (w.scan_blocks > SDG_SCAN_DIRECT) {
-      hipLaunchKernelGGL(sdg_scan_sums, scan_grid, dim3(1024), 0, st, w.b, w.a, w.scan_sums, w.scan_blocks);
-      sums = w.scan_sums;
-    }
-    hipLaunchKernelGGL(sdg_scan, scan_grid, dim3(1024), 0, st, w.b, w.a, sums, w.scan_blocks);
-    hipLaunchKernelGGL(sdg_scatter, dim3(kamd_cdiv(M, 256) + kamd_cdiv(N, 256), B), dim3(256), 0, st, w.b, w.a);
+    // every workgroup must be resident (grid barrier): at most one per CU, fewer for small inputs
+    int nwg = kamd_cdiv((long long)B * ((long long)N + M), SDG_BUILD_THREADS);
+    const int cus = sdg_num_cus();
+    if (nwg > cus) nwg = cus;
+    const int two_level = w.scan_blocks > 2 * 160 ? 1 : 0;
+    hipLaunchKernelGGL(sdg_build, dim3(nwg), dim3(SDG_BUILD_THREADS), 0, st, w.b, w.a, B, pair ? 1 : 0, w.scan_sums,
+                       w.scan_blocks, two_level, w.barrier);
   }
   KAMD_CHECK(hipGetLastError());
   {
     ProfScope p(K_SDG_QUERY, st);
     const int big = (pair && M > N) ? M : N;
-    hipLaunchKernelGGL(sdg_query, dim3(kamd_cdiv((long long)big * SDG_GROUP, 256), B, pair ? 2 : 1), dim3(256), 0, st, w.a,
-                       w.b, dist1, idx1, dist2, idx2);
+    const dim3 grid(kamd_cdiv((long long)big * SDG_GROUP, 256), B, pair ? 2 : 1);
+    w.fuse.out = out;
+    w.fuse.w1 = w1;
+    w.fuse.w2 = w2;
+    w.fuse.c1 = w1 * (1.f / (float)N);
+    w.fuse.c2 = w2 * (1.f / (float)M);
+    w.fuse.squared = squared;
+    if (mode == SDG_PLAIN)
+      hipLaunchKernelGGL(sdg_query<SDG_PLAIN>, grid, dim3(256), 0, st, w.a, w.b, dist1, idx1, dist2, idx2, w.fuse);
+    else if (mode == SDG_VALUE)
+      hipLaunchKernelGGL(sdg_query<SDG_VALUE>, grid, dim3(256), 0, st, w.a, w.b, dist1, idx1, dist2, idx2, w.fuse);
+    else
+      hipLaunchKernelGGL(sdg_query<SDG_GRAD>, grid, dim3(256), 0, st, w.a, w.b, dist1, idx1, dist2, idx2, w.fuse);
   }
   KAMD_RETURN_LAST_ERROR();
 }
@@ -417,20 +585,43 @@ bool sdgrid_applicable(int B, int N, int M) {
   // below this the brute-force kernels are as fast as the launches of the grid pipeline
   return B >= 1 && B <= 65535 && M >= 8192 && N >= 2048 && (long long)B * (long long)(M > N ? M : N) < (1ll << 30);
 }
-size_t sdgrid_workspace_bytes(int B, int N, int M) { return sdg_layout(nullptr, B, N, M, nullptr, nullptr, false).total; }
+size_t sdgrid_workspace_bytes(int B, int N, int M) {
+  return sdg_layout(nullptr, B, N, M, nullptr, nullptr, false, SDG_PLAIN).total;
+}
 
 int sdgrid_forward_f32(hipStream_t st, int B, int N, int M, const float* p1, const float* p2, float* dist, int64_t* idx,
                        void* workspace) {
-  return sdg_run(st, B, N, M, p1, p2, dist, idx, nullptr, nullptr, workspace, false);
+  return sdg_run(st, B, N, M, p1, p2, dist, idx, nullptr, nullptr, workspace, false, SDG_PLAIN, 1.f, 1.f, 1, nullptr);
 }
 
 bool sdgrid_pair_applicable(int B, int N, int M) { return sdgrid_applicable(B, N, M) && sdgrid_applicable(B, M, N); }
 size_t sdgrid_pair_workspace_bytes(int B, int N, int M) {
-  return sdg_layout(nullptr, B, N, M, nullptr, nullptr, true).total;
+  return sdg_layout(nullptr, B, N, M, nullptr, nullptr, true, SDG_PLAIN).total;
 }
 int sdgrid_pair_forward_f32(hipStream_t st, int B, int N, int M, const float* p1, const float* p2, float* dist1,
                             int64_t* idx1, float* dist2, int64_t* idx2, void* workspace) {
-  return sdg_run(st, B, N, M, p1, p2, dist1, idx1, dist2, idx2, workspace, true);
+  return sdg_run(st, B, N, M, p1, p2, dist1, idx1, dist2, idx2, workspace, true, SDG_PLAIN, 1.f, 1.f, 1, nullptr);
+}
+
+size_t sdgrid_chamfer_workspace_bytes(int B, int N, int M, bool with_grad) {
+  return sdg_layout(nullptr, B, N, M, nullptr, nullptr, true, with_grad ? SDG_GRAD : SDG_VALUE).total;
+}
+int sdgrid_chamfer_forward_f32(hipStream_t st, int B, int N, int M, const float* p1, const float* p2, float w1, float w2,
+                               int squared, bool with_grad, float* out, float* dist1, int64_t* idx1, float* dist2,
+                               int64_t* idx2, void* workspace) {
+  return sdg_run(st, B, N, M, p1, p2, dist1, idx1, dist2, idx2, workspace, true, with_grad ? SDG_GRAD : SDG_VALUE, w1, w2,
+                 squared, out);
+}
+int sdgrid_chamfer_backward_f32(hipStream_t st, int B, int N, int M, const float* grad, void* workspace, float* g1,
+                                float* g2) {
+  const SdgWs w = sdg_layout(workspace, B, N, M, nullptr, nullptr, true, SDG_GRAD);
+  const long long total = (long long)B * ((long long)N + M) * 3;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  ProfScope p(K_SD_BACKWARD, st);
+  hipLaunchKernelGGL(sdg_chamfer_apply, dim3((unsigned)blocks), dim3(256), 0, st, B, (long long)N * 3, (long long)M * 3, grad,
+                     w.fuse.own_a, w.fuse.scat_a, w.fuse.own_b, w.fuse.scat_b, g1, g2);
+  KAMD_RETURN_LAST_ERROR();
 }
 
 }  // namespace kamd

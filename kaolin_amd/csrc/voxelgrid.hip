@@ -7,10 +7,12 @@
 // torch.unique and a host sync per round, then round(p*(R-1)), unique again, scatter into a dense grid.
 // The result only depends on the SET {original vertices} U {all midpoints}, and marking a voxel is
 // idempotent, so the whole op becomes one streaming pass with no sort, no de-duplication and no host sync:
-//   vox_extent_partial_kernel : per-mesh minimum / maximum in 32 partials (origin / scale of the normalisation when the
-//                         caller gives none);
-//   vox_vertices_kernel : one thread per vertex normalises it ((v - origin) / scale), keeps it, marks its voxel;
-//   vox_faces_kernel    : the subdivision tree of a face is deterministic, so a thread is given
+//   vox_clear_extent_kernel : zero-fills the grid (16-byte stores; 67 MB at 256^3: the op's HBM floor) while its first
+//                         workgroups reduce the per-mesh minimum / maximum into 32 partials (origin / scale of the
+//                         normalisation when the caller gives none);
+//   vox_mark_kernel     : the first B*V threads normalise one vertex each ((v - origin) / scale) and mark its voxel; the
+//                         rest walk the faces, normalising their three vertices on the fly (same arithmetic, same values).
+//                         The subdivision tree of a face is deterministic, so a thread is given
 //                         (face, a base-4 path of L0 levels): it re-derives its sub-triangle by descending
 //                         the path (the thread whose remaining path digits are all 0 marks the ancestors'
 //                         midpoints, exactly once), then finishes the subtree depth-first, stackless, in registers.
@@ -25,7 +27,11 @@
 
 namespace {
 
-constexpr int VOX_MAXD = 20;   // depth-first levels below L0 (edges halve per level)
+// depth-first levels below L0.  Edges halve per level and subdivision stops below ~1/R, so depth d serves normalised
+// edges up to 2^d / R: 20 levels = a triangle 4096x larger than a 256^3 grid's unit cube (reachable only through a
+// caller-supplied scale that small; nearly all of such a triangle lies outside the grid).  Beyond the cap the subtree is
+// cut where the reference would keep splitting -- documented in trianglemeshes_to_voxelgrids' docstring.
+constexpr int VOX_MAXD = 20;
 constexpr int VOX_MAXL0 = 10;
 
 template <typename T> __device__ __forceinline__ T vox_rint(T x);
@@ -83,46 +89,51 @@ __device__ __forceinline__ T vox_nan_min(T a, T b) { return (a != a || a < b) ? 
 template <typename T>
 __device__ __forceinline__ T vox_nan_max(T a, T b) { return (a != a || a > b) ? a : b; }
 constexpr int VOX_NP = 32;  // partial extents per mesh
-// scratch layout (scalars): [B*4] origin xyz + scale | [B*VOX_NP*6] partial min xyz, max xyz | [B*V*3] normalised vertices
+// scratch layout (scalars): [B*4] origin xyz + scale | [B*VOX_NP*6] partial min xyz, max xyz
 template <typename T>
-__global__ __launch_bounds__(256) void vox_extent_partial_kernel(int V, const T* __restrict__ vertices, T* __restrict__ part) {
+__global__ __launch_bounds__(256) void vox_clear_extent_kernel(int B, int V, const T* __restrict__ vertices, T* __restrict__ part,
+                                                               uint4* __restrict__ grid16, size_t n16) {
   __shared__ T s_lo[3][4], s_hi[3][4];
-  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const T* vb = vertices + (size_t)b * V * 3;
-  T lo[3], hi[3];
+  if ((int)blockIdx.x < B * VOX_NP && V > 0) {
+    const int b = blockIdx.x / VOX_NP, slice = blockIdx.x % VOX_NP, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const T* vb = vertices + (size_t)b * V * 3;
+    T lo[3], hi[3];
 #pragma unroll
-  for (int a = 0; a < 3; ++a) lo[a] = hi[a] = vb[a];  // vertex 0 is neutral for min and max alike
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < V; i += VOX_NP * 256)
+    for (int a = 0; a < 3; ++a) lo[a] = hi[a] = vb[a];  // vertex 0 is neutral for min and max alike
+    for (int i = slice * 256 + threadIdx.x; i < V; i += VOX_NP * 256)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const T v = vb[(size_t)i * 3 + a];
+        lo[a] = vox_nan_min<T>(lo[a], v);
+        hi[a] = vox_nan_max<T>(hi[a], v);
+      }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const T v = vb[(size_t)i * 3 + a];
-      lo[a] = vox_nan_min<T>(lo[a], v);
-      hi[a] = vox_nan_max<T>(hi[a], v);
-    }
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      lo[a] = vox_nan_min<T>(lo[a], __shfl_xor(lo[a], d, 64));
-      hi[a] = vox_nan_max<T>(hi[a], __shfl_xor(hi[a], d, 64));
+      for (int d = 32; d >= 1; d >>= 1) {
+        lo[a] = vox_nan_min<T>(lo[a], __shfl_xor(lo[a], d, 64));
+        hi[a] = vox_nan_max<T>(hi[a], __shfl_xor(hi[a], d, 64));
+      }
+      if (lane == 0) {
+        s_lo[a][wave] = lo[a];
+        s_hi[a][wave] = hi[a];
+      }
     }
-    if (lane == 0) {
-      s_lo[a][wave] = lo[a];
-      s_hi[a][wave] = hi[a];
+    __syncthreads();
+    if (threadIdx.x < 3) {
+      const int a = threadIdx.x;
+      T l = s_lo[a][0], h = s_hi[a][0];
+      for (int w = 1; w < 4; ++w) {
+        l = vox_nan_min<T>(l, s_lo[a][w]);
+        h = vox_nan_max<T>(h, s_hi[a][w]);
+      }
+      T* o = part + (size_t)blockIdx.x * 6;
+      o[a] = l;
+      o[3 + a] = h;
     }
   }
-  __syncthreads();
-  if (threadIdx.x < 3) {
-    const int a = threadIdx.x;
-    T l = s_lo[a][0], h = s_hi[a][0];
-    for (int w = 1; w < 4; ++w) {
-      l = vox_nan_min<T>(l, s_lo[a][w]);
-      h = vox_nan_max<T>(h, s_hi[a][w]);
-    }
-    T* o = part + ((size_t)b * VOX_NP + blockIdx.x) * 6;
-    o[a] = l;
-    o[3 + a] = h;
-  }
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) grid16[i] = z;
 }
 // origin / scale of mesh b from the partials (re-derived by whoever needs them: 32 x 6 scalars from L2)
 template <typename T>
@@ -144,53 +155,80 @@ __device__ __forceinline__ void vox_norm_of(const T* __restrict__ part, const T*
   *sc = scale_in ? scale_in[b] : s;
 }
 
-// one thread per vertex: normalises it ((v - origin) / scale, two roundings as the reference's torch ops), keeps the
-// result for the face kernel and marks its voxel
+// origin / scale of the meshes a workgroup touches: wave w < 2 reduces the partials of mesh b0 + w (lane k = partial k)
+// into s_n[w]; a thread whose mesh is neither (tiny meshes, huge batches) derives its own
 template <typename T>
-__global__ __launch_bounds__(256) void vox_vertices_kernel(int V, int R, const T* __restrict__ vertices,
-                                                           const T* __restrict__ origin_in, const T* __restrict__ scale_in,
-                                                           const T* __restrict__ part, T* __restrict__ norm,
-                                                           T* __restrict__ nverts, T* __restrict__ grid) {
-  __shared__ T s_n[4];
-  const int b = blockIdx.y;
-  if (threadIdx.x == 0) {
-    T o[3], sc;
+__device__ __forceinline__ void vox_norm_cache(const T* __restrict__ part, const T* __restrict__ origin_in,
+                                               const T* __restrict__ scale_in, int B, int b0, T (*s_n)[4]) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wave < 2 && b0 + wave < B) {
+    const int b = b0 + wave;
+    const T* p = part + ((size_t)b * VOX_NP + (lane < VOX_NP ? lane : 0)) * 6;
+    T s = 0, o[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      T l = p[a], h = p[3 + a];
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        l = vox_nan_min<T>(l, __shfl_xor(l, d, 64));
+        h = vox_nan_max<T>(h, __shfl_xor(h, d, 64));
+      }
+      o[a] = origin_in ? origin_in[b * 3 + a] : l;
+      const T ext = h - o[a];
+      s = a == 0 ? ext : vox_nan_max<T>(s, ext);
+    }
+    if (lane == 0) {
+      s_n[wave][0] = o[0];
+      s_n[wave][1] = o[1];
+      s_n[wave][2] = o[2];
+      s_n[wave][3] = scale_in ? scale_in[b] : s;
+    }
+  }
+  __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void vox_mark_kernel(long long nvert, long long total, int B, int V, int F, int R, int L0,
+                                                       double thr_d, const T* __restrict__ vertices,
+                                                       const int64_t* __restrict__ faces, const T* __restrict__ origin_in,
+                                                       const T* __restrict__ scale_in, const T* __restrict__ part,
+                                                       T* __restrict__ norm, T* __restrict__ grid_all) {
+  __shared__ T s_n[2][4];
+  const long long gid0 = (long long)blockIdx.x * 256, gid = gid0 + threadIdx.x;
+  const unsigned int npath = 1u << (2 * L0);
+  // mesh of the workgroup's first thread
+  const int b0 = gid0 < nvert ? (int)(gid0 / V) : (int)((gid0 - nvert) / npath / F);
+  vox_norm_cache<T>(part, origin_in, scale_in, B, b0, s_n);
+  if (gid >= total) return;
+  const bool is_vertex = gid < nvert;
+  const long long bf = is_vertex ? 0 : (gid - nvert) / npath;
+  const int b = is_vertex ? (int)(gid / V) : (int)(bf / F);
+  T o[3], sc;
+  if (b == b0 || b == b0 + 1) {
+    o[0] = s_n[b - b0][0];
+    o[1] = s_n[b - b0][1];
+    o[2] = s_n[b - b0][2];
+    sc = s_n[b - b0][3];
+  } else {
     vox_norm_of<T>(part, origin_in, scale_in, b, o, &sc);
-    s_n[0] = o[0];
-    s_n[1] = o[1];
-    s_n[2] = o[2];
-    s_n[3] = sc;
-    if (blockIdx.x == 0) {
+  }
+  T* grid = grid_all + (size_t)b * R * R * R;
+  const T* vb = vertices + (size_t)b * V * 3;
+  if (is_vertex) {
+    // one thread per vertex: (v - origin) / scale, two roundings as the reference's torch ops
+    const int i = (int)(gid - (long long)b * V);
+    if (i == 0) {
       norm[b * 4 + 0] = o[0];
       norm[b * 4 + 1] = o[1];
       norm[b * 4 + 2] = o[2];
       norm[b * 4 + 3] = sc;
     }
+    vox_mark<T>(grid, R, (vb[(size_t)i * 3] - o[0]) / sc, (vb[(size_t)i * 3 + 1] - o[1]) / sc, (vb[(size_t)i * 3 + 2] - o[2]) / sc);
+    return;
   }
-  __syncthreads();
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= V) return;
-  const size_t g = ((size_t)b * V + i) * 3;
-  const T x = (vertices[g] - s_n[0]) / s_n[3], y = (vertices[g + 1] - s_n[1]) / s_n[3], z = (vertices[g + 2] - s_n[2]) / s_n[3];
-  nverts[g] = x;
-  nverts[g + 1] = y;
-  nverts[g + 2] = z;
-  vox_mark<T>(grid + (size_t)b * R * R * R, R, x, y, z);
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void vox_faces_kernel(long long total, int V, int F, int R, int L0, double thr_d,
-                                                        const T* __restrict__ vertices,
-                                                        const int64_t* __restrict__ faces, T* __restrict__ grid_all) {
-  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= total) return;
-  const unsigned int npath = 1u << (2 * L0);
-  const unsigned int path = (unsigned int)(gid % npath);
-  const long long bf = gid / npath;
-  const int f = (int)(bf % F), b = (int)(bf / F);
+  const unsigned int path = (unsigned int)((gid - nvert) % npath);
+  const int f = (int)(bf % F);
   const T thr = (T)thr_d;
-  T* grid = grid_all + (size_t)b * R * R * R;
-  const T* vb = vertices + (size_t)b * V * 3;
   // everything below stays in registers: a per-level stack indexed by the depth would live in scratch memory (it did:
   // 1.6 KB per thread, and the kernel ran at a fifth of its present speed)
   T cur[9], mid[9];
@@ -198,7 +236,7 @@ __global__ __launch_bounds__(256) void vox_faces_kernel(long long total, int V, 
   for (int k = 0; k < 3; ++k) {
     const int64_t vi = faces[(size_t)f * 3 + k];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) cur[k * 3 + i] = vb[vi * 3 + i];
+    for (int i = 0; i < 3; ++i) cur[k * 3 + i] = (vb[vi * 3 + i] - o[i]) / sc;
   }
   // descend the path prefix
   for (int l = 0; l < L0; ++l) {
@@ -250,26 +288,33 @@ template <typename T>
 int vox_launch(hipStream_t st, int B, int V, int F, int R, const T* vertices, const int64_t* faces, const T* origin,
                const T* scale, T* scratch, T* grid) {
   if (B <= 0 || R <= 1) return 0;
-  KAMD_CHECK(kamd_zero_async(grid, (size_t)B * R * R * R * sizeof(T), st));
   T* norm = scratch;
   T* part = scratch + (size_t)B * 4;
-  T* nverts = part + (size_t)B * VOX_NP * 6;
-  if (V > 0) {
+  const size_t bytes = (size_t)B * R * R * R * sizeof(T);
+  // torch's allocations are 512-byte aligned and bytes is a multiple of 16 for every R >= 2 with T = double; float grids of
+  // odd R leave a tail of < 16 bytes to the generic fill
+  const size_t n16 = ((uintptr_t)grid & 15) == 0 ? bytes / 16 : 0;
+  {
     kamd::ProfScope prof_(kamd::K_VOX_VERTICES, st);
-    hipLaunchKernelGGL(vox_extent_partial_kernel<T>, dim3(VOX_NP, B), dim3(256), 0, st, V, vertices, part);
-    hipLaunchKernelGGL(vox_vertices_kernel<T>, dim3(kamd_cdiv(V, 256), B), dim3(256), 0, st, V, R, vertices, origin, scale,
-                       (const T*)part, norm, nverts, grid);
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > (size_t)KAMD_NUM_CU * 16) blocks = (size_t)KAMD_NUM_CU * 16;
+    if (V > 0 && blocks < (size_t)B * VOX_NP) blocks = (size_t)B * VOX_NP;
+    if (blocks > 0)
+      hipLaunchKernelGGL(vox_clear_extent_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, B, V, vertices, part,
+                         (uint4*)grid, n16);
+    if (n16 * 16 < bytes) KAMD_CHECK(kamd_zero_async((char*)grid + n16 * 16, bytes - n16 * 16, st));
     KAMD_CHECK(hipGetLastError());
   }
-  if (F > 0 && V > 0) {
+  if (V > 0) {
     int L0 = 0;
-    while (L0 < VOX_MAXL0 && (long long)B * F * (1ll << (2 * L0)) < (1ll << 18)) ++L0;
-    const long long total = (long long)B * F * (1ll << (2 * L0));
+    while (F > 0 && L0 < VOX_MAXL0 && (long long)B * F * (1ll << (2 * L0)) < (1ll << 18)) ++L0;
+    const long long nvert = (long long)B * V;
+    const long long total = nvert + (long long)B * F * (1ll << (2 * L0));
     const double thr = ((double)(R - 1) / ((double)R * (double)R)) * ((double)(R - 1) / ((double)R * (double)R));
     {
       kamd::ProfScope prof_(kamd::K_VOX_FACES, st);
-      hipLaunchKernelGGL(vox_faces_kernel<T>, dim3(kamd_cdiv(total, 256)), dim3(256), 0, st, total, V, F, R, L0, thr,
-                         (const T*)nverts, faces, grid);
+      hipLaunchKernelGGL(vox_mark_kernel<T>, dim3(kamd_cdiv(total, 256)), dim3(256), 0, st, nvert, total, B, V, F > 0 ? F : 1,
+                         R, L0, thr, vertices, faces, origin, scale, (const T*)part, norm, grid);
     }
     KAMD_CHECK(hipGetLastError());
   }
@@ -281,7 +326,8 @@ int vox_launch(hipStream_t st, int B, int V, int F, int R, const T* vertices, co
 extern "C" {
 size_t kamd_trianglemeshes_to_voxelgrids_workspace(int B, int V, int elem_size) {
   if (B <= 0) return 0;
-  return ((size_t)B * 4 + (size_t)B * VOX_NP * 6 + (size_t)B * (V > 0 ? V : 0) * 3) * (size_t)elem_size;
+  (void)V;
+  return ((size_t)B * 4 + (size_t)B * VOX_NP * 6) * (size_t)elem_size;
 }
 int kamd_trianglemeshes_to_voxelgrids_f32(void* stream, int B, int V, int F, int R, const float* vertices,
                                           const int64_t* faces, const float* origin, const float* scale, float* norm,

@@ -77,28 +77,39 @@ class _SidedDistancePairFunction(torch.autograd.Function):
 
 
 class _ChamferDistanceFunction(torch.autograd.Function):
-    """The whole of ``chamfer_distance`` as one autograd node for fp32 clouds on the GPU: one search pipeline for both
-    directions, the reference's expression for the value, and one kernel for the gradient of both clouds
+    """The whole of ``chamfer_distance`` as one autograd node for fp32 clouds on the GPU.  Large clouds: one operator
+    (``_C.metrics.chamfer_distance_forward``: workspace fill + grid build + search; the search launch also reduces the
+    two means and, when a gradient will be wanted, leaves d value / d points in the state) and a one-launch backward.
+    Smaller clouds: the two searches, the reference's expression for the value and one gradient kernel for both clouds
     (``_C.metrics.chamfer_distance_backward``) instead of a chain of ~10 small autograd nodes."""
 
     @staticmethod
     def forward(ctx, p1, p2, w1, w2, squared):
         a, b = p1.contiguous(), p2.contiguous()
-        both = _C.metrics.sided_distance_pair_forward(a, b)
-        if both is None:
-            dist1, near1 = _C.metrics.sided_distance_forward_cuda(a, b)
-            dist2, near2 = _C.metrics.sided_distance_forward_cuda(b, a)
-        else:
-            dist1, near1, dist2, near2 = both
+        ctx.set_materialize_grads(False)
+        with_grad = p1.requires_grad or p2.requires_grad
+        fused = _C.metrics.chamfer_distance_forward(a, b, w1, w2, squared, with_grad)
+        if fused is not None:
+            value, state = fused
+            ctx.fused_shape = (a.shape[0], a.shape[1], b.shape[1])
+            if with_grad:
+                ctx.save_for_backward(state)
+            return value
+        ctx.fused_shape = None
+        dist1, near1 = _C.metrics.sided_distance_forward_cuda(a, b)
+        dist2, near2 = _C.metrics.sided_distance_forward_cuda(b, a)
         ctx.save_for_backward(a, b, near1, near2, dist1, dist2)
         ctx.weights, ctx.squared = (w1, w2), squared
-        ctx.set_materialize_grads(False)
         return _chamfer_value(dist1, dist2, w1, w2, squared)
 
     @staticmethod
     def backward(ctx, grad):
         if grad is None:
             return None, None, None, None, None
+        if ctx.fused_shape is not None:
+            state, = ctx.saved_tensors
+            grad_a, grad_b = _C.metrics.chamfer_distance_backward_fused(grad.contiguous(), state, *ctx.fused_shape)
+            return grad_a, grad_b, None, None, None
         a, b, near1, near2, dist1, dist2 = ctx.saved_tensors
         grad_a, grad_b = _C.metrics.chamfer_distance_backward(grad.contiguous(), ctx.weights[0], ctx.weights[1],
                                                               ctx.squared, a, b, near1, near2, dist1, dist2)

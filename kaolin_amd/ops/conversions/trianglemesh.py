@@ -48,6 +48,11 @@ def trianglemeshes_to_voxelgrids(vertices, faces, resolution, origin=None, scale
 
     Returns:
         (torch.Tensor): binary voxelgrids (B, R, R, R) in the dtype of ``vertices``.
+
+    Note:
+        The GPU path subdivides a triangle at most ``L0 + 20`` times (``L0 <= 10`` levels are spread over threads), i.e.
+        it is exact for normalised edges up to about ``2**20 / resolution`` -- a mesh thousands of times larger than the
+        grid, which only a caller-supplied ``scale`` can produce.  Faces must index existing vertices (``IndexError``).
     """
     if not isinstance(resolution, int):
         raise TypeError(f"Expected resolution to be int "

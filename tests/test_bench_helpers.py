@@ -20,18 +20,20 @@ def test_dominant_kernel_is_the_largest_share_with_a_byte_count():
 
 
 def test_near_ties_go_to_a_kernel_that_is_alone_on_the_stream():
-    kernels = {'raster_tile_kernel': _k(0.1567), 'soft_search_kernel': _k(0.1547), 'soft_classify_kernel': _k(0.07)}
-    assert bench.pick_dominant(kernels) == 'soft_search_kernel'
-    kernels['soft_search_kernel'] = _k(0.14)                     # more than 5 % behind: no tie any more
-    assert bench.pick_dominant(kernels) == 'raster_tile_kernel'
-    only_overlapped = {'raster_tile_kernel': _k(0.2), 'raster_backward_kernel': _k(0.199)}
-    assert bench.pick_dominant(only_overlapped) == 'raster_tile_kernel'
+    # the two backward kernels overlap (side stream): a kernel that runs alone wins a near tie
+    kernels = {'raster_backward_kernel': _k(0.1567), 'soft_select_kernel': _k(0.1547), 'soft_eval_kernel': _k(0.07)}
+    assert bench.pick_dominant(kernels) == 'soft_select_kernel'
+    kernels['soft_select_kernel'] = _k(0.14)                     # more than 5 % behind: no tie any more
+    assert bench.pick_dominant(kernels) == 'raster_backward_kernel'
+    only_overlapped = {'soft_mask_backward_list_kernel': _k(0.2), 'raster_backward_kernel': _k(0.199)}
+    assert bench.pick_dominant(only_overlapped) == 'soft_mask_backward_list_kernel'
 
 
 def test_algorithmic_bytes_follow_the_survey_per_unit_figures():
     """SURVEY 8(d) per-unit figures x the units one launch processes: spot values at C4."""
     B, P, F, Fv = 8, 1024 * 1024, 50000, 25000
-    assert bench.algorithmic_bytes('soft_search_kernel', B, P, F, Fv, 3, 30) == B * (P * 12 + F * 40)
-    assert bench.algorithmic_bytes('soft_classify_kernel', B, P, F, Fv, 3, 30) == B * P * 12
+    assert bench.algorithmic_bytes('raster_tile_kernel', B, P, F, Fv, 3, 30) == B * (P * 32 + Fv * 88)
+    assert bench.algorithmic_bytes('soft_select_kernel', B, P, F, Fv, 3, 30) == B * (P * 8 + F * 40)
+    assert bench.algorithmic_bytes('soft_eval_kernel', B, P, F, Fv, 3, 30) == B * P * 4
     assert bench.algorithmic_bytes('fill_regions_kernel', B, P, F, Fv, 3, 30) == B * P * 30 * 13
     assert bench.algorithmic_bytes('pv_forward_kernel', B, P, F, Fv, 3, 30) is None
