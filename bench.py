@@ -309,9 +309,24 @@ def main():
         fv = v1[0][faces].unsqueeze(0).contiguous()
         q = (torch.rand((1, 1000000, 3), generator=torch.Generator().manual_seed(0)) * 1.2 - 0.6).to(dev)
         p2m_ms = per_call_ms(lambda: kal.metrics.trianglemesh.point_to_mesh_distance(q, fv), 3)
+        lib.kamd_profile_reset()
+        lib.kamd_profile_enable(1)                 # kernel durations of both: a separate, instrumented pass
+        for _ in range(5):
+            kal.ops.conversions.trianglemeshes_to_voxelgrids(v1, faces, 256)
+        kal.metrics.trianglemesh.point_to_mesh_distance(q, fv)
+        torch.cuda.synchronize()
+        lib.kamd_profile_enable(0)
+        kprof = {k: round(v[0] / v[1] * 1e3, 1) for k, v in _lib.kernel_profile(reset=True).items()}
+        vox_kernels = {k: v for k, v in kprof.items() if k.startswith('vox')}
         c5 = {'voxelgrid_256_us': round(vox_ms * 1e3, 1), 'voxelgrid_write_GBps': round(256 ** 3 * 4 / (vox_ms * 1e-3) / 1e9, 1),
+              'voxelgrid_kernels_avg_us': vox_kernels,
+              'voxelgrid_kernels_sum_frac_of_write_bound': round(256 ** 3 * 4 / 8e12 * 1e6 / max(sum(vox_kernels.values()), 1e-3), 3),
               'point_to_mesh_1Mx50k_ms': round(p2m_ms, 3),
-              'point_to_mesh_Gpairs_per_s': round(1e6 * F / (p2m_ms * 1e-3) / 1e9, 1)}
+              'point_to_mesh_kernels_avg_us': {k: v for k, v in kprof.items() if k.startswith('td_')},
+              'point_to_mesh_Gpairs_per_s': round(1e6 * F / (p2m_ms * 1e-3) / 1e9, 1),
+              # the all-pairs kernel issues 11 VALU lane-ops per (point, face) sphere test at 58 T lane-ops/s measured
+              # (profiles/r01_ubench_valu.txt): > 1 means the exact search evaluated that much less than all pairs
+              'point_to_mesh_allpairs_equiv_valu_frac': round(11.0 * 1e6 * F / (p2m_ms * 1e-3) / 58e12, 3)}
         # deftet_sparse_render fwd+bwd, view 0 of the same mesh, knum 30, free pixel coordinates
         with torch.no_grad():
             d_cam, d_img, _ = kal.render.mesh.prepare_vertices(
