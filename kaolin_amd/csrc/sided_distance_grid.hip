@@ -134,9 +134,8 @@ inline SdgWs sdg_layout(void* base, int B, int N, int M, const float* p1, const 
 // a few hundred thousand points: as four launches they cost more in launch gaps and host time than in work (36 us for
 // ~10 us of memory traffic at 100k + 100k points).  They are phases of one kernel whose workgroups are all resident
 // (grid <= the CU count, 512 threads each: a quarter of a CU's wave slots, so several such kernels can share the GPU
-// without starving each other) and meet at a grid barrier between phases: every thread publishes its stores
-// (__threadfence = release at agent scope: L2 write-back across XCDs), thread 0 of each workgroup arrives on one counter
-// and spins until all have, then acquires.
+// without starving each other) and meet at a grid barrier between phases: every wave waits for its own memory operations,
+// thread 0 of each workgroup arrives on one counter and spins until all have.
 
 // order-preserving float -> uint (negative values reversed below the positives); atomicMax on it is a float max, on
 // its complement a float min, and the all-zero word the workspace fill leaves is below every encoded value
@@ -148,23 +147,32 @@ __device__ __forceinline__ float sdg_unord(unsigned int o) {
   return __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 }
 
+// Data that crosses workgroups between phases (box words, cell counts, cell starts, scan totals) is written and read with
+// agent-scope relaxed atomics: on gfx950 those are write-through / cache-bypassing accesses (sc1), coherent across the
+// XCDs' L2s without any L2 write-back or invalidate.  A release / acquire fence at agent scope instead costs an L2
+// write-back per workgroup per barrier: the first version of this kernel, with fences, took 214 us for ~10 us of work.
+template <typename V>
+__device__ __forceinline__ V sdg_ld(const V* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename V>
+__device__ __forceinline__ void sdg_st(V* p, V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __device__ __forceinline__ void sdg_grid_barrier(unsigned int* counter, unsigned int target) {
-  __threadfence();
+  __builtin_amdgcn_s_waitcnt(0);  // this wave's stores and atomics have been performed
   __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
-    __threadfence();
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
   }
   __syncthreads();
 }
 
 // the grid geometry every consumer derives from the six words (same rules as grid_common.h's sdg_box)
-__device__ __forceinline__ Box sdg_box_decode(const unsigned int* __restrict__ w, int G) {
+template <bool COHERENT = false>
+__device__ __forceinline__ Box sdg_box_decode(const unsigned int* w, int G) {
   Box bx;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    const unsigned int ulo = w[a], uhi = w[3 + a];
+    const unsigned int ulo = COHERENT ? sdg_ld(w + a) : w[a], uhi = COHERENT ? sdg_ld(w + 3 + a) : w[3 + a];
     float lo = 0.f, hi = 0.f;  // no finite point on this axis
     if (ulo != 0u && uhi != 0u) {
       lo = sdg_unord(~ulo);
@@ -180,9 +188,8 @@ __device__ __forceinline__ Box sdg_box_decode(const unsigned int* __restrict__ w
 }
 
 // X = the targets' cloud, Y = the other one; own_box_y: Y is binned on its own box (chamfer), else on X's (sided_distance)
-__global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(Cloud X, Cloud Y, int B, int own_box_y, int* __restrict__ sums,
-                                                               int scan_blocks, int two_level,
-                                                               unsigned int* __restrict__ barrier) {
+__global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(Cloud X, Cloud Y, int B, int own_box_y, int* sums, int scan_blocks,
+                                                               int two_level, unsigned int* barrier) {
   __shared__ float s_red[6][SDG_BUILD_THREADS / 64];
   __shared__ int s_wave[SDG_BUILD_THREADS / 64];
   __shared__ int s_off;
@@ -253,7 +260,7 @@ __global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(Cloud X, Cloud Y,
     const bool first = i < X.n;
     if (!first) i -= X.n;
     const int n = first ? X.n : Y.n, G = first ? X.G : Y.G;
-    const Box bx = sdg_box_decode((first ? X.box : Y.box) + (size_t)b * 8, G);
+    const Box bx = sdg_box_decode<true>((first ? X.box : Y.box) + (size_t)b * 8, G);
     const float* Pt = (first ? X.pts : Y.pts) + ((size_t)b * n + i) * 3;
     const int cx = sdg_axis_cell(Pt[0], bx.lo[0], bx.inv[0], G);
     const int cy = sdg_axis_cell(Pt[1], bx.lo[1], bx.inv[1], G);
@@ -280,8 +287,8 @@ __global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(Cloud X, Cloud Y,
       const int* cnt = (first ? X.count : Y.count) + (size_t)b * NC;
       const int i = base + tid;
       __syncthreads();
-      const int tot = sdg_block_inclusive(i < NC ? cnt[i] : 0, s_wave);
-      if (tid == SDG_BUILD_THREADS - 1) sums[((size_t)z * B + b) * scan_blocks + blk] = tot;
+      const int tot = sdg_block_inclusive(i < NC ? sdg_ld(cnt + i) : 0, s_wave);
+      if (tid == SDG_BUILD_THREADS - 1) sdg_st(sums + ((size_t)z * B + b) * scan_blocks + blk, tot);
     }
     arrivals += nwg;
     sdg_grid_barrier(barrier, arrivals);
@@ -297,9 +304,9 @@ __global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(Cloud X, Cloud Y,
     int part = 0;
     if (two_level) {
       const int* my = sums + ((size_t)z * B + b) * scan_blocks;
-      for (int k = tid; k < blk; k += SDG_BUILD_THREADS) part += my[k];
+      for (int k = tid; k < blk; k += SDG_BUILD_THREADS) part += sdg_ld(my + k);
     } else {
-      for (int k = tid; k < base; k += SDG_BUILD_THREADS) part += cnt[k];
+      for (int k = tid; k < base; k += SDG_BUILD_THREADS) part += sdg_ld(cnt + k);
     }
     __syncthreads();  // s_wave / s_off of the previous unit have been read
     const int before = sdg_block_inclusive(part, s_wave);
@@ -307,11 +314,11 @@ __global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(Cloud X, Cloud Y,
     __syncthreads();
     const int off = s_off;
     const int i = base + tid;
-    const int v = i < NC ? cnt[i] : 0;
+    const int v = i < NC ? sdg_ld(cnt + i) : 0;
     __syncthreads();
     const int inc = sdg_block_inclusive(v, s_wave);
-    if (i < NC) start[i] = off + inc - v;
-    if (i == NC - 1) start[NC] = off + inc;
+    if (i < NC) sdg_st(start + i, off + inc - v);
+    if (i == NC - 1) sdg_st(start + NC, off + inc);
   }
   arrivals += nwg;
   sdg_grid_barrier(barrier, arrivals);
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(Cloud X, Cloud Y,
     if (!first) i -= X.n;
     const int n = first ? X.n : Y.n, G = first ? X.G : Y.G;
     const int2 cr = (first ? X.cellrank : Y.cellrank)[(size_t)b * n + i];
-    const int pos = (first ? X.start : Y.start)[(size_t)b * ((size_t)G * G * G + 1) + cr.x] + cr.y;
+    const int pos = sdg_ld((first ? X.start : Y.start) + (size_t)b * ((size_t)G * G * G + 1) + cr.x) + cr.y;
     const float* Pt = (first ? X.pts : Y.pts) + ((size_t)b * n + i) * 3;
     (first ? X.sorted : Y.sorted)[(size_t)b * n + pos] = make_float4(Pt[0], Pt[1], Pt[2], __int_as_float(i));
   }
@@ -496,14 +503,19 @@ __global__ __launch_bounds__(256) void sdg_query(Cloud A, Cloud T, float* __rest
     if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = term;
     __syncthreads();
     if (threadIdx.x == 0) {
-      if (!idle) kamd_atomic_add(fz.sums + (size_t)b * 2 + (fwd ? 0 : 1), (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]));
-      __threadfence();
+      // two device-scope atomics in program order, no fence (an agent-scope release would write back this XCD's L2 once per
+      // workgroup): the sum's RETURNING form has been performed when its value arrives, and the ticket is issued after it
+      unsigned int one = 1u;
+      if (!idle) {
+        const double old = __hip_atomic_fetch_add(fz.sums + (size_t)b * 2 + (fwd ? 0 : 1), (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]),
+                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" : "+v"(one) : "v"(old));
+      }
       const unsigned int total = gridDim.x * gridDim.y * gridDim.z;
-      s_last = __hip_atomic_fetch_add(fz.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == total - 1;
+      s_last = __hip_atomic_fetch_add(fz.done, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1;
     }
     __syncthreads();
     if (s_last) {
-      __threadfence();
       for (int i = threadIdx.x; i < (int)gridDim.y; i += 256) {
         const double s1 = __hip_atomic_load(fz.sums + (size_t)i * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const double s2 = __hip_atomic_load(fz.sums + (size_t)i * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
