@@ -3,10 +3,8 @@
 #include "tile_lists.h"
 
 namespace kamd {
-// rasterize.hip: the rasterizer's tile kernel with the soft mask's classification attached (fused dibr_rasterization);
-// bg_prefilled: the outputs already hold the background values, tiles without faces store nothing
+// rasterize.hip: the rasterizer's tile kernel with the soft mask's classification attached (fused dibr_rasterization)
 template <typename T>
 int raster2_draw(hipStream_t st, int B, int H, int W, int D, int F_dense, float multiplier, float eps, const T* rec,
-                 const tl::Lists& LR, const T* feat, T* interp, int64_t* sel_idx, T* weights, const tl::ClassifyOut& co,
-                 bool bg_prefilled);
+                 const tl::Lists& LR, const T* feat, T* interp, int64_t* sel_idx, T* weights, const tl::ClassifyOut& co);
 }  // namespace kamd

@@ -419,53 +419,10 @@ int soft_mask_backward_launch(hipStream_t st, int B, int H, int W, int F, int K,
   KAMD_RETURN_LAST_ERROR();
 }
 
-// ---- library-owned side stream ------------------------------------------------------------------------------------------
-// Forward: the background values of every output (85 % of the pixels at C4) are written by a fill launch on the side stream
-// while the binning launch -- atomic-latency-bound, little HBM traffic -- runs on the caller's.  Backward: the rasterizer's
-// and the soft mask's kernels are independent and both accumulate atomically into the same zero-initialised g_img: they run
-// concurrently, the soft mask's on the side stream.
-struct SideStream {
-  hipStream_t s = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-};
-std::mutex g_side_mu;
-SideStream g_side[16];
-// the side stream / events of the current device (created on first use); the caller holds g_side_mu while enqueuing
-int side_stream(SideStream** out) {
-  int dev = 0;
-  KAMD_CHECK(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 16) return (int)hipErrorInvalidDevice;
-  SideStream& ss = g_side[dev];
-  if (ss.s == nullptr) {
-    KAMD_CHECK(hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking));
-    KAMD_CHECK(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
-    KAMD_CHECK(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));
-  }
-  *out = &ss;
-  return 0;
-}
-
-// four 16-byte-aligned ranges in one launch: the first takes `v0`, the others zero
-__global__ __launch_bounds__(256) void bg_fill_kernel(uint4* __restrict__ p0, size_t n0, uint4 v0, uint4* __restrict__ p1, size_t n1,
-                                                      uint4* __restrict__ p2, size_t n2, uint4* __restrict__ p3, size_t n3) {
-  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-  const size_t total = n0 + n1 + n2 + n3, stride = (size_t)gridDim.x * 256;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
-    if (i < n0)
-      p0[i] = v0;
-    else if (i < n0 + n1)
-      p1[i - n0] = z;
-    else if (i < n0 + n1 + n2)
-      p2[i - n0 - n1] = z;
-    else
-      p3[i - n0 - n1 - n2] = z;
-  }
-}
-
 // ---- fused DIB-R front door: rasterize (front faces) + soft mask (all faces) in one call ------------------------------------
-// One binning launch serves both passes (the vertices are read once); the rasterizer's tile kernel classifies the pixels for
-// the soft mask and queues the search's work items, so the forward is: clear the list heads, bin (with the background fill
-// of the outputs beside it on the side stream), raster tiles, select, evaluate.
+// One binning launch per phase serves both passes (the vertices are read once); the rasterizer's tile kernel classifies
+// the pixels for the soft mask and queues the search's work items, so the forward is: clear counters, count, scan, emit,
+// raster tiles, search -- six launches on the caller's stream, no side stream.
 template <typename T>
 int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K, const T* z, int64_t z_face_stride,
                        int64_t z_vertex_stride, const T* img, const T* feat, const uint8_t* valid, const T* front,
@@ -481,38 +438,9 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
   tl::Lists LS = tl::lists_of(workspace, lay.s, B, true);
   T* rec_r = (T*)((char*)workspace + lay.r.rec);
   T* rec_s = (T*)((char*)workspace + lay.s.rec);
-  // background prefill (see SideStream): needs whole 16-byte chunks
-  const size_t P = (size_t)B * H * W;
-  const bool prefill = total_faces > 0 && P % 4 == 0 && kamd_env_int("KAMD_DIBR_PREFILL", 1) != 2 &&
-                       (((uintptr_t)interp | (uintptr_t)face_idx | (uintptr_t)weights | (uintptr_t)soft_mask) & 15) == 0;
-  std::unique_lock<std::mutex> lk(g_side_mu, std::defer_lock);
-  SideStream* ss = nullptr;
-  if (prefill) {
-    lk.lock();
-    KAMD_CHECK(side_stream(&ss));
-    // (while the profiler times EVERY kernel everything stays on `st`, so that each kernel's event pair times that kernel alone)
-    const hipStream_t side = kamd::prof_all() ? st : ss->s;
-    KAMD_CHECK(hipEventRecord(ss->fork, st));
-    KAMD_CHECK(hipStreamWaitEvent(side, ss->fork, 0));
-    {
-      kamd::ProfScope prof_(kamd::K_MEMSET, side);
-      const size_t n0 = P * 8 / 16, n1 = P * 3 * sizeof(T) / 16, n2 = P * D * sizeof(T) / 16, n3 = P * sizeof(T) / 16;
-      size_t blocks = (n0 + n1 + n2 + n3 + 255) / 256;
-      if (blocks > (size_t)KAMD_NUM_CU * 8) blocks = (size_t)KAMD_NUM_CU * 8;
-      hipLaunchKernelGGL(bg_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, side, (uint4*)face_idx, n0,
-                         make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu), (uint4*)weights, n1, (uint4*)interp, n2,
-                         (uint4*)soft_mask, n3);
-    }
-    // after the fork every exit goes through the join: the caller may free the buffers as soon as this returns
-    const int rc_join = (int)hipEventRecord(ss->join, side);
-    if (rc_join != 0) {
-      (void)hipStreamSynchronize(side);
-      return rc_join;
-    }
-  }
-  int rc = kamd_zero_async(workspace, lay.zero_bytes, st);
-  if (rc == 0) rc = kamd_zero_async(work, tl::WORK_HEADER * 4, st);
-  if (rc == 0 && total_faces > 0) {
+  KAMD_CHECK(kamd_zero_async(workspace, lay.zero_bytes, st));
+  KAMD_CHECK(kamd_zero_async(work, tl::WORK_HEADER * 4, st));
+  if (total_faces > 0) {
     tl::BinIn<T> in{};
     in.B = B;
     in.F = F;
@@ -532,13 +460,7 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
     kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
     hipLaunchKernelGGL((tl::bin_faces_kernel2<T, true, true>), dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, in, LR, LS);
   }
-  if (rc == 0) rc = (int)hipGetLastError();
-  if (prefill) {
-    const int rc_wait = (int)hipStreamWaitEvent(st, ss->join, 0);
-    if (rc == 0) rc = rc_wait;
-    lk.unlock();
-  }
-  if (rc != 0) return rc;
+  KAMD_CHECK(hipGetLastError());
   tl::ClassifyOut co{};
   co.soft_mask = soft_mask;
   co.sub_touched = LS.sub_touched;
@@ -548,14 +470,36 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
   co.work_items = reinterpret_cast<uint4*>(work + tl::WORK_HEADER);
   co.work_counts = work;
   co.shard_cap = tl::work_shard_cap(B, H, W);
-  KAMD_CHECK(kamd::raster2_draw<T>(st, B, H, W, D, F, (float)multiplier, eps, rec_r, LR, feat, interp, face_idx, weights, co,
-                                   prefill));
+  KAMD_CHECK(kamd::raster2_draw<T>(st, B, H, W, D, F, (float)multiplier, eps, rec_r, LR, feat, interp, face_idx, weights, co));
   if (total_faces > 0)
     KAMD_CHECK(soft2_search_launch<T>(st, B, H, W, F, K, sigmainv, (float)multiplier, rec_s, LS, work, soft_mask, (T*)nullptr,
                                       (int64_t*)nullptr, (uint8_t*)nullptr, (uint8_t*)nullptr, &list,
                                       (unsigned short*)((char*)workspace + lay.s.pixcnt),
                                       (T*)((char*)workspace + lay.s.prob_pm)));
   KAMD_RETURN_LAST_ERROR();
+}
+
+// the rasterizer's and the soft mask's backward kernels are independent and both accumulate atomically into the same
+// zero-initialised g_img: they run concurrently, the soft mask's on a library-owned side stream
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+std::mutex g_side_mu;
+SideStream g_side[16];
+// the side stream / events of the current device (created on first use); the caller holds g_side_mu while enqueuing
+int side_stream(SideStream** out) {
+  int dev = 0;
+  KAMD_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return (int)hipErrorInvalidDevice;
+  SideStream& ss = g_side[dev];
+  if (ss.s == nullptr) {
+    KAMD_CHECK(hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking));
+    KAMD_CHECK(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
+    KAMD_CHECK(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));
+  }
+  *out = &ss;
+  return 0;
 }
 
 template <typename T>

@@ -10,8 +10,7 @@
 //     1. bounding box of the finite targets (per batch item): workgroup minima / maxima merged with integer atomicMax on
 //        an order-preserving encoding, so that consumers read six words;
 //     2. cell id of every point and its rank inside the cell (the value the counting atomicAdd returns);
-//     3. exclusive scan of the cell counts (every 512-cell block sums the counts before it; a per-block-totals phase
-//        first on grids of more than 320 blocks);
+//     3. exclusive scan of the cell counts (per-block totals, then every 512-cell block adds up the totals before it);
 //     4. counting sort without further atomics: point -> start[cell] + rank, stored as float4 {x, y, z, original index};
 //   sdg_query  per query: seed with target 0 exactly as the reference does, then visit the cube of cells around
 //                    the query ring by ring; after each ring every unvisited target is provably farther than the
@@ -58,7 +57,7 @@ struct Cloud {
 // what chamfer_distance adds to the search (SDG_VALUE / SDG_GRAD): everything the value and the gradient need is
 // produced by the query launch itself
 struct Fuse {
-  double* sums;         // (B, 2) sum_i f(dist1_i), sum_j f(dist2_j); zero before the query
+  double* sums;         // (2, B, query workgroups per item and direction) partial sums of f(dist): plain stores, no init
   unsigned int* done;   // query workgroups finished; zero before the query
   float* out;           // (B) chamfer value, written by the last workgroup
   float* own_a;         // (B, N, 3) d value / d p1_i through p1_i's own nearest-point term (plain stores)
@@ -80,6 +79,8 @@ struct SdgWs {
   size_t total;
 };
 constexpr int SDG_BUILD_THREADS = 512;  // workgroup of the build kernel = cells per scan block
+// query workgroups of a chamfer launch at most (each leaves one partial sum)
+inline size_t sdg_partials(int B) { return (size_t)2 * B > 8192 ? (size_t)2 * B : 8192; }
 
 // pair = false: sided_distance(p1, p2): both clouds on p2's grid.  pair = true: each cloud on its own grid.
 inline SdgWs sdg_layout(void* base, int B, int N, int M, const float* p1, const float* p2, bool pair, int mode) {
@@ -104,15 +105,13 @@ inline SdgWs sdg_layout(void* base, int B, int N, int M, const float* p1, const 
   w.a.box = pair ? (unsigned int*)take((size_t)B * 8 * 4) : w.b.box;
   w.barrier = (unsigned int*)take(64);
   w.fuse = Fuse{};
-  if (mode >= SDG_VALUE) {
-    w.fuse.sums = (double*)take((size_t)B * 2 * 8);
-    w.fuse.done = (unsigned int*)take(64);
-  }
+  if (mode >= SDG_VALUE) w.fuse.done = (unsigned int*)take(64);
   if (mode >= SDG_GRAD) {
     w.fuse.scat_a = (float*)take((size_t)B * N * 12);
     w.fuse.scat_b = (float*)take((size_t)B * M * 12);
   }
   w.zero_bytes = off;
+  if (mode >= SDG_VALUE) w.fuse.sums = (double*)take(sdg_partials(B) * 8);
   if (mode >= SDG_GRAD) {
     w.fuse.own_a = (float*)take((size_t)B * N * 12);
     w.fuse.own_b = (float*)take((size_t)B * M * 12);
@@ -156,12 +155,15 @@ __device__ __forceinline__ V sdg_ld(const V* p) { return __hip_atomic_load(p, __
 template <typename V>
 __device__ __forceinline__ void sdg_st(V* p, V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__device__ __forceinline__ void sdg_grid_barrier(unsigned int* counter, unsigned int target) {
+__device__ __forceinline__ void sdg_grid_barrier(unsigned int* counter, unsigned int target, int naps) {
   __builtin_amdgcn_s_waitcnt(0);  // this wave's stores and atomics have been performed
   __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    // every poll is a coherent load of ONE address: hundreds of workgroups polling back to back queue up on its memory
+    // channel, in front of the arrivals they are waiting for -- nap between polls
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+      for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(8);
   }
   __syncthreads();
 }
@@ -189,7 +191,7 @@ __device__ __forceinline__ Box sdg_box_decode(const unsigned int* w, int G) {
 
 // X = the targets' cloud, Y = the other one; own_box_y: Y is binned on its own box (chamfer), else on X's (sided_distance)
 __global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(Cloud X, Cloud Y, int B, int own_box_y, int* sums, int scan_blocks,
-                                                               int two_level, unsigned int* barrier) {
+                                                               unsigned int* barrier, int naps) {
   __shared__ float s_red[6][SDG_BUILD_THREADS / 64];
   __shared__ int s_wave[SDG_BUILD_THREADS / 64];
   __shared__ int s_off;
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(Cloud X, Cloud Y,
     }
   }
   arrivals += nwg;
-  sdg_grid_barrier(barrier, arrivals);
+  sdg_grid_barrier(barrier, arrivals, naps);
 
   // ---- phase 2: cell id + rank inside the cell (the value the counting atomicAdd returns)
   const long long per_b = (long long)X.n + Y.n, total = per_b * B;
@@ -270,29 +272,27 @@ __global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(Cloud X, Cloud Y,
     (first ? X.cellrank : Y.cellrank)[(size_t)b * n + i] = make_int2(c, rank);
   }
   arrivals += nwg;
-  sdg_grid_barrier(barrier, arrivals);
+  sdg_grid_barrier(barrier, arrivals, naps);
 
-  // ---- phase 3: exclusive scan of the counts: start[c] = points in cells < c, start[NC] = n.  A unit = (cloud, batch
-  // item, block of SDG_BUILD_THREADS cells); it first needs the number of points before its block.  Small grids: it adds
-  // up the raw counts before it (block k reads k * 2 KB from L2) -- no inter-block dependency.  Large grids would make
-  // that quadratic read matter, so a first phase leaves per-block totals and the blocks add up those.
+  // ---- phase 3: exclusive scan of the counts: start[c] = points in cells < c, start[NC] = n.  A unit = (cloud, batch item,
+  // block of SDG_BUILD_THREADS cells).  3a leaves every block's total, 3b adds up the totals before its block and scans it:
+  // one or two coherent loads per thread in either phase (adding up the raw counts before a block instead would save the
+  // barrier but costs block-index dependent coherent loads per thread, which the hardware does not pipeline: 40 us).
   const int units3 = 2 * B * scan_blocks;
-  if (two_level) {
-    for (int u = wg; u < units3; u += nwg) {
-      const int z = u / (B * scan_blocks), b = (u / scan_blocks) % B, blk = u % scan_blocks;
-      const bool first = z == 0;
-      const int G = first ? X.G : Y.G, NC = G * G * G;
-      const int base = blk * SDG_BUILD_THREADS;
-      if (base >= NC || (first ? X.n : Y.n) == 0) continue;
-      const int* cnt = (first ? X.count : Y.count) + (size_t)b * NC;
-      const int i = base + tid;
-      __syncthreads();
-      const int tot = sdg_block_inclusive(i < NC ? sdg_ld(cnt + i) : 0, s_wave);
-      if (tid == SDG_BUILD_THREADS - 1) sdg_st(sums + ((size_t)z * B + b) * scan_blocks + blk, tot);
-    }
-    arrivals += nwg;
-    sdg_grid_barrier(barrier, arrivals);
+  for (int u = wg; u < units3; u += nwg) {
+    const int z = u / (B * scan_blocks), b = (u / scan_blocks) % B, blk = u % scan_blocks;
+    const bool first = z == 0;
+    const int G = first ? X.G : Y.G, NC = G * G * G;
+    const int base = blk * SDG_BUILD_THREADS;
+    if (base >= NC || (first ? X.n : Y.n) == 0) continue;
+    const int* cnt = (first ? X.count : Y.count) + (size_t)b * NC;
+    const int i = base + tid;
+    __syncthreads();
+    const int tot = sdg_block_inclusive(i < NC ? sdg_ld(cnt + i) : 0, s_wave);
+    if (tid == SDG_BUILD_THREADS - 1) sdg_st(sums + ((size_t)z * B + b) * scan_blocks + blk, tot);
   }
+  arrivals += nwg;
+  sdg_grid_barrier(barrier, arrivals, naps);
   for (int u = wg; u < units3; u += nwg) {
     const int z = u / (B * scan_blocks), b = (u / scan_blocks) % B, blk = u % scan_blocks;
     const bool first = z == 0;
@@ -301,27 +301,22 @@ __global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(Cloud X, Cloud Y,
     if (base >= NC || (first ? X.n : Y.n) == 0) continue;
     const int* cnt = (first ? X.count : Y.count) + (size_t)b * NC;
     int* start = (first ? X.start : Y.start) + (size_t)b * (NC + 1);
+    const int* my = sums + ((size_t)z * B + b) * scan_blocks;
     int part = 0;
-    if (two_level) {
-      const int* my = sums + ((size_t)z * B + b) * scan_blocks;
-      for (int k = tid; k < blk; k += SDG_BUILD_THREADS) part += sdg_ld(my + k);
-    } else {
-      for (int k = tid; k < base; k += SDG_BUILD_THREADS) part += sdg_ld(cnt + k);
-    }
+    for (int k = tid; k < blk; k += SDG_BUILD_THREADS) part += sdg_ld(my + k);
+    const int i = base + tid;
+    const int v = i < NC ? sdg_ld(cnt + i) : 0;
     __syncthreads();  // s_wave / s_off of the previous unit have been read
     const int before = sdg_block_inclusive(part, s_wave);
     if (tid == SDG_BUILD_THREADS - 1) s_off = before;
     __syncthreads();
     const int off = s_off;
-    const int i = base + tid;
-    const int v = i < NC ? sdg_ld(cnt + i) : 0;
-    __syncthreads();
     const int inc = sdg_block_inclusive(v, s_wave);
     if (i < NC) sdg_st(start + i, off + inc - v);
     if (i == NC - 1) sdg_st(start + NC, off + inc);
   }
   arrivals += nwg;
-  sdg_grid_barrier(barrier, arrivals);
+  sdg_grid_barrier(barrier, arrivals, naps);
 
   // ---- phase 4: counting-sort scatter without further atomics: point -> start[cell] + rank, as float4 {xyz, index}
   for (long long t = (long long)wg * SDG_BUILD_THREADS + tid; t < total; t += (long long)nwg * SDG_BUILD_THREADS) {
@@ -347,12 +342,15 @@ constexpr int SDG_GROUP = 8;  // lanes cooperating on one query (rows of the cel
 
 // the search for one query, shared by the one-direction and the two-direction kernels.  All SDG_GROUP lanes of a query
 // call it with the same (qx, qy, qz, c); on return every lane holds the query's (best, best_i).
+// TRACK: best_k = the winner's position in the sorted targets (-1 while the seed holds: the caller then looks target 0 up).
+template <bool TRACK>
 __device__ __forceinline__ void sdg_search(const Box& s_box, int G, float qx, float qy, float qz, int c,
                                            const float* __restrict__ T0, const int* __restrict__ start,
-                                           const float4* __restrict__ TS, int sub, float& best, int& best_i) {
+                                           const float4* __restrict__ TS, int sub, float& best, int& best_i, int& best_k) {
   // the reference's seed: target 0 unconditionally (a NaN distance sticks)
   best = sdg_dist(T0[0], T0[1], T0[2], qx, qy, qz);
   best_i = 0;
+  best_k = -1;
   if (best == best) {  // uniform within the group (same query)
     const int cx = c % G, cy = (c / G) % G, cz = c / (G * G);
     // rounding head-room of the geometric bound: cell membership is decided by a rounded (v - lo) * inv
@@ -398,6 +396,7 @@ __device__ __forceinline__ void sdg_search(const Box& s_box, int G, float qx, fl
             if (d < best || (d == best && ti < best_i)) {
               best = d;
               best_i = ti;
+              if (TRACK) best_k = k;
             }
           }
       }
@@ -405,9 +404,11 @@ __device__ __forceinline__ void sdg_search(const Box& s_box, int G, float qx, fl
       for (int m = 1; m < SDG_GROUP; m <<= 1) {  // lexicographic (dist, idx) minimum over the group
         const float od = __shfl_xor(best, m, 64);
         const int oi = __shfl_xor(best_i, m, 64);
+        const int ok = TRACK ? __shfl_xor(best_k, m, 64) : 0;
         if (od < best || (od == best && oi < best_i)) {
           best = od;
           best_i = oi;
+          if (TRACK) best_k = ok;
         }
       }
       // every target outside the cube of cells [c - r, c + r] is at least `bound` away from the query
@@ -444,33 +445,34 @@ __global__ __launch_bounds__(256) void sdg_query(Cloud A, Cloud T, float* __rest
                                                  float* __restrict__ dist2, int64_t* __restrict__ idx2, Fuse fz) {
   __shared__ Box s_box;
   __shared__ double s_sum[4];
-  __shared__ bool s_last;
   const int b = blockIdx.y;
   const bool fwd = blockIdx.z == 0;
   const int nq = fwd ? A.n : T.n, nt = fwd ? T.n : A.n, G = fwd ? T.G : A.G;
-  // the launch is sized for the larger cloud
-  const bool idle = (long long)blockIdx.x * 256 >= (long long)nq * SDG_GROUP;
-  if (MODE == SDG_PLAIN && idle) return;
+  const int NC = G * G * G;
+  const float* Tp = (fwd ? T.pts : A.pts) + (size_t)b * nt * 3;
+  const int* Tstart = (fwd ? T.start : A.start) + (size_t)b * (NC + 1);
+  const float4* Tsorted = (fwd ? T.sorted : A.sorted) + (size_t)b * nt;
+  if (threadIdx.x == 0) s_box = sdg_box_decode((fwd ? T.box : A.box) + (size_t)b * 8, G);
+  __syncthreads();
+  // 100k queries are only ~1.5 wavefronts per SIMD and every query is a chain of dependent loads (cell range ->
+  // targets): 8 lanes share a query so that 8x more loads are in flight; the lanes' (dist, idx) are merged with a
+  // 3-step butterfly after every ring
+  const int sub = threadIdx.x % SDG_GROUP;
   double term = 0.0;
-  if (!idle) {
-    if (threadIdx.x == 0) s_box = sdg_box_decode((fwd ? T.box : A.box) + (size_t)b * 8, G);
-    __syncthreads();
-    // 100k queries are only ~1.5 wavefronts per SIMD and every query is a chain of dependent loads (cell range ->
-    // targets): 8 lanes share a query so that 8x more loads are in flight; the lanes' (dist, idx) are merged with a
-    // 3-step butterfly after every ring
-    const int sub = threadIdx.x % SDG_GROUP;
-    const int slot = (blockIdx.x * 256 + threadIdx.x) / SDG_GROUP;
+  // a workgroup takes the chunks of 32 queries blockIdx.x, blockIdx.x + gridDim.x, ...: one chunk each in the plain
+  // search; the chamfer modes launch one resident set of workgroups, so that the value's closing atomics (a returning
+  // ticket per workgroup) are paid ~2000 times, not once per chunk (that cost 47 us at 100k x 100k)
+  const int nchunks = (int)(((long long)nq * SDG_GROUP + 255) / 256);
+  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const int slot = (chunk * 256 + threadIdx.x) / SDG_GROUP;
     const bool live = slot < nq;
-    const int NC = G * G * G;
     const float4 q = (fwd ? A.sorted : T.sorted)[(size_t)b * nq + (live ? slot : 0)];
     const int cx = sdg_axis_cell(q.x, s_box.lo[0], s_box.inv[0], G);
     const int cy = sdg_axis_cell(q.y, s_box.lo[1], s_box.inv[1], G);
     const int cz = sdg_axis_cell(q.z, s_box.lo[2], s_box.inv[2], G);
     float best;
-    int best_i;
-    const float* Tp = (fwd ? T.pts : A.pts) + (size_t)b * nt * 3;
-    sdg_search(s_box, G, q.x, q.y, q.z, (cz * G + cy) * G + cx, Tp, (fwd ? T.start : A.start) + (size_t)b * (NC + 1),
-               (fwd ? T.sorted : A.sorted) + (size_t)b * nt, sub, best, best_i);
+    int best_i, best_k;
+    sdg_search<MODE == SDG_GRAD>(s_box, G, q.x, q.y, q.z, (cz * G + cy) * G + cx, Tp, Tstart, Tsorted, sub, best, best_i, best_k);
     if (live && sub == 0) {
       const size_t o = (size_t)b * nq + __float_as_int(q.w);
       float* dist = fwd ? dist1 : dist2;
@@ -479,19 +481,25 @@ __global__ __launch_bounds__(256) void sdg_query(Cloud A, Cloud T, float* __rest
       if (idx != nullptr) idx[o] = best_i;
       if (MODE >= SDG_VALUE) {
         const float root = fz.squared ? best : sqrtf(best);
-        term = (double)root;
+        term += (double)root;
         if (MODE == SDG_GRAD) {
           // value = sum_b up_b * (w1 / N * sum_i f(dist1_i) + w2 / M * sum_j f(dist2_j)); d dist / d q = 2 (q - t)
+          // Both gradient arrays are laid out in the SORTED order of the cloud they belong to: this query's own term is a
+          // coalesced store at its slot, and the atomics of neighbouring queries land on neighbouring targets
           float k = fwd ? fz.c1 : fz.c2;
           if (!fz.squared) k = k / (2.f * root);
-          float* own = (fwd ? fz.own_a : fz.own_b) + o * 3;
-          float* scat = (fwd ? fz.scat_b : fz.scat_a) + ((size_t)b * nt + best_i) * 3;
-          const float qv[3] = {q.x, q.y, q.z};
+          if (best_k < 0) {  // the seed (target 0) is the nearest: its place in the sorted targets
+            const int2 cr = (fwd ? T.cellrank : A.cellrank)[(size_t)b * nt];
+            best_k = Tstart[cr.x] + cr.y;
+          }
+          const float4 t = Tsorted[best_k];
+          float* own = (fwd ? fz.own_a : fz.own_b) + ((size_t)b * nq + slot) * 3;
+          float* scat = (fwd ? fz.scat_b : fz.scat_a) + ((size_t)b * nt + best_k) * 3;
+          const float qv[3] = {q.x, q.y, q.z}, tv[3] = {t.x, t.y, t.z};
 #pragma unroll
           for (int a = 0; a < 3; ++a) {
-            const float x = Tp[(size_t)best_i * 3 + a];
-            own[a] = 2.f * (qv[a] - x) * k;
-            kamd_atomic_add(scat + a, 2.f * (x - qv[a]) * k);
+            own[a] = 2.f * (qv[a] - tv[a]) * k;
+            kamd_atomic_add(scat + a, 2.f * (tv[a] - qv[a]) * k);
           }
         }
       }
@@ -502,45 +510,63 @@ __global__ __launch_bounds__(256) void sdg_query(Cloud A, Cloud T, float* __rest
     for (int d = 32; d >= 1; d >>= 1) term += __shfl_xor(term, d, 64);
     if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = term;
     __syncthreads();
+    if (threadIdx.x >= 64) return;  // the closing ticket waits on a memory round trip: only one wavefront stays for it
+    // Every workgroup leaves its partial sum with a coherent store and takes a ticket; the last one adds the partials up in
+    // a fixed order (the value is deterministic) and writes the result.  (First version: one atomicAdd per workgroup on
+    // the item's sum -- 12 500 returning atomics on three addresses serialise at ~1.3 ns each: +47 us.)
+    int last = 0;
     if (threadIdx.x == 0) {
-      // two device-scope atomics in program order, no fence (an agent-scope release would write back this XCD's L2 once per
-      // workgroup): the sum's RETURNING form has been performed when its value arrives, and the ticket is issued after it
-      unsigned int one = 1u;
-      if (!idle) {
-        const double old = __hip_atomic_fetch_add(fz.sums + (size_t)b * 2 + (fwd ? 0 : 1), (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]),
-                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("" : "+v"(one) : "v"(old));
-      }
+      sdg_st(fz.sums + ((size_t)blockIdx.z * gridDim.y + b) * gridDim.x + blockIdx.x, (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]));
+      __builtin_amdgcn_s_waitcnt(0);  // the store has been performed before the ticket is issued
       const unsigned int total = gridDim.x * gridDim.y * gridDim.z;
-      s_last = __hip_atomic_fetch_add(fz.done, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1;
+      last = __hip_atomic_fetch_add(fz.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1 ? 1 : 0;
     }
-    __syncthreads();
-    if (s_last) {
-      for (int i = threadIdx.x; i < (int)gridDim.y; i += 256) {
-        const double s1 = __hip_atomic_load(fz.sums + (size_t)i * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double s2 = __hip_atomic_load(fz.sums + (size_t)i * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float m1 = (float)(s1 / (double)A.n), m2 = (float)(s2 / (double)T.n);
-        fz.out[i] = (fz.w1 == 1.f && fz.w2 == 1.f) ? m1 + m2 : fz.w1 * m1 + fz.w2 * m2;
+    if (__builtin_amdgcn_readfirstlane(last)) {
+      const int gx = gridDim.x, nb = gridDim.y;
+      const bool per_lane = gx < 32;  // many batch items, few workgroups each: a lane per item instead of a wavefront per item
+      for (int i0 = 0; i0 < nb; i0 += per_lane ? 64 : 1) {
+        const int i = per_lane ? i0 + (int)threadIdx.x : i0;
+        double s1 = 0.0, s2 = 0.0;
+        if (i < nb)
+          for (int x = per_lane ? 0 : (int)threadIdx.x; x < gx; x += per_lane ? 1 : 64) {
+            s1 += sdg_ld(fz.sums + (size_t)i * gx + x);
+            s2 += sdg_ld(fz.sums + ((size_t)nb + i) * gx + x);
+          }
+        if (!per_lane) {
+#pragma unroll
+          for (int d = 32; d >= 1; d >>= 1) {
+            s1 += __shfl_xor(s1, d, 64);
+            s2 += __shfl_xor(s2, d, 64);
+          }
+        }
+        if (i < nb && (per_lane || threadIdx.x == 0)) {
+          const float m1 = (float)(s1 / (double)A.n), m2 = (float)(s2 / (double)T.n);
+          fz.out[i] = (fz.w1 == 1.f && fz.w2 == 1.f) ? m1 + m2 : fz.w1 * m1 + fz.w2 * m2;
+        }
       }
     }
   }
 }
 
-// chamfer backward after a SDG_GRAD forward: grad_p = upstream[b] * (own + scattered)
-__global__ __launch_bounds__(256) void sdg_chamfer_apply(int B, long long na, long long nb, const float* __restrict__ grad,
+// chamfer backward after a SDG_GRAD forward: grad_p[original index] = upstream[b] * (own + scattered)[sorted position]
+__global__ __launch_bounds__(256) void sdg_chamfer_apply(int B, Cloud A, Cloud T, const float* __restrict__ grad,
                                                          const float* __restrict__ own_a, const float* __restrict__ scat_a,
                                                          const float* __restrict__ own_b, const float* __restrict__ scat_b,
                                                          float* __restrict__ g1, float* __restrict__ g2) {
-  const long long total = (long long)B * (na + nb);
+  const long long na = (long long)B * A.n, total = na + (long long)B * T.n;
   for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
-    const bool first = t < (long long)B * na;
-    const long long k = first ? t : t - (long long)B * na;
-    const int b = (int)(k / (first ? na : nb));
+    const bool first = t < na;
+    const long long k = first ? t : t - na;            // (batch item, sorted position) flattened
+    const int n = first ? A.n : T.n;
+    const int b = (int)(k / n);
     const float g = grad[b];
-    if (first)
-      g1[k] = g * (own_a[k] + scat_a[k]);
-    else
-      g2[k] = g * (own_b[k] + scat_b[k]);
+    const int orig = __float_as_int((first ? A.sorted : T.sorted)[k].w);
+    const float* own = (first ? own_a : own_b) + k * 3;
+    const float* scat = (first ? scat_a : scat_b) + k * 3;
+    float* out = (first ? g1 : g2) + ((long long)b * n + orig) * 3;
+    out[0] = g * (own[0] + scat[0]);
+    out[1] = g * (own[1] + scat[1]);
+    out[2] = g * (own[2] + scat[2]);
   }
 }
 
@@ -566,15 +592,27 @@ int sdg_run(hipStream_t st, int B, int N, int M, const float* p1, const float* p
     int nwg = kamd_cdiv((long long)B * ((long long)N + M), SDG_BUILD_THREADS);
     const int cus = sdg_num_cus();
     if (nwg > cus) nwg = cus;
-    const int two_level = w.scan_blocks > 2 * 160 ? 1 : 0;
+    // measured at 100k + 100k points (profiles/r02j): 128 workgroups and ~0.5 us between polls are the fastest (46 us; 256
+    // workgroups polling back to back: 53 us; 64 workgroups: 51 us)
+    const int cap = kamd_env_int("KAMD_SDG_WGS", 128);
+    if (nwg > cap) nwg = cap;
+    const int naps = kamd_env_int("KAMD_SDG_NAPS", 4);
     hipLaunchKernelGGL(sdg_build, dim3(nwg), dim3(SDG_BUILD_THREADS), 0, st, w.b, w.a, B, pair ? 1 : 0, w.scan_sums,
-                       w.scan_blocks, two_level, w.barrier);
+                       w.scan_blocks, w.barrier, naps);
   }
   KAMD_CHECK(hipGetLastError());
   {
     ProfScope p(K_SDG_QUERY, st);
     const int big = (pair && M > N) ? M : N;
-    const dim3 grid(kamd_cdiv((long long)big * SDG_GROUP, 256), B, pair ? 2 : 1);
+    int gx = kamd_cdiv((long long)big * SDG_GROUP, 256);
+    if (mode != SDG_PLAIN) {  // one resident set of workgroups (8 per CU) over all batch items and both directions
+      // (measured, profiles/r02l: 16 per CU 90 us, 8: 93, 32: 104, one chunk per workgroup: 108)
+      int resident = sdg_num_cus() * kamd_env_int("KAMD_SDG_QUERY_PER_CU", 16);
+      if (resident > 8192) resident = 8192;
+      resident /= B * 2;
+      if (gx > (resident > 1 ? resident : 1)) gx = resident > 1 ? resident : 1;
+    }
+    const dim3 grid(gx, B, pair ? 2 : 1);
     w.fuse.out = out;
     w.fuse.w1 = w1;
     w.fuse.w2 = w2;
@@ -627,12 +665,12 @@ int sdgrid_chamfer_forward_f32(hipStream_t st, int B, int N, int M, const float*
 int sdgrid_chamfer_backward_f32(hipStream_t st, int B, int N, int M, const float* grad, void* workspace, float* g1,
                                 float* g2) {
   const SdgWs w = sdg_layout(workspace, B, N, M, nullptr, nullptr, true, SDG_GRAD);
-  const long long total = (long long)B * ((long long)N + M) * 3;
+  const long long total = (long long)B * ((long long)N + M);
   long long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   ProfScope p(K_SD_BACKWARD, st);
-  hipLaunchKernelGGL(sdg_chamfer_apply, dim3((unsigned)blocks), dim3(256), 0, st, B, (long long)N * 3, (long long)M * 3, grad,
-                     w.fuse.own_a, w.fuse.scat_a, w.fuse.own_b, w.fuse.scat_b, g1, g2);
+  hipLaunchKernelGGL(sdg_chamfer_apply, dim3((unsigned)blocks), dim3(256), 0, st, B, w.a, w.b, grad, w.fuse.own_a, w.fuse.scat_a,
+                     w.fuse.own_b, w.fuse.scat_b, g1, g2);
   KAMD_RETURN_LAST_ERROR();
 }
 

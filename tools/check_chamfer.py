@@ -55,6 +55,24 @@ for _ in range(50):
 enq = (time.perf_counter() - t0) / 50
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 50
+def prof(fn, label):
+    lib.kamd_profile_reset(); lib.kamd_profile_enable(1)
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    lib.kamd_profile_enable(0)
+    print(label, {k: round(v[0] / v[1] * 1e3, 1) for k, v in _lib.kernel_profile(reset=True).items()}, flush=True)
+
+
+def fwd_only():
+    with torch.no_grad():
+        pc.chamfer_distance(base, p2)
+
+
+if os.environ.get('KAMD_CHECK_SPLIT'):
+    prof(fwd_only, 'forward, value only:')
+    prof(lambda: pc.chamfer_distance(base, p2), 'forward with gradient pieces:')
+    prof(lambda: pc._nearest_both_ways(base, p2), 'plain pair search:')
 lib.kamd_profile_reset(); lib.kamd_profile_enable(1)
 for _ in range(10):
     step()

@@ -10,7 +10,7 @@ from kaolin_amd.utils.testing import geodesic_sphere
 v, f = geodesic_sphere(50)
 fv = v.float()[f].cuda()[None]
 torch.manual_seed(0)
-for n in (100000, 1000000):
+for n in ([int(a) for a in sys.argv[1:]] or [100000, 1000000]):
     pts = (torch.rand(1, n, 3) * 1.2 - 0.1).cuda() - 0.5
     for _ in range(2):
         kal.metrics.trianglemesh.point_to_mesh_distance(pts, fv)
