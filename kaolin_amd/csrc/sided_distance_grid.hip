@@ -57,9 +57,7 @@ struct Cloud {
 // what chamfer_distance adds to the search (SDG_VALUE / SDG_GRAD): everything the value and the gradient need is
 // produced by the query launch itself
 struct Fuse {
-  double* sums;         // (2, B, query workgroups per item and direction) partial sums of f(dist): plain stores, no init
-  unsigned int* done;   // query workgroups finished; zero before the query
-  float* out;           // (B) chamfer value, written by the last workgroup
+  double* sums;         // (2, B, query workgroups per item and direction) partial sums of f(dist); no init needed
   float* own_a;         // (B, N, 3) d value / d p1_i through p1_i's own nearest-point term (plain stores)
   float* own_b;         // (B, M, 3)
   float* scat_a;        // (B, N, 3) ... through the terms of the p2 points whose nearest point is p1_i (atomics); zero before
@@ -105,7 +103,6 @@ inline SdgWs sdg_layout(void* base, int B, int N, int M, const float* p1, const 
   w.a.box = pair ? (unsigned int*)take((size_t)B * 8 * 4) : w.b.box;
   w.barrier = (unsigned int*)take(64);
   w.fuse = Fuse{};
-  if (mode >= SDG_VALUE) w.fuse.done = (unsigned int*)take(64);
   if (mode >= SDG_GRAD) {
     w.fuse.scat_a = (float*)take((size_t)B * N * 12);
     w.fuse.scat_b = (float*)take((size_t)B * M * 12);
@@ -436,7 +433,7 @@ __device__ __forceinline__ void sdg_search(const Box& s_box, int G, float qx, fl
 // The search runs on the TARGETS' grid; the queries only have to arrive in a spatially coherent order, which their own
 // sorted copy provides whichever grid it was sorted on.
 // MODE >= SDG_VALUE (chamfer_distance, kaolin/metrics/pointcloud.py:120-136): the launch also reduces f(dist) (f = identity
-// or sqrt) per direction -- wave shuffle, LDS, one double atomicAdd per workgroup -- and its last workgroup writes
+// or sqrt) per direction -- wave shuffle, LDS, one partial sum per workgroup; sdg_chamfer_value closes
 // w1 * mean1 + w2 * mean2.  MODE == SDG_GRAD: every query also leaves d value / d (its own point) and adds
 // d value / d (its nearest point) with float atomics, both already scaled by w / n [/ (2 sqrt(dist))]: the atomics ride in
 // a kernel that waits on dependent loads anyway, and the backward pass is one multiply by the upstream gradient.
@@ -459,9 +456,8 @@ __global__ __launch_bounds__(256) void sdg_query(Cloud A, Cloud T, float* __rest
   // 3-step butterfly after every ring
   const int sub = threadIdx.x % SDG_GROUP;
   double term = 0.0;
-  // a workgroup takes the chunks of 32 queries blockIdx.x, blockIdx.x + gridDim.x, ...: one chunk each in the plain
-  // search; the chamfer modes launch one resident set of workgroups, so that the value's closing atomics (a returning
-  // ticket per workgroup) are paid ~2000 times, not once per chunk (that cost 47 us at 100k x 100k)
+  // a workgroup takes the chunks of 32 queries blockIdx.x, blockIdx.x + gridDim.x, ...: one chunk each unless the chamfer
+  // modes' partial-sum buffer holds fewer workgroups than there are chunks
   const int nchunks = (int)(((long long)nq * SDG_GROUP + 255) / 256);
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     const int slot = (chunk * 256 + threadIdx.x) / SDG_GROUP;
@@ -510,41 +506,34 @@ __global__ __launch_bounds__(256) void sdg_query(Cloud A, Cloud T, float* __rest
     for (int d = 32; d >= 1; d >>= 1) term += __shfl_xor(term, d, 64);
     if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = term;
     __syncthreads();
-    if (threadIdx.x >= 64) return;  // the closing ticket waits on a memory round trip: only one wavefront stays for it
-    // Every workgroup leaves its partial sum with a coherent store and takes a ticket; the last one adds the partials up in
-    // a fixed order (the value is deterministic) and writes the result.  (First version: one atomicAdd per workgroup on
-    // the item's sum -- 12 500 returning atomics on three addresses serialise at ~1.3 ns each: +47 us.)
-    int last = 0;
-    if (threadIdx.x == 0) {
-      sdg_st(fz.sums + ((size_t)blockIdx.z * gridDim.y + b) * gridDim.x + blockIdx.x, (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]));
-      __builtin_amdgcn_s_waitcnt(0);  // the store has been performed before the ticket is issued
-      const unsigned int total = gridDim.x * gridDim.y * gridDim.z;
-      last = __hip_atomic_fetch_add(fz.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1 ? 1 : 0;
-    }
-    if (__builtin_amdgcn_readfirstlane(last)) {
-      const int gx = gridDim.x, nb = gridDim.y;
-      const bool per_lane = gx < 32;  // many batch items, few workgroups each: a lane per item instead of a wavefront per item
-      for (int i0 = 0; i0 < nb; i0 += per_lane ? 64 : 1) {
-        const int i = per_lane ? i0 + (int)threadIdx.x : i0;
-        double s1 = 0.0, s2 = 0.0;
-        if (i < nb)
-          for (int x = per_lane ? 0 : (int)threadIdx.x; x < gx; x += per_lane ? 1 : 64) {
-            s1 += sdg_ld(fz.sums + (size_t)i * gx + x);
-            s2 += sdg_ld(fz.sums + ((size_t)nb + i) * gx + x);
-          }
-        if (!per_lane) {
+    if (threadIdx.x == 0)
+      fz.sums[((size_t)blockIdx.z * gridDim.y + b) * gridDim.x + blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+  }
+}
+
+// Closes chamfer_distance: out[b] = w1 * mean1 + w2 * mean2 from the query workgroups' partial sums, added up in a fixed
+// order (the value is deterministic).  A launch of its own: finishing inside the query launch needs every workgroup to
+// take a ticket (or add to a shared sum) and WAIT for the answer before it can retire -- measured +35..47 us on a 61 us
+// kernel in every variant tried (returning atomics on the sums; coherent partial stores + one ticket; resident-set grids of
+// 4..64 workgroups per CU) -- against ~5 us for this launch.
+__global__ __launch_bounds__(256) void sdg_chamfer_value(int B, int gx, int N, int M, const double* __restrict__ partial, float w1,
+                                                         float w2, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // a wavefront per batch item
+  if (i >= B) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int x = lane; x < gx; x += 64) {
+    s1 += partial[(size_t)i * gx + x];
+    s2 += partial[((size_t)B + i) * gx + x];
+  }
 #pragma unroll
-          for (int d = 32; d >= 1; d >>= 1) {
-            s1 += __shfl_xor(s1, d, 64);
-            s2 += __shfl_xor(s2, d, 64);
-          }
-        }
-        if (i < nb && (per_lane || threadIdx.x == 0)) {
-          const float m1 = (float)(s1 / (double)A.n), m2 = (float)(s2 / (double)T.n);
-          fz.out[i] = (fz.w1 == 1.f && fz.w2 == 1.f) ? m1 + m2 : fz.w1 * m1 + fz.w2 * m2;
-        }
-      }
-    }
+  for (int d = 32; d >= 1; d >>= 1) {
+    s1 += __shfl_xor(s1, d, 64);
+    s2 += __shfl_xor(s2, d, 64);
+  }
+  if (lane == 0) {
+    const float m1 = (float)(s1 / (double)N), m2 = (float)(s2 / (double)M);
+    out[i] = (w1 == 1.f && w2 == 1.f) ? m1 + m2 : w1 * m1 + w2 * m2;
   }
 }
 
@@ -605,15 +594,11 @@ int sdg_run(hipStream_t st, int B, int N, int M, const float* p1, const float* p
     ProfScope p(K_SDG_QUERY, st);
     const int big = (pair && M > N) ? M : N;
     int gx = kamd_cdiv((long long)big * SDG_GROUP, 256);
-    if (mode != SDG_PLAIN) {  // one resident set of workgroups (8 per CU) over all batch items and both directions
-      // (measured, profiles/r02l: 16 per CU 90 us, 8: 93, 32: 104, one chunk per workgroup: 108)
-      int resident = sdg_num_cus() * kamd_env_int("KAMD_SDG_QUERY_PER_CU", 16);
-      if (resident > 8192) resident = 8192;
-      resident /= B * 2;
-      if (gx > (resident > 1 ? resident : 1)) gx = resident > 1 ? resident : 1;
+    if (mode != SDG_PLAIN) {  // every workgroup leaves one partial sum: at most as many as the buffer holds
+      const int cap = (int)(sdg_partials(B) / ((size_t)2 * B));
+      if (gx > cap) gx = cap;
     }
     const dim3 grid(gx, B, pair ? 2 : 1);
-    w.fuse.out = out;
     w.fuse.w1 = w1;
     w.fuse.w2 = w2;
     w.fuse.c1 = w1 * (1.f / (float)N);
@@ -625,6 +610,9 @@ int sdg_run(hipStream_t st, int B, int N, int M, const float* p1, const float* p
       hipLaunchKernelGGL(sdg_query<SDG_VALUE>, grid, dim3(256), 0, st, w.a, w.b, dist1, idx1, dist2, idx2, w.fuse);
     else
       hipLaunchKernelGGL(sdg_query<SDG_GRAD>, grid, dim3(256), 0, st, w.a, w.b, dist1, idx1, dist2, idx2, w.fuse);
+    if (mode != SDG_PLAIN)
+      hipLaunchKernelGGL(sdg_chamfer_value, dim3(kamd_cdiv(B, 4)), dim3(256), 0, st, B, gx, N, M, (const double*)w.fuse.sums, w1,
+                         w2, out);
   }
   KAMD_RETURN_LAST_ERROR();
 }
