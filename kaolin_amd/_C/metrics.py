@@ -66,11 +66,15 @@ def sided_distance_pair_forward(p1, p2):
     return [dist1, idx1, dist2, idx2]
 
 
+_CHAMFER_WS = {}      # (B, N, M, with_grad) -> workspace bytes (0: the shapes do not qualify)
+
+
 def chamfer_distance_forward(p1, p2, w1, w2, squared, with_grad):
     """``chamfer_distance`` (kaolin/metrics/pointcloud.py:89-136) of two fp32 clouds as one operator -> (value (B), state) or
     ``None`` when the shapes do not qualify for the shared-grid search (the caller then composes it from
     ``sided_distance_forward_cuda``).  ``state`` is the workspace holding the gradient pieces for
-    :func:`chamfer_distance_backward_fused` (``with_grad``).  Not part of the reference's ``kaolin._C``."""
+    :func:`chamfer_distance_backward_fused` (``with_grad``).  Not part of the reference's ``kaolin._C``.
+    This is a hot host path (the 100k x 100k training step is host-bound): shape checks inline, sizes cached."""
     fn = 'sided_distance_forward_cuda'   # argument errors read as the reference's (its chamfer_distance fails in this operator)
     batch_size, num_p1, num_p2 = p1.size(0), p1.size(1), p2.size(1)
     if not (p1.is_cuda and p2.is_cuda and p1.device == p2.device and p1.is_contiguous() and p2.is_contiguous() and
@@ -84,34 +88,42 @@ def chamfer_distance_forward(p1, p2, w1, w2, squared, with_grad):
     if p1.dtype != torch.float32:
         return None
     lib = _lib.load()
-    nbytes = lib.kamd_chamfer_distance_forward_workspace(batch_size, num_p1, num_p2, 1 if with_grad else 0)
+    key = (batch_size, num_p1, num_p2, bool(with_grad))
+    nbytes = _CHAMFER_WS.get(key)
+    if nbytes is None:
+        nbytes = lib.kamd_chamfer_distance_forward_workspace(batch_size, num_p1, num_p2, 1 if with_grad else 0)
+        if len(_CHAMFER_WS) > 64:
+            _CHAMFER_WS.clear()
+        _CHAMFER_WS[key] = nbytes
     if nbytes == 0:
         return None
     device = p1.device
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         out = torch.empty((batch_size,), dtype=torch.float32, device=device)
         ws = torch.empty(((nbytes + 7) // 8,), dtype=torch.int64, device=device)
         st = lib.kamd_chamfer_distance_forward_f32(
-            _lib.stream_ptr(device), batch_size, num_p1, num_p2, p1.data_ptr(), p2.data_ptr(), float(w1), float(w2),
-            1 if squared else 0, 1 if with_grad else 0, out.data_ptr(), None, None, None, None, ws.data_ptr())
-    _lib.check(st, 'chamfer_distance_forward')
+            torch.cuda.current_stream().cuda_stream, batch_size, num_p1, num_p2, p1.data_ptr(), p2.data_ptr(), float(w1),
+            float(w2), 1 if squared else 0, 1 if with_grad else 0, out.data_ptr(), None, None, None, None, ws.data_ptr())
+    if st != 0:
+        _lib.check(st, 'chamfer_distance_forward')
     return out, ws
 
 
 def chamfer_distance_backward_fused(grad_output, state, batch_size, num_p1, num_p2):
     """-> [grad_p1 (B, N, 3), grad_p2 (B, M, 3)] from the state of a ``with_grad`` :func:`chamfer_distance_forward`."""
     fn = 'chamfer_distance_backward'
-    torch_check(grad_output.is_cuda and grad_output.dtype == torch.float32 and grad_output.numel() == batch_size,
-                f'{fn}: grad_output must be a Float CUDA tensor of size {{batch_size}}')
+    if not (grad_output.is_cuda and grad_output.dtype == torch.float32 and grad_output.numel() == batch_size):
+        torch_check(False, f'{fn}: grad_output must be a Float CUDA tensor of size {{batch_size}}')
     device = state.device
     lib = _lib.load()
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         g1 = torch.empty((batch_size, num_p1, 3), dtype=torch.float32, device=device)
         g2 = torch.empty((batch_size, num_p2, 3), dtype=torch.float32, device=device)
         st = lib.kamd_chamfer_distance_backward_fused_f32(
-            _lib.stream_ptr(device), batch_size, num_p1, num_p2, grad_output.data_ptr(), state.data_ptr(),
+            torch.cuda.current_stream().cuda_stream, batch_size, num_p1, num_p2, grad_output.data_ptr(), state.data_ptr(),
             g1.data_ptr(), g2.data_ptr())
-    _lib.check(st, fn)
+    if st != 0:
+        _lib.check(st, fn)
     return [g1, g2]
 
 

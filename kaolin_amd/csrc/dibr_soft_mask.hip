@@ -534,6 +534,14 @@ int dibr_backward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K
 }  // namespace
 
 #ifdef KAMD_PHASE_PROF
+extern "C" int kamd_debug_phase_cycles_bin(unsigned long long* out16, int reset) {
+  int rc = (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(tl::g_phase_bin), 16 * sizeof(unsigned long long));
+  if (reset) {
+    unsigned long long z[16] = {0};
+    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(tl::g_phase_bin), z, sizeof(z));
+  }
+  return rc;
+}
 extern "C" int kamd_debug_phase_cycles(unsigned long long* out16, int reset) {
   int rc = (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_select), 16 * sizeof(unsigned long long));
   if (reset) {

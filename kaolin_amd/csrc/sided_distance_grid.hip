@@ -512,26 +512,39 @@ __global__ __launch_bounds__(256) void sdg_query(Cloud A, Cloud T, float* __rest
 }
 
 // Closes chamfer_distance: out[b] = w1 * mean1 + w2 * mean2 from the query workgroups' partial sums, added up in a fixed
-// order (the value is deterministic).  A launch of its own: finishing inside the query launch needs every workgroup to
-// take a ticket (or add to a shared sum) and WAIT for the answer before it can retire -- measured +35..47 us on a 61 us
-// kernel in every variant tried (returning atomics on the sums; coherent partial stores + one ticket; resident-set grids of
-// 4..64 workgroups per CU) -- against ~5 us for this launch.
+// order (the value is deterministic).  A workgroup per batch item, every thread a strided share of the partials with
+// independent loads in flight.  (Measured on the way here, profiles/r02n_chamfer.txt: the same sum as ONE wavefront's loop of
+// dependent load -> add steps -- first inside the query launch's last workgroup, then here -- is a chain of ~50 memory
+// round trips: +35 us on a 61 us search.)
 __global__ __launch_bounds__(256) void sdg_chamfer_value(int B, int gx, int N, int M, const double* __restrict__ partial, float w1,
                                                          float w2, float* __restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // a wavefront per batch item
-  if (i >= B) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int x = lane; x < gx; x += 64) {
-    s1 += partial[(size_t)i * gx + x];
-    s2 += partial[((size_t)B + i) * gx + x];
+  __shared__ double s_part[2][4];
+  const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double* p1 = partial + (size_t)i * gx;
+  const double* p2 = partial + ((size_t)B + i) * gx;
+  double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int x0 = threadIdx.x; x0 < gx; x0 += 4 * 256) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int x = x0 + k * 256;
+      a1[k] += x < gx ? p1[x] : 0.0;
+      a2[k] += x < gx ? p2[x] : 0.0;
+    }
   }
+  double s1 = (a1[0] + a1[1]) + (a1[2] + a1[3]), s2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     s1 += __shfl_xor(s1, d, 64);
     s2 += __shfl_xor(s2, d, 64);
   }
   if (lane == 0) {
+    s_part[0][wave] = s1;
+    s_part[1][wave] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s1 = (s_part[0][0] + s_part[0][1]) + (s_part[0][2] + s_part[0][3]);
+    s2 = (s_part[1][0] + s_part[1][1]) + (s_part[1][2] + s_part[1][3]);
     const float m1 = (float)(s1 / (double)N), m2 = (float)(s2 / (double)M);
     out[i] = (w1 == 1.f && w2 == 1.f) ? m1 + m2 : w1 * m1 + w2 * m2;
   }
@@ -611,8 +624,7 @@ int sdg_run(hipStream_t st, int B, int N, int M, const float* p1, const float* p
     else
       hipLaunchKernelGGL(sdg_query<SDG_GRAD>, grid, dim3(256), 0, st, w.a, w.b, dist1, idx1, dist2, idx2, w.fuse);
     if (mode != SDG_PLAIN)
-      hipLaunchKernelGGL(sdg_chamfer_value, dim3(kamd_cdiv(B, 4)), dim3(256), 0, st, B, gx, N, M, (const double*)w.fuse.sums, w1,
-                         w2, out);
+      hipLaunchKernelGGL(sdg_chamfer_value, dim3(B), dim3(256), 0, st, B, gx, N, M, (const double*)w.fuse.sums, w1, w2, out);
   }
   KAMD_RETURN_LAST_ERROR();
 }

@@ -22,6 +22,7 @@
 // one counter and one small chunk table per tile.
 #pragma once
 #include "common.h"
+#include "phase_prof.h"
 #include "tile_bins.h"  // Box4 / Rec4 / pixel_x / pixel_y / FaceLayout / wave helpers
 
 namespace kamd {
@@ -361,8 +362,15 @@ struct BinIn {
   T* rec_s;
 };
 
+#ifdef KAMD_PHASE_PROF
+static __device__ unsigned long long g_phase_bin[16];  // [0..7] phases, [10] longest wavefront, [11] > 1000 ticks (10 us at 100 MHz), [12] > 2500
+#endif
 template <typename T, bool DO_R, bool DO_S>
 __global__ __launch_bounds__(256) void bin_faces_kernel2(BinIn<T> in, Lists LR, Lists LS) {
+  PHASE_DECL;
+#ifdef KAMD_PHASE_PROF
+  const unsigned long long wall0 = wall_clock64();  // 100 MHz
+#endif
   const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
   bool live = f < in.total_faces;
   int b = 0;
@@ -377,6 +385,7 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(BinIn<T> in, Lists LR, 
       if (f >= in.first[in.B]) live = false;
     }
   }
+  PHASE_MARK(0);
   bool act_r = false, act_s = false, big_r = false, big_s = false;
   int rx0 = 0, rx1 = 0, ry0 = 0, ry1 = 0, sx0 = 0, sx1 = 0, sy0 = 0, sy1 = 0;
   PixRange pr_s{0, 0, 0, 0, false};
@@ -384,6 +393,10 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(BinIn<T> in, Lists LR, 
     T v[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) v[i] = in.img[f * 6 + i] * in.mult;
+#ifdef KAMD_PHASE_PROF
+    asm volatile("s_waitcnt vmcnt(0)");
+#endif
+    PHASE_MARK(1);
     T xmin = nan_min<T>(nan_min<T>(v[0], v[2]), v[4]), xmax = nan_max<T>(nan_max<T>(v[0], v[2]), v[4]);
     T ymin = nan_min<T>(nan_min<T>(v[1], v[3]), v[5]), ymax = nan_max<T>(nan_max<T>(v[1], v[3]), v[5]);
     if (DO_R) {
@@ -410,6 +423,7 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(BinIn<T> in, Lists LR, 
         r[2] = Rec4<T>{v[4], v[5], z0, z1};
         r[3] = Rec4<T>{z2, keep ? (T)1 : (T)0, 0, 0};
       }
+      PHASE_MARK(2);
       PixRange pr;
       if (keep && pixel_range<T>(bx0, by0, bx1, by1, in.H, in.W, in.multiplier, &pr)) {
         act_r = true;
@@ -420,6 +434,7 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(BinIn<T> in, Lists LR, 
         big_r = pr.everywhere || rx1 - rx0 >= 8 || ry1 - ry0 >= 8;
       }
     }
+    PHASE_MARK(3);
     if (DO_S) {
       T bx0, by0, bx1, by1;
       if (in.bbox_s != nullptr) {
@@ -448,6 +463,7 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(BinIn<T> in, Lists LR, 
           rc[k] = 1.0 / ((double)down + SOFT_EPS);
         }
       }
+      PHASE_MARK(4);
       if (pixel_range<T>(bx0, by0, bx1, by1, in.H, in.W, in.multiplier, &pr_s)) {
         act_s = true;
         sx0 = pr_s.c_lo / S_TILE;
@@ -458,8 +474,22 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(BinIn<T> in, Lists LR, 
       }
     }
   }
+  PHASE_MARK(5);
   if (DO_R) wave_bin<false>(act_r, big_r, b, first_b, f, rx0, rx1, ry0, ry1, 0, 0, 0, 0, LR);
+  PHASE_MARK(6);
   if (DO_S) wave_bin<true>(act_s, big_s, b, first_b, f, sx0, sx1, sy0, sy1, pr_s.c_lo, pr_s.c_hi, pr_s.r_lo, pr_s.r_hi, LS);
+  PHASE_MARK(7);
+  PHASE_FLUSH(g_phase_bin);
+#ifdef KAMD_PHASE_PROF
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned long long tot = wall_clock64() - wall0;
+    atomicAdd(&g_phase_bin[14], tot);
+    atomicMax(&g_phase_bin[10], tot);
+    if (tot > 1000ull) atomicAdd(&g_phase_bin[11], 1ull);
+    if (tot > 2500ull) atomicAdd(&g_phase_bin[12], 1ull);
+    atomicAdd(&g_phase_bin[13], 1ull);
+  }
+#endif
 }
 
 // ---- consumers: the candidate faces of a tile ------------------------------------------------------------------------------

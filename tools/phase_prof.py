@@ -13,16 +13,20 @@ feat = torch.cat(feats, -1).contiguous()
 for _ in range(2):
     kal.render.mesh.dibr_rasterization(H, W, fz, fimg, feat, nz)
 torch.cuda.synchronize()
-buf, buf2 = (ctypes.c_ulonglong * 16)(), (ctypes.c_ulonglong * 16)()
+buf, buf2, buf3 = (ctypes.c_ulonglong * 16)(), (ctypes.c_ulonglong * 16)(), (ctypes.c_ulonglong * 16)()
 raw = ctypes.CDLL(_lib.LIB_PATH)
 raw.kamd_debug_phase_cycles(buf, 1)
 raw.kamd_debug_phase_cycles_raster(buf2, 1)
+raw.kamd_debug_phase_cycles_bin(buf3, 1)
 n = 5
 for _ in range(n):
     kal.render.mesh.dibr_rasterization(H, W, fz, fimg, feat, nz)
 torch.cuda.synchronize()
 raw.kamd_debug_phase_cycles(buf, 0)
 raw.kamd_debug_phase_cycles_raster(buf2, 0)
+raw.kamd_debug_phase_cycles_bin(buf3, 0)
+print('bin_faces: phases (index math | vertex loads | raster record incl. z loads | raster range | soft record | soft range | raster lists | soft lists) Mticks/step', [round(buf3[i] / n / 1e6, 1) for i in range(8)],
+      'longest wavefront', buf3[10], 'ticks (10 ns each); wavefronts > 1000 ticks', buf3[11] / n, '> 2500', buf3[12] / n, 'of', buf3[13] / n, '; mean wavefront', round(buf3[14] / max(buf3[13], 1) / 100.0, 2), 'us')
 for title, b, names in (
         ('soft_select', buf, ['setup', 'order entries', 'stream+cull', 'chunk masks', 'accept+transposes', 'pair write', 'tail']),
         ('raster_tile', buf2, ['setup (touched)', 'entries load', 'scan+ids', 'stage+cull+readlane', 'mask (readlane)',
