@@ -58,13 +58,12 @@ def algorithmic_bytes(kernel, B, P, F, Fv, D, K, esz=4):
     output it produces written once (intermediate records / lists are NOT counted: they are this design's own traffic)."""
     per = {
         # face_idx (i64) + 3 weights + D features out; the front faces' 13 scalars + 3*D feature scalars in
-        'raster_tile_kernel': P * (8 + 3 * esz + D * esz) + Fv * (13 * esz + 3 * D * esz),
+        # (in the fused operator it also writes the soft mask of every pixel the silhouette band does not reach)
+        'raster_tile_kernel': P * (8 + 3 * esz + D * esz + esz) + Fv * (13 * esz + 3 * D * esz),
         'raster_backward_kernel': P * (8 + 3 * esz + D * esz) + F * (6 * esz * 2 + 3 * D * esz * 2),
         'fill_regions_kernel': P * K * (esz + 8 + 1),
         # select reads face_idx of the uncovered pixels' tiles and the faces' 6 coordinates + 4 box scalars
         'soft_select_kernel': P * 8 + F * 10 * esz,
-        # eval writes the soft mask
-        'soft_eval_kernel': P * esz,
         'soft_mask_backward_kernel': P * (8 + 2 * esz) + F * 6 * esz * 2,
         'soft_mask_backward_list_kernel': P * (2 * esz) + F * 6 * esz * 2,
         'bin_faces_kernel': F * (13 * esz),
@@ -197,7 +196,7 @@ def main():
     lib.kamd_profile_reset()
     lib.kamd_profile_select(kernel_ids.get(dom, -1) if dom else -1)
     lib.kamd_profile_enable(1 if dom else 0)
-    dt = timed(dibr_step, args.steps, 0)
+    dt = timed(dibr_step, args.steps, 2)      # (two untimed steps in this mode: its event pool is created on first use)
     dibr_enqueue_ms = timed.enqueue_ms
     lib.kamd_profile_enable(0)
     lib.kamd_profile_select(-1)

@@ -1,4 +1,6 @@
 """Host shims for ``kaolin._C.metrics`` (bindings.cpp:103-108)."""
+import os
+
 import torch
 
 from .. import _lib
@@ -20,7 +22,7 @@ def sided_distance_forward_cuda(p1, p2):
     check_size(fn, p2_arg, [batch_size, num_p2, 3])
     sfx = _lib.dtype_suffix(p1.dtype, fn, _SD_TYPES)
     lib = _lib.load()
-    with torch.cuda.device(p1.device):
+    with _lib.on_device(p1.device):
         # the reference allocates zeros (sided_distance.cpp:80-81); every kernel path writes all B x N entries, so only
         # the degenerate "no target" case (nothing is launched) needs them
         alloc = torch.zeros if num_p2 == 0 else torch.empty
@@ -53,7 +55,7 @@ def sided_distance_pair_forward(p1, p2):
     nbytes = lib.kamd_sided_distance_pair_forward_workspace(batch_size, num_p1, num_p2, p1.element_size())
     if nbytes == 0:
         return None
-    with torch.cuda.device(p1.device):
+    with _lib.on_device(p1.device):
         dist1 = torch.empty((batch_size, num_p1), dtype=p1.dtype, device=p1.device)
         idx1 = torch.empty((batch_size, num_p1), dtype=torch.long, device=p1.device)
         dist2 = torch.empty((batch_size, num_p2), dtype=p1.dtype, device=p1.device)
@@ -88,7 +90,8 @@ def chamfer_distance_forward(p1, p2, w1, w2, squared, with_grad):
     if p1.dtype != torch.float32:
         return None
     lib = _lib.load()
-    key = (batch_size, num_p1, num_p2, bool(with_grad))
+    # (the library's choice of search also depends on a measurement knob read from the environment)
+    key = (batch_size, num_p1, num_p2, bool(with_grad), os.environ.get('KAMD_SIDED_DISTANCE'))
     nbytes = _CHAMFER_WS.get(key)
     if nbytes is None:
         nbytes = lib.kamd_chamfer_distance_forward_workspace(batch_size, num_p1, num_p2, 1 if with_grad else 0)
@@ -147,7 +150,7 @@ def chamfer_distance_backward(grad_output, w1, w2, squared, p1, p2, idx1, idx2, 
     torch_check(p1.dtype == torch.float32 and p2.dtype == torch.float32 and grad_output.dtype == torch.float32,
                 f'{fn}: only Float clouds are supported')
     lib = _lib.load()
-    with torch.cuda.device(p1.device):
+    with _lib.on_device(p1.device):
         g1, g2 = torch.empty_like(p1), torch.empty_like(p2)     # the kernels write every entry
         st = lib.kamd_chamfer_distance_backward_f32(
             _lib.stream_ptr(p1.device), batch_size, num_p1, num_p2, _lib.ptr(grad_output), float(w1), float(w2),
@@ -171,7 +174,7 @@ def sided_distance_backward_cuda(grad_output, p1, p2, idx):
     check_same_size(fn, idx_arg, g_arg)
     sfx = _lib.dtype_suffix(p1.dtype, fn, _SD_TYPES)
     lib = _lib.load()
-    with torch.cuda.device(p1.device):
+    with _lib.on_device(p1.device):
         g1 = torch.zeros_like(p1)
         g2 = torch.zeros_like(p2)
         st = getattr(lib, f'kamd_sided_distance_backward_{sfx}')(
@@ -212,7 +215,7 @@ def unbatched_triangle_distance_forward_cuda(points, face_vertices, dist, face_i
     torch_check(face_idx.dtype == torch.long, 'expected scalar type Long but found ' + str(face_idx.dtype))
     torch_check(dist_type.dtype == torch.int32, 'expected scalar type Int but found ' + str(dist_type.dtype))
     lib = _lib.load()
-    with torch.cuda.device(points.device):
+    with _lib.on_device(points.device):
         ws = _lib.workspace(
             lib.kamd_triangle_distance_forward_workspace(num_points, num_faces, points.element_size()),
             points.device)
@@ -240,7 +243,7 @@ def unbatched_triangle_distance_backward_cuda(grad_dist, points, face_vertices, 
     _check_sizes('grad_face_vertices', grad_face_vertices, [num_faces, 3, 3], 'num_faces, 3, 3')
     sfx = _lib.dtype_suffix(points.dtype, fn)
     lib = _lib.load()
-    with torch.cuda.device(points.device):
+    with _lib.on_device(points.device):
         st = getattr(lib, f'kamd_triangle_distance_backward_{sfx}')(
             _lib.stream_ptr(points.device), num_points, num_faces, _lib.ptr(grad_dist), _lib.ptr(points),
             _lib.ptr(face_vertices), _lib.ptr(face_idx), _lib.ptr(dist_type), _lib.ptr(grad_points),

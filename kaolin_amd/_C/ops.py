@@ -30,7 +30,7 @@ def trianglemeshes_to_voxelgrids_cuda(vertices, faces, resolution, origin=None, 
         # the kernels gather vertices unchecked; the reference's indexing raises (a device assert) on such a mesh
         raise IndexError(f'{fn}: faces hold an index outside [0, num_vertices)')
     lib = _lib.load()
-    with torch.cuda.device(v.device):
+    with _lib.on_device(v.device):
         grid = torch.empty((B, R, R, R), dtype=v.dtype, device=v.device)
         norm = _lib.workspace(lib.kamd_trianglemeshes_to_voxelgrids_workspace(B, V, v.element_size()), v.device)
         st = getattr(lib, f'kamd_trianglemeshes_to_voxelgrids_{sfx}')(
@@ -55,7 +55,7 @@ def unbatched_mesh_intersection_cuda(points, verts_1, verts_2, verts_3):
         torch_check(t.dtype == points.dtype, 'expected points and vertices to have the same scalar type')
     sfx = _lib.dtype_suffix(points.dtype, fn)
     lib = _lib.load()
-    with torch.cuda.device(points.device):
+    with _lib.on_device(points.device):
         result = torch.empty(n, dtype=points.dtype, device=points.device)
         st = getattr(lib, f'kamd_mesh_intersection_{sfx}')(
             _lib.stream_ptr(points.device), n, m, _lib.ptr(points), _lib.ptr(verts_1), _lib.ptr(verts_2),
@@ -89,7 +89,7 @@ def mesh_to_spc_cuda(face_vertices, level):
         return [torch.empty(0, dtype=torch.uint8, device=dev), torch.empty(0, dtype=torch.long, device=dev),
                 torch.zeros((0, 3), dtype=torch.float32, device=dev)]
 
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         n = face_vertices.size(0)
         if n == 0:
             return empty_result()

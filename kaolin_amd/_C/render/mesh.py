@@ -32,7 +32,7 @@ def packed_rasterize_forward_cuda(height, width, face_vertices_z, face_vertices_
     if first_idx_face_per_mesh.dtype != torch.long:
         raise RuntimeError(f'expected scalar type Long but found {_lib._PRETTY.get(first_idx_face_per_mesh.dtype)}')
     lib = _lib.load()
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         # every element of the three outputs is written by the kernel (uncovered pixels: -1 / 0 / 0),
         # which is what at::full(-1) / at::zeros give in the reference
         sel = torch.empty((batch_size, height, width), dtype=torch.long, device=device)
@@ -72,7 +72,7 @@ def rasterize_backward_cuda(grad_interpolated_features, interpolated_features, s
     dtype, device = grad_interpolated_features.dtype, grad_interpolated_features.device
     sfx = _lib.dtype_suffix(dtype, 'rasterize_backward_cuda')
     lib = _lib.load()
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         g_img = torch.zeros_like(face_vertices_image)
         g_feat = torch.zeros_like(face_features) if need_feature_grad else None
         st = getattr(lib, f'kamd_rasterize_backward_{sfx}')(
@@ -104,7 +104,7 @@ def dibr_soft_mask_forward_cuda(face_vertices_image, face_large_bboxes, selected
     sfx = _lib.dtype_suffix(dtype, 'dibr_soft_mask_forward_cuda')
     knum = int(knum)
     lib = _lib.load()
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         # the library initialises the K-buffers itself (prob 0, idx -1, type 0) in one streaming pass
         soft_mask = torch.empty((batch_size, height, width), dtype=dtype, device=device)
         prob = torch.empty((batch_size, height, width, knum), dtype=dtype, device=device)
@@ -146,7 +146,7 @@ def dibr_soft_mask_backward_cuda(grad_soft_mask, soft_mask, selected_face_idx, c
     dtype, device = face_vertices_image.dtype, face_vertices_image.device
     sfx = _lib.dtype_suffix(dtype, 'dibr_soft_mask_backward_cuda')
     lib = _lib.load()
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         g_img = torch.zeros_like(face_vertices_image)
         st = getattr(lib, f'kamd_dibr_soft_mask_backward_{sfx}')(
             _lib.stream_ptr(device), batch_size, height, width, num_faces, knum,
@@ -175,7 +175,7 @@ def dibr_soft_mask_forward_lean(face_vertices_image, face_large_bboxes, selected
     dtype, device = face_vertices_image.dtype, face_vertices_image.device
     sfx = _lib.dtype_suffix(dtype, fn)
     lib = _lib.load()
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         soft_mask = torch.empty((batch_size, height, width), dtype=dtype, device=device)
         hits = _hit_list(batch_size, height, width, knum, dtype, device, num_faces)
         ws = _lib.workspace(lib.kamd_dibr_soft_mask_forward_workspace(batch_size, height, width, num_faces, int(knum),
@@ -206,7 +206,7 @@ def dibr_soft_mask_backward_lean(grad_soft_mask, soft_mask, hits, face_vertices_
     dtype, device = face_vertices_image.dtype, face_vertices_image.device
     sfx = _lib.dtype_suffix(dtype, fn)
     lib = _lib.load()
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         g_img = torch.zeros_like(face_vertices_image)
         st = getattr(lib, f'kamd_dibr_soft_mask_backward_lean_{sfx}')(
             _lib.stream_ptr(device), batch_size, height, width, num_faces, knum,
@@ -281,7 +281,7 @@ def dibr_soft_mask_forward_fused(face_vertices_image, selected_face_idx, sigmain
     dtype, device = face_vertices_image.dtype, face_vertices_image.device
     sfx = _lib.dtype_suffix(dtype, fn)
     lib = _lib.load()
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         soft_mask = torch.empty((batch_size, height, width), dtype=dtype, device=device)
         hits = _hit_list(batch_size, height, width, knum, dtype, device, num_faces)
         ws = _lib.workspace(lib.kamd_dibr_soft_mask_forward_workspace(batch_size, height, width, num_faces, int(knum),
@@ -322,7 +322,7 @@ def rasterize_forward_fused(height, width, face_vertices_z, face_vertices_image,
         if a.t.dtype != dtype:
             raise RuntimeError(f'expected scalar type {_lib._PRETTY[dtype]} but found {_lib._PRETTY.get(a.t.dtype, a.t.dtype)}')
     lib = _lib.load()
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         face_idx = torch.empty((batch_size, height, width), dtype=torch.long, device=device)
         wts = torch.empty((batch_size, height, width, 3), dtype=dtype, device=device)
         interp = torch.empty((batch_size, height, width, feat_dim), dtype=dtype, device=device)
@@ -386,7 +386,7 @@ def dibr_rasterization_forward_fused(height, width, face_vertices_z, face_vertic
     front_stride = 1
     if front is not None:
         front, front_stride, _ = _face_strides(front, False)
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         face_idx = torch.empty((batch_size, height, width), dtype=torch.long, device=device)
         wts = torch.empty((batch_size, height, width, 3), dtype=dtype, device=device)
         interp = torch.empty((batch_size, height, width, feat_dim), dtype=dtype, device=device)
@@ -427,7 +427,7 @@ def dibr_rasterization_backward_fused(grad_features, grad_soft_mask, face_idx, o
     dtype, device = face_vertices_image.dtype, face_vertices_image.device
     sfx = _lib.dtype_suffix(dtype, fn)
     lib = _lib.load()
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         g_img = torch.zeros_like(face_vertices_image)
         g_feat = torch.zeros_like(face_features) if need_feature_grad else None
         st = getattr(lib, f'kamd_dibr_rasterization_backward_{sfx}')(
@@ -499,7 +499,7 @@ def prepare_vertices_forward_fused(vertices, faces, camera_proj, camera_rot, cam
     c = lambda t: None if t is None else t.to(dtype).contiguous()  # noqa: E731
     proj, rot, trans, tf = c(camera_proj.reshape(-1)), c(camera_rot), c(camera_trans), c(camera_transform)
     faces = faces.contiguous()
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         fv_cam = torch.empty((B, F, 3, 3), dtype=dtype, device=device)
         fv_img = torch.empty((B, F, 3, 2), dtype=dtype, device=device)
         nrm = torch.empty((B, F, 3), dtype=dtype, device=device)
@@ -523,7 +523,7 @@ def prepare_vertices_backward_fused(vertices, faces, camera_proj, camera_rot, ca
     faces = faces.contiguous()
     offsets, entries, _ = vertex_face_adjacency(faces, V)
     g = [None if t is None else t.contiguous() for t in (grad_cam, grad_img, grad_nrm)]
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         g_vertices = torch.empty((B, V, 3), dtype=dtype, device=device)
         st = getattr(lib, f'kamd_prepare_vertices_backward_{sfx}')(
             _lib.stream_ptr(device), B, V, F, _lib.ptr(v), vstride, _lib.ptr(faces), _lib.ptr(proj), _lib.ptr(rot),
@@ -565,7 +565,7 @@ def deftet_sparse_render_forward_cuda(face_vertices_z, face_vertices_image, face
     sfx = _lib.dtype_suffix(dtype, fn)
     lib = _lib.load()
     knum = int(knum)
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         face_idx = torch.empty((batch_size, num_points, knum), dtype=torch.long, device=device)
         depths, w0, w1 = (torch.empty((batch_size, num_points, knum), dtype=dtype, device=device) for _ in range(3))
         ws, nbytes = _deftet_workspace(lib, batch_size, num_faces, num_points, dtype, device)
@@ -595,7 +595,7 @@ def deftet_sparse_render_forward_fused(face_vertices_z, face_vertices_image, fac
     lib = _lib.load()
     knum = int(knum)
     shape = (batch_size, num_points, knum)
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         tmp_idx = torch.empty(shape, dtype=torch.long, device=device)
         tmp_d, tmp_w0, tmp_w1 = (torch.empty(shape, dtype=dtype, device=device) for _ in range(3))
         hit_count = torch.empty((batch_size, num_points), dtype=torch.int32, device=device)
@@ -632,7 +632,7 @@ def deftet_sparse_render_backward_cuda(grad_interpolated_features, face_idx, wei
     dtype, device = grad_interpolated_features.dtype, grad_interpolated_features.device
     sfx = _lib.dtype_suffix(dtype, fn)
     lib = _lib.load()
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         g_img = torch.zeros_like(face_vertices_image)
         g_feat = torch.zeros_like(face_features)
         st = getattr(lib, f'kamd_deftet_sparse_render_backward_{sfx}')(
@@ -651,7 +651,7 @@ def mask_iou_forward_fused(lhs_mask, rhs_mask):
     lib = _lib.load()
     B, P = lhs_mask.shape[0], lhs_mask[0].numel() if lhs_mask.shape[0] else 0
     device = lhs_mask.device
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         loss = torch.empty((), dtype=lhs_mask.dtype, device=device)
         sums = torch.empty((B, 2), dtype=torch.float64, device=device)
         ws = _lib.workspace(lib.kamd_mask_iou_workspace(B), device)
@@ -668,7 +668,7 @@ def mask_iou_backward_fused(grad_loss, other_mask, sums):
     lib = _lib.load()
     B, P = other_mask.shape[0], other_mask[0].numel() if other_mask.shape[0] else 0
     device = other_mask.device
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         grad = torch.empty_like(other_mask)
         g = grad_loss.to(other_mask.dtype).reshape(1).contiguous()
         st = getattr(lib, f'kamd_mask_iou_backward_{sfx}')(_lib.stream_ptr(device), B, P, _lib.ptr(g), _lib.ptr(other_mask),
@@ -686,7 +686,7 @@ def texture_mapping_forward_fused(uv, texture_maps, bilinear):
     B, N = uv.shape[0], uv.shape[1]
     C, TH, TW = texture_maps.shape[1:]
     device = uv.device
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         out = torch.empty((B, N, C), dtype=uv.dtype, device=device)
         st = getattr(lib, f'kamd_texture_mapping_forward_{sfx}')(_lib.stream_ptr(device), B, N, C, TH, TW, int(bool(bilinear)),
                                                                  _lib.ptr(uv), _lib.ptr(texture_maps), _lib.ptr(out))
@@ -702,7 +702,7 @@ def texture_mapping_backward_fused(uv, texture_maps, grad_out, bilinear, need_te
     B, N = uv.shape[0], uv.shape[1]
     C, TH, TW = texture_maps.shape[1:]
     device = uv.device
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         g_tex = torch.zeros_like(texture_maps) if need_tex else None
         g_uv = torch.empty_like(uv) if need_uv else None
         st = getattr(lib, f'kamd_texture_mapping_backward_{sfx}')(
