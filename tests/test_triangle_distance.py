@@ -182,10 +182,12 @@ def test_gpu_full_size_properties():
 @pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [torch.float, torch.double])
 @pytest.mark.parametrize('kind', ['sphere', 'sphere_plus_large', 'soup', 'two_blobs'])
-def test_gpu_sweep_vs_oracle_and_brute(dtype, kind):
+@pytest.mark.parametrize('group', [64, 128, 256])
+def test_gpu_sweep_vs_oracle_and_brute(dtype, kind, group):
     """The Morton-tile sweep (forced here; by default it takes over from 65536 queries): dist / face_idx / dist_type must
     equal the oracle and the all-pairs kernels (KAMD_TRIANGLE_DISTANCE=brute) bit for bit -- small faces, a few huge
-    faces among them, a random triangle soup (every tile sphere is huge), and a mesh far from part of the queries."""
+    faces among them, a random triangle soup (every tile sphere is huge), and a mesh far from part of the queries; with each
+    of the sweep's three workgroup sizes (picked from the query count by default)."""
     from kaolin_amd.utils.testing import geodesic_sphere
     torch.manual_seed(11)
     v, f = geodesic_sphere(16)                      # 5120 faces
@@ -204,10 +206,12 @@ def test_gpu_sweep_vs_oracle_and_brute(dtype, kind):
         pts = torch.cat([torch.rand(3000, 3, dtype=dtype) * 8 - 4, torch.randn(3000, 3, dtype=dtype) * 0.3 + 3.0])
     d_ref, i_ref, t_ref = oracle.triangle_distance_forward(pts, fv, omp=True)
     os.environ['KAMD_TRIANGLE_DISTANCE'] = 'sweep'
+    os.environ['KAMD_TS_THREADS'] = str(group)
     try:
         dist, idx, typ = _gpu_fwd(pts, fv)
     finally:
         del os.environ['KAMD_TRIANGLE_DISTANCE']
+        del os.environ['KAMD_TS_THREADS']
     assert torch.equal(idx.cpu(), i_ref) and torch.equal(typ.cpu(), t_ref) and torch.equal(dist.cpu(), d_ref)
     os.environ['KAMD_TRIANGLE_DISTANCE'] = 'brute'
     try:
