@@ -66,18 +66,21 @@ def _closest_point_regions(points, tris):
     ab, bc, ca = b - a, c - b, a - c
     normal = -torch.cross(ab, ca, dim=-1)
 
+    def dot(u, v):                     # x, y, z products added left to right (the order the reference's oracle and kernels use)
+        return u[..., 0] * v[..., 0] + u[..., 1] * v[..., 1] + u[..., 2] * v[..., 2]
+
     def along(origin, edge):           # parameter of the projection of the point on the edge's line
-        return ((points - origin) * edge).sum(-1) / (edge * edge).sum(-1)
+        return dot(points - origin, edge) / dot(edge, edge)
 
     def outside(origin, edge):         # on the outer side of the edge, seen in the triangle's plane (or on the line)
-        return (torch.cross(normal, edge, dim=-1) * (points - origin)).sum(-1) <= 0
+        return dot(torch.cross(normal, edge, dim=-1), points - origin) <= 0
 
     t_ab, t_bc, t_ca = along(a, ab), along(b, bc), along(c, ca)
     conds = [(t_ca > 1.) & (t_ab < 0.), (t_ab > 1.) & (t_bc < 0.), (t_bc > 1.) & (t_ca < 0.),
              (t_ab >= 0.) & (t_ab <= 1.) & outside(a, ab), (t_bc >= 0.) & (t_bc <= 1.) & outside(b, bc),
              (t_ca >= 0.) & (t_ca <= 1.) & outside(c, ca)]
     unit = normal / normal.norm(dim=-1, keepdim=True)
-    on_plane = points - unit * ((points - a) * unit).sum(-1, keepdim=True)
+    on_plane = points - unit * dot(points - a, unit).unsqueeze(-1)
     cands = [a.expand_as(on_plane), b.expand_as(on_plane), c.expand_as(on_plane), a + ab * t_ab.unsqueeze(-1),
              b + bc * t_bc.unsqueeze(-1), c + ca * t_ca.unsqueeze(-1)]
     region = torch.zeros(on_plane.shape[:-1], dtype=torch.int32, device=points.device)
@@ -101,7 +104,9 @@ def _unbatched_naive_point_to_mesh_distance(points, face_vertices):
         for s0 in range(0, n, step):
             p = points[s0:s0 + step].detach().unsqueeze(1)                       # (c, 1, 3) against (1, F, 3, 3)
             _, closest = _closest_point_regions(p, face_vertices.detach().unsqueeze(0))
-            nearest[s0:s0 + step] = ((closest - p) ** 2).sum(-1).argmin(dim=1)
+            delta = closest - p
+            nearest[s0:s0 + step] = (delta[..., 0] * delta[..., 0] + delta[..., 1] * delta[..., 1] +
+                                     delta[..., 2] * delta[..., 2]).argmin(dim=1)
     region, closest = _closest_point_regions(points, face_vertices[nearest])
     return ((closest - points) ** 2).sum(-1), nearest, region
 
