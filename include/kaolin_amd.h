@@ -354,6 +354,9 @@ int kamd_texture_mapping_backward_f64(void* stream, int B, int64_t N, int C, int
 /* call is still stream-ordered for the caller.  g_img (zeroed by the caller)  */
 /* receives BOTH gradient contributions; g_feat may be NULL (feature gradient  */
 /* not needed: not computed).  workspace: kamd_dibr_rasterization_workspace.   */
+/* grad_img_to_zero (optional, (B,F,3,2)): cleared by the forward's one fill      */
+/* launch so that the caller can hand it to ..._backward as g_img without a fill */
+/* launch of its own.                                                            */
 /* ------------------------------------------------------------------------- */
 size_t kamd_dibr_rasterization_workspace(int B, int H, int W, int F, int K, int elem_size);
 int kamd_dibr_rasterization_forward_f32(void* stream, int B, int H, int W, int F, int D, int K,
@@ -364,7 +367,7 @@ int kamd_dibr_rasterization_forward_f32(void* stream, int B, int H, int W, int F
                                         int64_t* face_idx, float* weights, float* soft_mask,
                                         int32_t* hit_pair, float* hit_prob,
                                         uint8_t* hit_type, int32_t* item_count, uint32_t* work,
-                                        void* workspace);
+                                        void* workspace, float* grad_img_to_zero);
 int kamd_dibr_rasterization_forward_f64(void* stream, int B, int H, int W, int F, int D, int K,
                                         const double* z, int64_t z_face_stride, int64_t z_vertex_stride,
                                         const double* img, const double* feat, const uint8_t* valid,
@@ -373,7 +376,7 @@ int kamd_dibr_rasterization_forward_f64(void* stream, int B, int H, int W, int F
                                         int64_t* face_idx, double* weights, double* soft_mask,
                                         int32_t* hit_pair, double* hit_prob,
                                         uint8_t* hit_type, int32_t* item_count, uint32_t* work,
-                                        void* workspace);
+                                        void* workspace, double* grad_img_to_zero);
 int kamd_dibr_rasterization_backward_f32(void* stream, int B, int H, int W, int F, int D, int K,
                                          const float* grad_feat, const float* grad_soft,
                                          const int64_t* face_idx, const float* weights,

@@ -351,12 +351,14 @@ def _face_strides(t, inner):
 
 
 def dibr_rasterization_forward_fused(height, width, face_vertices_z, face_vertices_image, face_features, valid_faces,
-                                     sigmainv, boxlen, knum, multiplier, eps):
+                                     sigmainv, boxlen, knum, multiplier, eps, prepare_grad=False):
     """``rasterize_forward_fused`` + ``dibr_soft_mask_forward_fused`` in one library call (ours): the same kernels
     sharing one binning pass, the rasterizer's tile kernel classifying the pixels for the soft mask.  ``valid_faces`` is either
     the bool mask of the faces to rasterize or a FLOAT (B, F) tensor ``n`` standing for the mask ``n >= 0`` (the face
     normals' z of ``dibr_rasterization``): that one, and ``face_vertices_z``, may be last-index views and are read in
-    place.  -> (interpolated_features, face_idx, output_weights, soft_mask, hits)"""
+    place.  -> (interpolated_features, face_idx, output_weights, soft_mask, hits, grad_buffer): with ``prepare_grad`` the
+    last one is a zeroed ``grad_face_vertices_image`` for :func:`dibr_rasterization_backward_fused`, cleared by the same fill
+    launch as the operator's own list heads (a fill launch of its own in the backward costs ~5 us); else ``None``."""
     fn = 'dibr_rasterization_forward_fused'
     front = None
     if valid_faces is not None and valid_faces.is_floating_point():
@@ -392,6 +394,7 @@ def dibr_rasterization_forward_fused(height, width, face_vertices_z, face_vertic
         interp = torch.empty((batch_size, height, width, feat_dim), dtype=dtype, device=device)
         soft_mask = torch.empty((batch_size, height, width), dtype=dtype, device=device)
         hits = _hit_list(batch_size, height, width, knum, dtype, device, num_faces)
+        g_img = torch.empty_like(face_vertices_image) if prepare_grad else None
         ws = _lib.workspace(lib.kamd_dibr_rasterization_workspace(batch_size, height, width, num_faces, int(knum), esz), device)
         st = getattr(lib, f'kamd_dibr_rasterization_forward_{sfx}')(
             _lib.stream_ptr(device), batch_size, height, width, num_faces, feat_dim, int(knum),
@@ -400,17 +403,18 @@ def dibr_rasterization_forward_fused(height, width, face_vertices_z, face_vertic
             float(multiplier), float(eps), float(sigmainv), float(boxlen * multiplier),
             _lib.ptr(interp), _lib.ptr(face_idx), _lib.ptr(wts), _lib.ptr(soft_mask),
             _lib.ptr(hits[0]), _lib.ptr(hits[1]), _lib.ptr(hits[2]), _lib.ptr(hits[3]), _lib.ptr(hits[4]),
-            _lib.ptr(ws))
+            _lib.ptr(ws), _lib.ptr(g_img))
     _lib.check(st, fn)
-    return interp, face_idx, wts, soft_mask, hits
+    return interp, face_idx, wts, soft_mask, hits, g_img
 
 
 def dibr_rasterization_backward_fused(grad_features, grad_soft_mask, face_idx, output_weights, soft_mask, hits,
                                       face_vertices_image, face_features, sigmainv, knum, multiplier, eps,
-                                      need_feature_grad=True):
+                                      need_feature_grad=True, zeroed_grad_image=None):
     """Backward of :func:`dibr_rasterization_forward_fused`: the rasterizer's and the soft mask's backward kernels run
     concurrently and accumulate into ONE grad_face_vertices_image. -> (grad_face_vertices_image, grad_face_features);
-    ``need_feature_grad=False`` (static features: autograd's ``needs_input_grad``) skips the second one -> None."""
+    ``need_feature_grad=False`` (static features: autograd's ``needs_input_grad``) skips the second one -> None.
+    ``zeroed_grad_image``: the buffer the forward cleared for this call (accumulated into and returned)."""
     fn = 'dibr_rasterization_backward_fused'
     args = [Arg(grad_features, 'grad_features', 1), Arg(grad_soft_mask, 'grad_soft_mask', 2), Arg(face_idx, 'face_idx', 3),
             Arg(output_weights, 'output_weights', 4), Arg(soft_mask, 'soft_mask', 5),
@@ -428,7 +432,7 @@ def dibr_rasterization_backward_fused(grad_features, grad_soft_mask, face_idx, o
     sfx = _lib.dtype_suffix(dtype, fn)
     lib = _lib.load()
     with _lib.on_device(device):
-        g_img = torch.zeros_like(face_vertices_image)
+        g_img = zeroed_grad_image if zeroed_grad_image is not None else torch.zeros_like(face_vertices_image)
         g_feat = torch.zeros_like(face_features) if need_feature_grad else None
         st = getattr(lib, f'kamd_dibr_rasterization_backward_{sfx}')(
             _lib.stream_ptr(device), batch_size, height, width, num_faces, feat_dim, int(knum),

@@ -77,7 +77,7 @@ for _t in ('f32', 'f64'):
     SIGNATURES[f'kamd_dibr_soft_mask_forward_fused_{_t}'] = (
         _i, [_vp, _i, _i, _i, _i, _i, _vp, _dbl, _dbl, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_dibr_rasterization_forward_{_t}'] = (
-        _i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _dbl, _f, _f, _dbl] + [_vp] * 10)
+        _i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _dbl, _f, _f, _dbl] + [_vp] * 11)
     SIGNATURES[f'kamd_rasterize_forward_fused_strided_{_t}'] = (
         _i, [_vp, _i, _i, _i, _i, _i, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _dbl, _f, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_dibr_rasterization_backward_{_t}'] = (

@@ -112,3 +112,41 @@ static inline int kamd_fill_async(void* ptr, size_t bytes, int byte, hipStream_t
   return (int)hipGetLastError();
 }
 static inline int kamd_zero_async(void* ptr, size_t bytes, hipStream_t st) { return kamd_fill_async(ptr, bytes, 0, st); }
+
+// up to three ranges cleared by ONE launch (a launch costs ~5 us of stream time however little it does: the DIB-R forward
+// clears its list heads, its work-list header and the gradient buffer its backward will accumulate into).  Ranges that are
+// not whole 16-byte chunks fall back to a launch of their own.
+__global__ __launch_bounds__(256) static void kamd_zero3_kernel(uint4* __restrict__ p0, size_t n0, uint4* __restrict__ p1, size_t n1,
+                                                               uint4* __restrict__ p2, size_t n2) {
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  const size_t total = n0 + n1 + n2, stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    if (i < n0)
+      p0[i] = z;
+    else if (i < n0 + n1)
+      p1[i - n0] = z;
+    else
+      p2[i - n0 - n1] = z;
+  }
+}
+static inline int kamd_zero3_async(void* a, size_t na, void* b, size_t nb, void* c, size_t nc, hipStream_t st) {
+  void* p[3] = {a, b, c};
+  size_t n[3] = {a ? na : 0, b ? nb : 0, c ? nc : 0};
+  size_t n16[3] = {0, 0, 0};
+  for (int i = 0; i < 3; ++i) {
+    if (n[i] == 0) continue;
+    if (((uintptr_t)p[i] & 15) == 0 && n[i] % 16 == 0) {
+      n16[i] = n[i] / 16;
+    } else {
+      const int rc = kamd_zero_async(p[i], n[i], st);
+      if (rc != 0) return rc;
+    }
+  }
+  const size_t total = n16[0] + n16[1] + n16[2];
+  if (total == 0) return 0;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > (size_t)KAMD_NUM_CU * 16) blocks = (size_t)KAMD_NUM_CU * 16;
+  hipLaunchKernelGGL(kamd_zero3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint4*)p[0], n16[0], (uint4*)p[1], n16[1],
+                     (uint4*)p[2], n16[2]);
+  return (int)hipGetLastError();
+}

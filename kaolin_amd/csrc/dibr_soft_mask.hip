@@ -428,7 +428,7 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
                        int64_t z_vertex_stride, const T* img, const T* feat, const uint8_t* valid, const T* front,
                        int64_t front_stride, double multiplier, float eps, float sigmainv, double margin, T* interp,
                        int64_t* face_idx, T* weights, T* soft_mask, const HitList2<T>& list, unsigned int* work,
-                       void* workspace) {
+                       void* workspace, T* g_img_zero) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
   const long long total_faces = (long long)B * F;
   if (workspace == nullptr || work == nullptr) return (int)hipErrorInvalidValue;
@@ -438,8 +438,10 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
   tl::Lists LS = tl::lists_of(workspace, lay.s, B, true);
   T* rec_r = (T*)((char*)workspace + lay.r.rec);
   T* rec_s = (T*)((char*)workspace + lay.s.rec);
-  KAMD_CHECK(kamd_zero_async(workspace, lay.zero_bytes, st));
-  KAMD_CHECK(kamd_zero_async(work, tl::WORK_HEADER * 4, st));
+  // one launch clears the list heads, the work-list header and (when the caller will differentiate) the buffer the backward
+  // kernels accumulate into
+  KAMD_CHECK(kamd_zero3_async(workspace, lay.zero_bytes, work, tl::WORK_HEADER * 4, g_img_zero,
+                              (size_t)total_faces * 6 * sizeof(T), st));
   if (total_faces > 0) {
     tl::BinIn<T> in{};
     in.B = B;
@@ -622,11 +624,11 @@ size_t kamd_dibr_rasterization_workspace(int B, int H, int W, int F, int K, int 
       int64_t z_vertex_stride, const T* img, const T* feat, const uint8_t* valid, const T* front,                     \
       int64_t front_stride, double multiplier, float eps, float sigmainv, double margin, T* interp, int64_t* face_idx, \
       T* weights, T* soft_mask, int32_t* hit_pair, T* hit_prob, uint8_t* hit_type, int32_t* item_count,               \
-      uint32_t* work, void* workspace) {                                                                              \
+      uint32_t* work, void* workspace, T* grad_img_to_zero) {                                                         \
     HitList2<T> l{(int2*)hit_pair, hit_prob, hit_type, item_count};                                                   \
     return dibr_forward_fused<T>((hipStream_t)stream, B, H, W, F, D, K, z, z_face_stride, z_vertex_stride, img, feat,  \
                                  valid, front, front_stride, multiplier, eps, sigmainv, margin, interp, face_idx,     \
-                                 weights, soft_mask, l, work, workspace);                                             \
+                                 weights, soft_mask, l, work, workspace, grad_img_to_zero);                           \
   }                                                                                                                   \
   int kamd_dibr_rasterization_backward_##SFX(                                                                         \
       void* stream, int B, int H, int W, int F, int D, int K, const T* grad_feat, const T* grad_soft,                 \

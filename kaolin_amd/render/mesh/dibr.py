@@ -66,9 +66,11 @@ class DibrRasterizationCuda(torch.autograd.Function):
         # of prepare_vertices' outputs -- the library reads them in place (no compare kernel, no contiguous copies)
         if not valid_faces.is_floating_point():
             valid_faces = valid_faces.contiguous()
-        feats, face_idx, weights, soft_mask, hits = _C.render.mesh.dibr_rasterization_forward_fused(
+        # when the image coordinates will be differentiated, the forward's fill launch also clears the gradient buffer the
+        # backward kernels accumulate into (held from here to the backward: B*F*6 scalars)
+        feats, face_idx, weights, soft_mask, hits, ctx.zeroed_grad = _C.render.mesh.dibr_rasterization_forward_fused(
             height, width, face_vertices_z, face_vertices_image, face_features, valid_faces,
-            sigmainv, boxlen, knum, multiplier, eps)
+            sigmainv, boxlen, knum, multiplier, eps, prepare_grad=ctx.needs_input_grad[3])
         ctx.save_for_backward(face_idx, weights, soft_mask, face_vertices_image, face_features, *hits)
         ctx.mark_non_differentiable(face_idx)
         # no zero tensors for the gradients of outputs nobody differentiates (the index output alone is B*H*W*8 bytes)
@@ -86,10 +88,11 @@ class DibrRasterizationCuda(torch.autograd.Function):
             grad_feats = torch.zeros(soft_mask.shape + (face_features.shape[-1],), dtype=soft_mask.dtype, device=soft_mask.device)
         if grad_soft_mask is None:
             grad_soft_mask = torch.zeros_like(soft_mask)
+        zeroed, ctx.zeroed_grad = ctx.zeroed_grad, None     # (a second backward through a retained graph clears its own)
         g_img, g_feat = _C.render.mesh.dibr_rasterization_backward_fused(
             grad_feats.contiguous(), grad_soft_mask.contiguous(), face_idx, weights, soft_mask, ctx.saved_tensors[5:],
             face_vertices_image, face_features, sigmainv, knum, multiplier, eps,
-            need_feature_grad=ctx.needs_input_grad[4])
+            need_feature_grad=ctx.needs_input_grad[4], zeroed_grad_image=zeroed)
         return None, None, None, g_img, g_feat, None, None, None, None, None, None
 
 

@@ -413,6 +413,28 @@ def test_static_features_skip_their_gradient(D):
         assert rel_close(grads[1], grads[0], 1e-5), name
 
 
+def test_gradient_buffer_cleared_by_the_forward_is_used_once():
+    """The fused forward clears the buffer its backward accumulates into (one fill launch for both).  A second backward
+    through a retained graph must not accumulate on top of the first result, and a forward whose image coordinates do not
+    require grad must not leave a buffer behind."""
+    fz, fimg, feats, nz = _scene(8, 2, torch.float)
+    H, W = 64, 72
+    feat = torch.cat(feats, -1).cuda()
+    a = fimg.cuda().requires_grad_()
+    out, soft, _ = kal().render.mesh.dibr_rasterization(H, W, fz.cuda(), a, feat, nz.cuda())
+    loss = out.sum() + (soft * 3.).sum()
+    loss.backward(retain_graph=True)
+    first = a.grad.clone()
+    a.grad = None
+    loss.backward()
+    assert rel_close(a.grad, first, 1e-5)
+    f = feat.clone().requires_grad_()
+    out2, soft2, _ = kal().render.mesh.dibr_rasterization(H, W, fz.cuda(), fimg.cuda(), f, nz.cuda())
+    assert out2.grad_fn.zeroed_grad is None
+    out2.sum().backward()
+    assert f.grad is not None
+
+
 def test_nan_vertex_matches_reference_glue():
     """torch.min / torch.max propagate NaN, so a face with a NaN vertex has a NaN box that rejects no pixel; the
     fused binning must give the reference glue's result (`_packed_forward`), not confine the face to its finite corners."""
