@@ -396,7 +396,9 @@ int soft_mask_backward_list_launch(hipStream_t st, int B, int H, int W, int F, i
   if ((long long)B * H * W <= 0 || F <= 0) return 0;
   {
     kamd::ProfScope prof_(kamd::K_SOFT_BACKWARD_LIST, st);
-    static const int per_cu = kamd_env_int("KAMD_SOFT_BWD_PER_CU", 8);
+    // static shares of the work list: two resident sets' worth of workgroups balance better than one (with the pipelined
+    // loads, profiles/r02w_sweep.txt: 8 per CU 92 us, 12: 84, 16: 74, 24: 77; step median 0.611 -> 0.596 ms)
+    static const int per_cu = kamd_env_int("KAMD_SOFT_BWD_PER_CU", 16);
     hipLaunchKernelGGL(soft_mask_backward_list_kernel2<T>, dim3(KAMD_NUM_CU * per_cu), dim3(256), 0, st, B, H, W, F, K, grad,
                        soft_mask, list, work, tl::work_shard_cap(B, H, W), tl::pass_geom(H, W, tl::S_TILE).tiles_x, img,
                        (T)img_scale, sigmainv, multiplier, g_img, kamd_env_int("KAMD_BWD_MODE", 0));
