@@ -335,7 +335,10 @@ __device__ __forceinline__ float sdg_dist(float tx, float ty, float tz, float qx
   return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
 
-constexpr int SDG_GROUP = 8;  // lanes cooperating on one query (rows of the cell cube are dealt round-robin)
+#ifndef KAMD_SDG_GROUP
+#define KAMD_SDG_GROUP 4  // build knob; 100k x 100k (profiles/r02y_sdg.txt): 2 lanes 60 us, 4: 56, 8: 61, 16: 85 for both directions
+#endif
+constexpr int SDG_GROUP = KAMD_SDG_GROUP;  // lanes cooperating on one query (rows of the cell cube are dealt round-robin)
 
 // the search for one query, shared by the one-direction and the two-direction kernels.  All SDG_GROUP lanes of a query
 // call it with the same (qx, qy, qz, c); on return every lane holds the query's (best, best_i).
@@ -452,8 +455,8 @@ __global__ __launch_bounds__(256) void sdg_query(Cloud A, Cloud T, float* __rest
   if (threadIdx.x == 0) s_box = sdg_box_decode((fwd ? T.box : A.box) + (size_t)b * 8, G);
   __syncthreads();
   // 100k queries are only ~1.5 wavefronts per SIMD and every query is a chain of dependent loads (cell range ->
-  // targets): 8 lanes share a query so that 8x more loads are in flight; the lanes' (dist, idx) are merged with a
-  // 3-step butterfly after every ring
+  // targets): SDG_GROUP lanes share a query so that as many more loads are in flight; the lanes' (dist, idx) are merged
+  // with a butterfly after every ring
   const int sub = threadIdx.x % SDG_GROUP;
   double term = 0.0;
   // a workgroup takes the chunks of 32 queries blockIdx.x, blockIdx.x + gridDim.x, ...: one chunk each unless the chamfer
