@@ -76,7 +76,10 @@ struct SdgWs {
   size_t zero_bytes;    // prefix of the workspace that must be zeroed (counts, boxes, barrier, sums, scatter sides)
   size_t total;
 };
-constexpr int SDG_BUILD_THREADS = 512;  // workgroup of the build kernel = cells per scan block
+#ifndef KAMD_SDG_BUILD_THREADS
+#define KAMD_SDG_BUILD_THREADS 512  // build knob for experiments
+#endif
+constexpr int SDG_BUILD_THREADS = KAMD_SDG_BUILD_THREADS;  // workgroup of the build kernel = cells per scan block
 // query workgroups of a chamfer launch at most (each leaves one partial sum)
 inline size_t sdg_partials(int B) { return (size_t)2 * B > 8192 ? (size_t)2 * B : 8192; }
 
