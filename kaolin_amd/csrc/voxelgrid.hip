@@ -16,7 +16,7 @@
 //                         (face, a base-4 path of L0 levels): it re-derives its sub-triangle by descending
 //                         the path (the thread whose remaining path digits are all 0 marks the ancestors'
 //                         midpoints, exactly once), then finishes the subtree depth-first, stackless, in registers.
-//                         L0 is picked on the host from B*F alone so that >= 256k threads exist whatever the mesh (12
+//                         L0 is picked on the host from B*F alone so that >= 160k threads exist whatever the mesh (12
 //                         huge faces or 10^6 tiny ones); more threads only repeat the shared path prefix.
 // Arithmetic as the reference's torch ops, in the tensor's dtype: midpoint (a+b)/2, squared edge
 // (dx*dx + dy*dy) + dz*dz (torch.sum's order for 3 elements), threshold rounded to the dtype,
@@ -297,7 +297,8 @@ int vox_launch(hipStream_t st, int B, int V, int F, int R, const T* vertices, co
   {
     kamd::ProfScope prof_(kamd::K_VOX_VERTICES, st);
     size_t blocks = (n16 + 255) / 256;
-    if (blocks > (size_t)KAMD_NUM_CU * 16) blocks = (size_t)KAMD_NUM_CU * 16;
+    const size_t per_cu = (size_t)kamd_env_int("KAMD_VOX_FILL_PER_CU", 16);  // (measurement knob)
+    if (blocks > (size_t)KAMD_NUM_CU * per_cu) blocks = (size_t)KAMD_NUM_CU * per_cu;
     if (V > 0 && blocks < (size_t)B * VOX_NP) blocks = (size_t)B * VOX_NP;
     if (blocks > 0)
       hipLaunchKernelGGL(vox_clear_extent_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, B, V, vertices, part,
@@ -307,7 +308,11 @@ int vox_launch(hipStream_t st, int B, int V, int F, int R, const T* vertices, co
   }
   if (V > 0) {
     int L0 = 0;
-    while (F > 0 && L0 < VOX_MAXL0 && (long long)B * F * (1ll << (2 * L0)) < (1ll << 18)) ++L0;
+    // enough threads to fill the GPU, no more: every extra level repeats the shared path prefix in four times the threads
+    // (profiles/r02_vox_threads.txt, 256^3: 50k faces 23.7 / 16.2 / 24.5 / 70 us with 50k / 200k / 800k / 3.2M threads; 80 faces
+    // 88 / 29 / 25 / 51 us with 20k / 82k / 330k / 1.3M)
+    const long long target = kamd_env_int("KAMD_VOX_THREADS", 160000);
+    while (F > 0 && L0 < VOX_MAXL0 && (long long)B * F * (1ll << (2 * L0)) < target) ++L0;
     const long long nvert = (long long)B * V;
     const long long total = nvert + (long long)B * F * (1ll << (2 * L0));
     const double thr = ((double)(R - 1) / ((double)R * (double)R)) * ((double)(R - 1) / ((double)R * (double)R));
