@@ -55,20 +55,10 @@ __device__ __forceinline__ void kamd_atomic_add(__half* p, __half v) {
 __device__ __forceinline__ float kamd_hround(float x) { return __half2float(__float2half(x)); }
 
 // ---- persistent-kernel grids -------------------------------------------------------------------------------------
-// Persistent kernels (static round-robin over a worklist, `for (i = blockIdx.x; i < n; i += gridDim.x)`) want exactly
-// one resident set of workgroups: with more, the surplus is dispatched only when the first set retires and runs its
-// equal share on a mostly idle GPU (soft_search at 142 VGPRs holds 12 one-wave workgroups per CU, not the 16 it used to
-// be launched with: two dispatch rounds instead of 1.33 rounds' worth of work).  The runtime's occupancy query knows the
-// kernel's registers and LDS; the answer is clamped to [lo, hi] so that a wrong one cannot cost more than the old grid.
-template <typename Kernel>
-static inline int kamd_resident_blocks_per_cu(Kernel kernel, int threads, int lo, int hi) {
-  int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, 0) != hipSuccess) {
-    (void)hipGetLastError();  // the query is advisory: do not leave its error for the launch checks
-    nb = hi;
-  }
-  return nb < lo ? lo : (nb > hi ? hi : nb);
-}
+// Persistent kernels (static round-robin over a worklist, `for (i = blockIdx.x; i < n; i += gridDim.x)`) are launched with
+// a fixed number of workgroups per CU, found by sweeps (12-32: see the launch sites).  Sizing the grid to exactly one
+// resident set from the runtime's occupancy query was tried at the end of round 1 and measured at the start of round 2:
+// slower every time (soft_search 133 -> 146 us) -- items differ in cost, and more, smaller static shares balance better.
 // measurement knob: an integer from the environment (grid sweeps on the GPU box), `dflt` when unset or not positive
 static inline int kamd_env_int(const char* name, int dflt) {
   const char* v = getenv(name);
