@@ -354,6 +354,8 @@ int kamd_texture_mapping_backward_f64(void* stream, int B, int64_t N, int C, int
 /* call is still stream-ordered for the caller.  g_img (zeroed by the caller)  */
 /* receives BOTH gradient contributions; g_feat may be NULL (feature gradient  */
 /* not needed: not computed).  workspace: kamd_dibr_rasterization_workspace.   */
+/* `weights` is meaningful only where face_idx >= 0 (background tiles do not write */
+/* it: the backward reads it only there).                                         */
 /* grad_img_to_zero (optional, (B,F,3,2)): cleared by the forward's one fill      */
 /* launch so that the caller can hand it to ..._backward as g_img without a fill */
 /* launch of its own.                                                            */

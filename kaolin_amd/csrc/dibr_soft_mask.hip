@@ -474,7 +474,8 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
   co.work_items = reinterpret_cast<uint4*>(work + tl::WORK_HEADER);
   co.work_counts = work;
   co.shard_cap = tl::work_shard_cap(B, H, W);
-  KAMD_CHECK(kamd::raster2_draw<T>(st, B, H, W, D, F, (float)multiplier, eps, rec_r, LR, feat, interp, face_idx, weights, co));
+  KAMD_CHECK(kamd::raster2_draw<T>(st, B, H, W, D, F, (float)multiplier, eps, rec_r, LR, feat, interp, face_idx, weights, co,
+                                   kamd_env_int("KAMD_DIBR_BG_WEIGHTS", 2) != 1));
   if (total_faces > 0)
     KAMD_CHECK(soft2_search_launch<T>(st, B, H, W, F, K, sigmainv, (float)multiplier, rec_s, LS, work, soft_mask, (T*)nullptr,
                                       (int64_t*)nullptr, (uint8_t*)nullptr, (uint8_t*)nullptr, &list,

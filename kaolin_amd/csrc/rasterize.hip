@@ -274,17 +274,19 @@ int rasterize_backward_launch(hipStream_t st, int B, int H, int W, int F, int D,
 namespace kamd {
 template <typename T>
 int raster2_draw(hipStream_t st, int B, int H, int W, int D, int F_dense, float multiplier, float eps, const T* rec,
-                 const tl::Lists& LR, const T* feat, T* interp, int64_t* sel_idx, T* weights, const tl::ClassifyOut& co) {
+                 const tl::Lists& LR, const T* feat, T* interp, int64_t* sel_idx, T* weights, const tl::ClassifyOut& co,
+                 bool weights_internal) {
   kamd::ProfScope prof_(kamd::K_RASTER_TILE, st);
   hipLaunchKernelGGL((raster_tile_kernel2<T, true>), dim3(LR.ntiles * B), dim3(256), 0, st, B, F_dense,
                      (const int64_t*)nullptr, H, W, D, pixel_scale(multiplier, H, W), eps,
-                     raster2_wide_ok(W, interp, sel_idx, weights, co.soft_mask), kamd_env_int("KAMD_RASTER_MODE", 0), rec, LR, feat, interp, sel_idx, weights, co);
+                     raster2_wide_ok(W, interp, sel_idx, weights, co.soft_mask) | (weights_internal ? 2 : 0),
+                     kamd_env_int("KAMD_RASTER_MODE", 0), rec, LR, feat, interp, sel_idx, weights, co);
   return (int)hipGetLastError();
 }
 template int raster2_draw<float>(hipStream_t, int, int, int, int, int, float, float, const float*, const tl::Lists&, const float*,
-                                 float*, int64_t*, float*, const tl::ClassifyOut&);
+                                 float*, int64_t*, float*, const tl::ClassifyOut&, bool);
 template int raster2_draw<double>(hipStream_t, int, int, int, int, int, float, float, const double*, const tl::Lists&,
-                                  const double*, double*, int64_t*, double*, const tl::ClassifyOut&);
+                                  const double*, double*, int64_t*, double*, const tl::ClassifyOut&, bool);
 }  // namespace kamd
 
 #ifdef KAMD_PHASE_PROF
