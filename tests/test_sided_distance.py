@@ -472,3 +472,27 @@ def test_integer_clouds_follow_c_semantics(dtype):
             np.add.at(want_g2[bb], want_i[bb], (2 * (sel[bb] - a[bb]) * grad.numpy().astype(wide)[bb][:, None]).astype(npdt).astype(wide))
     assert np.array_equal(g1.cpu().numpy(), want_g1)
     assert np.array_equal(g2.cpu().numpy(), want_g2.astype(npdt))
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(180)
+def test_fused_chamfer_on_concurrent_streams():
+    """The grid build of the nearest-point search is one persistent kernel whose workgroups meet at grid barriers: three
+    streams issuing it at the same time must neither hang nor disturb each other (the value is deterministic: bit-equal to
+    the single-stream results)."""
+    pc = _pc()
+    g = torch.Generator().manual_seed(0)
+    clouds = [(torch.rand(1, 30000, 3, generator=g).cuda(), torch.rand(1, 25000, 3, generator=g).cuda()) for _ in range(3)]
+    ref = [pc.chamfer_distance(a, b) for a, b in clouds]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in clouds]
+    for _ in range(8):
+        outs = []
+        for s, (a, b) in zip(streams, clouds):
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                outs.append(pc.chamfer_distance(a, b))
+        for s in streams:
+            torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, r) for o, r in zip(outs, ref))
