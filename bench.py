@@ -121,7 +121,7 @@ def main():
     # before the step ends; with one process this is a no-op.
     reducer = D.SharedGradientReducer([verts])
 
-    def make_step(features):
+    def make_step(features, tutorial_loss=False):
         def step():
             verts.grad = None
             features.grad = None
@@ -130,12 +130,18 @@ def main():
             feat, soft, face_idx = kal.render.mesh.dibr_rasterization(
                 H, W, fv_cam[..., 2], fv_img, features, normals[..., 2])
             # (features * G1).sum() + (soft_mask * G2).sum(), written as two dot products (one pass each way)
-            loss = torch.dot(feat.reshape(-1), G1f) + torch.dot(soft.reshape(-1), G2f)
+            if tutorial_loss:
+                # the DIB-R tutorial's objective: L1 image loss + silhouette IoU (kaolin.metrics.render.mask_iou, fused here)
+                loss = torch.mean(torch.abs(feat - G1)) + kal.metrics.render.mask_iou(soft, target_mask)
+            else:
+                loss = torch.dot(feat.reshape(-1), G1f) + torch.dot(soft.reshape(-1), G2f)
             loss.backward()
             reducer.wait()
             return face_idx
         return step
+    target_mask = (G2 > 0.5).float()
     dibr_step = make_step(feats3)
+    dibr_step_tutorial = make_step(feats3, tutorial_loss=True)
     dibr_step_feature_grad = make_step(feats3_grad)
 
     def per_step_ms(fn, steps):
@@ -211,6 +217,11 @@ def main():
     feature_grad = {'ms_per_step': round(fg_dt / args.steps * 1e3, 4), 'per_step_ms': fg_stats,
                     'value': round(world * V * H * W * args.steps / fg_dt / 1e6, 2), 'unit': 'Mpixels/s',
                     'note': 'same step with face_features.requires_grad (gradients to vertices AND features)'}
+
+    tl_dt = timed(dibr_step_tutorial, args.steps, args.warmup)
+    tutorial = {'ms_per_step': round(tl_dt / args.steps * 1e3, 4), 'per_step_ms': per_step_ms(dibr_step_tutorial, max(args.steps, 20)),
+                'note': 'same step with the tutorial\'s objective: torch L1 image loss + kaolin.metrics.render.mask_iou (one fused '
+                        'pass each way) instead of the two dot products'}
 
     covered = float((face_idx >= 0).float().mean())
     traffic, step_traffic = None, None
@@ -398,7 +409,7 @@ def main():
                                    f'prepare_vertices + vertex-gradient all-reduce (posted from the autograd hook) inside the step',
                        'views_per_gpu': V, 'global_views': V * world, 'height': H, 'width': W, 'faces': F,
                        'covered_pixel_fraction': round(covered, 4), 'parallelism': f'views sharded {world}-way'},
-            'per_step_ms': step_stats, 'feature_grad_variant': feature_grad,
+            'per_step_ms': step_stats, 'feature_grad_variant': feature_grad, 'tutorial_loss_variant': tutorial,
             'roofline': roofline, 'step_roofline': step_roofline, 'step_traffic': step_traffic, 'kernels': kernels,
             'kernels_note': f'per-kernel table: separate pass of {args.steps} steps with HIP events around every launch '
                             f'({inst_ms_per_step:.4f} ms/step: the events and the single-stream order they need cost the '
