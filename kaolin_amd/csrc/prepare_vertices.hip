@@ -75,33 +75,77 @@ template <typename T>
 __global__ __launch_bounds__(256) void pv_forward_kernel(
     int B, int V, int F, const T* __restrict__ vertices, long long vstride, const int64_t* __restrict__ faces,
     const T* __restrict__ proj, const T* __restrict__ rot, const T* __restrict__ trans, const T* __restrict__ transform,
-    T* __restrict__ fv_cam, T* __restrict__ fv_img, T* __restrict__ normals) {
+    T* __restrict__ fv_cam, T* __restrict__ fv_img, T* __restrict__ normals, int wide_ok) {
+  // Every thread produces 18 scalars in three row-major outputs (9 + 6 + 3 per face): stored lane by lane, each store
+  // instruction would scatter 4-byte pieces over a dozen cache lines.  A wavefront's 64 faces are contiguous in all three
+  // outputs, so the scalars go through LDS and leave as 16-byte chunks that tile whole lines.
+  __shared__ __attribute__((aligned(16))) T s_out[4][64 * 18];
+  const long long total = (long long)B * F;
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (long long)B * F) return;
-  const int b = (int)(gid / F), f = (int)(gid % F);
-  const Camera<T> cam = load_camera<T>(b, rot, trans, transform);
-  const T p0 = proj[0], p1 = proj[1], p2 = proj[2];
-  P3<T> c[3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long gid0 = gid - lane;  // first face of this wavefront
+  const bool live = gid < total;
+  const bool full = wide_ok && gid0 + 64 <= total;  // (wave-uniform; wide_ok: the three outputs are 16-byte aligned)
+  T* sc = s_out[wave];                   // [64 * 9] camera | [64 * 6] image | [64 * 3] normals
+  T* si = sc + 64 * 9;
+  T* sn = si + 64 * 6;
+  if (live) {
+    const int b = (int)(gid / F), f = (int)(gid % F);
+    const Camera<T> cam = load_camera<T>(b, rot, trans, transform);
+    const T p0 = proj[0], p1 = proj[1], p2 = proj[2];
+    P3<T> c[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int64_t vi = faces[(size_t)f * 3 + k];
-    const T* vp = vertices + (size_t)b * vstride + (size_t)vi * 3;
-    c[k] = to_camera<T>(cam, p3<T>(vp[0], vp[1], vp[2]));
-    T* oc = fv_cam + ((size_t)gid * 3 + k) * 3;
-    oc[0] = c[k].x;
-    oc[1] = c[k].y;
-    oc[2] = c[k].z;
-    const T px = c[k].x * p0, py = c[k].y * p1, pz = c[k].z * p2;
-    T* oi = fv_img + ((size_t)gid * 3 + k) * 2;
-    oi[0] = px / pz;
-    oi[1] = py / pz;
+    for (int k = 0; k < 3; ++k) {
+      const int64_t vi = faces[(size_t)f * 3 + k];
+      const T* vp = vertices + (size_t)b * vstride + (size_t)vi * 3;
+      c[k] = to_camera<T>(cam, p3<T>(vp[0], vp[1], vp[2]));
+      const T px = c[k].x * p0, py = c[k].y * p1, pz = c[k].z * p2;
+      const T ix = px / pz, iy = py / pz;
+      if (full) {
+        sc[lane * 9 + k * 3 + 0] = c[k].x;
+        sc[lane * 9 + k * 3 + 1] = c[k].y;
+        sc[lane * 9 + k * 3 + 2] = c[k].z;
+        si[lane * 6 + k * 2 + 0] = ix;
+        si[lane * 6 + k * 2 + 1] = iy;
+      } else {
+        T* oc = fv_cam + ((size_t)gid * 3 + k) * 3;
+        oc[0] = c[k].x;
+        oc[1] = c[k].y;
+        oc[2] = c[k].z;
+        T* oi = fv_img + ((size_t)gid * 3 + k) * 2;
+        oi[0] = ix;
+        oi[1] = iy;
+      }
+    }
+    const P3<T> n = cross3<T>(c[1] - c[0], c[2] - c[0]);
+    const T s = pv_sqrt(dot3<T>(n, n)) + (T)1e-10;
+    const T nx = n.x / s, ny = n.y / s, nz = n.z / s;
+    if (full) {
+      sn[lane * 3 + 0] = nx;
+      sn[lane * 3 + 1] = ny;
+      sn[lane * 3 + 2] = nz;
+    } else {
+      T* on = normals + (size_t)gid * 3;
+      on[0] = nx;
+      on[1] = ny;
+      on[2] = nz;
+    }
   }
-  const P3<T> n = cross3<T>(c[1] - c[0], c[2] - c[0]);
-  const T s = pv_sqrt(dot3<T>(n, n)) + (T)1e-10;
-  T* on = normals + (size_t)gid * 3;
-  on[0] = n.x / s;
-  on[1] = n.y / s;
-  on[2] = n.z / s;
+  if (!full) return;
+  // (only this wavefront reads what it wrote: wavefront-level ordering is enough)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  constexpr int PER16 = 16 / (int)sizeof(T);
+  const uint4* lc = reinterpret_cast<const uint4*>(sc);
+  const uint4* li = reinterpret_cast<const uint4*>(si);
+  const uint4* ln = reinterpret_cast<const uint4*>(sn);
+  uint4* gc = reinterpret_cast<uint4*>(fv_cam + (size_t)gid0 * 9);
+  uint4* gi = reinterpret_cast<uint4*>(fv_img + (size_t)gid0 * 6);
+  uint4* gn = reinterpret_cast<uint4*>(normals + (size_t)gid0 * 3);
+  for (int i = lane; i < 64 * 9 / PER16; i += 64) gc[i] = lc[i];
+  for (int i = lane; i < 64 * 6 / PER16; i += 64) gi[i] = li[i];
+  for (int i = lane; i < 64 * 3 / PER16; i += 64) gn[i] = ln[i];
 }
 
 template <typename T>
@@ -186,7 +230,8 @@ extern "C" {
     {                                                                                                                  \
       kamd::ProfScope prof_(kamd::K_PV_FORWARD, st);                                                                   \
       hipLaunchKernelGGL(pv_forward_kernel<T>, dim3(kamd_cdiv((long long)B * F, 256)), dim3(256), 0, st, B, V, F,      \
-                         vertices, (long long)vstride, faces, proj, rot, trans, transform, fv_cam, fv_img, normals);   \
+                         vertices, (long long)vstride, faces, proj, rot, trans, transform, fv_cam, fv_img, normals,    \
+                         ((((uintptr_t)fv_cam | (uintptr_t)fv_img | (uintptr_t)normals) & 15) == 0) ? 1 : 0);          \
     }                                                                                                                  \
     KAMD_RETURN_LAST_ERROR();                                                                                          \
   }                                                                                                                    \
