@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void sdg_query(Cloud A, Cloud T, float* __rest
   // with a butterfly after every ring
   const int sub = threadIdx.x % SDG_GROUP;
   double term = 0.0;
-  // a workgroup takes the chunks of 32 queries blockIdx.x, blockIdx.x + gridDim.x, ...: one chunk each unless the chamfer
+  // a workgroup takes the chunks of 256 / SDG_GROUP queries blockIdx.x, blockIdx.x + gridDim.x, ...: one chunk each unless the chamfer
   // modes' partial-sum buffer holds fewer workgroups than there are chunks
   const int nchunks = (int)(((long long)nq * SDG_GROUP + 255) / 256);
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
