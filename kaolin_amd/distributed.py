@@ -27,7 +27,9 @@ def init_from_env(backend=None):
     if use_cuda:
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1))
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group(backend or ('nccl' if use_cuda else 'gloo'), init_method='env://')
+    # (KAMD_DIST_BACKEND=gloo: several ranks sharing one GPU, where RCCL refuses duplicate devices -- tests of the control flow)
+    backend = backend or os.environ.get('KAMD_DIST_BACKEND') or ('nccl' if use_cuda else 'gloo')
+    dist.init_process_group(backend, init_method='env://')
     return True
 
 
