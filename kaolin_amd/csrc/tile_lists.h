@@ -32,9 +32,18 @@ constexpr int R_TILE = 16;            // rasterizer tile: 16 x 16 pixels = one 2
 constexpr int S_TILE = 32;            // soft-mask tile: 32 x 32 pixels = 16 sub-tiles of 16 x 4 (work items of the search)
 constexpr int S_SUBS = (S_TILE / SUB_W) * (S_TILE / SUB_H);  // 16
 constexpr int REC_R = 16;             // raster record scalars: box[4] a.xy b.xy c.xy z[3] flag pad2
-// soft record: large box[4] a.xy b.xy c.xy pad2, then the three edges' reciprocals 1 / (|edge|^2 + EPS) as doubles
-// (dibr_soft_mask_cuda.cu:128-139 divides by that sum for every (pixel, face) pair; the divisor depends on the face only)
+// soft record: large box[4] | body: a.xy b.xy c.xy pad2, then the three edges' reciprocals 1 / (|edge|^2 + EPS) as doubles
+// (dibr_soft_mask_cuda.cu:128-139 divides by that sum for every (pixel, face) pair; the divisor depends on the face only).
+// The boxes of all faces come first, as an array of their own (16 bytes per face), then the bodies: the select kernel
+// streams thousands of boxes per work item and never looks at a body, the eval kernel the other way round.
 constexpr int rec_s_scalars(int elem_size) { return elem_size == 4 ? 20 : 16; }
+constexpr int rec_s_body_scalars(int elem_size) { return rec_s_scalars(elem_size) - 4; }
+template <typename T>
+__host__ __device__ inline const T* soft_box(const T* rec, size_t face) { return rec + face * 4; }
+template <typename T>
+__host__ __device__ inline const T* soft_body(const T* rec, size_t total_faces, size_t face) {
+  return rec + total_faces * 4 + face * rec_s_body_scalars((int)sizeof(T));
+}
 constexpr double SOFT_EPS = 1e-7;     // the reference's literal EPS (dibr_soft_mask_cuda.cu:23), a double
 constexpr int WORK_SHARDS = 8;        // worklist shards (one append counter each; workgroup id & 7 picks the shard)
 
@@ -449,12 +458,12 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(BinIn<T> in, Lists LR, 
         by1 = ymax + in.margin;
       }
       {
-        constexpr int RS = rec_s_scalars((int)sizeof(T));
-        Rec4<T>* r = reinterpret_cast<Rec4<T>*>(in.rec_s + (size_t)f * RS);
-        r[0] = Rec4<T>{bx0, by0, bx1, by1};
-        r[1] = Rec4<T>{v[0], v[1], v[2], v[3]};
-        r[2] = Rec4<T>{v[4], v[5], 0, 0};
-        double* rc = reinterpret_cast<double*>(in.rec_s + (size_t)f * RS + 12);
+        *reinterpret_cast<Rec4<T>*>(const_cast<T*>(soft_box<T>(in.rec_s, (size_t)f))) = Rec4<T>{bx0, by0, bx1, by1};
+        T* body = const_cast<T*>(soft_body<T>(in.rec_s, (size_t)in.total_faces, (size_t)f));
+        Rec4<T>* r = reinterpret_cast<Rec4<T>*>(body);
+        r[0] = Rec4<T>{v[0], v[1], v[2], v[3]};
+        r[1] = Rec4<T>{v[4], v[5], 0, 0};
+        double* rc = reinterpret_cast<double*>(body + 8);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           const T x1 = v[k * 2], y1 = v[k * 2 + 1], x2 = v[((k + 1) % 3) * 2], y2 = v[((k + 1) % 3) * 2 + 1];
