@@ -7,7 +7,8 @@
 // 1024^2 x 50k faces, O(tiles x F) in general).  Here a tile owns a compact LIST of entries
 //
 //        entry = { block : the index of 64 consecutive faces of the packed face list,
-//                  mask  : which of those 64 faces may touch the tile }            (16 bytes)
+//                  mask  : which of those 64 faces may touch the tile,
+//                  sub   : (soft pass) which of the tile's 16 sub-tiles those faces reach }   (16 bytes)
 //
 // produced by one ballot of the wavefront that holds those 64 faces -- consecutive faces of a mesh are usually
 // neighbours on screen, so an entry carries many faces, and inside an entry the ascending face order the reference's
@@ -67,7 +68,7 @@ constexpr unsigned int BRUTE_BIT = 0x80000000u;  // set in a tile's counter when
 struct Lists {
   unsigned int* count;        // [B * ntiles]         zeroed; entries appended to the tile (| BRUTE_BIT)
   unsigned int* tab;          // [B * ntiles * maxc]  zeroed; chunk c of the tile lives at pool chunk tab[..] - 1
-  uint4* inl;                 // [B * ntiles * C]     the tile's first C entries {block, 0, mask.lo, mask.hi}
+  uint4* inl;                 // [B * ntiles * C]     the tile's first C entries {block, sub-tile bits, mask.lo, mask.hi}
   uint4* pool;                // [cap_chunks * OVC]
   unsigned int* pool_top;     // zeroed
   unsigned int cap_chunks;
@@ -304,7 +305,8 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
     unsigned int my_sub = 0u;
     auto flush = [&]() {
       const size_t ti = (size_t)bL * L.ntiles + (my_t >= 0 ? my_t : 0);
-      append_entry(my_t >= 0, L, ti, make_uint4(block, 0u, (unsigned int)my_bal, (unsigned int)(my_bal >> 32)));
+      // (soft pass: the entry also carries the sub-tiles its faces reach, so that a work item can skip whole entries)
+      append_entry(my_t >= 0, L, ti, make_uint4(block, SOFT ? my_sub : 0u, (unsigned int)my_bal, (unsigned int)(my_bal >> 32)));
       if (SOFT && my_t >= 0 && my_sub != 0u) atomicOr(L.sub_touched + ti, my_sub);
       my_t = -1;
       k = 0;
