@@ -9,7 +9,8 @@ Headline metric (BASELINE.json): Mpixels/s of DIB-R forward+backward at 1024x102
 the hot path over one batch of synthetic camera views on every rank (config C4 of SURVEY.md 8(d)):
     prepare_vertices(shared vertices) -> dibr_rasterization(8 views/GPU of a 50 000-triangle geodesic sphere,
     D = 3 features, knum = 30, sigmainv = 7000, boxlen = 0.02) -> backward of (features*G1).sum() +
-    (soft_mask*G2).sum() down to the shared vertices -> ONE all-reduce of the vertex gradient (N > 1).
+    (soft_mask*G2).sum() (kaolin_amd.metrics.render.weighted_sum: one fused pass each way; "torch_loss_variant" = the same
+    loss as two torch dots) down to the shared vertices -> ONE all-reduce of the vertex gradient (N > 1).
 Views are sharded over ranks (weak scaling: 8 views per GPU), no collective on the data path.  Inputs are
 resident in HBM when the timed region starts.  The same run also times chamfer_distance fwd+bwd at
 100k x 100k (config C3, one batch item per GPU) and reports it under "chamfer".
@@ -121,7 +122,7 @@ def main():
     # before the step ends; with one process this is a no-op.
     reducer = D.SharedGradientReducer([verts])
 
-    def make_step(features, tutorial_loss=False):
+    def make_step(features, tutorial_loss=False, torch_loss=False):
         def step():
             verts.grad = None
             features.grad = None
@@ -129,12 +130,15 @@ def main():
                 verts.unsqueeze(0).expand(V, -1, -1), faces, proj, camera_rot=rot, camera_trans=trans)
             feat, soft, face_idx = kal.render.mesh.dibr_rasterization(
                 H, W, fv_cam[..., 2], fv_img, features, normals[..., 2])
-            # (features * G1).sum() + (soft_mask * G2).sum(), written as two dot products (one pass each way)
             if tutorial_loss:
                 # the DIB-R tutorial's objective: L1 image loss + silhouette IoU (kaolin.metrics.render.mask_iou, fused here)
                 loss = torch.mean(torch.abs(feat - G1)) + kal.metrics.render.mask_iou(soft, target_mask)
-            else:
+            elif torch_loss:
+                # the linear loss in plain torch, written as two dot products (rocBLAS: one pass each way per dot)
                 loss = torch.dot(feat.reshape(-1), G1f) + torch.dot(soft.reshape(-1), G2f)
+            else:
+                # (features * G1).sum() + (soft_mask * G2).sum(): one fused pass over both G-buffers each way
+                loss = kal.metrics.render.weighted_sum(feat, G1, soft, G2)
             loss.backward()
             reducer.wait()
             return face_idx
@@ -142,6 +146,7 @@ def main():
     target_mask = (G2 > 0.5).float()
     dibr_step = make_step(feats3)
     dibr_step_tutorial = make_step(feats3, tutorial_loss=True)
+    dibr_step_torch_loss = make_step(feats3, torch_loss=True)
     dibr_step_feature_grad = make_step(feats3_grad)
 
     def per_step_ms(fn, steps):
@@ -222,6 +227,11 @@ def main():
     tutorial = {'ms_per_step': round(tl_dt / args.steps * 1e3, 4), 'per_step_ms': per_step_ms(dibr_step_tutorial, max(args.steps, 20)),
                 'note': 'same step with the tutorial\'s objective: torch L1 image loss + kaolin.metrics.render.mask_iou (one fused '
                         'pass each way) instead of the two dot products'}
+
+    tq_dt = timed(dibr_step_torch_loss, args.steps, args.warmup)
+    torch_loss = {'ms_per_step': round(tq_dt / args.steps * 1e3, 4), 'per_step_ms': per_step_ms(dibr_step_torch_loss, max(args.steps, 20)),
+                  'note': 'same step with the linear loss written in torch (two rocBLAS dots, an add, two full-size products '
+                          'backward) instead of kaolin_amd.metrics.render.weighted_sum'}
 
     covered = float((face_idx >= 0).float().mean())
     traffic, step_traffic = None, None
@@ -405,11 +415,11 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'C4: dibr_rasterization fwd+bwd, {V} views/GPU at {H}x{W} of a {F}-triangle geodesic '
                                    f'sphere (shared vertices), D=3 static face features (uv + mask channel; gradient w.r.t. the vertices only), '
-                                   f'knum=30, sigmainv=7000, boxlen=0.02, '
+                                   f'knum=30, sigmainv=7000, boxlen=0.02, loss = sum(features*G1) + sum(soft_mask*G2) (fused weighted_sum), '
                                    f'prepare_vertices + vertex-gradient all-reduce (posted from the autograd hook) inside the step',
                        'views_per_gpu': V, 'global_views': V * world, 'height': H, 'width': W, 'faces': F,
                        'covered_pixel_fraction': round(covered, 4), 'parallelism': f'views sharded {world}-way'},
-            'per_step_ms': step_stats, 'feature_grad_variant': feature_grad, 'tutorial_loss_variant': tutorial,
+            'per_step_ms': step_stats, 'feature_grad_variant': feature_grad, 'tutorial_loss_variant': tutorial, 'torch_loss_variant': torch_loss,
             'roofline': roofline, 'step_roofline': step_roofline, 'step_traffic': step_traffic, 'kernels': kernels,
             'kernels_note': f'per-kernel table: separate pass of {args.steps} steps with HIP events around every launch '
                             f'({inst_ms_per_step:.4f} ms/step: the events and the single-stream order they need cost the '

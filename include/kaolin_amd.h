@@ -326,6 +326,21 @@ int kamd_mask_iou_backward_f32(void* stream, int B, int64_t P, const float* grad
                                const double* sums, float* grad);
 int kamd_mask_iou_backward_f64(void* stream, int B, int64_t P, const double* grad_loss, const double* other,
                                const double* sums, double* grad);
+/* The linear loss sum(x1 * w1) + sum(x2 * w2) over two G-buffers of one render  */
+/* (image features and soft mask against fixed weights; no reference operator -- */
+/* in torch: two dots, an add, two full-size products backward).  Forward: one   */
+/* pass over the four arrays + a one-workgroup finish, out = the scalar; n2 = 0  */
+/* for a single pair.  Backward: g1 = grad_out[0] * w1, g2 = grad_out[0] * w2 in */
+/* one pass (a NULL gradient is skipped).  workspace: kamd_weighted_sum2_workspace() bytes. */
+size_t kamd_weighted_sum2_workspace(void);
+int kamd_weighted_sum2_forward_f32(void* stream, int64_t n1, const float* x1, const float* w1, int64_t n2,
+                                   const float* x2, const float* w2, void* workspace, float* out);
+int kamd_weighted_sum2_forward_f64(void* stream, int64_t n1, const double* x1, const double* w1, int64_t n2,
+                                   const double* x2, const double* w2, void* workspace, double* out);
+int kamd_weighted_sum2_backward_f32(void* stream, const float* grad_out, int64_t n1, const float* w1, float* g1,
+                                    int64_t n2, const float* w2, float* g2);
+int kamd_weighted_sum2_backward_f64(void* stream, const double* grad_out, int64_t n1, const double* w1, double* g1,
+                                    int64_t n2, const double* w2, double* g2);
 /* kaolin.render.mesh.texture_mapping (kaolin/render/mesh/utils.py:23-76), one  */
 /* gather kernel each way: uv (B, N, 2) OpenGL-style in [0, 1] (clamped), tex   */
 /* (B, C, TH, TW), out (B, N, C); grid_sample arithmetic (align_corners=False,  */

@@ -681,6 +681,42 @@ def mask_iou_backward_fused(grad_loss, other_mask, sums):
     return grad
 
 
+def weighted_sum2_forward(x1, w1, x2=None, w2=None):
+    """sum(x1 * w1) (+ sum(x2 * w2)) -> scalar tensor, one pass over the arrays (``kamd_weighted_sum2_forward_*``)."""
+    fn = 'weighted_sum2'
+    sfx = _lib.dtype_suffix(x1.dtype, fn)
+    lib = _lib.load()
+    device = x1.device
+    n1 = x1.numel()
+    n2 = x2.numel() if x2 is not None else 0
+    with _lib.on_device(device):
+        out = torch.empty((), dtype=x1.dtype, device=device)
+        ws = _lib.workspace(lib.kamd_weighted_sum2_workspace(), device)
+        st = getattr(lib, f'kamd_weighted_sum2_forward_{sfx}')(
+            _lib.stream_ptr(device), n1, _lib.ptr(x1), _lib.ptr(w1), n2, _lib.ptr(x2) if n2 else None,
+            _lib.ptr(w2) if n2 else None, _lib.ptr(ws), _lib.ptr(out))
+    _lib.check(st, fn)
+    return out
+
+
+def weighted_sum2_backward(grad_out, w1, w2=None, need1=True, need2=True):
+    """(grad_out * w1, grad_out * w2) in one pass; a gradient that is not needed (or has no array) is None."""
+    fn = 'weighted_sum2'
+    sfx = _lib.dtype_suffix(w1.dtype, fn)
+    lib = _lib.load()
+    device = w1.device
+    with _lib.on_device(device):
+        g = grad_out.to(w1.dtype).reshape(1).contiguous()
+        g1 = torch.empty_like(w1) if need1 else None
+        g2 = torch.empty_like(w2) if (need2 and w2 is not None) else None
+        st = getattr(lib, f'kamd_weighted_sum2_backward_{sfx}')(
+            _lib.stream_ptr(device), _lib.ptr(g), w1.numel(), _lib.ptr(w1), _lib.ptr(g1) if g1 is not None else None,
+            w2.numel() if w2 is not None else 0, _lib.ptr(w2) if w2 is not None else None,
+            _lib.ptr(g2) if g2 is not None else None)
+    _lib.check(st, fn)
+    return g1, g2
+
+
 def texture_mapping_forward_fused(uv, texture_maps, bilinear):
     """uv (B, N, 2), texture_maps (B, C, h, w) -> (B, N, C): clamp, OpenGL -> grid coordinates, sampling and the output layout
     of kaolin/render/mesh/utils.py:23-76 in one gather kernel."""

@@ -41,6 +41,7 @@ SIGNATURES = {
     'kamd_dibr_rasterization_workspace': (_sz, [_i, _i, _i, _i, _i, _i]),
     'kamd_trianglemeshes_to_voxelgrids_workspace': (_sz, [_i, _i, _i]),
     'kamd_mask_iou_workspace': (_sz, [_i]),
+    'kamd_weighted_sum2_workspace': (_sz, []),
     'kamd_deftet_forward_workspace': (_sz, [_i, _i, _i, _i]),
     'kamd_mesh_to_spc_stage_levels': (_i, []),
     'kamd_mesh_to_spc_scan_workspace': (_sz, [_i64]),
@@ -84,6 +85,8 @@ for _t in ('f32', 'f64'):
         _i, [_vp, _i, _i, _i, _i, _i, _i] + [_vp] * 12 + [_dbl, _f, _f, _vp, _vp])
     SIGNATURES[f'kamd_mask_iou_forward_{_t}'] = (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_mask_iou_backward_{_t}'] = (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp])
+    SIGNATURES[f'kamd_weighted_sum2_forward_{_t}'] = (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp])
+    SIGNATURES[f'kamd_weighted_sum2_backward_{_t}'] = (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp])
     SIGNATURES[f'kamd_texture_mapping_forward_{_t}'] = (_i, [_vp, _i, _i64, _i, _i, _i, _i, _vp, _vp, _vp])
     SIGNATURES[f'kamd_texture_mapping_backward_{_t}'] = (_i, [_vp, _i, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_prepare_vertices_forward_{_t}'] = (

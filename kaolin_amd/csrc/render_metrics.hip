@@ -8,6 +8,12 @@
 // texture_mapping (kaolin/render/mesh/utils.py:23-76) is clamp, scale, flip, grid_sample, permute; here one gather
 // kernel each way with grid_sample's own coordinate arithmetic (align_corners = False, border padding, nearest = round half
 // to even, bilinear), writing the (B, N, C) layout directly.
+//
+// weighted_sum2: the linear loss sum(x1 * w1) + sum(x2 * w2) over two G-buffers of one render (image features and soft
+// mask against fixed weights -- what gradient checks and benchmarks of a renderer back-propagate).  In torch that is two
+// rocBLAS dots (two kernels each), an add, and two full-size products backward; here ONE pass over the four arrays forward
+// (16-byte loads, per-workgroup partial sums in double, a one-workgroup finish) and ONE elementwise pass backward that
+// writes both gradients g * w1, g * w2.
 #include "common.h"
 #include "profile.h"
 #include "../../include/kaolin_amd.h"
@@ -194,6 +200,130 @@ __global__ __launch_bounds__(256) void texture_mapping_backward_kernel(long long
   }
 }
 
+
+// ---- weighted sum of two arrays -----------------------------------------------------------------------------------------
+constexpr int WS_THREADS = 256;
+constexpr int WS_GROUPS = 4096;  // partial sums (16 workgroups per CU)
+
+// workgroup g of G takes the g-th contiguous share of the array's 16-byte chunks (DRAM pages and TLB entries are walked
+// once, by one workgroup); the unaligned / tail scalars go to the last threads of the grid
+template <typename T>
+__device__ __forceinline__ double ws_dot_range(const T* __restrict__ x, const T* __restrict__ w, long long n) {
+  constexpr int V = 16 / (int)sizeof(T);
+  constexpr int U = 4;  // 16-byte load pairs in flight per thread
+  double acc = 0;
+  const bool wide = ((((uintptr_t)x) | ((uintptr_t)w)) & 15) == 0;
+  const long long nv = wide ? n / V : 0;
+  const long long share = (nv + gridDim.x - 1) / gridDim.x;
+  const long long lo = (long long)blockIdx.x * share, hi = lo + share < nv ? lo + share : nv;
+  const uint4* xv = reinterpret_cast<const uint4*>(x);
+  const uint4* wv = reinterpret_cast<const uint4*>(w);
+  long long i = lo + threadIdx.x;
+  for (; i + (U - 1) * WS_THREADS < hi; i += U * WS_THREADS) {
+    uint4 a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a[u] = xv[i + u * WS_THREADS];
+      b[u] = wv[i + u * WS_THREADS];
+    }
+    T part = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const T* pa = reinterpret_cast<const T*>(&a[u]);
+      const T* pb = reinterpret_cast<const T*>(&b[u]);
+#pragma unroll
+      for (int k = 0; k < V; ++k) part += pa[k] * pb[k];
+    }
+    acc += (double)part;
+  }
+  for (; i < hi; i += WS_THREADS) {
+    const uint4 a = xv[i], b = wv[i];
+    const T* pa = reinterpret_cast<const T*>(&a);
+    const T* pb = reinterpret_cast<const T*>(&b);
+    T part = 0;
+#pragma unroll
+    for (int k = 0; k < V; ++k) part += pa[k] * pb[k];
+    acc += (double)part;
+  }
+  const long long tid = (long long)blockIdx.x * WS_THREADS + threadIdx.x, nthreads = (long long)gridDim.x * WS_THREADS;
+  for (long long j = nv * V + (nthreads - 1 - tid); j < n; j += nthreads) acc += (double)(x[j] * w[j]);
+  return acc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(WS_THREADS) void weighted_sum2_partial_kernel(long long n1, const T* __restrict__ x1,
+                                                                           const T* __restrict__ w1, long long n2,
+                                                                           const T* __restrict__ x2, const T* __restrict__ w2,
+                                                                           double* __restrict__ partial) {
+  __shared__ double s_p[WS_THREADS / 64];
+  double acc = ws_dot_range<T>(x1, w1, n1) + ws_dot_range<T>(x2, w2, n2);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0;
+    for (int w = 0; w < WS_THREADS / 64; ++w) a += s_p[w];
+    partial[blockIdx.x] = a;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void weighted_sum2_finish_kernel(int groups, const double* __restrict__ partial, T* __restrict__ out) {
+  __shared__ double s_p[4];
+  double acc = 0;
+  for (int i = threadIdx.x; i < groups; i += 256) acc += partial[i];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = (T)(s_p[0] + s_p[1] + s_p[2] + s_p[3]);
+}
+
+template <typename T>
+__device__ __forceinline__ void ws_scale_range(T g, const T* __restrict__ w, T* __restrict__ out, long long n) {
+  constexpr int V = 16 / (int)sizeof(T);
+  constexpr int U = 4;
+  const bool wide = ((((uintptr_t)w) | ((uintptr_t)out)) & 15) == 0;
+  const long long nv = wide ? n / V : 0;
+  const long long share = (nv + gridDim.x - 1) / gridDim.x;
+  const long long lo = (long long)blockIdx.x * share, hi = lo + share < nv ? lo + share : nv;
+  const uint4* wv = reinterpret_cast<const uint4*>(w);
+  uint4* ov = reinterpret_cast<uint4*>(out);
+  long long i = lo + threadIdx.x;
+  for (; i + (U - 1) * WS_THREADS < hi; i += U * WS_THREADS) {
+    uint4 b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) b[u] = wv[i + u * WS_THREADS];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      T* pb = reinterpret_cast<T*>(&b[u]);
+#pragma unroll
+      for (int k = 0; k < V; ++k) pb[k] = g * pb[k];
+      ov[i + u * WS_THREADS] = b[u];
+    }
+  }
+  for (; i < hi; i += WS_THREADS) {
+    uint4 b = wv[i];
+    T* pb = reinterpret_cast<T*>(&b);
+#pragma unroll
+    for (int k = 0; k < V; ++k) pb[k] = g * pb[k];
+    ov[i] = b;
+  }
+  const long long tid = (long long)blockIdx.x * WS_THREADS + threadIdx.x, nthreads = (long long)gridDim.x * WS_THREADS;
+  for (long long j = nv * V + (nthreads - 1 - tid); j < n; j += nthreads) out[j] = g * w[j];
+}
+
+template <typename T>
+__global__ __launch_bounds__(WS_THREADS) void weighted_sum2_backward_kernel(const T* __restrict__ grad_out, long long n1,
+                                                                            const T* __restrict__ w1, T* __restrict__ g1,
+                                                                            long long n2, const T* __restrict__ w2,
+                                                                            T* __restrict__ g2) {
+  const T g = grad_out[0];
+  if (g1 != nullptr) ws_scale_range<T>(g, w1, g1, n1);
+  if (g2 != nullptr) ws_scale_range<T>(g, w2, g2, n2);
+}
+
 template <typename T>
 int mask_iou_forward(hipStream_t st, int B, long long P, const T* lhs, const T* rhs, double* partial, double* sums, T* loss) {
   if (B <= 0) return 0;
@@ -239,9 +369,29 @@ int texture_backward(hipStream_t st, int B, long long N, int C, int TH, int TW, 
   return (int)hipGetLastError();
 }
 
+template <typename T>
+int weighted_sum2_forward(hipStream_t st, long long n1, const T* x1, const T* w1, long long n2, const T* x2, const T* w2,
+                          double* partial, T* out) {
+  kamd::ProfScope prof_(kamd::K_WEIGHTED_SUM, st);
+  hipLaunchKernelGGL(weighted_sum2_partial_kernel<T>, dim3(WS_GROUPS), dim3(WS_THREADS), 0, st, n1 > 0 ? n1 : 0, x1, w1,
+                     n2 > 0 ? n2 : 0, x2, w2, partial);
+  hipLaunchKernelGGL(weighted_sum2_finish_kernel<T>, dim3(1), dim3(256), 0, st, WS_GROUPS, (const double*)partial, out);
+  return (int)hipGetLastError();
+}
+template <typename T>
+int weighted_sum2_backward(hipStream_t st, const T* grad_out, long long n1, const T* w1, T* g1, long long n2, const T* w2, T* g2) {
+  if ((g1 == nullptr || n1 <= 0) && (g2 == nullptr || n2 <= 0)) return 0;
+  kamd::ProfScope prof_(kamd::K_WEIGHTED_SUM, st);
+  hipLaunchKernelGGL(weighted_sum2_backward_kernel<T>, dim3(WS_GROUPS), dim3(WS_THREADS), 0, st, grad_out, n1 > 0 ? n1 : 0, w1, g1,
+                     n2 > 0 ? n2 : 0, w2, g2);
+  return (int)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t kamd_weighted_sum2_workspace(void) { return (size_t)WS_GROUPS * sizeof(double); }
 
 size_t kamd_mask_iou_workspace(int B) { return B > 0 ? (size_t)B * MI_GROUPS * 2 * sizeof(double) : 0; }
 
@@ -253,6 +403,15 @@ size_t kamd_mask_iou_workspace(int B) { return B > 0 ? (size_t)B * MI_GROUPS * 2
   int kamd_mask_iou_backward_##SFX(void* stream, int B, int64_t P, const T* grad_loss, const T* other,                \
                                    const double* sums, T* grad) {                                                      \
     return mask_iou_backward<T>((hipStream_t)stream, B, (long long)P, grad_loss, other, sums, grad);                  \
+  }                                                                                                                    \
+  int kamd_weighted_sum2_forward_##SFX(void* stream, int64_t n1, const T* x1, const T* w1, int64_t n2, const T* x2,   \
+                                       const T* w2, void* workspace, T* out) {                                        \
+    return weighted_sum2_forward<T>((hipStream_t)stream, (long long)n1, x1, w1, (long long)n2, x2, w2,                \
+                                    (double*)workspace, out);                                                         \
+  }                                                                                                                    \
+  int kamd_weighted_sum2_backward_##SFX(void* stream, const T* grad_out, int64_t n1, const T* w1, T* g1, int64_t n2,  \
+                                        const T* w2, T* g2) {                                                         \
+    return weighted_sum2_backward<T>((hipStream_t)stream, grad_out, (long long)n1, w1, g1, (long long)n2, w2, g2);    \
   }                                                                                                                    \
   int kamd_texture_mapping_forward_##SFX(void* stream, int B, int64_t N, int C, int TH, int TW, int bilinear,         \
                                          const T* uv, const T* tex, T* out) {                                          \

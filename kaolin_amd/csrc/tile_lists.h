@@ -32,7 +32,7 @@ namespace tl {
 constexpr int R_TILE = 16;            // rasterizer tile: 16 x 16 pixels = one 256-thread workgroup (4 sub-tiles of 16 x 4)
 constexpr int S_TILE = 32;            // soft-mask tile: 32 x 32 pixels = 16 sub-tiles of 16 x 4 (work items of the search)
 constexpr int S_SUBS = (S_TILE / SUB_W) * (S_TILE / SUB_H);  // 16
-constexpr int REC_R = 16;             // raster record scalars: box[4] a.xy b.xy c.xy z[3] flag pad2
+constexpr int REC_R = 20;             // raster record scalars: box[4] (empty for a filtered face) | a.xy b.xy | c.xy z.ab | A0 A1 B0 B1 | C0 C1 K z.c (edge_coefficients)
 // soft record: large box[4] | body: a.xy b.xy c.xy pad2, then the three edges' reciprocals 1 / (|edge|^2 + EPS) as doubles
 // (dibr_soft_mask_cuda.cu:128-139 divides by that sum for every (pixel, face) pair; the divisor depends on the face only).
 // The boxes of all faces come first, as an array of their own (16 bytes per face), then the bodies: the select kernel
@@ -44,6 +44,59 @@ __host__ __device__ inline const T* soft_box(const T* rec, size_t face) { return
 template <typename T>
 __host__ __device__ inline const T* soft_body(const T* rec, size_t total_faces, size_t face) {
   return rec + total_faces * 4 + face * rec_s_body_scalars((int)sizeof(T));
+}
+// Conservative edge functions of one face, formed once by the binning kernel for the fp32 rasterizer's first sweep.
+// The reference evaluates, per pixel p inside the face's box and in float,
+//   w0 = (b - p) x (c - p), w1 = (c - p) x (a - p), w2 = (a - p) x (b - p), norm = w0 + w1 + w2 (+- eps)
+// and drops the face when some w_i / norm < 0 (rasterization_cuda.cu:139-150).  In real arithmetic w_i is affine in p
+// (w0 = b x c + px (by - cy) + py (cx - bx), ...) and norm is twice the signed area.  Each computed w_i differs from the
+// real one by at most 4.0001 u S_i (u = 2^-24, S_0 = |bx - px||cy - py| + |by - py||cx - px|, ...: two subtractions, a
+// product and the final subtraction, each within u), the computed norm by at most 6.1 u (S_0 + S_1 + S_2).  So when the
+// area exceeds that bound for every pixel of the box, the sign s of norm is the area's at every pixel, and a pixel whose
+// real s w_i lies below -(4.0001 u S_i + 1e-30) has a computed w_i of the opposite sign to norm and of magnitude > 1e-30:
+// the quotient is a negative number (no underflow to -0 while |norm| < 1.3e6, eps <= 1) and the reference drops the face.
+// The kernel tests, for edges 0 and 1,
+//   e_i = fma(A_i, px, fma(B_i, py, C_i)) < 0,   A_i = fl(s alpha_i), B_i = fl(s beta_i), C_i = fl(s gamma_i + M_i)
+// with the coefficients formed in double and M_i = 32 u (S_i,max + Q_i) + 1e-30, Q_i = |alpha_i| X + |beta_i| Y + |gamma_i|
+// (X, Y = the box's largest |px|, |py|): 4.0001 u S_i for the reference's own rounding plus <= 3 u (Q_i + M_i) =: d_i for
+// the three coefficient roundings and the two fma roundings -- an eightfold margin.  The third edge costs no coefficients:
+// w0 + w1 + w2 is the area in real arithmetic, so s w2 = |area| - s w0 - s w1 and the kernel tests e0 + e1 > K with
+// K = (|area| + M0 + M1 + M2 + 8 u (Q0 + Q1 + M0 + M1)) (1 + 4u) rounded to float: e0 + e1 <= |area| - s w2 + M0 + M1 +
+// d0 + d1, the float sum adds u |e0 + e1| <= u (Q0 + Q1 + M0 + M1)(1 + ...), so e0 + e1 > K implies s w2 < -M2.
+// No test drops a face the reference keeps; faces kept by mistake (pixels within ~1e-4 of an edge, relative to the face)
+// fall to the exact sweep that follows, which repeats the reference's arithmetic.  Faces whose area is not safely away
+// from zero, whose box is not finite (a NaN limit rejects no pixel) or whose coefficients are not, get A = B = 0, C = 1,
+// K = 3: never dropped here.   out: e0.A e0.B e0.C e1.A e1.B e1.C K
+__device__ __forceinline__ void edge_coefficients(const float* v, float x0, float y0, float x1, float y1, float* out) {
+  const double ax = v[0], ay = v[1], bx = v[2], by = v[3], cx = v[4], cy = v[5];
+  const double xlo = x0, xhi = x1, ylo = y0, yhi = y1;
+  const double al[3] = {by - cy, cy - ay, ay - by};
+  const double be[3] = {cx - bx, ax - cx, bx - ax};
+  const double ga[3] = {bx * cy - by * cx, cx * ay - cy * ax, ax * by - ay * bx};
+  const double area2 = ga[0] + ga[1] + ga[2];
+  const double axm = fmax(fabs(ax - xlo), fabs(ax - xhi)), aym = fmax(fabs(ay - ylo), fabs(ay - yhi));
+  const double bxm = fmax(fabs(bx - xlo), fabs(bx - xhi)), bym = fmax(fabs(by - ylo), fabs(by - yhi));
+  const double cxm = fmax(fabs(cx - xlo), fabs(cx - xhi)), cym = fmax(fabs(cy - ylo), fabs(cy - yhi));
+  const double S[3] = {bxm * cym + bym * cxm, cxm * aym + cym * axm, axm * bym + aym * bxm};
+  const double X = fmax(fabs(xlo), fabs(xhi)), Y = fmax(fabs(ylo), fabs(yhi));
+  const double u = 1.0 / 16777216.0;
+  const double sgn = area2 < 0 ? -1.0 : 1.0;
+  bool ok = fabs(area2) > 32.0 * u * (S[0] + S[1] + S[2]) && fabs(area2) < 1e6 && X < 1e30 && Y < 1e30;  // (NaN: false)
+  double Q[3], M[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    Q[i] = fabs(al[i]) * X + fabs(be[i]) * Y + fabs(ga[i]);
+    M[i] = 32.0 * u * (S[i] + Q[i]) + 1e-30;
+  }
+  const double K = (fabs(area2) + M[0] + M[1] + M[2] + 8.0 * u * (Q[0] + Q[1] + M[0] + M[1])) * (1.0 + 4.0 * u);
+  ok = ok && K < 1e30;  // (bounds every coefficient)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    out[i * 3 + 0] = ok ? (float)(sgn * al[i]) : 0.0f;
+    out[i * 3 + 1] = ok ? (float)(sgn * be[i]) : 0.0f;
+    out[i * 3 + 2] = ok ? (float)(sgn * ga[i] + M[i]) : 1.0f;
+  }
+  out[6] = ok ? (float)K : 3.0f;
 }
 constexpr double SOFT_EPS = 1e-7;     // the reference's literal EPS (dibr_soft_mask_cuda.cu:23), a double
 constexpr int WORK_SHARDS = 8;        // worklist shards (one append counter each; workgroup id & 7 picks the shard)
@@ -429,10 +482,18 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(BinIn<T> in, Lists LR, 
           z2 = in.z[f * in.lay.z_face + 2 * in.lay.z_vertex];
         }
         Rec4<T>* r = reinterpret_cast<Rec4<T>*>(in.rec_r + (size_t)f * REC_R);
-        r[0] = Rec4<T>{bx0, by0, bx1, by1};
+        // (a face the rasterizer filters -- invalid / back facing -- is on no list; the overflow fallback walks every
+        // record of the mesh, so its box is stored empty: every strip rejects it)
+        r[0] = keep ? Rec4<T>{bx0, by0, bx1, by1} : Rec4<T>{(T)INFINITY, (T)INFINITY, -(T)INFINITY, -(T)INFINITY};
         r[1] = Rec4<T>{v[0], v[1], v[2], v[3]};
         r[2] = Rec4<T>{v[4], v[5], z0, z1};
-        r[3] = Rec4<T>{z2, keep ? (T)1 : (T)0, 0, 0};
+        T e7[7] = {0, 0, 1, 0, 0, 1, 3};
+        if constexpr (sizeof(T) == 4) {
+          if (keep) edge_coefficients(v, bx0, by0, bx1, by1, e7);
+        }
+        r[2] = Rec4<T>{v[4], v[5], z0, z1};
+        r[3] = Rec4<T>{e7[0], e7[3], e7[1], e7[4]};  // the two edges' A, then B: operand pairs of one packed fma
+        r[4] = Rec4<T>{e7[2], e7[5], e7[6], z2};
       }
       PHASE_MARK(2);
       PixRange pr;

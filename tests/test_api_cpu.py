@@ -143,3 +143,16 @@ def test_check_sign_cpu_branch_matches_the_kernel_oracle():
         mid[:, 0] -= 1.                                           # same (y, z) as an edge midpoint
         pts = torch.cat([pts, on_vertices[None], mid[None]], dim=1)
         assert torch.equal(check_sign(verts, f, pts), oracle.check_sign(verts, f, pts))
+
+
+def test_weighted_sum_cpu_fallback_is_the_torch_expression():
+    from kaolin_amd.metrics.render import weighted_sum
+    g = torch.Generator().manual_seed(5)
+    x1, w1 = torch.rand(4, 5, generator=g, requires_grad=True), torch.rand(4, 5, generator=g)
+    x2, w2 = torch.rand(7, generator=g), torch.rand(7, generator=g)
+    out = weighted_sum(x1, w1, x2, w2)
+    assert torch.allclose(out, (x1 * w1).sum() + (x2 * w2).sum())
+    out.backward()
+    assert torch.equal(x1.grad, w1)
+    with pytest.raises(ValueError):
+        weighted_sum(x1, w1, x2)

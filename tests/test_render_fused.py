@@ -63,3 +63,48 @@ def test_cpu_inputs_take_the_torch_chain():
     assert abs(float(mask_iou(a, a)) - (1. - float(((a * a).flatten(1).sum(1) / ((2 * a - a * a).flatten(1).sum(1) + 1e-10)).mean()))) < 1e-6
     out = texture_mapping(torch.rand(1, 4, 2), torch.rand(1, 3, 8, 8))
     assert out.shape == (1, 4, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('shapes', [((2, 37, 41, 3), (2, 37, 41)), ((1, 5), None), ((8, 256, 256, 3), (8, 256, 256))])
+def test_weighted_sum_fused_matches_torch(dtype, shapes):
+    """kaolin_amd.metrics.render.weighted_sum (one fused pass each way) against the torch expression that defines it:
+    value within 1e-6 relative of the float64 sum, gradients = weights * upstream gradient exactly (one product)."""
+    from kaolin_amd.metrics.render import weighted_sum
+    g = torch.Generator().manual_seed(3)
+    s1, s2 = shapes
+    x1 = torch.rand(s1, generator=g, dtype=dtype).cuda().requires_grad_()
+    w1 = (torch.rand(s1, generator=g, dtype=dtype) - 0.3).cuda()
+    if s2 is not None:
+        x2 = torch.rand(s2, generator=g, dtype=dtype).cuda().requires_grad_()
+        w2 = (torch.rand(s2, generator=g, dtype=dtype) - 0.3).cuda()
+        out = weighted_sum(x1, w1, x2, w2)
+        ref = (x1.double() * w1.double()).sum() + (x2.double() * w2.double()).sum()
+    else:
+        x2 = w2 = None
+        out = weighted_sum(x1, w1)
+        ref = (x1.double() * w1.double()).sum()
+    assert out.dtype == dtype and out.dim() == 0
+    assert abs(float(out) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
+    (out * 1.5).backward()
+    assert torch.equal(x1.grad, (torch.tensor(1.5, dtype=dtype, device='cuda') * w1))
+    if x2 is not None:
+        assert torch.equal(x2.grad, (torch.tensor(1.5, dtype=dtype, device='cuda') * w2))
+
+
+@pytest.mark.gpu
+def test_weighted_sum_unaligned_views_and_partial_gradients():
+    from kaolin_amd.metrics.render import weighted_sum
+    g = torch.Generator().manual_seed(4)
+    base = torch.rand(1003, generator=g).cuda()
+    x1 = base[1:1001].clone().requires_grad_()          # contiguous, 1000 elements
+    w1 = torch.rand(1001, generator=g).cuda()[1:]        # a view at a 4-byte offset: the kernels take the scalar path
+    x2 = torch.rand(77, generator=g).cuda()              # no gradient wanted
+    w2 = torch.rand(77, generator=g).cuda()
+    out = weighted_sum(x1, w1, x2, w2)
+    ref = (x1.double() * w1.double()).sum() + (x2.double() * w2.double()).sum()
+    assert abs(float(out) - float(ref)) <= 1e-6 * abs(float(ref))
+    out.backward()
+    assert torch.equal(x1.grad, w1)
+

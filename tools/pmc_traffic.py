@@ -21,15 +21,15 @@ rot, trans = kal.render.camera.generate_rotate_translate_matrices(
 proj = kal.render.camera.generate_perspective_projection(math.pi / 4).to(dev)
 g = torch.Generator().manual_seed(0)
 feats3 = torch.cat([torch.rand((1, F, 3, 2), generator=g).to(dev).expand(V, -1, -1, -1), torch.ones((V, F, 3, 1), device=dev)], -1).contiguous()
-G1 = torch.rand((V, H, W, 3), generator=g).to(dev).reshape(-1)
-G2 = torch.rand((V, H, W), generator=g).to(dev).reshape(-1)
+G1 = torch.rand((V, H, W, 3), generator=g).to(dev)
+G2 = torch.rand((V, H, W), generator=g).to(dev)
 
 
 def step():
     verts.grad = None
     cam, img, nrm = kal.render.mesh.prepare_vertices(verts.unsqueeze(0).expand(V, -1, -1), faces, proj, camera_rot=rot, camera_trans=trans)
     feat, soft, idx = kal.render.mesh.dibr_rasterization(H, W, cam[..., 2], img, feats3, nrm[..., 2])
-    (torch.dot(feat.reshape(-1), G1) + torch.dot(soft.reshape(-1), G2)).backward()
+    kal.metrics.render.weighted_sum(feat, G1, soft, G2).backward()
     return img, idx
 
 
