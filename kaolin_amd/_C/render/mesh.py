@@ -235,11 +235,13 @@ def _hit_list(batch_size, height, width, knum, dtype, device, num_faces=0):
             _work_buffer(batch_size, height, width, device))
 
 
-def work_items(work):
-    """Item ids (int64, 1-D) recorded in a worklist buffer (tests / debugging; synchronises)."""
+def work_items(work, batch_size, height, width):
+    """Item ids (int64, 1-D) recorded in a worklist buffer (tests / debugging; synchronises).  Layout (tile_lists.h): 16
+    header words (8 shard counters), 8 shards x shard_cap items of 4 words, then one coverage byte per 16 x 16 tile."""
     counts = work[:8].tolist()
-    shard_cap = (work.numel() - 16) // (8 * 4)
-    items = work[16:].view(8, shard_cap, 4)
+    n_groups = batch_size * ((width + 15) // 16) * ((height + 15) // 16)
+    shard_cap = 4 * ((n_groups + 7) // 8)
+    items = work[16:16 + 8 * shard_cap * 4].view(8, shard_cap, 4)
     return torch.cat([items[s, :min(c, shard_cap), 0] for s, c in enumerate(counts)]).long()
 
 
@@ -247,7 +249,7 @@ def hit_list_entries(hits, knum, batch_size, height, width):
     """Flattens a segmented hit list -> (pix, face, prob, type) 1-D tensors of the recorded hits, pix = flat (b, row, col)
     index (tests / debugging)."""
     hit_pair, hit_prob, hit_type, item_count, work = hits
-    items = work_items(work)
+    items = work_items(work, batch_size, height, width)
     n = items.numel()
     counts = item_count[items].long()
     starts = items * (64 * int(knum))

@@ -475,6 +475,7 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
   co.work_items = reinterpret_cast<uint4*>(work + tl::WORK_HEADER);
   co.work_counts = work;
   co.shard_cap = tl::work_shard_cap(B, H, W);
+  co.tile_cov = reinterpret_cast<unsigned char*>(work + tl::work_cov_offset_words(B, H, W));
   KAMD_CHECK(kamd::raster2_draw<T>(st, B, H, W, D, F, (float)multiplier, eps, rec_r, LR, feat, interp, face_idx, weights, co,
                                    kamd_env_int("KAMD_DIBR_BG_WEIGHTS", 2) != 1));
   if (total_faces > 0)
@@ -525,14 +526,11 @@ int dibr_backward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K
                                              (float)multiplier, g_img);
   int rc2 = (int)hipEventRecord(ss->join, side);
   if (rc == 0) rc = rc2;
-  if (rc == 0) {
-    if (sizeof(T) == 4)
-      rc = kamd_rasterize_backward_f32(st, B, H, W, F, D, (const float*)grad_feat, face_idx, (const float*)weights,
-                                       (const float*)img, (const float*)feat, eps, (float*)g_img, (float*)g_feat);
-    else
-      rc = kamd_rasterize_backward_f64(st, B, H, W, F, D, (const double*)grad_feat, face_idx, (const double*)weights,
-                                       (const double*)img, (const double*)feat, eps, (double*)g_img, (double*)g_feat);
-  }
+  if (rc == 0)
+    rc = kamd::raster_backward_draw<T>(st, B, H, W, F, D, grad_feat, face_idx, weights, img, feat, eps, g_img, g_feat,
+                                       kamd_env_int("KAMD_BWD_TILE_COV", 1) == 1  // (2: off, for A/B runs)
+                                           ? reinterpret_cast<const unsigned char*>(work + tl::work_cov_offset_words(B, H, W))
+                                           : nullptr);
   rc2 = (int)hipStreamWaitEvent(st, ss->join, 0);
   return rc != 0 ? rc : rc2;
 }

@@ -205,7 +205,12 @@ inline unsigned int work_shard_cap(int B, int H, int W) {
   const size_t n_groups = (size_t)B * g.ntiles;
   return (unsigned int)(4 * ((n_groups + WORK_SHARDS - 1) / WORK_SHARDS));
 }
-inline size_t work_words(int B, int H, int W) { return WORK_HEADER + (size_t)WORK_SHARDS * work_shard_cap(B, H, W) * 4; }
+// ... then one byte per (mesh, 16 x 16 tile) [b * ntiles + tile]: does the tile hold a covered pixel?  (Written by the
+// rasterizer's tile kernel in the fused path; the rasterizer's backward kernel leaves a tile without one at once.)
+inline size_t work_cov_offset_words(int B, int H, int W) { return WORK_HEADER + (size_t)WORK_SHARDS * work_shard_cap(B, H, W) * 4; }
+inline size_t work_words(int B, int H, int W) {
+  return work_cov_offset_words(B, H, W) + ((size_t)B * pass_geom(H, W, R_TILE).ntiles + 3) / 4;
+}
 
 inline Lists lists_of(void* ws, const PassLayout& p, int B, bool soft) {
   char* c = (char*)ws;
@@ -597,6 +602,7 @@ struct ClassifyOut {
   uint4* work_items;
   unsigned int* work_counts;
   unsigned int shard_cap;
+  unsigned char* tile_cov;          // [B * ntiles_r] (work_cov_offset_words), or nullptr
 };
 
 // exclusive prefix over the 256 threads of a workgroup; *total = sum.  `scratch`: 4 ints of LDS.
@@ -621,7 +627,8 @@ __device__ __forceinline__ void queue_items(unsigned long long unc, bool has_fac
                                             int wave, int lane, const unsigned int* __restrict__ sub_touched,
                                             const unsigned int* __restrict__ big_count_s, int tiles_x_s, int ntiles_s,
                                             uint4* __restrict__ work_items, unsigned int* __restrict__ work_counts,
-                                            unsigned int shard_cap, unsigned long long* s_item_unc) {
+                                            unsigned int shard_cap, unsigned long long* s_item_unc, bool covered = false,
+                                            unsigned char* __restrict__ tile_cov = nullptr, size_t cov_index = 0) {
   bool item = false;
   if (unc != 0ull && has_faces) {
     const int sy = tile_y + wave * SUB_H;
@@ -630,8 +637,9 @@ __device__ __forceinline__ void queue_items(unsigned long long unc, bool has_fac
     item = ((sub_touched[(size_t)b * ntiles_s + st] >> ss) & 1u) != 0u || big_count_s[b] != 0u;
   }
   if (lane == 0) s_item_unc[wave] = item ? unc : 0ull;
-  __syncthreads();
+  const int any_covered = __syncthreads_or(covered ? 1 : 0);
   if (threadIdx.x == 0) {
+    if (tile_cov != nullptr) tile_cov[cov_index] = any_covered ? 1 : 0;
     int n = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) n += s_item_unc[w] != 0ull ? 1 : 0;

@@ -350,7 +350,7 @@ def test_fused_front_door_equals_reference_glue_plus_contract_operator(dtype, wi
     bbox = torch.cat([scaled.min(dim=-2)[0] - 0.02 * 1000., scaled.max(dim=-2)[0] + 0.02 * 1000.], -1)
     s1, h1 = m.dibr_soft_mask_forward_lean(scaled, bbox, y, 7000, 30, 1000.)
     s2, h2 = m.dibr_soft_mask_forward_fused(fimg.cuda(), y, 7000, 0.02, 30, 1000.)
-    i1, i2 = m.work_items(h1[4]).sort()[0], m.work_items(h2[4]).sort()[0]   # queued in a run-dependent order
+    i1, i2 = m.work_items(h1[4], scaled.shape[0], H, W).sort()[0], m.work_items(h2[4], scaled.shape[0], H, W).sort()[0]   # queued in a run-dependent order
     assert torch.equal(s1, s2) and torch.equal(i1, i2) and torch.equal(h1[3][i1], h2[3][i2])
     g = torch.rand(s1.shape, device='cuda', dtype=dtype)
     g1 = m.dibr_soft_mask_backward_lean(g, s1, h1, scaled, 7000, 30, 1000.)
