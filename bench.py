@@ -299,6 +299,43 @@ def main():
                    'host_enqueue_ms_per_step': round(chamfer_enqueue_ms, 4),
                    'kernels_avg_us': {k: round(v[0] / v[1] * 1e3, 2) for k, v in cprof.items()},
                    'hbm_frac_of_8TBps': round(192.0 * n / (cdt / args.steps) / 1e9 / HBM_PEAK_GBS, 6)}
+        # The step above wraps the operator in torch glue for the shared parameter (base + offset, .sum(), their backward
+        # nodes and the reduction to 3 floats): ~10 small host-bound torch calls.  Two more readings of the same work:
+        # (a) the operator alone -- chamfer_distance forward + backward to both clouds from a given upstream gradient,
+        # no collective; (b) the step above captured once with torch.cuda.graph and replayed (N = 1 only: no host in it).
+        p1_leaf = base.clone().requires_grad_()
+        upstream = torch.ones(1, device=dev)
+
+        def chamfer_operator():
+            p1_leaf.grad = None
+            p2.grad = None
+            kal.metrics.pointcloud.chamfer_distance(p1_leaf, p2).backward(upstream)
+
+        odt = timed(chamfer_operator, args.steps, args.warmup)
+        chamfer['operator_only'] = {'ms_per_step': round(odt / args.steps * 1e3, 4),
+                                    'host_enqueue_ms_per_step': round(timed.enqueue_ms, 4),
+                                    'value': round(pairs / odt / 1e6, 1),
+                                    'note': 'chamfer_distance fwd + bwd (gradients to both clouds) from a given upstream '
+                                            'gradient; no shared parameter, no collective'}
+        if world == 1:
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        chamfer_step()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    chamfer_step()
+                gdt = timed(graph.replay, args.steps, args.warmup)
+                chamfer['graph_replay_ms_per_step'] = round(gdt / args.steps * 1e3, 4)
+                del graph
+            except Exception as exc:                    # (a capture failure must not cost the run its headline line)
+                chamfer['graph_replay_ms_per_step'] = None
+                chamfer['graph_replay_error'] = str(exc)[:200]
+                torch.cuda.synchronize()
         # the all-pairs kernels for comparison (VALU-bound: 6.7 lane-ops per pair, sided_distance.hip header)
         os.environ['KAMD_SIDED_DISTANCE'] = 'brute'
         lib.kamd_profile_reset()

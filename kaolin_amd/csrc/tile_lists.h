@@ -434,8 +434,16 @@ struct BinIn {
 #ifdef KAMD_PHASE_PROF
 static __device__ unsigned long long g_phase_bin[16];  // [0..7] phases, [10] longest wavefront, [11] > 1000 ticks (10 us at 100 MHz), [12] > 2500
 #endif
+#ifndef KAMD_BIN_WAVES
+#define KAMD_BIN_WAVES 0  // waves per SIMD the binning kernel is compiled for (0: the compiler's choice, 70 VGPRs = 7; 8 spills: 48.6 vs 44.2 us)
+#endif
 template <typename T, bool DO_R, bool DO_S>
-__global__ __launch_bounds__(256) void bin_faces_kernel2(BinIn<T> in, Lists LR, Lists LS) {
+#if KAMD_BIN_WAVES > 0
+__global__ __launch_bounds__(256, KAMD_BIN_WAVES) void bin_faces_kernel2(
+#else
+__global__ __launch_bounds__(256) void bin_faces_kernel2(
+#endif
+    BinIn<T> in, Lists LR, Lists LS) {
   PHASE_DECL;
 #ifdef KAMD_PHASE_PROF
   const unsigned long long wall0 = wall_clock64();  // 100 MHz
