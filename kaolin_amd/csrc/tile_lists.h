@@ -323,6 +323,68 @@ __device__ __forceinline__ void append_entry(bool on, const Lists& L, size_t ti,
   }
 }
 
+// The same for one entry of each of two lists (the rasterizer's and the soft mask's): each step is taken for both before
+// the next one, so that the two counter atomics (and the two pool atomics) are in flight together -- the binning kernel
+// is bound by these dependent round trips, not by instructions.  The no-cycle argument above holds step by step.
+struct PendingEntry {
+  bool on;
+  size_t ti;
+  uint4 entry;
+};
+__device__ __forceinline__ void append_entry_pair(const PendingEntry& pa, const Lists& La, const PendingEntry& pb, const Lists& Lb) {
+  const PendingEntry* pe[2] = {&pa, &pb};
+  const Lists* Ls[2] = {&La, &Lb};
+  unsigned int slot[2] = {0, 0}, c[2] = {0, 0}, i[2] = {0, 0}, v[2] = {0, 0};
+  bool pooled[2] = {false, false};
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+    if (pe[q]->on) slot[q] = atomicAdd(Ls[q]->count + pe[q]->ti, 1u) & ~BRUTE_BIT;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const Lists& L = *Ls[q];
+    if (pe[q]->on) {
+      if (slot[q] < (unsigned int)L.C) {
+        L.inl[pe[q]->ti * L.C + slot[q]] = pe[q]->entry;
+      } else {
+        const unsigned int o = slot[q] - (unsigned int)L.C;
+        c[q] = o / OVC_PAYLOAD;
+        i[q] = o - c[q] * OVC_PAYLOAD;
+        if (c[q] >= (unsigned int)L.maxc)
+          atomicOr(L.count + pe[q]->ti, BRUTE_BIT);
+        else
+          pooled[q] = true;
+      }
+    }
+  }
+  unsigned int p[2] = {0, 0};
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+    if (pooled[q] && i[q] == 0) p[q] = atomicAdd(Ls[q]->pool_top, 1u);
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+    if (pooled[q] && i[q] == 0) {
+      v[q] = p[q] < Ls[q]->cap_chunks ? p[q] + 1u : 0xFFFFFFFFu;
+      __hip_atomic_store(Ls[q]->tab + pe[q]->ti * Ls[q]->maxc + c[q], v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+    if (pooled[q] && i[q] != 0) {
+      unsigned int* link = Ls[q]->tab + pe[q]->ti * Ls[q]->maxc + c[q];
+      do {
+        v[q] = __hip_atomic_load(link, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v[q] == 0u) __builtin_amdgcn_s_sleep(1);
+      } while (v[q] == 0u);
+    }
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+    if (pooled[q]) {
+      if (v[q] == 0xFFFFFFFFu)
+        atomicOr(Ls[q]->count + pe[q]->ti, BRUTE_BIT);
+      else
+        Ls[q]->pool[(size_t)(v[q] - 1u) * OVC + 1u + i[q]] = pe[q]->entry;
+    }
+}
+
 // ---- one wavefront bins its 64 faces into one pass' lists ---------------------------------------------------------------
 // `active`: the lane's face takes part; (b, first_b): its mesh and the mesh's first packed face; tile rectangle
 // [tx0,tx1] x [ty0,ty1]; `big`: the rectangle exceeds 8 x 8 tiles (or the box is NaN).  `block` = packed face index >> 6
@@ -333,7 +395,11 @@ __device__ __forceinline__ void append_entry(bool on, const Lists& L, size_t ti,
 // parked one per lane and appended 64 tiles at a time (a returning atomic per step would serialise the loop on L2 latency).
 template <bool SOFT>
 __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long first_b, long long f, int tx0, int tx1,
-                                         int ty0, int ty1, int c_lo, int c_hi, int r_lo, int r_hi, const Lists& L) {
+                                         int ty0, int ty1, int c_lo, int c_hi, int r_lo, int r_hi, const Lists& L,
+                                         PendingEntry* deferred = nullptr) {
+  // `deferred`: the wavefront's LAST batch of entries is handed back instead of appended (the caller appends it together
+  // with the other pass' last batch: append_entry_pair)
+  if (deferred != nullptr) deferred->on = false;
   const int lane = threadIdx.x & 63;
   const unsigned int block = (unsigned int)(f >> 6);
   unsigned long long remaining = __ballot(active);
@@ -400,7 +466,14 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
       }
       if (++k == 64) flush();
     }
-    flush();
+    if (deferred != nullptr && remaining == 0ull) {
+      deferred->on = my_t >= 0;
+      deferred->ti = (size_t)bL * L.ntiles + (my_t >= 0 ? my_t : 0);
+      deferred->entry = make_uint4(block, SOFT ? my_sub : 0u, (unsigned int)my_bal, (unsigned int)(my_bal >> 32));
+      if (SOFT && my_t >= 0 && my_sub != 0u) atomicOr(L.sub_touched + deferred->ti, my_sub);
+    } else {
+      flush();
+    }
   }
 }
 
@@ -560,9 +633,17 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(
     }
   }
   PHASE_MARK(5);
-  if (DO_R) wave_bin<false>(act_r, big_r, b, first_b, f, rx0, rx1, ry0, ry1, 0, 0, 0, 0, LR);
-  PHASE_MARK(6);
-  if (DO_S) wave_bin<true>(act_s, big_s, b, first_b, f, sx0, sx1, sy0, sy1, pr_s.c_lo, pr_s.c_hi, pr_s.r_lo, pr_s.r_hi, LS);
+  if (DO_R && DO_S) {
+    PendingEntry er, es;
+    wave_bin<false>(act_r, big_r, b, first_b, f, rx0, rx1, ry0, ry1, 0, 0, 0, 0, LR, &er);
+    PHASE_MARK(6);
+    wave_bin<true>(act_s, big_s, b, first_b, f, sx0, sx1, sy0, sy1, pr_s.c_lo, pr_s.c_hi, pr_s.r_lo, pr_s.r_hi, LS, &es);
+    append_entry_pair(er, LR, es, LS);
+  } else {
+    if (DO_R) wave_bin<false>(act_r, big_r, b, first_b, f, rx0, rx1, ry0, ry1, 0, 0, 0, 0, LR);
+    PHASE_MARK(6);
+    if (DO_S) wave_bin<true>(act_s, big_s, b, first_b, f, sx0, sx1, sy0, sy1, pr_s.c_lo, pr_s.c_hi, pr_s.r_lo, pr_s.r_hi, LS);
+  }
   PHASE_MARK(7);
   PHASE_FLUSH(g_phase_bin);
 #ifdef KAMD_PHASE_PROF
