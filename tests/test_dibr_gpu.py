@@ -125,6 +125,61 @@ def test_rasterize_edge_cases():
     assert int(idx.max()) < F and int(idx.max()) >= 0
 
 
+def _adversarial_faces(seed, n, dtype):
+    """Faces built to sit where the conservative edge test of the tile kernel decides: slivers, near-zero and zero areas,
+    vertices on pixel centres (edge functions exactly 0), shared edges through pixel centres, both windings, faces far
+    larger than the image, duplicated vertices."""
+    g = torch.Generator().manual_seed(seed)
+    H = W = 48
+    px = (2 * torch.arange(W, dtype=torch.float64) + 1 - W) / W          # pixel centres in NDC (x); y is the mirror image
+    pick = lambda k: px[torch.randint(0, W, (k,), generator=g)]
+    faces = []
+    for i in range(n):
+        kind = i % 8
+        if kind == 0:     # all three vertices on pixel centres: edges run exactly through centres
+            v = torch.stack([torch.stack([pick(1)[0], -pick(1)[0]]) for _ in range(3)])
+        elif kind == 1:   # sliver: third vertex almost on the line through the first two
+            a, b = torch.rand(2, generator=g, dtype=torch.float64) * 2 - 1, torch.rand(2, generator=g, dtype=torch.float64) * 2 - 1
+            t = torch.rand(1, generator=g, dtype=torch.float64)
+            v = torch.stack([a, b, a + t * (b - a) + (torch.rand(2, generator=g, dtype=torch.float64) - 0.5) * 1e-6])
+        elif kind == 2:   # exactly degenerate: two equal vertices
+            a, b = torch.rand(2, generator=g, dtype=torch.float64) * 2 - 1, torch.rand(2, generator=g, dtype=torch.float64) * 2 - 1
+            v = torch.stack([a, b, b.clone()])
+        elif kind == 3:   # far larger than the image
+            v = (torch.rand((3, 2), generator=g, dtype=torch.float64) - 0.5) * 40
+        elif kind == 4:   # about one pixel, anywhere (sub-pixel offsets)
+            c = torch.rand(2, generator=g, dtype=torch.float64) * 2 - 1
+            v = c + (torch.rand((3, 2), generator=g, dtype=torch.float64) - 0.5) * (3.0 / W)
+        elif kind == 5:   # axis-aligned right triangle whose legs lie on pixel-centre lines
+            x0, x1, y0, y1 = pick(1)[0], pick(1)[0], -pick(1)[0], -pick(1)[0]
+            v = torch.stack([torch.stack([x0, y0]), torch.stack([x1, y0]), torch.stack([x0, y1])])
+        elif kind == 6:   # ordinary
+            v = torch.rand((3, 2), generator=g, dtype=torch.float64) * 2 - 1
+        else:             # the previous face with the opposite winding (shared edges, equal depths elsewhere)
+            v = faces[-1].flip(0)
+        faces.append(v)
+    img = torch.stack(faces).unsqueeze(0).to(dtype)                       # (1, n, 3, 2)
+    z = -(torch.rand((1, n, 3), generator=g, dtype=torch.float64) + 1)
+    z[0, 3::8] -= 1.5                                                     # the huge faces lie behind the others
+    z = z.to(dtype)
+    feat = torch.rand((1, n, 3, 2), generator=g, dtype=torch.float64).to(dtype)
+    return H, W, z, img, feat
+
+
+@pytest.mark.parametrize('dtype', [torch.float, torch.double])
+@pytest.mark.parametrize('multiplier,eps', [(1000, 1e-8), (1, 1e-8), (1000, 0.5), (1000, 2.0), (1e5, 1e-8), (1000, 1e-30)])
+@pytest.mark.parametrize('seed', [0, 1])
+def test_rasterize_adversarial_faces_bit_exact(dtype, multiplier, eps, seed):
+    """The fp32 tile kernel drops (pixel, face) pairs early with conservative affine edge functions (tile_lists.h,
+    edge_coefficients) and repeats the reference's arithmetic for the rest: face_idx, weights and features must stay
+    bit-identical to the oracle where that early test is closest to wrong -- and for an eps its bounds do not cover."""
+    H, W, z, img, feat = _adversarial_faces(seed, 400, dtype)
+    r_feat, r_idx, r_w = oracle.rasterize(H, W, z, img, feat, None, multiplier=multiplier, eps=eps, omp=True)
+    out, face_idx = kal().render.mesh.rasterize(H, W, z.cuda(), img.cuda(), feat.cuda(), None, multiplier=multiplier, eps=eps)
+    assert torch.equal(face_idx.cpu(), r_idx)
+    assert torch.equal(out.cpu(), r_feat)
+
+
 # ------------------------------------------------------------------ soft mask vs the CUDA goldens
 def _simple(dtype):
     img = torch.tensor(SIMPLE_IMG, dtype=dtype).cuda()
