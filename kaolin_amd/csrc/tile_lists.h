@@ -577,7 +577,6 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(
         if constexpr (sizeof(T) == 4) {
           if (keep) edge_coefficients(v, bx0, by0, bx1, by1, e7);
         }
-        r[2] = Rec4<T>{v[4], v[5], z0, z1};
         r[3] = Rec4<T>{e7[0], e7[3], e7[1], e7[4]};  // the two edges' A, then B: operand pairs of one packed fma
         r[4] = Rec4<T>{e7[2], e7[5], e7[6], z2};
       }
