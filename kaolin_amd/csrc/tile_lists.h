@@ -561,24 +561,25 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(
         by1 = in.bbox_r[f * 4 + 3];
       }
       {
-        T z0 = 0, z1 = 0, z2 = 0;
-        if (in.z != nullptr) {
-          z0 = in.z[f * in.lay.z_face + 0 * in.lay.z_vertex];
-          z1 = in.z[f * in.lay.z_face + 1 * in.lay.z_vertex];
-          z2 = in.z[f * in.lay.z_face + 2 * in.lay.z_vertex];
-        }
         Rec4<T>* r = reinterpret_cast<Rec4<T>*>(in.rec_r + (size_t)f * REC_R);
-        // (a face the rasterizer filters -- invalid / back facing -- is on no list; the overflow fallback walks every
-        // record of the mesh, so its box is stored empty: every strip rejects it)
+        // (a face the rasterizer filters -- invalid / back facing, half of a closed mesh -- is on no list; the overflow
+        // fallback walks every record of the mesh, so its box is stored empty: every strip rejects it, and the rest of
+        // its record is never looked at nor written)
         r[0] = keep ? Rec4<T>{bx0, by0, bx1, by1} : Rec4<T>{(T)INFINITY, (T)INFINITY, -(T)INFINITY, -(T)INFINITY};
-        r[1] = Rec4<T>{v[0], v[1], v[2], v[3]};
-        r[2] = Rec4<T>{v[4], v[5], z0, z1};
-        T e7[7] = {0, 0, 1, 0, 0, 1, 3};
-        if constexpr (sizeof(T) == 4) {
-          if (keep) edge_coefficients(v, bx0, by0, bx1, by1, e7);
+        if (keep) {
+          T z0 = 0, z1 = 0, z2 = 0;
+          if (in.z != nullptr) {
+            z0 = in.z[f * in.lay.z_face + 0 * in.lay.z_vertex];
+            z1 = in.z[f * in.lay.z_face + 1 * in.lay.z_vertex];
+            z2 = in.z[f * in.lay.z_face + 2 * in.lay.z_vertex];
+          }
+          r[1] = Rec4<T>{v[0], v[1], v[2], v[3]};
+          r[2] = Rec4<T>{v[4], v[5], z0, z1};
+          T e7[7] = {0, 0, 1, 0, 0, 1, 3};
+          if constexpr (sizeof(T) == 4) edge_coefficients(v, bx0, by0, bx1, by1, e7);
+          r[3] = Rec4<T>{e7[0], e7[3], e7[1], e7[4]};  // the two edges' A, then B: operand pairs of one packed fma
+          r[4] = Rec4<T>{e7[2], e7[5], e7[6], z2};
         }
-        r[3] = Rec4<T>{e7[0], e7[3], e7[1], e7[4]};  // the two edges' A, then B: operand pairs of one packed fma
-        r[4] = Rec4<T>{e7[2], e7[5], e7[6], z2};
       }
       PHASE_MARK(2);
       PixRange pr;
