@@ -229,7 +229,9 @@ int kamd_dibr_soft_mask_backward_f64(void* stream, int B, int H, int W, int F, i
 /* FACE-MAJOR (the pixels of one face are consecutive).  item_count holds        */
 /* ceil(W/32)*ceil(H/32)*16*B ints.  `work` (kamd_dibr_soft_mask_work_words      */
 /* 32-bit words) receives the worklist: 8 sharded item counters, then the items  */
-/* {item, uncovered-pixel mask}; the backward walks it.  No shared append        */
+/* {item, uncovered-pixel mask}; the backward walks it.  The fused               */
+/* dibr_rasterization forward appends one byte per (mesh, 16x16-pixel tile):      */
+/* does the tile hold a covered pixel (read by its backward).  No shared append   */
 /* counter for the hits: ~20k same-address atomics per step would serialise.     */
 /* Requires B*H*W < 2^31.                                                        */
 /* Records each of the four hit arrays must hold (64*K per sub-tile slot).       */
