@@ -217,9 +217,22 @@ def dibr_soft_mask_backward_lean(grad_soft_mask, soft_mask, hits, face_vertices_
     return g_img
 
 
+_SIZES = {}   # (query, shape...) -> size: the library's size queries are pure functions of the shape (a ctypes call each)
+
+
+def _size(query, *shape):
+    key = (query,) + shape
+    n = _SIZES.get(key)
+    if n is None:
+        if len(_SIZES) > 256:
+            _SIZES.clear()
+        n = _SIZES[key] = int(getattr(_lib.load(), query)(*shape))
+    return n
+
+
 def _work_buffer(batch_size, height, width, device):
     """The search's worklist: 8 sharded item counters (16-word header), then the items {item id, uncovered-pixel mask}."""
-    n = max(int(_lib.load().kamd_dibr_soft_mask_work_words(batch_size, height, width)), 16)
+    n = max(_size('kamd_dibr_soft_mask_work_words', batch_size, height, width), 16)
     return torch.empty(n, dtype=torch.int32, device=device)
 
 
@@ -227,7 +240,7 @@ def _hit_list(batch_size, height, width, knum, dtype, device, num_faces=0):
     """Storage of the segmented hit list: 64*K record slots per 16x4-pixel sub-tile slot (just the used parts are ever
     touched) -- pair records {face, pixel << 16 | rank} as (cap, 2) int32, probabilities, types --, one count per
     sub-tile slot, and the worklist of the sub-tiles that were searched."""
-    cap = max(int(_lib.load().kamd_dibr_soft_mask_lean_capacity(batch_size, height, width, int(knum))), 1)
+    cap = max(_size('kamd_dibr_soft_mask_lean_capacity', batch_size, height, width, int(knum)), 1)
     n_sub = ((width + 31) // 32) * ((height + 31) // 32) * 16 * batch_size
     return (torch.empty((cap, 2), dtype=torch.int32, device=device),
             torch.empty(cap, dtype=dtype, device=device), torch.empty(cap, dtype=torch.uint8, device=device),
@@ -397,7 +410,7 @@ def dibr_rasterization_forward_fused(height, width, face_vertices_z, face_vertic
         soft_mask = torch.empty((batch_size, height, width), dtype=dtype, device=device)
         hits = _hit_list(batch_size, height, width, knum, dtype, device, num_faces)
         g_img = torch.empty_like(face_vertices_image) if prepare_grad else None
-        ws = _lib.workspace(lib.kamd_dibr_rasterization_workspace(batch_size, height, width, num_faces, int(knum), esz), device)
+        ws = _lib.workspace(_size('kamd_dibr_rasterization_workspace', batch_size, height, width, num_faces, int(knum), esz), device)
         st = getattr(lib, f'kamd_dibr_rasterization_forward_{sfx}')(
             _lib.stream_ptr(device), batch_size, height, width, num_faces, feat_dim, int(knum),
             _lib.ptr(z), int(z_face), int(z_vertex), _lib.ptr(face_vertices_image), _lib.ptr(face_features),
