@@ -487,7 +487,8 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
 }
 
 // the rasterizer's and the soft mask's backward kernels are independent and both accumulate atomically into the same
-// zero-initialised g_img: they run concurrently, the soft mask's on a library-owned side stream
+// zero-initialised g_img; with KAMD_BWD_SIDE_STREAM=1 they run concurrently, the soft mask's on a library-owned side stream
+// (the default until the rasterizer's backward learnt to skip empty tiles; see dibr_backward_fused)
 struct SideStream {
   hipStream_t s = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
@@ -514,11 +515,23 @@ int dibr_backward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K
                         const int64_t* face_idx, const T* weights, const T* soft_mask, const HitList2<T>& list,
                         const unsigned int* work, const T* img, const T* feat, double multiplier, float eps, float sigmainv,
                         T* g_img, T* g_feat) {
+  // The two backward kernels are independent and used to overlap on a side stream (61 || 73 us: ~110 together).  Since the
+  // rasterizer's backward leaves empty tiles at once (48 us) the fork / join events and the contention cost more than the
+  // overlap saves: one stream, step -9 us (KAMD_BWD_SIDE_STREAM=1 restores the side stream, for A/B runs; while the
+  // profiler times EVERY kernel everything stays on `st` anyway, so that each event pair times one kernel alone).
+  static const bool use_side = kamd_env_int("KAMD_BWD_SIDE_STREAM", 0) == 1;
+  const unsigned char* tile_cov = kamd_env_int("KAMD_BWD_TILE_COV", 1) == 1  // (2: off, for A/B runs)
+                                      ? reinterpret_cast<const unsigned char*>(work + tl::work_cov_offset_words(B, H, W))
+                                      : nullptr;
+  if (!use_side || kamd::prof_all()) {
+    KAMD_CHECK(soft_mask_backward_list_launch<T>(st, B, H, W, F, K, grad_soft, soft_mask, list, work, img, multiplier, sigmainv,
+                                                 (float)multiplier, g_img));
+    return kamd::raster_backward_draw<T>(st, B, H, W, F, D, grad_feat, face_idx, weights, img, feat, eps, g_img, g_feat, tile_cov);
+  }
   std::lock_guard<std::mutex> lk(g_side_mu);
   SideStream* ss;
   KAMD_CHECK(side_stream(&ss));
-  // (while the profiler times EVERY kernel everything stays on `st`, so that each kernel's event pair times that kernel alone)
-  const hipStream_t side = kamd::prof_all() ? st : ss->s;
+  const hipStream_t side = ss->s;
   KAMD_CHECK(hipEventRecord(ss->fork, st));
   KAMD_CHECK(hipStreamWaitEvent(side, ss->fork, 0));
   // after the fork every exit goes through the join: the caller may free the buffers as soon as this returns
@@ -527,10 +540,7 @@ int dibr_backward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K
   int rc2 = (int)hipEventRecord(ss->join, side);
   if (rc == 0) rc = rc2;
   if (rc == 0)
-    rc = kamd::raster_backward_draw<T>(st, B, H, W, F, D, grad_feat, face_idx, weights, img, feat, eps, g_img, g_feat,
-                                       kamd_env_int("KAMD_BWD_TILE_COV", 1) == 1  // (2: off, for A/B runs)
-                                           ? reinterpret_cast<const unsigned char*>(work + tl::work_cov_offset_words(B, H, W))
-                                           : nullptr);
+    rc = kamd::raster_backward_draw<T>(st, B, H, W, F, D, grad_feat, face_idx, weights, img, feat, eps, g_img, g_feat, tile_cov);
   rc2 = (int)hipStreamWaitEvent(st, ss->join, 0);
   return rc != 0 ? rc : rc2;
 }
