@@ -366,9 +366,10 @@ int kamd_texture_mapping_backward_f64(void* stream, int B, int64_t N, int C, int
 /* kernels as the separate entry points, sharing one binning pass: the faces  */
 /* are binned for both operators in one launch per phase, and the rasterizer's */
 /* tile kernel classifies the pixels for the soft mask.  The two backward      */
-/* kernels do not depend on each other: the soft mask's is enqueued on an      */
-/* internal side stream forked from / joined to `stream` with events, so the   */
-/* call is still stream-ordered for the caller.  g_img (zeroed by the caller)  */
+/* kernels do not depend on each other; they are enqueued one after the other  */
+/* on `stream` (with KAMD_BWD_SIDE_STREAM=1 the soft mask's goes to an         */
+/* internal side stream forked from / joined to `stream` with events: still    */
+/* stream-ordered for the caller).  g_img (zeroed by the caller)               */
 /* receives BOTH gradient contributions; g_feat may be NULL (feature gradient  */
 /* not needed: not computed).  workspace: kamd_dibr_rasterization_workspace.   */
 /* `weights` is meaningful only where face_idx >= 0 (background tiles do not write */
