@@ -247,7 +247,8 @@ __global__ __launch_bounds__(64) void soft_mask_backward_kernel(
 template <typename T>
 int soft2_search_launch(hipStream_t st, int B, int H, int W, int F, int K, float sigmainv, float multiplier, const T* rec,
                         const tl::Lists& LS, const unsigned int* work, T* soft_mask, T* prob, int64_t* idx, uint8_t* type,
-                        uint8_t* hit_count, const HitList2<T>* lean, unsigned short* pixcnt, T* prob_pm) {
+                        uint8_t* hit_count, const HitList2<T>* lean, unsigned short* pixcnt, T* prob_pm,
+                        void* zero_p = nullptr, size_t zero_bytes = 0) {  // (a 16-byte aligned range the eval launch clears)
   const unsigned int shard_cap = tl::work_shard_cap(B, H, W);
   const long long n_sub = (long long)B * LS.ntiles * tl::S_SUBS;
   Select2Args<T> sa{};
@@ -285,6 +286,8 @@ int soft2_search_launch(hipStream_t st, int B, int H, int W, int F, int K, float
   ea.idx_out = idx;
   ea.type_out = type;
   ea.prob_pm = prob_pm;
+  ea.zero_p = (uint4*)zero_p;
+  ea.zero_n16 = zero_bytes / 16;
   // one wavefront (select) / workgroup (eval) per work item; the number of items is known on the device only, so the
   // grids cover the worklist round-robin
   static const int sel_per_cu = kamd_env_int("KAMD_SOFT_SELECT_PER_CU", 32);
@@ -443,8 +446,12 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
   T* rec_s = (T*)((char*)workspace + lay.s.rec);
   // one launch clears the list heads, the work-list header and (when the caller will differentiate) the buffer the backward
   // kernels accumulate into
-  KAMD_CHECK(kamd_zero3_async(workspace, lay.zero_bytes, work, tl::WORK_HEADER * 4, g_img_zero,
-                              (size_t)total_faces * 6 * sizeof(T), st));
+  // (the gradient buffer is not needed before the backward pass: when the eval kernel will run, IT clears the buffer --
+  // 9.6 MB at C4 that would otherwise hold up the binning kernel by ~4 us)
+  const size_t g_bytes = (size_t)total_faces * 6 * sizeof(T);
+  const bool zero_in_eval = g_img_zero != nullptr && total_faces > 0 && ((uintptr_t)g_img_zero & 15) == 0 && g_bytes % 16 == 0 &&
+                            kamd_env_int("KAMD_DIBR_ZERO_IN_EVAL", 1) == 1;
+  KAMD_CHECK(kamd_zero3_async(workspace, lay.zero_bytes, work, tl::WORK_HEADER * 4, zero_in_eval ? nullptr : g_img_zero, g_bytes, st));
   if (total_faces > 0) {
     tl::BinIn<T> in{};
     in.B = B;
@@ -482,7 +489,8 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
     KAMD_CHECK(soft2_search_launch<T>(st, B, H, W, F, K, sigmainv, (float)multiplier, rec_s, LS, work, soft_mask, (T*)nullptr,
                                       (int64_t*)nullptr, (uint8_t*)nullptr, (uint8_t*)nullptr, &list,
                                       (unsigned short*)((char*)workspace + lay.s.pixcnt),
-                                      (T*)((char*)workspace + lay.s.prob_pm)));
+                                      (T*)((char*)workspace + lay.s.prob_pm), zero_in_eval ? (void*)g_img_zero : nullptr,
+                                      zero_in_eval ? g_bytes : 0));
   KAMD_RETURN_LAST_ERROR();
 }
 
