@@ -90,6 +90,69 @@ def pick_dominant(kernels):
     return next((k for k in near if k not in OVERLAPPED), ranked[0])
 
 
+def cpu_reference_extras(n_points=100000, slice_rows=4096, raster_res=32, sphere_frequency=50, seed=0):
+    """The other CPU readings BASELINE.md section 3 plans beside the DIB-R oracle figure, each on a bounded sample (CPU
+    only; a few seconds together):
+      * chamfer, restated kernel: the C oracle of K5 (OpenMP) on `slice_rows` query rows against all `n_points` targets,
+        both directions -- the brute-force cost is linear in the rows, so pairs/s of the slice is pairs/s of the item;
+      * chamfer, torch oracle: the dense `_sided_distance` formulation of the reference's tests on 1024-row chunks;
+      * rasterizer, torch oracle: `_naive_deftet_sparse_render(knum=1)` (what the reference's rasterizer tests are
+        pinned to) on raster_res^2 pixels of view 0 of the bench's mesh."""
+    import oracle
+    oracle.build()
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(seed)
+    p1, p2 = torch.rand((1, n_points, 3), generator=g), torch.rand((1, n_points, 3), generator=g)
+    rows = min(slice_rows, n_points)
+    t0 = time.perf_counter()
+    d12, i12 = oracle.sided_distance_forward(p1[:, :rows], p2, omp=True)
+    d21, i21 = oracle.sided_distance_forward(p2[:, :rows], p1, omp=True)
+    oracle.sided_distance_backward(torch.ones_like(d12), p1[:, :rows], p2, i12)
+    oracle.sided_distance_backward(torch.ones_like(d21), p2[:, :rows], p1, i21)
+    dt_c = time.perf_counter() - t0
+    out = {'chamfer_restated_kernel': {
+        'value': round(2.0 * rows * n_points / dt_c / 1e6, 1), 'unit': 'Mpoint-pairs/s', 'cores': oracle.num_threads(True), 'kind': 'port',
+        'sample': f'{rows} query rows x {n_points} targets, both directions fwd + bwd, C oracle (OpenMP over rows), {dt_c:.2f} s'}}
+    chunk = min(1024, rows)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        t12 = kal.metrics.pointcloud._sided_distance(p1[:, :chunk], p2)
+        t21 = kal.metrics.pointcloud._sided_distance(p2[:, :chunk], p1)
+    dt_t = time.perf_counter() - t0
+    out['chamfer_torch_oracle'] = {
+        'value': round(2.0 * chunk * n_points / dt_t / 1e6, 1), 'unit': 'Mpoint-pairs/s', 'cores': threads, 'kind': 'port',
+        'agrees_with_restated_kernel': bool(torch.equal(t12, d12[:, :chunk]) and torch.equal(t21, d21[:, :chunk])),
+        'sample': f'_sided_distance (dense torch formulation, forward values only) on one {chunk} x {n_points} chunk per direction, {dt_t:.2f} s'}
+    # rasterizer: view 0 of the bench's scene on a coarse pixel grid (the cost per pixel does not depend on the resolution)
+    verts, faces = T.geodesic_sphere(sphere_frequency)
+    cams = T.fibonacci_cameras(8, 2.5)[:1]
+    rot, trans = kal.render.camera.generate_rotate_translate_matrices(cams, torch.zeros((1, 3)), torch.tensor([[0., 1., 0.]]))
+    proj = kal.render.camera.generate_perspective_projection(math.pi / 4)
+    with torch.no_grad():
+        fv_cam, fv_img, _ = kal.render.mesh.prepare_vertices(verts.float().unsqueeze(0), faces, proj, camera_rot=rot, camera_trans=trans)
+    fz = fv_cam[..., 2].contiguous()
+    F = faces.shape[0]
+    feats = torch.rand((1, F, 3, 3), generator=g)
+    r = raster_res
+    xs = (2. * torch.arange(r, dtype=torch.float) + 1. - r) / r
+    ys = (r - 2. * torch.arange(r, dtype=torch.float) - 1.) / r
+    pix = torch.stack([xs.unsqueeze(0).expand(r, r), ys.unsqueeze(1).expand(r, r)], dim=-1).reshape(1, r * r, 2)
+    rng = torch.tensor([[[float(fz.min()) - 1e-2, float(fz.max()) + 1e-2]]]).expand(1, r * r, 2).contiguous()
+    a_img = fv_img.clone().requires_grad_()
+    t0 = time.perf_counter()
+    img, idx = kal.render.mesh.deftet._naive_deftet_sparse_render(pix, rng, fz, a_img, feats, 1)
+    img.sum().backward()
+    dt_r = time.perf_counter() - t0
+    ref_idx = oracle.rasterize(r, r, fz, fv_img, feats, omp=True)[1]
+    out['rasterize_torch_oracle'] = {
+        'value': round(r * r / dt_r / 1e6, 6), 'unit': 'Mpixels/s', 'cores': threads, 'kind': 'port',
+        'face_idx_equals_restated_kernel': bool(torch.equal(idx[..., 0].reshape(1, r, r), ref_idx)),
+        'sample': f'_naive_deftet_sparse_render(knum=1) fwd + autograd bwd (rasterizer only, no soft mask) on {r}x{r} pixels of one view of '
+                  f'the {F}-triangle mesh, {dt_r:.2f} s'}
+    return out
+
+
 def main():
     args = parse()
     D.init_from_env()
@@ -444,6 +507,10 @@ def main():
                'sample': f'{reps} pass(es) over 1 view of the same {F}-triangle mesh at {sres}x{sres} (the brute-force reference algorithm costs '
                          f'O(faces) per pixel at any resolution), oracle forward (OpenMP over pixels) + both backward passes '
                          f'(single thread), {cdt:.1f} s'}
+        try:                                                   # BASELINE.md section 3's other CPU readings (a few seconds)
+            cpu['other_paths'] = cpu_reference_extras(args.chamfer_points, sphere_frequency=args.sphere_frequency)
+        except Exception as exc:                               # (must not cost the run its headline line)
+            cpu['other_paths'] = {'error': str(exc)[:200]}
 
     if rank == 0:
         out = {
@@ -467,6 +534,7 @@ def main():
         }
         print(json.dumps(out))
     if D.is_distributed():
+        D.barrier()     # rank 0 still runs the C5 extras and prints the line: the group goes down only when every rank is done
         torch.distributed.destroy_process_group()
 
 
