@@ -505,3 +505,18 @@ def test_nan_vertex_matches_reference_glue():
     assert torch.equal(b_, y)
     assert torch.equal(torch.nan_to_num(a, nan=-7.), torch.nan_to_num(x, nan=-7.))
     assert torch.equal(torch.nan_to_num(c, nan=-7.), torch.nan_to_num(w, nan=-7.))
+
+
+def test_meshes_without_faces():
+    """B*F = 0: every pixel is background (index -1, zero features, zero soft mask), nothing is launched on the faces; the
+    calls after it are unaffected."""
+    H, W = 24, 40
+    z = torch.zeros((2, 0, 3)).cuda()
+    out, soft, idx = kal().render.mesh.dibr_rasterization(H, W, z, torch.zeros((2, 0, 3, 2)).cuda(), torch.zeros((2, 0, 3, 3)).cuda(),
+                                                          torch.zeros((2, 0)).cuda())
+    assert bool((idx == -1).all()) and float(soft.abs().max()) == 0. and float(out.abs().max()) == 0.
+    assert out.shape == (2, H, W, 3) and soft.shape == (2, H, W) and idx.shape == (2, H, W)
+    fz, fimg, feats, nz = _scene(6, 2, torch.float)
+    ref = oracle.dibr_rasterization(H, W, fz, fimg, torch.cat(feats, -1), nz, omp=True)
+    out, soft, idx = kal().render.mesh.dibr_rasterization(H, W, fz.cuda(), fimg.cuda(), torch.cat(feats, -1).cuda(), nz.cuda())
+    assert torch.equal(idx.cpu(), ref['face_idx']) and rel_close(soft, ref['soft_mask'])
