@@ -50,6 +50,11 @@ def parse():
     ap.add_argument('--chamfer-points', type=int, default=100000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-chamfer', action='store_true')
+    ap.add_argument('--cpu-extras', action='store_true',
+                    help='also time the C oracle / torch oracles of chamfer and the torch oracle of the rasterizer on the CPU '
+                         '(cpu_baseline.other_paths). Off by default: on the 128-core GPU box the dense torch oracle did not '
+                         'finish within the 100 s a profiling call had left (7 s on an 8-core container), so the default run '
+                         'keeps to the DIB-R oracle sample')
     ap.add_argument('--no-c5', action='store_true', help='skip the voxelgrid / point-to-mesh extras (config C5)')
     return ap.parse_args()
 
@@ -95,12 +100,12 @@ def cpu_reference_extras(n_points=100000, slice_rows=4096, raster_res=32, sphere
     only; a few seconds together):
       * chamfer, restated kernel: the C oracle of K5 (OpenMP) on `slice_rows` query rows against all `n_points` targets,
         both directions -- the brute-force cost is linear in the rows, so pairs/s of the slice is pairs/s of the item;
-      * chamfer, torch oracle: the dense `_sided_distance` formulation of the reference's tests on 1024-row chunks;
+      * chamfer, torch oracle: the dense `_sided_distance` formulation of the reference's tests on a 256-row chunk per direction;
       * rasterizer, torch oracle: `_naive_deftet_sparse_render(knum=1)` (what the reference's rasterizer tests are
         pinned to) on raster_res^2 pixels of view 0 of the bench's mesh."""
     import oracle
     oracle.build()
-    threads = os.cpu_count() or 1
+    threads = min(os.cpu_count() or 1, 32)   # (the dense formulation's GB-sized temporaries scale badly beyond a few dozen threads)
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(seed)
     p1, p2 = torch.rand((1, n_points, 3), generator=g), torch.rand((1, n_points, 3), generator=g)
@@ -114,7 +119,7 @@ def cpu_reference_extras(n_points=100000, slice_rows=4096, raster_res=32, sphere
     out = {'chamfer_restated_kernel': {
         'value': round(2.0 * rows * n_points / dt_c / 1e6, 1), 'unit': 'Mpoint-pairs/s', 'cores': oracle.num_threads(True), 'kind': 'port',
         'sample': f'{rows} query rows x {n_points} targets, both directions fwd + bwd, C oracle (OpenMP over rows), {dt_c:.2f} s'}}
-    chunk = min(1024, rows)
+    chunk = min(256, rows)
     t0 = time.perf_counter()
     with torch.no_grad():
         t12 = kal.metrics.pointcloud._sided_distance(p1[:, :chunk], p2)
@@ -122,7 +127,8 @@ def cpu_reference_extras(n_points=100000, slice_rows=4096, raster_res=32, sphere
     dt_t = time.perf_counter() - t0
     out['chamfer_torch_oracle'] = {
         'value': round(2.0 * chunk * n_points / dt_t / 1e6, 1), 'unit': 'Mpoint-pairs/s', 'cores': threads, 'kind': 'port',
-        'agrees_with_restated_kernel': bool(torch.equal(t12, d12[:, :chunk]) and torch.equal(t21, d21[:, :chunk])),
+        'max_rel_diff_vs_restated_kernel': float(max(((t12 - d12[:, :chunk]).abs() / d12[:, :chunk].clamp(min=1e-30)).max(),
+                                                     ((t21 - d21[:, :chunk]).abs() / d21[:, :chunk].clamp(min=1e-30)).max())),
         'sample': f'_sided_distance (dense torch formulation, forward values only) on one {chunk} x {n_points} chunk per direction, {dt_t:.2f} s'}
     # rasterizer: view 0 of the bench's scene on a coarse pixel grid (the cost per pixel does not depend on the resolution)
     verts, faces = T.geodesic_sphere(sphere_frequency)
@@ -507,10 +513,11 @@ def main():
                'sample': f'{reps} pass(es) over 1 view of the same {F}-triangle mesh at {sres}x{sres} (the brute-force reference algorithm costs '
                          f'O(faces) per pixel at any resolution), oracle forward (OpenMP over pixels) + both backward passes '
                          f'(single thread), {cdt:.1f} s'}
-        try:                                                   # BASELINE.md section 3's other CPU readings (a few seconds)
-            cpu['other_paths'] = cpu_reference_extras(args.chamfer_points, sphere_frequency=args.sphere_frequency)
-        except Exception as exc:                               # (must not cost the run its headline line)
-            cpu['other_paths'] = {'error': str(exc)[:200]}
+        if args.cpu_extras:                                    # BASELINE.md section 3's other CPU readings (opt-in, see parse())
+            try:
+                cpu['other_paths'] = cpu_reference_extras(args.chamfer_points, sphere_frequency=args.sphere_frequency)
+            except Exception as exc:                           # (must not cost the run its headline line)
+                cpu['other_paths'] = {'error': str(exc)[:200]}
 
     if rank == 0:
         out = {

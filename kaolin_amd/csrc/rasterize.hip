@@ -70,6 +70,9 @@ __device__ __forceinline__ T barycentric_jacobian(const T* v, T aw, T bw, T cw, 
   return k3;
 }
 
+#ifndef KAMD_RBWD_ORDER
+#define KAMD_RBWD_ORDER 1  // workgroup order of the backward: 1 = views interleaved, tile rows from the middle of the image outwards
+#endif                     // (as the forward's tile kernel; 0 = view-major, row-major: 49.4 vs 45.4 us at C4, 9 us of the step with feature gradients)
 // DT > 0: feature count known at compile time (block-merged through LDS); DT == 0: any D, per-lane global atomics.
 // GF = false: the caller does not need d/d(face_features) (static texture coordinates, the usual DIB-R set-up): only the
 // 6 image-coordinate values per face are merged instead of 6 + 3*D -- 2.5x fewer DPP merges and LDS atomics at D = 3.
@@ -80,15 +83,21 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(
     T* __restrict__ g_img, T* __restrict__ g_feat, const unsigned char* __restrict__ tile_cov) {
   // (fused dibr_rasterization: the forward pass noted which tiles hold a covered pixel -- 85 % of C4's do not, and
   // finding that out from face_idx costs a 2-KB read and a barrier per workgroup: 24 of this kernel's 60 us)
-  if (tile_cov != nullptr && tile_cov[blockIdx.x] == 0) return;
+  // workgroup = 16x16 pixels of one image; wavefront = 16x4
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+#if KAMD_RBWD_ORDER
+  // views interleaved, tile rows from the middle of the image outwards: the workgroups that find covered pixels start first
+  const int b = blockIdx.x % B, k_ = blockIdx.x / B, kr_ = k_ / tiles_x, mid_ = tiles_y >> 1;
+  const int tile = ((kr_ & 1) ? mid_ - ((kr_ + 1) >> 1) : mid_ + (kr_ >> 1)) * tiles_x + (k_ - kr_ * tiles_x);
+#else
+  const int tile = blockIdx.x % (tiles_x * tiles_y), b = blockIdx.x / (tiles_x * tiles_y);
+#endif
+  if (tile_cov != nullptr && tile_cov[(size_t)b * (tiles_x * tiles_y) + tile] == 0) return;
   constexpr int NV = (DT > 0 && GF) ? 6 + 3 * DT : 6;
   __shared__ int s_key[DT > 0 ? RB_HT : 1];
   __shared__ T s_acc[DT > 0 ? RB_HT * NV : 1];
   __shared__ int s_used[DT > 0 ? 256 : 1];
   __shared__ int s_nused;
-  // workgroup = 16x16 pixels of one image; wavefront = 16x4
-  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
-  const int tile = blockIdx.x % (tiles_x * tiles_y), b = blockIdx.x / (tiles_x * tiles_y);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = (tile % tiles_x) * 16 + (lane & 15), row = (tile / tiles_x) * 16 + wave * 4 + (lane >> 4);
   const bool in_image = col < W && row < H;

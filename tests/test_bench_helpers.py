@@ -37,3 +37,13 @@ def test_algorithmic_bytes_follow_the_survey_per_unit_figures():
     assert bench.algorithmic_bytes('soft_eval_kernel', B, P, F, Fv, 3, 30) is None
     assert bench.algorithmic_bytes('fill_regions_kernel', B, P, F, Fv, 3, 30) == B * P * 30 * 13
     assert bench.algorithmic_bytes('pv_forward_kernel', B, P, F, Fv, 3, 30) is None
+
+
+def test_cpu_reference_extras_small_sample():
+    """The opt-in CPU readings (bench.py --cpu-extras): the C oracle and the dense torch oracle of chamfer agree to rounding,
+    the torch oracle of the rasterizer picks the faces the restated kernel picks."""
+    r = bench.cpu_reference_extras(n_points=1500, slice_rows=300, raster_res=8, sphere_frequency=4)
+    assert r['chamfer_restated_kernel']['value'] > 0 and r['chamfer_restated_kernel']['unit'] == 'Mpoint-pairs/s'
+    assert r['chamfer_torch_oracle']['max_rel_diff_vs_restated_kernel'] < 1e-5
+    assert r['rasterize_torch_oracle']['face_idx_equals_restated_kernel'] is True
+    assert all(v['kind'] == 'port' and v['cores'] >= 1 for v in r.values())

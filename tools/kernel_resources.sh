@@ -2,7 +2,7 @@
 # usage: tools/kernel_resources.sh <file.hip> [name filter]  -- registers / LDS / scratch per kernel (hipcc -Rpass-analysis)
 cd "$(dirname "$0")/../kaolin_amd/csrc"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fno-math-errno \
-  -Rpass-analysis=kernel-resource-usage -c "$1" -o /dev/null 2>&1 | python3 -c "
+  -Rpass-analysis=kernel-resource-usage ${KR_DEFS:-} -c "$1" -o /dev/null 2>&1 | python3 -c "
 import re,sys
 cur=None
 for line in sys.stdin:

@@ -6,11 +6,11 @@
 set -u
 tag=${1:-r01x}; pmc=${2:-}
 repo=$(pwd); out=$repo/gpurun_out/$tag; mkdir -p $out
-timeout 1200 python -m pytest tests -m gpu -q -x --durations=15 > $out/pytest_gpu.log 2>&1; tail -2 $out/pytest_gpu.log
-timeout 600 python bench.py 2> $out/bench.err | tail -1 > $out/bench.json
+timeout 300 python -m pytest tests -m gpu -q -x --durations=15 --timeout 120 > $out/pytest_gpu.log 2>&1; tail -2 $out/pytest_gpu.log
+timeout 200 python bench.py 2> $out/bench.err | tail -1 > $out/bench.json
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python $repo/bench.py --no-cpu-baseline 2> $out/prof.err | tail -1 > $out/bench_under_rocprof.json
+timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python $repo/bench.py --no-cpu-baseline 2> $out/prof.err | tail -1 > $out/bench_under_rocprof.json
 find $out/prof -name '*kernel_stats.csv' -exec cp {} $out/kernel_stats.csv \;
 if [ -n "$pmc" ]; then
   timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_f -- python $repo/tools/pmc_traffic.py > /dev/null 2>&1
