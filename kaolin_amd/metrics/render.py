@@ -44,7 +44,7 @@ def mask_iou(lhs_mask, rhs_mask):
     """
     if lhs_mask.shape != rhs_mask.shape or lhs_mask.dim() != 3:
         raise AssertionError('mask_iou expects two masks of identical shape (B, H, W)')
-    if (lhs_mask.is_cuda and rhs_mask.is_cuda and lhs_mask.dtype == rhs_mask.dtype and
+    if (lhs_mask.is_cuda and rhs_mask.is_cuda and lhs_mask.device == rhs_mask.device and lhs_mask.dtype == rhs_mask.dtype and
             lhs_mask.dtype in (torch.float32, torch.float64) and lhs_mask.numel() > 0 and
             lhs_mask.shape[0] <= 65535):      # (the kernels put the batch on a grid dimension)
         return _MaskIoUCuda.apply(lhs_mask, rhs_mask)

@@ -126,7 +126,9 @@ def texture_mapping(texture_coordinates, texture_maps, mode='nearest'):
     if (mode in ('nearest', 'bilinear') and texture_coordinates.is_cuda and texture_maps.is_cuda and
             texture_coordinates.dtype == texture_maps.dtype and texture_coordinates.dtype in (torch.float32, torch.float64) and
             texture_maps.dim() == 4 and texture_coordinates.shape[-1] == 2 and texture_coordinates.numel() > 0 and
-            texture_maps.shape[0] == texture_coordinates.shape[0] and texture_maps[0].numel() > 0):
+            texture_maps.shape[0] == texture_coordinates.shape[0] and texture_maps[0].numel() > 0 and
+            texture_coordinates.device == texture_maps.device and
+            texture_maps.shape[0] <= 65535):      # (the kernels put the batch on a grid dimension)
         B, C = texture_coordinates.shape[0], texture_maps.shape[1]
         out = _TextureMappingCuda.apply(texture_coordinates.reshape(B, -1, 2), texture_maps, mode == 'bilinear')
         return out.reshape(B, *texture_coordinates.shape[1:-1], C)
