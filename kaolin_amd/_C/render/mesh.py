@@ -373,7 +373,11 @@ def dibr_rasterization_forward_fused(height, width, face_vertices_z, face_vertic
     normals' z of ``dibr_rasterization``): that one, and ``face_vertices_z``, may be last-index views and are read in
     place.  -> (interpolated_features, face_idx, output_weights, soft_mask, hits, grad_buffer): with ``prepare_grad`` the
     last one is a zeroed ``grad_face_vertices_image`` for :func:`dibr_rasterization_backward_fused`, cleared by the same fill
-    launch as the operator's own list heads (a fill launch of its own in the backward costs ~5 us); else ``None``."""
+    launch as the operator's own list heads (a fill launch of its own in the backward costs ~5 us); else ``None``.
+    ``output_weights`` is INTERNAL to the autograd node (the backward reads it only where ``face_idx >= 0``): where
+    ``face_idx == -1`` its content is UNDEFINED (background tiles do not write it: 12 of their 36 bytes per pixel) -- unlike
+    :func:`rasterize_forward_fused` / the reference operator, which store zeros there.  Mask with ``face_idx >= 0`` before
+    looking at it."""
     fn = 'dibr_rasterization_forward_fused'
     front = None
     if valid_faces is not None and valid_faces.is_floating_point():
@@ -485,15 +489,21 @@ _FACES_OK = {}
 
 def faces_in_range(faces, num_vertices):
     """True when every index of `faces` addresses a vertex (the reference's index_select would raise otherwise; the fused
-    kernels read unchecked).  One host read per `faces` tensor, cached like the adjacency (mesh topology is static)."""
+    kernels read unchecked).  One reduction and one host read per `faces` tensor, cached like the adjacency (mesh topology
+    is static); the entry keeps `faces` alive, so that its data_ptr cannot be handed to another tensor of the same shape
+    while the entry exists (a recycled address would hit a stale answer)."""
     key = (faces.data_ptr(), tuple(faces.shape), faces._version, int(num_vertices), str(faces.device))
     hit = _FACES_OK.get(key)
     if hit is None:
-        hit = bool(faces.numel() == 0 or (int(faces.min()) >= 0 and int(faces.max()) < num_vertices))
+        if faces.numel() == 0:
+            ok = True
+        else:
+            lo, hi = torch.stack(torch.aminmax(faces)).tolist()     # min and max in one pass, one synchronising read
+            ok = lo >= 0 and hi < num_vertices
         if len(_FACES_OK) > 16:
             _FACES_OK.clear()
-        _FACES_OK[key] = hit
-    return hit
+        hit = _FACES_OK[key] = (ok, faces)
+    return hit[0]
 
 
 def _pv_common(vertices, faces, camera_proj, camera_rot, camera_trans, camera_transform):

@@ -435,7 +435,11 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
                        int64_t front_stride, double multiplier, float eps, float sigmainv, double margin, T* interp,
                        int64_t* face_idx, T* weights, T* soft_mask, const HitList2<T>& list, unsigned int* work,
                        void* workspace, T* g_img_zero) {
-  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  if (B <= 0 || H <= 0 || W <= 0) {
+    // an empty image: no kernel runs, but the caller's gradient buffer (allocated uninitialised) is returned by the backward
+    if (g_img_zero != nullptr && B > 0 && F > 0) KAMD_CHECK(kamd_zero_async(g_img_zero, (size_t)B * F * 6 * sizeof(T), st));
+    return 0;
+  }
   const long long total_faces = (long long)B * F;
   if (workspace == nullptr || work == nullptr) return (int)hipErrorInvalidValue;
   if ((long long)B * H * W >= (1ll << 31)) return (int)hipErrorInvalidValue;

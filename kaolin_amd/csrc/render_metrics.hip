@@ -189,9 +189,10 @@ __global__ __launch_bounds__(256) void texture_mapping_backward_kernel(long long
         gsy += g * ((t01 - t00) * wx0 + (t11 - t10) * wx1);
       }
       if (g_uv) {
-        // chain: source index <- border clip (gradient 0 outside [0, size - 1]) <- * size / 2 <- (u * 2 - 1, flipped for v)
-        // <- clamp(uv, 0, 1) (gradient passes inside the closed interval, as torch.clamp)
-        const T cx = (ux >= (T)0 && ux <= (T)(TW - 1)) ? (T)1 : (T)0, cy = (uy >= (T)0 && uy <= (T)(TH - 1)) ? (T)1 : (T)0;
+        // chain: source index <- border clip <- * size / 2 <- (u * 2 - 1, flipped for v) <- clamp(uv, 0, 1) (gradient passes
+        // inside the closed interval, as torch.clamp).  grid_sample's clip_coordinates_set_grad gives the borders THEMSELVES
+        // gradient 0 (in <= 0 or in >= size - 1): the interval is open, e.g. TW = 2, u = 0.25 sits exactly on index 0
+        const T cx = (ux > (T)0 && ux < (T)(TW - 1)) ? (T)1 : (T)0, cy = (uy > (T)0 && uy < (T)(TH - 1)) ? (T)1 : (T)0;
         const T ku = (u_raw >= (T)0 && u_raw <= (T)1) ? (T)1 : (T)0, kv = (v_raw >= (T)0 && v_raw <= (T)1) ? (T)1 : (T)0;
         g_uv[((size_t)b * N + i) * 2 + 0] = gsx * cx * ((T)TW / (T)2) * (T)2 * ku;
         g_uv[((size_t)b * N + i) * 2 + 1] = gsy * cy * ((T)TH / (T)2) * (T)(-2) * kv;

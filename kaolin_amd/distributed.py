@@ -17,12 +17,19 @@ __all__ = ['init_from_env', 'is_distributed', 'rank', 'world_size', 'shard_range
            'all_reduce_gradients', 'SharedGradientReducer', 'all_gather_batch', 'barrier']
 
 
+def _forced():
+    """KAMD_DIST_FORCE=1: keep the whole distributed control flow (process group, gradient hooks, collectives, barriers) for
+    a world of ONE rank -- lets a 1-GPU box execute the RCCL path (``python -m torch.distributed.run --nproc-per-node 1``)."""
+    return os.environ.get('KAMD_DIST_FORCE') == '1'
+
+
 def init_from_env(backend=None):
     """Initialises the default process group from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (as exported by
-    ``python -m torch.distributed.run``); binds this process to GPU LOCAL_RANK.  No-op for a single process."""
+    ``python -m torch.distributed.run``); binds this process to GPU LOCAL_RANK.  No-op for a single process (unless
+    KAMD_DIST_FORCE=1, see :func:`_forced`)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world <= 1 or dist.is_initialized():
-        return world > 1
+    if (world <= 1 and not (_forced() and 'RANK' in os.environ)) or dist.is_initialized():
+        return world > 1 or (_forced() and dist.is_initialized())
     use_cuda = torch.cuda.is_available()
     if use_cuda:
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1))
@@ -34,7 +41,7 @@ def init_from_env(backend=None):
 
 
 def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _forced())
 
 
 def rank():
@@ -92,7 +99,13 @@ class SharedGradientReducer:
     late.  Single process: a no-op.
 
         reducer = SharedGradientReducer([vertices, texture])
-        loss.backward(); reducer.wait(); optimizer.step()
+        loss.backward(); reducer.wait(); optimizer.step(); optimizer.zero_grad()
+
+    The hook reduces ``p.grad`` ITSELF, i.e. whatever has accumulated there: clear the gradients (``zero_grad`` /
+    ``p.grad = None``) between two ``backward()`` calls.  When gradients are accumulated over several micro-batches, wrap all
+    but the last ``backward()`` in :meth:`no_sync` (as with DistributedDataParallel) -- otherwise the sum reduced after the
+    first micro-batch is reduced again after the second and counts ``world_size`` times.  The hooks stay registered until
+    :meth:`remove`.
     """
 
     def __init__(self, params, average=False):
@@ -100,10 +113,25 @@ class SharedGradientReducer:
         self.average = average
         self._pending = []
         self.posted = 0
+        self._sync = True
         self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
 
+    def no_sync(self):
+        """Context manager: ``backward()`` calls inside accumulate locally, nothing is posted (gradient accumulation over
+        micro-batches; the first ``backward()`` outside reduces the accumulated sum once)."""
+        reducer = self
+
+        class _NoSync:
+            def __enter__(self):
+                self.prev, reducer._sync = reducer._sync, False
+
+            def __exit__(self, *exc):
+                reducer._sync = self.prev
+                return False
+        return _NoSync()
+
     def _hook(self, p):
-        if not is_distributed() or p.grad is None:
+        if not self._sync or not is_distributed() or p.grad is None:
             return
         g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
         self._pending.append((p, g, _all_reduce_tensor(g, async_op=True)))

@@ -156,3 +156,25 @@ def test_weighted_sum_cpu_fallback_is_the_torch_expression():
     assert torch.equal(x1.grad, w1)
     with pytest.raises(ValueError):
         weighted_sum(x1, w1, x2)
+
+
+def test_faces_in_range_cache_pins_its_tensor():
+    """the index-range check is cached per `faces` tensor by (data_ptr, shape, version): the entry must keep
+    the tensor alive, otherwise a new mesh of the same shape allocated at the recycled address would inherit the answer."""
+    import gc
+    import weakref
+    from kaolin_amd._C.render import mesh as m
+    m._FACES_OK.clear()
+    good = torch.tensor([[0, 1, 2], [2, 3, 1]])
+    ref = weakref.ref(good)
+    assert m.faces_in_range(good, 4) is True
+    del good
+    gc.collect()
+    assert ref() is not None                       # pinned by the cache entry: its address cannot be reused
+    bad = torch.tensor([[0, 1, 2], [2, 7, 1]])     # same shape, out of range
+    assert bad.data_ptr() != ref().data_ptr()
+    assert m.faces_in_range(bad, 4) is False and m.faces_in_range(bad, 8) is True
+    neg = torch.tensor([[0, -1, 2]])
+    assert m.faces_in_range(neg, 4) is False
+    bad[1, 1] = 3                                   # in-place edit bumps the version: re-checked
+    assert m.faces_in_range(bad, 4) is True

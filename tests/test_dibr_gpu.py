@@ -520,3 +520,18 @@ def test_meshes_without_faces():
     ref = oracle.dibr_rasterization(H, W, fz, fimg, torch.cat(feats, -1), nz, omp=True)
     out, soft, idx = kal().render.mesh.dibr_rasterization(H, W, fz.cuda(), fimg.cuda(), torch.cat(feats, -1).cuda(), nz.cuda())
     assert torch.equal(idx.cpu(), ref['face_idx']) and rel_close(soft, ref['soft_mask'])
+
+
+def test_zero_sized_image_gives_zero_gradients():
+    """H = 0 (or W = 0) with faces present: no kernel runs, and the gradient buffer the forward prepared for the
+    backward (allocated uninitialised) must still come back as zeros."""
+    import kaolin_amd  # noqa: F401
+    fz, fimg, feats, nz = _scene(4, 2, torch.float)
+    feat = torch.cat(feats, -1).cuda()
+    for H, W in ((0, 16), (16, 0)):
+        a = fimg.cuda().requires_grad_()
+        torch.empty(1 << 20, device='cuda').fill_(float('nan'))            # poison what the allocator hands out next
+        out, soft, idx = kal().render.mesh.dibr_rasterization(H, W, fz.cuda(), a, feat, nz.cuda())
+        assert out.shape == (2, H, W, 3) and soft.shape == (2, H, W) and idx.shape == (2, H, W)
+        (out.sum() + soft.sum()).backward()
+        assert a.grad is not None and float(a.grad.abs().max()) == 0.

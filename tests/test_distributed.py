@@ -201,3 +201,128 @@ def test_two_process_dibr_view_sharding_matches_single_process(tmp_path):
     assert torch.equal(res['soft'], full['soft'][:3].cpu())
     g_full, g = full['grad'].cpu().double(), res['grad'].double()
     assert float((g - g_full).abs().max()) <= 1e-5 * float(g_full.abs().max())
+
+
+# ---- gradient accumulation over micro-batches: no_sync() (a second backward() must not reduce twice) ------
+def _accum_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from kaolin_amd import distributed as D
+    assert D.init_from_env('gloo')
+    torch.manual_seed(2)
+    verts = torch.rand(20, 3, dtype=torch.double, requires_grad=True)
+    cams = torch.rand(8, 3, dtype=torch.double) + 2.0
+    mine = D.shard_views(cams)                      # 4 views per rank, two micro-batches of 2
+    reducer = D.SharedGradientReducer([verts])
+    with reducer.no_sync():
+        _view_loss(verts, mine[:2]).backward()
+    assert reducer.posted == 0                      # accumulated locally, nothing on the wire
+    _view_loss(verts, mine[2:]).backward()
+    assert reducer.posted == 1                      # the accumulated sum, reduced once
+    reducer.wait()
+    reducer.remove()
+    if rank == 0:
+        torch.save({'verts': verts.grad}, out)
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_micro_batches_reduce_once(tmp_path):
+    out = str(tmp_path / 'accum.pt')
+    mp.spawn(_accum_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out)
+    torch.manual_seed(2)
+    verts = torch.rand(20, 3, dtype=torch.double, requires_grad=True)
+    cams = torch.rand(8, 3, dtype=torch.double) + 2.0
+    _view_loss(verts, cams).backward()
+    assert torch.allclose(res['verts'], verts.grad, rtol=1e-12, atol=1e-14)
+
+
+# ---- a world of ONE rank with the whole distributed control flow (KAMD_DIST_FORCE=1) ------------------------------------
+_ONE_RANK_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, os.environ['KAMD_ROOT'])
+import torch
+import torch.distributed as dist
+from kaolin_amd import distributed as D
+assert D.init_from_env(), 'KAMD_DIST_FORCE=1 must initialise a process group for WORLD_SIZE=1'
+assert D.is_distributed() and D.world_size() == 1 and D.rank() == 0
+want = os.environ['KAMD_EXPECT_BACKEND']
+assert dist.get_backend() == want, dist.get_backend()
+dev = torch.device('cuda', torch.cuda.current_device()) if want == 'nccl' else torch.device('cpu')
+torch.manual_seed(4)
+verts = torch.rand(3000, 3, device=dev, requires_grad=True)
+cams = torch.rand(6, 3, device=dev) + 2.0
+reducer = D.SharedGradientReducer([verts])
+steps = []
+for step in range(3):                       # several steps: the Work objects of one step must not leak into the next
+    verts.grad = None
+    rel = verts.unsqueeze(0) - D.shard_views(cams).unsqueeze(1)
+    ((rel[..., :2] / (1.0 + rel[..., 2:].abs())).pow(2).sum() + 0.1 * rel.norm(dim=-1).sum()).backward()
+    assert reducer.posted == step + 1       # posted from autograd's hook, on the backward thread
+    reducer.wait()                          # the current stream waits for the collective's stream
+    steps.append(verts.grad.clone())
+reducer.remove()
+D.barrier()
+if dev.type == 'cuda':
+    torch.cuda.synchronize()
+# all-reduce(SUM) over one rank is the identity: the gradient must equal the one computed without any collective
+v2 = verts.detach().clone().requires_grad_()
+rel = v2.unsqueeze(0) - cams.unsqueeze(1)
+((rel[..., :2] / (1.0 + rel[..., 2:].abs())).pow(2).sum() + 0.1 * rel.norm(dim=-1).sum()).backward()
+assert all(torch.equal(s, v2.grad) for s in steps)
+t = torch.tensor([1.5], device=dev, dtype=torch.double)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+g = D.all_gather_batch(torch.ones(2, 1, device=dev))
+assert float(t) == 1.5 and g.shape == (2, 1)
+print(json.dumps({'ok': True, 'backend': dist.get_backend(), 'posted': reducer.posted}))
+dist.destroy_process_group()
+'''
+
+
+def _run_one_rank(tmp_path, backend, extra_env=None):
+    import subprocess
+    script = tmp_path / 'one_rank_worker.py'
+    script.write_text(_ONE_RANK_WORKER)
+    env = dict(os.environ, KAMD_DIST_FORCE='1', KAMD_ROOT=ROOT, KAMD_EXPECT_BACKEND=backend, **(extra_env or {}))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert '"ok": true' in res.stdout
+    return res.stdout
+
+
+def test_forced_one_rank_world_gloo(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 1` with KAMD_DIST_FORCE=1: process group, hooked all-reduce,
+    wait, barrier, all-gather all execute for a world of one rank (gloo on CPU here; RCCL below)."""
+    _run_one_rank(tmp_path, 'gloo', {'KAMD_DIST_BACKEND': 'gloo', 'CUDA_VISIBLE_DEVICES': '', 'HIP_VISIBLE_DEVICES': ''})
+
+
+@pytest.mark.gpu
+def test_forced_one_rank_world_rccl(tmp_path):
+    """The same over RCCL (backend "nccl") on the one GPU a box has: ncclAllReduce posted from autograd's
+    post-accumulate hook with async_op=True, Work.wait() on the caller's stream, barrier, destroy -- the N > 1 control
+    flow of bench.py and SharedGradientReducer on the backend the 8-GPU run uses."""
+    out = _run_one_rank(tmp_path, 'nccl')
+    assert '"backend": "nccl"' in out
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_one_rank_rccl(tmp_path):
+    """bench.py launched exactly as the driver launches it for N > 1 (torch.distributed.run, env rendezvous), one rank,
+    KAMD_DIST_FORCE=1: init_process_group('nccl'), sharded views, the hooked vertex-gradient all-reduce inside the timed
+    steps, the MAX-over-ranks reduction of the time, barrier and teardown all run on RCCL.  Small shapes (a smoke run)."""
+    import json
+    import subprocess
+    env = dict(os.environ, KAMD_DIST_FORCE='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1',
+           '--res', '256', '--sphere-frequency', '16', '--views-per-gpu', '4', '--chamfer-points', '20000', '--no-c5',
+           '--no-cpu-baseline']
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 1 and line['value'] > 0 and line['distributed']['backend'] == 'nccl'
+    assert line['distributed']['collectives_posted_per_step'] == 1

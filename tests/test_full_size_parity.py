@@ -58,6 +58,73 @@ def test_c4_one_view_1024_vs_oracle(view):
     assert rel_close(a.grad, r_img + r_soft, 1e-5)
 
 
+def _check_views_vs_oracle(H, W, fz, fimg, feat, nz, dtype_tol=1e-5, expect_cover=None, features_exact=True):
+    """dibr_rasterization on the GPU for every view of the batch at once vs the oracle's batched run: face_idx equal,
+    features bit for bit, soft mask and both gradients within `dtype_tol` relative."""
+    ref = oracle.dibr_rasterization(H, W, fz, fimg, feat, nz, omp=True)
+    a = fimg.cuda().requires_grad_()
+    f = feat.cuda().requires_grad_()
+    out, soft, face_idx = kal().render.mesh.dibr_rasterization(H, W, fz.cuda(), a, f, nz.cuda())
+    for v in range(fz.shape[0]):
+        assert torch.equal(face_idx[v].cpu(), ref['face_idx'][v]), f'face_idx differs in view {v}'
+    if expect_cover is not None:
+        cov = float((face_idx >= 0).float().mean())
+        assert expect_cover[0] < cov < expect_cover[1], cov
+    if features_exact:
+        assert torch.equal(out.detach().cpu(), ref['features'])
+    else:
+        assert rel_close(out.detach(), ref['features'], dtype_tol)
+    assert rel_close(soft.detach(), ref['soft_mask'], dtype_tol)
+    band = (ref['soft_mask'] > 0) & (ref['soft_mask'] < 1)
+    assert torch.equal((soft.detach().cpu() > 0) & (soft.detach().cpu() < 1), band)
+    g = torch.Generator().manual_seed(7)
+    g_feat_out = torch.rand(out.shape, generator=g, dtype=out.dtype)
+    g_soft_out = torch.rand(soft.shape, generator=g, dtype=out.dtype)
+    ((out * g_feat_out.cuda()).sum() + (soft * g_soft_out.cuda()).sum()).backward()
+    r_img, r_feat = oracle.rasterize_backward(g_feat_out, ref['face_idx'], ref['weights'], fimg, feat, 1e-8)
+    r_soft = oracle.dibr_soft_mask_backward(g_soft_out, ref['soft_mask'], ref['face_idx'], ref['close_face_prob'],
+                                            ref['close_face_idx'], ref['close_face_dist_type'], ref['scaled_vertices'],
+                                            7000, 1000.)
+    for v in range(fz.shape[0]):   # per view: a view with small gradients must not hide behind another one's scale
+        assert rel_close(f.grad[v], r_feat[v], dtype_tol), f'feature gradient, view {v}'
+        assert rel_close(a.grad[v], (r_img + r_soft)[v], dtype_tol), f'vertex gradient, view {v}'
+    return int(band.sum())
+
+
+def test_c4_batched_8_views_1024_vs_oracle():
+    """The call the bench times: ALL 8 views of config C4 in one dibr_rasterization call (batch index inside every kernel:
+    tile lists per view, work items of different views interleaved) against the oracle's 8 views."""
+    from kaolin_amd.utils import testing as T
+    fz, fimg, feats, nz = T.sphere_scene(level=50, num_views=8, device='cpu')
+    band = _check_views_vs_oracle(1024, 1024, fz, fimg, torch.cat(feats, -1).contiguous(), nz, expect_cover=(0.15, 0.25))
+    assert band > 80000
+
+
+def test_c4_f64_one_view_1024_vs_oracle():
+    """fp64 takes its own rasterizer branch (per-pixel box masks + sign sweep, raster2.inc): one 1024^2 view of the
+    50 000-triangle sphere against the fp64 oracle -- face_idx equal, gradients 1e-5 (reference dtypes:
+    tests/python/kaolin/render/mesh/test_rasterization.py:40, test_dibr.py:36)."""
+    from kaolin_amd.utils import testing as T
+    fz, fimg, feats, nz = T.sphere_scene(level=50, num_views=8, device='cpu', dtype=torch.double)
+    v = 3
+    _check_views_vs_oracle(1024, 1024, fz[v:v + 1].contiguous(), fimg[v:v + 1].contiguous(),
+                           torch.cat([x[v:v + 1] for x in feats], -1).contiguous(), nz[v:v + 1].contiguous(),
+                           expect_cover=(0.15, 0.25))
+
+
+@pytest.mark.parametrize('shift', [(0.42, -0.36), (0.85, 0.0), (-0.3, -0.9)], ids=['off_centre', 'right_edge', 'bottom_edge'])
+def test_c4_off_centre_and_partially_off_screen_1024_vs_oracle(shift):
+    """The workgroup -> tile order of the rasterizer kernels is a performance choice; the result must not depend on where
+    the object sits.  The C4 mesh moved off the middle of the image, and moved until part of it leaves the image (boxes
+    clipped by the image border, tiles whose lists only hold faces that are partly outside)."""
+    from kaolin_amd.utils import testing as T
+    fz, fimg, feats, nz = T.sphere_scene(level=50, num_views=8, device='cpu')
+    v = 1
+    fimg = (fimg[v:v + 1] + torch.tensor(shift)).contiguous()
+    _check_views_vs_oracle(1024, 1024, fz[v:v + 1].contiguous(), fimg, torch.cat([x[v:v + 1] for x in feats], -1).contiguous(),
+                           nz[v:v + 1].contiguous(), expect_cover=(0.05, 0.25))
+
+
 def test_c4_kbuffer_operator_1024_vs_oracle():
     """The reference-contract soft-mask operator (K-buffers) at 1024^2 / 50k faces: idx and type bit-exact, prob 1e-5."""
     from kaolin_amd.utils import testing as T
@@ -92,7 +159,13 @@ def test_c3_chamfer_100k_x_100k_vs_oracle():
     assert torch.equal(i21[:, sl.cuda()].cpu(), r_i) and torch.equal(d21[:, sl.cuda()].detach().cpu(), r_d)
     # chamfer_distance = mean(d12) + mean(d21) (reference: kaolin/metrics/pointcloud.py:89-136) and its gradient
     loss = pc.chamfer_distance(a, b)
-    ref_loss = d12.detach().double().mean() + d21.detach().double().mean()
+    # the loss against the ORACLE's distances: all 100 000 rows of both directions through the all-pairs oracle (2e10
+    # pairs, OpenMP over rows), which also pins every nearest index, not only the slices above
+    o12, oi12 = oracle.sided_distance_forward(p1, p2, omp=True)
+    o21, oi21 = oracle.sided_distance_forward(p2, p1, omp=True)
+    assert torch.equal(i12.cpu(), oi12) and torch.equal(i21.cpu(), oi21)
+    assert torch.equal(d12.detach().cpu(), o12) and torch.equal(d21.detach().cpu(), o21)
+    ref_loss = o12.double().mean() + o21.double().mean()
     assert abs(float(loss) - float(ref_loss)) <= 1e-5 * float(ref_loss)
     loss.sum().backward()
     w = torch.full((1, n), 1.0 / n)

@@ -56,6 +56,22 @@ def test_texture_mapping_fused_matches_torch(dtype, mode, dense):
         assert float(u1.grad.abs().max()) == 0.
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float, torch.double])
+def test_texture_mapping_uv_gradient_on_the_borders(dtype):
+    """grid_sample's border clip gives a source index that lands EXACTLY on 0 or size - 1 gradient zero
+    (clip_coordinates_set_grad: in <= 0, in >= size - 1); a 2 x 2 texture puts u = 0.25 / 0.75 exactly there."""
+    from kaolin_amd.render.mesh.utils import texture_mapping, _texture_mapping_torch
+    tex = torch.tensor([[[[1., 3.], [7., 2.]], [[0.5, 4.], [6., 9.]]]], dtype=dtype).cuda()
+    uv = torch.tensor([[[0.25, 0.25], [0.75, 0.75], [0.25, 0.6], [0.4, 0.75], [0.5, 0.5], [0.3, 0.7]]], dtype=dtype).cuda()
+    u1, u2 = uv.clone().requires_grad_(), uv.clone().requires_grad_()
+    w = torch.tensor([[1.5, -2.0]], dtype=dtype).cuda()
+    (texture_mapping(u1, tex, 'bilinear') * w).sum().backward()
+    (_texture_mapping_torch(u2, tex, 'bilinear') * w).sum().backward()
+    assert float(u2.grad[0, 0].abs().max()) == 0. and float(u2.grad[0, 4].abs().max()) > 0.   # (the case is what it claims)
+    assert torch.allclose(u1.grad, u2.grad, rtol=1e-5, atol=1e-6)
+
+
 def test_cpu_inputs_take_the_torch_chain():
     from kaolin_amd.metrics.render import mask_iou
     from kaolin_amd.render.mesh.utils import texture_mapping

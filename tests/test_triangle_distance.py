@@ -160,8 +160,8 @@ def test_gpu_batched_api_and_errors():
 
 @pytest.mark.gpu
 def test_gpu_full_size_properties():
-    """C5 shape (1M queries x 50k-face sphere): (i) a random subset of queries agrees bit-for-bit with the
-    oracle; (ii) for the unit-radius-0.5 sphere the distance is close to (|p| - 0.5)^2; (iii) splitting
+    """C5 shape (1M queries x 50k-face sphere): (i) 8192 randomly chosen queries agree bit-for-bit with the
+    oracle (distance, face index, region code); (ii) for the unit-radius-0.5 sphere the distance is close to (|p| - 0.5)^2; (iii) splitting
     the queries in two halves gives the same answers (queries are independent)."""
     from kaolin_amd.utils.testing import geodesic_sphere
     v, f = geodesic_sphere(50)
@@ -169,7 +169,7 @@ def test_gpu_full_size_properties():
     torch.manual_seed(0)
     pts = (torch.rand(1000000, 3) * 1.2 - 0.6).cuda()
     dist, idx, typ = _tm().point_to_mesh_distance(pts[None], fv[None])
-    sel = torch.randperm(1000000)[:300]
+    sel = torch.randperm(1000000)[:8192]        # (8192 x 50 000 pairs: about a second of the OpenMP oracle)
     d_ref, i_ref, t_ref = oracle.triangle_distance_forward(pts[sel.cuda()].cpu(), fv.cpu(), omp=True)
     assert torch.equal(dist[0, sel.cuda()].cpu(), d_ref) and torch.equal(idx[0, sel.cuda()].cpu(), i_ref)
     assert torch.equal(typ[0, sel.cuda()].cpu(), t_ref)
