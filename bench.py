@@ -50,11 +50,12 @@ def parse():
     ap.add_argument('--chamfer-points', type=int, default=100000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-chamfer', action='store_true')
-    ap.add_argument('--cpu-extras', action='store_true',
-                    help='also time the C oracle / torch oracles of chamfer and the torch oracle of the rasterizer on the CPU '
-                         '(cpu_baseline.other_paths). Off by default: on the 128-core GPU box the dense torch oracle did not '
-                         'finish within the 100 s a profiling call had left (7 s on an 8-core container), so the default run '
-                         'keeps to the DIB-R oracle sample')
+    ap.add_argument('--no-cpu-extras', action='store_true',
+                    help='skip cpu_baseline.other_paths: the C oracle / the torch oracles of chamfer and the torch oracle of the '
+                         'rasterizer (BASELINE.md section 3), each on a bounded sample, in a child process with a hard time limit')
+    ap.add_argument('--cpu-extras-only', action='store_true', help=argparse.SUPPRESS)   # the child process of the line above
+    ap.add_argument('--no-contract-ops', action='store_true',
+                    help='skip the timing of the four reference-contract (K-buffer) operators at C4')
     ap.add_argument('--no-c5', action='store_true', help='skip the voxelgrid / point-to-mesh extras (config C5)')
     return ap.parse_args()
 
@@ -63,9 +64,11 @@ def algorithmic_bytes(kernel, B, P, F, Fv, D, K, esz=4):
     """Contract bytes per launch: every operator input the kernel consumes read once, every operator
     output it produces written once (intermediate records / lists are NOT counted: they are this design's own traffic)."""
     per = {
-        # face_idx (i64) + 3 weights + D features out; the front faces' 13 scalars + 3*D feature scalars in
-        # (in the fused operator it also writes the soft mask of every pixel the silhouette band does not reach)
-        'raster_tile_kernel': P * (8 + 3 * esz + D * esz + esz) + Fv * (13 * esz + 3 * D * esz),
+        # SURVEY 8(d) K1: P (20 + 4D) out -- face_idx (i64), 3 weights, D features -- + F' (52 + 12D) in -- the front faces'
+        # 13 scalars + 3 D feature scalars: 32 B/pixel + 88 B/front face at D = 3.  (The fused operator's launch also writes
+        # the soft mask of the pixels it settles, 4 B/pixel, and skips the 12 B/pixel of background weights: see
+        # roofline.bytes_note)
+        'raster_tile_kernel': P * (8 + 3 * esz + D * esz) + Fv * (13 * esz + 3 * D * esz),
         'raster_backward_kernel': P * (8 + 3 * esz + D * esz) + F * (6 * esz * 2 + 3 * D * esz * 2),
         'fill_regions_kernel': P * K * (esz + 8 + 1),
         # select reads face_idx of the uncovered pixels' tiles and the faces' 6 coordinates + 4 box scalars
@@ -105,7 +108,7 @@ def cpu_reference_extras(n_points=100000, slice_rows=4096, raster_res=32, sphere
         pinned to) on raster_res^2 pixels of view 0 of the bench's mesh."""
     import oracle
     oracle.build()
-    threads = min(os.cpu_count() or 1, 32)   # (the dense formulation's GB-sized temporaries scale badly beyond a few dozen threads)
+    threads = min(os.cpu_count() or 1, 16)   # (the dense formulation's temporaries scale badly beyond a few dozen threads)
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(seed)
     p1, p2 = torch.rand((1, n_points, 3), generator=g), torch.rand((1, n_points, 3), generator=g)
@@ -119,17 +122,23 @@ def cpu_reference_extras(n_points=100000, slice_rows=4096, raster_res=32, sphere
     out = {'chamfer_restated_kernel': {
         'value': round(2.0 * rows * n_points / dt_c / 1e6, 1), 'unit': 'Mpoint-pairs/s', 'cores': oracle.num_threads(True), 'kind': 'port',
         'sample': f'{rows} query rows x {n_points} targets, both directions fwd + bwd, C oracle (OpenMP over rows), {dt_c:.2f} s'}}
-    chunk = min(256, rows)
+    chunk = min(64, rows)     # (64 x 100 000 x 3 floats = 77 MB per temporary)
     t0 = time.perf_counter()
+    done, worst = 0, 0.0
     with torch.no_grad():
-        t12 = kal.metrics.pointcloud._sided_distance(p1[:, :chunk], p2)
-        t21 = kal.metrics.pointcloud._sided_distance(p2[:, :chunk], p1)
+        while done + chunk <= rows and time.perf_counter() - t0 < 3.0:       # 64-row chunks for about three seconds
+            t12 = kal.metrics.pointcloud._sided_distance(p1[:, done:done + chunk], p2)
+            t21 = kal.metrics.pointcloud._sided_distance(p2[:, done:done + chunk], p1)
+            for t, d in ((t12, d12), (t21, d21)):
+                ref = d[:, done:done + chunk]
+                worst = max(worst, float(((t - ref).abs() / ref.clamp(min=1e-30)).max()))
+            done += chunk
     dt_t = time.perf_counter() - t0
     out['chamfer_torch_oracle'] = {
-        'value': round(2.0 * chunk * n_points / dt_t / 1e6, 1), 'unit': 'Mpoint-pairs/s', 'cores': threads, 'kind': 'port',
-        'max_rel_diff_vs_restated_kernel': float(max(((t12 - d12[:, :chunk]).abs() / d12[:, :chunk].clamp(min=1e-30)).max(),
-                                                     ((t21 - d21[:, :chunk]).abs() / d21[:, :chunk].clamp(min=1e-30)).max())),
-        'sample': f'_sided_distance (dense torch formulation, forward values only) on one {chunk} x {n_points} chunk per direction, {dt_t:.2f} s'}
+        'value': round(2.0 * done * n_points / dt_t / 1e6, 1), 'unit': 'Mpoint-pairs/s', 'cores': threads, 'kind': 'port',
+        'max_rel_diff_vs_restated_kernel': worst,
+        'sample': f'_sided_distance (the dense torch formulation the reference\'s tests use as their oracle, restated; forward values '
+                  f'only) on {done // chunk} chunks of {chunk} x {n_points} per direction, {dt_t:.2f} s'}
     # rasterizer: view 0 of the bench's scene on a coarse pixel grid (the cost per pixel does not depend on the resolution)
     verts, faces = T.geodesic_sphere(sphere_frequency)
     cams = T.fibonacci_cameras(8, 2.5)[:1]
@@ -159,8 +168,75 @@ def cpu_reference_extras(n_points=100000, slice_rows=4096, raster_res=32, sphere
     return out
 
 
+def time_contract_operators(verts, faces, proj, rot, trans, feats3, G1, G2, H, W, reps):
+    """ms per call of packed_rasterize_forward_cuda / rasterize_backward_cuda / dibr_soft_mask_forward_cuda /
+    dibr_soft_mask_backward_cuda on the bench's 8 views (reference: kaolin/csrc/render/mesh/rasterization.cpp:49-168,
+    dibr_soft_mask.cpp:48-183), with the operator-contract bytes each one moves."""
+    m = kal._C.render.mesh
+    V = rot.shape[0]
+    F = faces.shape[0]
+    with torch.no_grad():
+        fv_cam, fv_img, normals = kal.render.mesh.prepare_vertices(verts.detach().unsqueeze(0).expand(V, -1, -1), faces, proj,
+                                                                   camera_rot=rot, camera_trans=trans)
+        fz, nz = fv_cam[..., 2].contiguous(), normals[..., 2]
+        # the reference's glue (rasterization.py:292-327, dibr.py:31-39), outside the timed calls
+        valid = nz >= 0
+        mesh_of, faces_of = torch.where(valid)
+        packed_img = (fv_img[mesh_of, faces_of] * 1000.).contiguous()
+        packed_z, packed_feat = fz[mesh_of, faces_of].contiguous(), feats3[mesh_of, faces_of].contiguous()
+        first_idx = torch.zeros(V + 1, dtype=torch.long, device=fz.device)
+        first_idx[1:] = torch.cumsum(valid.sum(dim=1), dim=0)
+        bboxes = torch.cat((packed_img.min(dim=1)[0], packed_img.max(dim=1)[0]), dim=1).contiguous()
+        scaled = (fv_img * 1000.).contiguous()
+        large = torch.cat([scaled.min(dim=-2)[0] - 20., scaled.max(dim=-2)[0] + 20.], dim=-1).contiguous()
+    Fp = int(first_idx[-1])
+    P = V * H * W
+
+    def ev_time(fn):
+        out = fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tot = 0.0
+        for _ in range(reps):
+            e0.record()
+            out = fn()
+            e1.record()
+            e1.synchronize()
+            tot += e0.elapsed_time(e1)
+        return tot / reps, out
+
+    t_k1, (interp, sel, wts) = ev_time(lambda: m.packed_rasterize_forward_cuda(H, W, packed_z, packed_img, bboxes, packed_feat,
+                                                                              first_idx, 1000., 1e-8))
+    lookup = (sel + first_idx[:-1].reshape(-1, 1, 1)).reshape(-1)
+    face_idx = faces_of[lookup.clamp_(min=0, max=max(Fp - 1, 0))].reshape(sel.shape).contiguous()
+    face_idx[sel == -1] = -1
+    t_k2, _ = ev_time(lambda: m.rasterize_backward_cuda(G1, interp, face_idx, wts, fv_img, feats3, 1e-8))
+    t_k3, (soft, prob, idx, typ) = ev_time(lambda: m.dibr_soft_mask_forward_cuda(scaled, large, face_idx, 7000., 30, 1000.))
+    t_k4, _ = ev_time(lambda: m.dibr_soft_mask_backward_cuda(G2, soft, face_idx, prob, idx, typ, scaled, 7000., 1000.))
+    D_, K = 3, 30
+    by = {'packed_rasterize_forward_cuda': P * (20 + 4 * D_) + Fp * (52 + 12 * D_),
+          'rasterize_backward_cuda': P * (20 + 4 * D_) + V * F * (48 + 24 * D_),
+          'dibr_soft_mask_forward_cuda': P * (12 + 13 * K) + V * F * 40,
+          'dibr_soft_mask_backward_cuda': P * (16 + 13 * K) + V * F * 48}
+    ms = {'packed_rasterize_forward_cuda': t_k1, 'rasterize_backward_cuda': t_k2, 'dibr_soft_mask_forward_cuda': t_k3,
+          'dibr_soft_mask_backward_cuda': t_k4}
+    ops = {k: {'ms': round(ms[k], 4), 'contract_bytes': by[k], 'GBps': round(by[k] / (ms[k] * 1e-3) / 1e9, 1),
+               'frac_of_8TBps': round(by[k] / (ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for k in ms}
+    tot_ms, tot_b = sum(ms.values()), sum(by.values())
+    del prob, idx, typ
+    return {'views': V, 'ops': ops, 'sum_ms': round(tot_ms, 4), 'contract_bytes': tot_b,
+            'GBps': round(tot_b / (tot_ms * 1e-3) / 1e9, 1), 'frac_of_8TBps': round(tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            'Mpixels_per_s': round(P / (tot_ms * 1e-3) / 1e6, 1),
+            'note': 'the four reference-contract operators called one after the other as the reference\'s autograd Functions call '
+                    'them (K-buffers materialised: 390 B/pixel written by K3, read by K4); operator calls only, the torch glue '
+                    'around them is outside the events'}
+
+
 def main():
     args = parse()
+    if args.cpu_extras_only:
+        print(json.dumps(cpu_reference_extras(args.chamfer_points, sphere_frequency=args.sphere_frequency)))
+        return
     D.init_from_env()
     rank, world = D.rank(), D.world_size()
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP operators have no CPU fallback)'
@@ -243,7 +319,7 @@ def main():
         torch.cuda.synchronize()
         D.barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if D.is_distributed():
             t = torch.tensor([dt], device=dev, dtype=torch.double)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = float(t.item())
@@ -276,7 +352,9 @@ def main():
     lib.kamd_profile_reset()
     lib.kamd_profile_select(kernel_ids.get(dom, -1) if dom else -1)
     lib.kamd_profile_enable(1 if dom else 0)
+    posted0 = reducer.posted
     dt = timed(dibr_step, args.steps, 2)      # (two untimed steps in this mode: its event pool is created on first use)
+    reducer_posted_per_step = (reducer.posted - posted0) / (args.steps + 2)
     dibr_enqueue_ms = timed.enqueue_ms
     lib.kamd_profile_enable(0)
     lib.kamd_profile_select(-1)
@@ -301,6 +379,41 @@ def main():
     torch_loss = {'ms_per_step': round(tq_dt / args.steps * 1e3, 4), 'per_step_ms': per_step_ms(dibr_step_torch_loss, max(args.steps, 20)),
                   'note': 'same step with the linear loss written in torch (two rocBLAS dots, an add, two full-size products '
                           'backward) instead of kaolin_amd.metrics.render.weighted_sum'}
+
+    # ---------------- the reference-contract operators at C4 (the eight `_C` entry points; here the four of the
+    # DIB-R path with their K-buffers): the only place where 8(d)'s contract bytes -- 872 B/pixel + 296 B/face -- are
+    # physically moved.  Each operator is called through kaolin_amd._C exactly as the reference's autograd Functions call
+    # it (packed faces / K-buffers); durations from events around the call, inputs prepared outside.
+    contract_ops = None
+    if rank == 0 and not args.no_contract_ops:
+        try:
+            contract_ops = time_contract_operators(verts, faces, proj, rot, trans, feats3, G1, G2, H, W, max(args.steps // 2, 5))
+        except Exception as exc:                        # (must not cost the run its headline line)
+            contract_ops = {'error': f'{type(exc).__name__}: {str(exc)[:200]}'}
+            torch.cuda.synchronize()
+
+    # ---------------- the same step replayed as a HIP graph (N = 1: no host in it)
+    graph_replay = None
+    if world == 1:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    dibr_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                dibr_step()
+            gdt = timed(graph.replay, args.steps, args.warmup)
+            graph_replay = {'ms_per_step': round(gdt / args.steps * 1e3, 4), 'per_step_ms': per_step_ms(graph.replay, max(args.steps, 20)),
+                            'note': 'the eager step above captured once with torch.cuda.graph and replayed: what the GPU needs '
+                                    'when the host enqueues nothing'}
+            del graph
+        except Exception as exc:
+            graph_replay = {'error': f'{type(exc).__name__}: {str(exc)[:200]}'}
+            torch.cuda.synchronize()
 
     covered = float((face_idx >= 0).float().mean())
     traffic, step_traffic = None, None
@@ -328,6 +441,13 @@ def main():
                     'unit': 'GB/s', 'frac': round(dom_gbps / HBM_PEAK_GBS, 4),
                     'traffic': traffic, 'avg_launch_us': round(dom_us, 2),
                     'algorithmic_bytes_per_launch': dom_bytes}
+        if traffic:
+            # the same duration against the bytes the PMC counters saw the kernel move (FETCH_SIZE + WRITE_SIZE)
+            roofline['frac_on_counter_bytes'] = round(traffic / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        if dom == 'raster_tile_kernel':
+            roofline['bytes_note'] = ('algorithmic bytes = SURVEY 8(d) K1: 32 B/pixel (face_idx i64 + 3 weights + 3 features) + 88 B '
+                                      'per front face; the fused launch also writes 4 B/pixel of soft mask and leaves the 12 B/pixel of '
+                                      'background weights unwritten (internal to the autograd node)')
     # whole-step figure against the contract bytes of SURVEY.md 8(d): 872 B/pixel + 296 B/face (D=3, K=30, fp32)
     contract = V * (H * W * 872 + F * 296)
     lean = V * (H * W * 48 + F * 136)
@@ -513,11 +633,19 @@ def main():
                'sample': f'{reps} pass(es) over 1 view of the same {F}-triangle mesh at {sres}x{sres} (the brute-force reference algorithm costs '
                          f'O(faces) per pixel at any resolution), oracle forward (OpenMP over pixels) + both backward passes '
                          f'(single thread), {cdt:.1f} s'}
-        if args.cpu_extras:                                    # BASELINE.md section 3's other CPU readings (opt-in, see parse())
+        if not args.no_cpu_extras:
+            # BASELINE.md section 3's other CPU readings (the torch formulations the reference's tests use as oracles, and the
+            # restated chamfer kernel), each on a bounded sample.  In a child process without a GPU and with a hard limit:
+            # whatever the host does with them, the run keeps its headline line.
+            import subprocess
             try:
-                cpu['other_paths'] = cpu_reference_extras(args.chamfer_points, sphere_frequency=args.sphere_frequency)
-            except Exception as exc:                           # (must not cost the run its headline line)
-                cpu['other_paths'] = {'error': str(exc)[:200]}
+                res = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-extras-only', '--chamfer-points',
+                                      str(args.chamfer_points), '--sphere-frequency', str(args.sphere_frequency)],
+                                     env=dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES=''),
+                                     capture_output=True, text=True, timeout=75)
+                cpu['other_paths'] = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1])
+            except Exception as exc:
+                cpu['other_paths'] = {'error': f'{type(exc).__name__}: {str(exc)[:160]}'}
 
     if rank == 0:
         out = {
@@ -537,6 +665,10 @@ def main():
                             f'difference); the timed region brackets the roofline kernel only',
             'instrumented_ms_per_step': round(inst_ms_per_step, 4),
             'host_enqueue_ms_per_step': round(dibr_enqueue_ms, 4),
+            'graph_replay': graph_replay, 'contract_operators': contract_ops,
+            'distributed': {'initialized': D.is_distributed(),
+                            'backend': torch.distributed.get_backend() if D.is_distributed() else None,
+                            'collectives_posted_per_step': round(reducer_posted_per_step, 3)},
             'cpu_baseline': cpu, 'chamfer': chamfer, 'c5': c5,
         }
         print(json.dumps(out))

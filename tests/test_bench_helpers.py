@@ -32,7 +32,7 @@ def test_near_ties_go_to_a_kernel_that_is_alone_on_the_stream():
 def test_algorithmic_bytes_follow_the_survey_per_unit_figures():
     """SURVEY 8(d) per-unit figures x the units one launch processes: spot values at C4."""
     B, P, F, Fv = 8, 1024 * 1024, 50000, 25000
-    assert bench.algorithmic_bytes('raster_tile_kernel', B, P, F, Fv, 3, 30) == B * (P * 36 + Fv * 88)
+    assert bench.algorithmic_bytes('raster_tile_kernel', B, P, F, Fv, 3, 30) == B * (P * 32 + Fv * 88)   # SURVEY 8(d) K1: P (20 + 4D) + F' (52 + 12D)
     assert bench.algorithmic_bytes('soft_select_kernel', B, P, F, Fv, 3, 30) == B * (P * 8 + F * 40)
     assert bench.algorithmic_bytes('soft_eval_kernel', B, P, F, Fv, 3, 30) is None
     assert bench.algorithmic_bytes('fill_regions_kernel', B, P, F, Fv, 3, 30) == B * P * 30 * 13
