@@ -241,6 +241,10 @@ __global__ __launch_bounds__(64) void soft_mask_backward_kernel(
 }
 
 // ---- launches ---------------------------------------------------------------------------------------------------------
+// what a flat hit record can address: (b * F + face) in 29 bits, row and column in 16 bits each
+inline bool flat_list_fits(int B, int H, int W, int F) {
+  return (long long)B * (F > 0 ? F : 0) < (1ll << FLAT_KEY_BITS) && H <= 65535 && W <= 65535;
+}
 // The standalone operators: bin the enlarged boxes (count, scan, emit), classify the pixels from the given
 // selected_face_idx, search.  `work` (kamd_dibr_soft_mask_work_words 32-bit words) receives the worklist; the autograd
 // path keeps it for the backward pass.
@@ -339,7 +343,7 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
   if (B <= 0 || H <= 0 || W <= 0) return 0;
   const long long total_faces = (long long)B * F;
   if (workspace == nullptr || work == nullptr) return (int)hipErrorInvalidValue;
-  if (lean != nullptr && (long long)B * H * W >= (1ll << 31)) return (int)hipErrorInvalidValue;
+  if (lean != nullptr && ((long long)B * H * W >= (1ll << 31) || !flat_list_fits(B, H, W, F))) return (int)hipErrorInvalidValue;
   const tl::Layout lay = tl::make_layout(B, H, W, total_faces, (int)sizeof(T), false, true, K);
   tl::Lists LS = tl::lists_of(workspace, lay.s, B, true);
   tl::Lists none{};
@@ -400,12 +404,10 @@ int soft_mask_backward_list_launch(hipStream_t st, int B, int H, int W, int F, i
   if ((long long)B * H * W <= 0 || F <= 0) return 0;
   {
     kamd::ProfScope prof_(kamd::K_SOFT_BACKWARD_LIST, st);
-    // static shares of the work list: two resident sets' worth of workgroups balance better than one (with the pipelined
-    // loads, profiles/r02w_sweep.txt: 8 per CU 92 us, 12: 84, 16: 74, 24: 77; step median 0.611 -> 0.596 ms)
+    // persistent workgroups over the rounds of 256 hits (their number is known on the device only)
     static const int per_cu = kamd_env_int("KAMD_SOFT_BWD_PER_CU", 16);
-    hipLaunchKernelGGL(soft_mask_backward_list_kernel2<T>, dim3(KAMD_NUM_CU * per_cu), dim3(256), 0, st, B, H, W, F, K, grad,
-                       soft_mask, list, work, tl::work_shard_cap(B, H, W), tl::pass_geom(H, W, tl::S_TILE).tiles_x, img,
-                       (T)img_scale, sigmainv, multiplier, g_img, kamd_env_int("KAMD_BWD_MODE", 0));
+    hipLaunchKernelGGL(soft_mask_backward_flat_kernel<T>, dim3(KAMD_NUM_CU * per_cu), dim3(256), 0, st, H, W, F, 1.0f / (float)F,
+                       grad, soft_mask, list, img, (T)img_scale, sigmainv, multiplier, g_img, kamd_env_int("KAMD_BWD_MODE", 0));
   }
   KAMD_RETURN_LAST_ERROR();
 }
@@ -442,7 +444,7 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
   }
   const long long total_faces = (long long)B * F;
   if (workspace == nullptr || work == nullptr) return (int)hipErrorInvalidValue;
-  if ((long long)B * H * W >= (1ll << 31)) return (int)hipErrorInvalidValue;
+  if ((long long)B * H * W >= (1ll << 31) || !flat_list_fits(B, H, W, F)) return (int)hipErrorInvalidValue;
   const tl::Layout lay = tl::make_layout(B, H, W, total_faces, (int)sizeof(T), true, true, K);
   tl::Lists LR = tl::lists_of(workspace, lay.r, B, false);
   tl::Lists LS = tl::lists_of(workspace, lay.s, B, true);
@@ -617,28 +619,28 @@ size_t kamd_dibr_rasterization_workspace(int B, int H, int W, int F, int K, int 
   int kamd_dibr_soft_mask_forward_lean_##SFX(void* stream, int B, int H, int W, int F, int K, const T* img,          \
                                              const T* large_bbox, const int64_t* sel_idx, float sigmainv,            \
                                              float multiplier, T* soft_mask, int32_t* hit_pair, T* hit_prob,         \
-                                             uint8_t* hit_type, int32_t* item_count, uint32_t* work,                 \
+                                             int32_t* hit_rec, int32_t* item_count, uint32_t* work,                 \
                                              void* workspace) {                                                       \
-    HitList2<T> l{(int2*)hit_pair, hit_prob, hit_type, item_count};                                                  \
+    HitList2<T> l{(int2*)hit_pair, hit_prob, (uint2*)hit_rec, item_count, work + FLAT_COUNT_WORD};                                                  \
     return soft_mask_forward_launch<T>((hipStream_t)stream, B, H, W, F, K, img, large_bbox, sel_idx, sigmainv,       \
                                        multiplier, soft_mask, nullptr, nullptr, nullptr, workspace, nullptr, &l,     \
                                        work);                                                                         \
   }                                                                                                                   \
   int kamd_dibr_soft_mask_backward_lean_##SFX(void* stream, int B, int H, int W, int F, int K, const T* grad,        \
                                               const T* soft_mask, const int32_t* hit_pair, const T* hit_prob,        \
-                                              const uint8_t* hit_type, const int32_t* item_count,                    \
+                                              const int32_t* hit_rec, const int32_t* item_count,                    \
                                               const uint32_t* work, const T* img, double img_scale, float sigmainv,   \
                                               float multiplier, T* g_img) {                                           \
-    HitList2<T> l{(int2*)hit_pair, (T*)hit_prob, (uint8_t*)hit_type, (int*)item_count};                              \
+    HitList2<T> l{(int2*)hit_pair, (T*)hit_prob, (uint2*)hit_rec, (int*)item_count, (unsigned int*)work + FLAT_COUNT_WORD};                              \
     return soft_mask_backward_list_launch<T>((hipStream_t)stream, B, H, W, F, K, grad, soft_mask, l, work, img,      \
                                              img_scale, sigmainv, multiplier, g_img);                                 \
   }                                                                                                                   \
   int kamd_dibr_soft_mask_forward_fused_##SFX(void* stream, int B, int H, int W, int F, int K, const T* img,         \
                                               double multiplier, double margin, const int64_t* sel_idx,              \
                                               float sigmainv, T* soft_mask, int32_t* hit_pair, T* hit_prob,          \
-                                              uint8_t* hit_type, int32_t* item_count, uint32_t* work,                \
+                                              int32_t* hit_rec, int32_t* item_count, uint32_t* work,                \
                                               void* workspace) {                                                      \
-    HitList2<T> l{(int2*)hit_pair, hit_prob, hit_type, item_count};                                                  \
+    HitList2<T> l{(int2*)hit_pair, hit_prob, (uint2*)hit_rec, item_count, work + FLAT_COUNT_WORD};                                                  \
     return soft_mask_forward_launch<T>((hipStream_t)stream, B, H, W, F, K, img, nullptr, sel_idx, sigmainv,          \
                                        (float)multiplier, soft_mask, nullptr, nullptr, nullptr, workspace, nullptr,  \
                                        &l, work, true, multiplier, margin);                                           \
@@ -647,9 +649,9 @@ size_t kamd_dibr_rasterization_workspace(int B, int H, int W, int F, int K, int 
       void* stream, int B, int H, int W, int F, int D, int K, const T* z, int64_t z_face_stride,                      \
       int64_t z_vertex_stride, const T* img, const T* feat, const uint8_t* valid, const T* front,                     \
       int64_t front_stride, double multiplier, float eps, float sigmainv, double margin, T* interp, int64_t* face_idx, \
-      T* weights, T* soft_mask, int32_t* hit_pair, T* hit_prob, uint8_t* hit_type, int32_t* item_count,               \
+      T* weights, T* soft_mask, int32_t* hit_pair, T* hit_prob, int32_t* hit_rec, int32_t* item_count,               \
       uint32_t* work, void* workspace, T* grad_img_to_zero) {                                                         \
-    HitList2<T> l{(int2*)hit_pair, hit_prob, hit_type, item_count};                                                   \
+    HitList2<T> l{(int2*)hit_pair, hit_prob, (uint2*)hit_rec, item_count, work + FLAT_COUNT_WORD};                                                   \
     return dibr_forward_fused<T>((hipStream_t)stream, B, H, W, F, D, K, z, z_face_stride, z_vertex_stride, img, feat,  \
                                  valid, front, front_stride, multiplier, eps, sigmainv, margin, interp, face_idx,     \
                                  weights, soft_mask, l, work, workspace, grad_img_to_zero);                           \
@@ -657,9 +659,9 @@ size_t kamd_dibr_rasterization_workspace(int B, int H, int W, int F, int K, int 
   int kamd_dibr_rasterization_backward_##SFX(                                                                         \
       void* stream, int B, int H, int W, int F, int D, int K, const T* grad_feat, const T* grad_soft,                 \
       const int64_t* face_idx, const T* weights, const T* soft_mask, const int32_t* hit_pair, const T* hit_prob,      \
-      const uint8_t* hit_type, const int32_t* item_count, const uint32_t* work, const T* img, const T* feat,          \
+      const int32_t* hit_rec, const int32_t* item_count, const uint32_t* work, const T* img, const T* feat,          \
       double multiplier, float eps, float sigmainv, T* g_img, T* g_feat) {                                            \
-    HitList2<T> l{(int2*)hit_pair, (T*)hit_prob, (uint8_t*)hit_type, (int*)item_count};                               \
+    HitList2<T> l{(int2*)hit_pair, (T*)hit_prob, (uint2*)hit_rec, (int*)item_count, (unsigned int*)work + FLAT_COUNT_WORD};                               \
     return dibr_backward_fused<T>((hipStream_t)stream, B, H, W, F, D, K, grad_feat, grad_soft, face_idx, weights,     \
                                   soft_mask, l, work, img, feat, multiplier, eps, sigmainv, g_img, g_feat);           \
   }
