@@ -220,39 +220,44 @@ int kamd_dibr_soft_mask_backward_f64(void* stream, int B, int H, int W, int F, i
 
 /* Compact-list variant used by this package's own autograd Function (not part  */
 /* of the reference's interface): same search, same soft_mask, but instead of   */
-/* the (B,H,W,K) K-buffers every accepted (pixel, face) hit is appended to     */
-/* three parallel arrays: hit_pair (two int32 per record: the mesh-relative     */
-/* face, and (pixel of the sub-tile 0..63) << 16 | rank of the hit among the    */
-/* pixel's hits), hit_prob, hit_type.  The list is SEGMENTED: a work item (a 16x4-pixel sub-tile    */
-/* that has hits to search), identified by item = (32x32 tile * B + b) * 16 +    */
-/* sub-tile, owns the records [item*64*K, item*64*K + item_count[item]), stored  */
-/* FACE-MAJOR (the pixels of one face are consecutive).  item_count holds        */
-/* ceil(W/32)*ceil(H/32)*16*B ints.  `work` (kamd_dibr_soft_mask_work_words      */
-/* 32-bit words) receives the worklist: 8 sharded item counters, then the items  */
-/* {item, uncovered-pixel mask}; the backward walks it.  The fused               */
-/* dibr_rasterization forward appends one byte per (mesh, 16x16-pixel tile):      */
-/* does the tile hold a covered pixel (read by its backward).  No shared append   */
-/* counter for the hits: ~20k same-address atomics per step would serialise.     */
-/* Requires B*H*W < 2^31.                                                        */
-/* Records each of the four hit arrays must hold (64*K per sub-tile slot).       */
+/* the (B,H,W,K) K-buffers the accepted (pixel, face) hits are kept as lists:   */
+/*  hit_pair  (two int32 per record: the mesh-relative face, and (pixel of the  */
+/*            sub-tile 0..63) << 16 | rank of the hit among the pixel's hits):  */
+/*            what the search leaves for the evaluation, SEGMENTED: a work item */
+/*            (a 16x4-pixel sub-tile that has hits to search), item = (32x32    */
+/*            tile * B + b) * 16 + sub-tile, owns the records [item*64*K,        */
+/*            item*64*K + item_count[item]), FACE-MAJOR (the pixels of one face  */
+/*            are consecutive);                                                   */
+/*  hit_rec / hit_prob  the evaluated hits as ONE flat list of work[8] records    */
+/*            (every item appended as one contiguous range): hit_rec = two int32  */
+/*            {(b*F + face) | which-of-six << 29, row << 16 | col}, hit_prob the   */
+/*            probability -- all the backward pass reads (it streams the list in   */
+/*            rounds of 256 records, no items).  Requires B*F < 2^29, H, W < 2^16. */
+/* item_count holds ceil(W/32)*ceil(H/32)*16*B ints.  `work`                      */
+/* (kamd_dibr_soft_mask_work_words 32-bit words) receives the worklist: 8 sharded */
+/* item counters, the flat list's record count (word 8), then the items {item,    */
+/* uncovered-pixel mask}.  The fused dibr_rasterization forward appends one byte  */
+/* per (mesh, 16x16-pixel tile): does the tile hold a covered pixel (read by its  */
+/* backward).  Requires B*H*W < 2^31.                                             */
+/* Records each of the three hit arrays must hold (64*K per sub-tile slot).       */
 size_t kamd_dibr_soft_mask_lean_capacity(int B, int H, int W, int K);
 size_t kamd_dibr_soft_mask_work_words(int B, int H, int W);
 int kamd_dibr_soft_mask_forward_lean_f32(void* stream, int B, int H, int W, int F, int K,
                                          const float* img, const float* large_bbox,
                                          const int64_t* sel_idx, float sigmainv, float multiplier,
                                          float* soft_mask, int32_t* hit_pair,
-                                         float* hit_prob, uint8_t* hit_type, int32_t* item_count,
+                                         float* hit_prob, int32_t* hit_rec, int32_t* item_count,
                                          uint32_t* work, void* workspace);
 int kamd_dibr_soft_mask_forward_lean_f64(void* stream, int B, int H, int W, int F, int K,
                                          const double* img, const double* large_bbox,
                                          const int64_t* sel_idx, float sigmainv, float multiplier,
                                          double* soft_mask, int32_t* hit_pair,
-                                         double* hit_prob, uint8_t* hit_type, int32_t* item_count,
+                                         double* hit_prob, int32_t* hit_rec, int32_t* item_count,
                                          uint32_t* work, void* workspace);
 int kamd_dibr_soft_mask_backward_lean_f32(void* stream, int B, int H, int W, int F, int K,
                                           const float* grad, const float* soft_mask,
                                           const int32_t* hit_pair,
-                                          const float* hit_prob, const uint8_t* hit_type,
+                                          const float* hit_prob, const int32_t* hit_rec,
                                           const int32_t* item_count, const uint32_t* work,
                                           const float* img,
                                           double img_scale, float sigmainv, float multiplier,
@@ -260,7 +265,7 @@ int kamd_dibr_soft_mask_backward_lean_f32(void* stream, int B, int H, int W, int
 int kamd_dibr_soft_mask_backward_lean_f64(void* stream, int B, int H, int W, int F, int K,
                                           const double* grad, const double* soft_mask,
                                           const int32_t* hit_pair,
-                                          const double* hit_prob, const uint8_t* hit_type,
+                                          const double* hit_prob, const int32_t* hit_rec,
                                           const int32_t* item_count, const uint32_t* work,
                                           const double* img,
                                           double img_scale, float sigmainv, float multiplier,
@@ -302,13 +307,13 @@ int kamd_dibr_soft_mask_forward_fused_f32(void* stream, int B, int H, int W, int
                                           const float* img, double multiplier, double margin,
                                           const int64_t* sel_idx, float sigmainv,
                                           float* soft_mask, int32_t* hit_pair,
-                                          float* hit_prob, uint8_t* hit_type, int32_t* item_count,
+                                          float* hit_prob, int32_t* hit_rec, int32_t* item_count,
                                           uint32_t* work, void* workspace);
 int kamd_dibr_soft_mask_forward_fused_f64(void* stream, int B, int H, int W, int F, int K,
                                           const double* img, double multiplier, double margin,
                                           const int64_t* sel_idx, float sigmainv,
                                           double* soft_mask, int32_t* hit_pair,
-                                          double* hit_prob, uint8_t* hit_type, int32_t* item_count,
+                                          double* hit_prob, int32_t* hit_rec, int32_t* item_count,
                                           uint32_t* work, void* workspace);
 
 /* ------------------------------------------------------------------------- */
@@ -386,7 +391,7 @@ int kamd_dibr_rasterization_forward_f32(void* stream, int B, int H, int W, int F
                                         float eps, float sigmainv, double margin, float* interp,
                                         int64_t* face_idx, float* weights, float* soft_mask,
                                         int32_t* hit_pair, float* hit_prob,
-                                        uint8_t* hit_type, int32_t* item_count, uint32_t* work,
+                                        int32_t* hit_rec, int32_t* item_count, uint32_t* work,
                                         void* workspace, float* grad_img_to_zero);
 int kamd_dibr_rasterization_forward_f64(void* stream, int B, int H, int W, int F, int D, int K,
                                         const double* z, int64_t z_face_stride, int64_t z_vertex_stride,
@@ -395,14 +400,14 @@ int kamd_dibr_rasterization_forward_f64(void* stream, int B, int H, int W, int F
                                         float eps, float sigmainv, double margin, double* interp,
                                         int64_t* face_idx, double* weights, double* soft_mask,
                                         int32_t* hit_pair, double* hit_prob,
-                                        uint8_t* hit_type, int32_t* item_count, uint32_t* work,
+                                        int32_t* hit_rec, int32_t* item_count, uint32_t* work,
                                         void* workspace, double* grad_img_to_zero);
 int kamd_dibr_rasterization_backward_f32(void* stream, int B, int H, int W, int F, int D, int K,
                                          const float* grad_feat, const float* grad_soft,
                                          const int64_t* face_idx, const float* weights,
                                          const float* soft_mask, const int32_t* hit_pair,
                                          const float* hit_prob,
-                                         const uint8_t* hit_type, const int32_t* item_count,
+                                         const int32_t* hit_rec, const int32_t* item_count,
                                          const uint32_t* work, const float* img, const float* feat,
                                          double multiplier, float eps, float sigmainv,
                                          float* g_img, float* g_feat);
@@ -411,7 +416,7 @@ int kamd_dibr_rasterization_backward_f64(void* stream, int B, int H, int W, int 
                                          const int64_t* face_idx, const double* weights,
                                          const double* soft_mask, const int32_t* hit_pair,
                                          const double* hit_prob,
-                                         const uint8_t* hit_type, const int32_t* item_count,
+                                         const int32_t* hit_rec, const int32_t* item_count,
                                          const uint32_t* work, const double* img, const double* feat,
                                          double multiplier, float eps, float sigmainv,
                                          double* g_img, double* g_feat);

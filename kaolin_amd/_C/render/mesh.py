@@ -194,7 +194,7 @@ def dibr_soft_mask_backward_lean(grad_soft_mask, soft_mask, hits, face_vertices_
     """Backward of :func:`dibr_soft_mask_forward_lean` / ``_fused`` -> grad_face_vertices_image (B,F,3,2), w.r.t. the
     unscaled input.  ``face_vertices_image * img_scale`` must be the scaled vertices the forward searched with."""
     fn = 'dibr_soft_mask_backward_lean'
-    hit_pair, hit_prob, hit_type, item_count, work = hits
+    hit_pair, hit_prob, hit_rec, item_count, work = hits
     knum = int(knum)
     args = [Arg(grad_soft_mask, 'grad_soft_mask', 1), Arg(soft_mask, 'soft_mask', 2),
             Arg(face_vertices_image, 'face_vertices_image', 4)]
@@ -211,7 +211,7 @@ def dibr_soft_mask_backward_lean(grad_soft_mask, soft_mask, hits, face_vertices_
         st = getattr(lib, f'kamd_dibr_soft_mask_backward_lean_{sfx}')(
             _lib.stream_ptr(device), batch_size, height, width, num_faces, knum,
             _lib.ptr(grad_soft_mask), _lib.ptr(soft_mask), _lib.ptr(hit_pair), _lib.ptr(hit_prob),
-            _lib.ptr(hit_type), _lib.ptr(item_count), _lib.ptr(work), _lib.ptr(face_vertices_image), float(img_scale), float(sigmainv),
+            _lib.ptr(hit_rec), _lib.ptr(item_count), _lib.ptr(work), _lib.ptr(face_vertices_image), float(img_scale), float(sigmainv),
             float(multiplier), _lib.ptr(g_img))
     _lib.check(st, fn)
     return g_img
@@ -237,20 +237,22 @@ def _work_buffer(batch_size, height, width, device):
 
 
 def _hit_list(batch_size, height, width, knum, dtype, device, num_faces=0):
-    """Storage of the segmented hit list: 64*K record slots per 16x4-pixel sub-tile slot (just the used parts are ever
-    touched) -- pair records {face, pixel << 16 | rank} as (cap, 2) int32, probabilities, types --, one count per
-    sub-tile slot, and the worklist of the sub-tiles that were searched."""
+    """Storage of the hit lists: 64*K record slots per 16x4-pixel sub-tile slot (just the used parts are ever touched) for
+    the segmented pair records the search leaves {face, pixel << 16 | rank} as (cap, 2) int32, and for the flat list of the
+    evaluated hits -- probabilities and (cap, 2) int32 records {(b*F + face) | which << 29, row << 16 | col} --, one count
+    per sub-tile slot, and the worklist of the sub-tiles that were searched (word 8 of its header: the flat list's length)."""
     cap = max(_size('kamd_dibr_soft_mask_lean_capacity', batch_size, height, width, int(knum)), 1)
     n_sub = ((width + 31) // 32) * ((height + 31) // 32) * 16 * batch_size
     return (torch.empty((cap, 2), dtype=torch.int32, device=device),
-            torch.empty(cap, dtype=dtype, device=device), torch.empty(cap, dtype=torch.uint8, device=device),
+            torch.empty(cap, dtype=dtype, device=device), torch.empty((cap, 2), dtype=torch.int32, device=device),
             torch.empty(max(n_sub, 1), dtype=torch.int32, device=device),
             _work_buffer(batch_size, height, width, device))
 
 
 def work_items(work, batch_size, height, width):
     """Item ids (int64, 1-D) recorded in a worklist buffer (tests / debugging; synchronises).  Layout (tile_lists.h): 16
-    header words (8 shard counters), 8 shards x shard_cap items of 4 words, then one coverage byte per 16 x 16 tile."""
+    header words (8 shard counters, the flat hit list's length), 8 shards x shard_cap items of 4 words, then one coverage
+    byte per 16 x 16 tile."""
     counts = work[:8].tolist()
     n_groups = batch_size * ((width + 15) // 16) * ((height + 15) // 16)
     shard_cap = 4 * ((n_groups + 7) // 8)
@@ -258,27 +260,18 @@ def work_items(work, batch_size, height, width):
     return torch.cat([items[s, :min(c, shard_cap), 0] for s, c in enumerate(counts)]).long()
 
 
-def hit_list_entries(hits, knum, batch_size, height, width):
-    """Flattens a segmented hit list -> (pix, face, prob, type) 1-D tensors of the recorded hits, pix = flat (b, row, col)
-    index (tests / debugging)."""
-    hit_pair, hit_prob, hit_type, item_count, work = hits
-    items = work_items(work, batch_size, height, width)
-    n = items.numel()
-    counts = item_count[items].long()
-    starts = items * (64 * int(knum))
-    total = int(counts.sum())
-    seg = torch.repeat_interleave(torch.arange(n, device=counts.device), counts)
-    within = torch.arange(total, device=counts.device) - torch.repeat_interleave(torch.cumsum(counts, 0) - counts, counts)
-    pos = starts[seg] + within
-    # item = (tile * B + b) * 16 + sub; tile = 32x32 pixels, sub-tile = 16x4 pixels, 2 sub-tiles across
-    it = items[seg]
-    sub, b, tile = it % 16, (it // 16) % batch_size, it // (16 * batch_size)
-    tiles_x = (width + 31) // 32
-    u = (hit_pair[pos, 1] >> 16).long()
-    col = (tile % tiles_x) * 32 + (sub % 2) * 16 + (u % 16)
-    row = (tile // tiles_x) * 32 + (sub // 2) * 4 + (u // 16)
+def hit_list_entries(hits, num_faces, batch_size, height, width):
+    """The flat hit list -> (pix, face, prob, type) 1-D tensors of the recorded hits, pix = flat (b, row, col) index, face
+    mesh-relative, type = which-of-six + 1 as in the K-buffers (tests / debugging; synchronises)."""
+    hit_pair, hit_prob, hit_rec, item_count, work = hits
+    n = int(work[8])
+    rec = hit_rec[:n].long()
+    key = rec[:, 0] & ((1 << 29) - 1)
+    which = (rec[:, 0] >> 29) & 7
+    b, face = key // int(num_faces), key % int(num_faces)
+    row, col = (rec[:, 1] >> 16) & 0xFFFF, rec[:, 1] & 0xFFFF
     pix = (b * height + row) * width + col
-    return pix, hit_pair[pos, 0], hit_prob[pos], hit_type[pos]
+    return pix, face, hit_prob[:n], which + 1
 
 
 def dibr_soft_mask_forward_fused(face_vertices_image, selected_face_idx, sigmainv, boxlen, knum, multiplier):

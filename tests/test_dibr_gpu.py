@@ -370,7 +370,8 @@ def test_kbuffer_operators_match_lean_autograd_path(dtype):
     soft, prob, idx, typ = m.dibr_soft_mask_forward_cuda(scaled, bbox, face_idx, 7000., 30, 1000.)
     soft2, hits = m.dibr_soft_mask_forward_lean(scaled, bbox, face_idx, 7000., 30, 1000.)
     assert torch.equal(soft, soft2)
-    l_pix, l_face, l_prob, l_type = m.hit_list_entries(hits, 30, 2, H, W)
+    l_pix, l_face, l_prob, l_type = m.hit_list_entries(hits, fimg.shape[1], 2, H, W)
+    assert int(hits[3][m.work_items(hits[4], 2, H, W)].sum()) == l_pix.numel()     # the items' segmented pair counts add up to it
     assert l_pix.numel() == int((idx >= 0).sum())
     # same multiset of (pixel, face, type, prob)
     pix = torch.nonzero(idx >= 0)
