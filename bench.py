@@ -57,6 +57,11 @@ def parse():
     ap.add_argument('--no-contract-ops', action='store_true',
                     help='skip the timing of the four reference-contract (K-buffer) operators at C4')
     ap.add_argument('--no-c5', action='store_true', help='skip the voxelgrid / point-to-mesh extras (config C5)')
+    ap.add_argument('--quick', action='store_true',
+                    help='development probe: the headline step and its kernel table only (no variants, graph replay, contract '
+                         'operators, chamfer, C5, CPU baseline)')
+    ap.add_argument('--look-at', type=float, nargs=3, default=[0., 0., 0.],
+                    help='point the cameras look at (default: the mesh centre; e.g. 0.35 -0.3 0 renders the object off-centre)')
     return ap.parse_args()
 
 
@@ -234,6 +239,8 @@ def time_contract_operators(verts, faces, proj, rot, trans, feats3, G1, G2, H, W
 
 def main():
     args = parse()
+    if args.quick:
+        args.no_cpu_baseline = args.no_chamfer = args.no_c5 = args.no_contract_ops = True
     if args.cpu_extras_only:
         print(json.dumps(cpu_reference_extras(args.chamfer_points, sphere_frequency=args.sphere_frequency)))
         return
@@ -251,7 +258,7 @@ def main():
     faces = faces.to(dev)
     F = faces.shape[0]
     cams = D.shard_views(T.fibonacci_cameras(V * world, 2.5)).to(dev)     # this rank's views of the shared mesh
-    look_at = torch.zeros((V, 3), device=dev)
+    look_at = torch.tensor([args.look_at], device=dev, dtype=torch.float).repeat(V, 1)
     up = torch.tensor([[0., 1., 0.]], device=dev).repeat(V, 1)
     rot, trans = kal.render.camera.generate_rotate_translate_matrices(cams, look_at, up)
     proj = kal.render.camera.generate_perspective_projection(math.pi / 4).to(dev)
@@ -363,22 +370,24 @@ def main():
     mpix = world * V * H * W * args.steps / dt / 1e6
 
     step_stats = per_step_ms(dibr_step, max(args.steps, 20))
-    # variant with gradients w.r.t. the face features as well (raster_backward adds its feature-gradient atomics)
-    fg_dt = timed(dibr_step_feature_grad, args.steps, args.warmup)
-    fg_stats = per_step_ms(dibr_step_feature_grad, max(args.steps, 20))
-    feature_grad = {'ms_per_step': round(fg_dt / args.steps * 1e3, 4), 'per_step_ms': fg_stats,
-                    'value': round(world * V * H * W * args.steps / fg_dt / 1e6, 2), 'unit': 'Mpixels/s',
-                    'note': 'same step with face_features.requires_grad (gradients to vertices AND features)'}
+    feature_grad = tutorial = torch_loss = None
+    if not args.quick:
+        # variant with gradients w.r.t. the face features as well (raster_backward adds its feature-gradient atomics)
+        fg_dt = timed(dibr_step_feature_grad, args.steps, args.warmup)
+        fg_stats = per_step_ms(dibr_step_feature_grad, max(args.steps, 20))
+        feature_grad = {'ms_per_step': round(fg_dt / args.steps * 1e3, 4), 'per_step_ms': fg_stats,
+                        'value': round(world * V * H * W * args.steps / fg_dt / 1e6, 2), 'unit': 'Mpixels/s',
+                        'note': 'same step with face_features.requires_grad (gradients to vertices AND features)'}
 
-    tl_dt = timed(dibr_step_tutorial, args.steps, args.warmup)
-    tutorial = {'ms_per_step': round(tl_dt / args.steps * 1e3, 4), 'per_step_ms': per_step_ms(dibr_step_tutorial, max(args.steps, 20)),
-                'note': 'same step with the tutorial\'s objective: torch L1 image loss + kaolin.metrics.render.mask_iou (one fused '
-                        'pass each way) instead of the two dot products'}
+        tl_dt = timed(dibr_step_tutorial, args.steps, args.warmup)
+        tutorial = {'ms_per_step': round(tl_dt / args.steps * 1e3, 4), 'per_step_ms': per_step_ms(dibr_step_tutorial, max(args.steps, 20)),
+                    'note': 'same step with the tutorial\'s objective: torch L1 image loss + kaolin.metrics.render.mask_iou (one fused '
+                            'pass each way) instead of the two dot products'}
 
-    tq_dt = timed(dibr_step_torch_loss, args.steps, args.warmup)
-    torch_loss = {'ms_per_step': round(tq_dt / args.steps * 1e3, 4), 'per_step_ms': per_step_ms(dibr_step_torch_loss, max(args.steps, 20)),
-                  'note': 'same step with the linear loss written in torch (two rocBLAS dots, an add, two full-size products '
-                          'backward) instead of kaolin_amd.metrics.render.weighted_sum'}
+        tq_dt = timed(dibr_step_torch_loss, args.steps, args.warmup)
+        torch_loss = {'ms_per_step': round(tq_dt / args.steps * 1e3, 4), 'per_step_ms': per_step_ms(dibr_step_torch_loss, max(args.steps, 20)),
+                      'note': 'same step with the linear loss written in torch (two rocBLAS dots, an add, two full-size products '
+                              'backward) instead of kaolin_amd.metrics.render.weighted_sum'}
 
     # ---------------- the reference-contract operators at C4 (the eight `_C` entry points; here the four of the
     # DIB-R path with their K-buffers): the only place where 8(d)'s contract bytes -- 872 B/pixel + 296 B/face -- are
@@ -394,7 +403,7 @@ def main():
 
     # ---------------- the same step replayed as a HIP graph (N = 1: no host in it)
     graph_replay = None
-    if world == 1:
+    if world == 1 and not args.quick:
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -657,7 +666,8 @@ def main():
                                    f'knum=30, sigmainv=7000, boxlen=0.02, loss = sum(features*G1) + sum(soft_mask*G2) (fused weighted_sum), '
                                    f'prepare_vertices + vertex-gradient all-reduce (posted from the autograd hook) inside the step',
                        'views_per_gpu': V, 'global_views': V * world, 'height': H, 'width': W, 'faces': F,
-                       'covered_pixel_fraction': round(covered, 4), 'parallelism': f'views sharded {world}-way'},
+                       'covered_pixel_fraction': round(covered, 4), 'parallelism': f'views sharded {world}-way',
+                       'look_at': list(args.look_at)},
             'per_step_ms': step_stats, 'feature_grad_variant': feature_grad, 'tutorial_loss_variant': tutorial, 'torch_loss_variant': torch_loss,
             'roofline': roofline, 'step_roofline': step_roofline, 'step_traffic': step_traffic, 'kernels': kernels,
             'kernels_note': f'per-kernel table: separate pass of {args.steps} steps with HIP events around every launch '

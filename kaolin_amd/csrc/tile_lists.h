@@ -130,7 +130,14 @@ struct Lists {
   unsigned int* big_list;     // [total_faces]     mesh b's segment starts at its first packed face
   unsigned int* sub_touched;  // [B * ntiles]      zeroed; soft pass only: bit s = some enlarged box reaches sub-tile s
   int tiles_x, ntiles;
+  // raster pass only (nullptr: none): the order in which the tile kernels visit a view's tile rows, heaviest first
+  unsigned int* row_work;     // [B * tiles_y]     zeroed; faces listed in the row's tiles, summed while the lists are built
+  unsigned int* ticket;       // zeroed; workgroups of the binning launch that have finished
+  unsigned short* row_order;  // [B * tiles_y]     written by the last workgroup: row_order[b * tiles_y + k] = k-th heaviest row of view b
 };
+constexpr int ROW_ORDER_MAX_ROWS = 256;      // tile rows per view (images up to 4096 pixels high) ...
+constexpr int ROW_ORDER_LDS = 2048;          // ... sorted in LDS, ROW_ORDER_LDS / tiles_y views at a time
+inline bool row_order_supported(int H) { return (H + R_TILE - 1) / R_TILE <= ROW_ORDER_MAX_ROWS; }
 
 inline size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline unsigned int pool_chunks(long long total_faces, long long n_tiles_total) {
@@ -143,7 +150,8 @@ inline unsigned int pool_chunks(long long total_faces, long long n_tiles_total) 
 // Host-side layout of one pass inside a workspace.  All zeroed arrays of both passes are placed in ONE contiguous region
 // at the start of the workspace so that a single fill kernel clears them.
 struct PassLayout {
-  size_t count, tab, pool_top, big_count, sub_touched;  // inside the zero region
+  size_t count, tab, pool_top, big_count, sub_touched, row_work, ticket;  // inside the zero region
+  size_t row_order;                      // raster pass: (B * tiles_y) u16 (the fused operator keeps it in its `work` buffer instead)
   size_t inl, pool, big_list, rec;                      // after it
   size_t pixcnt, prob_pm;                // soft pass: hits per (item, pixel) (u16); pixel-major probabilities (knum > 128 only)
   unsigned int cap_chunks;
@@ -168,6 +176,8 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
     L.r.tab = off; off += a256(ntr * L.r.maxc * 4);
     L.r.pool_top = off; off += 256;
     L.r.big_count = off; off += a256((size_t)B * 4);
+    L.r.row_work = off; off += a256((size_t)B * L.r.g.tiles_y * 4);
+    L.r.ticket = off; off += 256;
   }
   if (with_s) {
     L.s.count = off; off += a256(nts * 4);
@@ -183,6 +193,7 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
     L.r.pool = off; off += a256((size_t)L.r.cap_chunks * OVC * 16);
     L.r.big_list = off; off += a256((size_t)total_faces * 4);
     L.r.rec = off; off += a256((size_t)total_faces * REC_R * esz);
+    L.r.row_order = off; off += a256((size_t)B * L.r.g.tiles_y * 2);
   }
   if (with_s) {
     L.s.cap_chunks = pool_chunks(total_faces, (long long)nts);
@@ -208,8 +219,12 @@ inline unsigned int work_shard_cap(int B, int H, int W) {
 // ... then one byte per (mesh, 16 x 16 tile) [b * ntiles + tile]: does the tile hold a covered pixel?  (Written by the
 // rasterizer's tile kernel in the fused path; the rasterizer's backward kernel leaves a tile without one at once.)
 inline size_t work_cov_offset_words(int B, int H, int W) { return WORK_HEADER + (size_t)WORK_SHARDS * work_shard_cap(B, H, W) * 4; }
-inline size_t work_words(int B, int H, int W) {
+// ... then the forward's tile-row order (B * tiles_y u16, Lists::row_order), which the rasterizer's backward kernel follows too
+inline size_t work_order_offset_words(int B, int H, int W) {
   return work_cov_offset_words(B, H, W) + ((size_t)B * pass_geom(H, W, R_TILE).ntiles + 3) / 4;
+}
+inline size_t work_words(int B, int H, int W) {
+  return work_order_offset_words(B, H, W) + ((size_t)B * pass_geom(H, W, R_TILE).tiles_y + 1) / 2;
 }
 
 inline Lists lists_of(void* ws, const PassLayout& p, int B, bool soft) {
@@ -228,7 +243,17 @@ inline Lists lists_of(void* ws, const PassLayout& p, int B, bool soft) {
   l.sub_touched = soft ? (unsigned int*)(c + p.sub_touched) : nullptr;
   l.tiles_x = p.g.tiles_x;
   l.ntiles = p.g.ntiles;
+  l.row_work = nullptr;   // (set by the launches that want the data-driven row order: with_row_order)
+  l.ticket = nullptr;
+  l.row_order = nullptr;
   return l;
+}
+// raster pass: sum the rows' work while binning and leave the row order at `order` (B * tiles_y u16)
+inline void with_row_order(Lists& l, void* ws, const PassLayout& p, unsigned short* order) {
+  char* c = (char*)ws;
+  l.row_work = (unsigned int*)(c + p.row_work);
+  l.ticket = (unsigned int*)(c + p.ticket);
+  l.row_order = order;
 }
 
 // ---- conservative pixel range of a half-open box -----------------------------------------------------------------------
@@ -424,10 +449,16 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
       const unsigned long long rows = h >= 8 ? ~0ull : ((1ull << (8 * h)) - 1ull);
       pending = (rowm * 0x0101010101010101ull) & rows;
     }
-    int my_t = -1, k = 0;
+    int my_t = -1, k = 0, my_row = 0;
     unsigned long long my_bal = 0ull;
     unsigned int my_sub = 0u;
+    // (raster pass: the faces an entry lists count as work of its tile row -- what the tile kernels' row order is made from)
+    auto note_row = [&]() {
+      if (!SOFT && L.row_work != nullptr && my_t >= 0)
+        atomicAdd(L.row_work + (size_t)bL * (L.ntiles / L.tiles_x) + my_row, (unsigned int)__popcll(my_bal));
+    };
     auto flush = [&]() {
+      note_row();
       const size_t ti = (size_t)bL * L.ntiles + (my_t >= 0 ? my_t : 0);
       // (soft pass: the entry also carries the sub-tiles its faces reach, so that a work item can skip whole entries)
       append_entry(my_t >= 0, L, ti, make_uint4(block, SOFT ? my_sub : 0u, (unsigned int)my_bal, (unsigned int)(my_bal >> 32)));
@@ -461,12 +492,14 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
       }
       if (lane == k) {
         my_t = ty * L.tiles_x + tx;
+        my_row = ty;
         my_bal = bal;
         my_sub = sub;
       }
       if (++k == 64) flush();
     }
     if (deferred != nullptr && remaining == 0ull) {
+      note_row();
       deferred->on = my_t >= 0;
       deferred->ti = (size_t)bL * L.ntiles + (my_t >= 0 ? my_t : 0);
       deferred->entry = make_uint4(block, SOFT ? my_sub : 0u, (unsigned int)my_bal, (unsigned int)(my_bal >> 32));
@@ -503,6 +536,46 @@ struct BinIn {
   T* rec_r;
   T* rec_s;
 };
+
+// ---- the tile kernels' row order ------------------------------------------------------------------------------------------
+// The workgroup of a tile with faces lives ~100x longer than a background tile's, so the tile kernels visit a view's tile
+// rows heaviest first: the long workgroups start first and the background rows stream out beside their tail (round 2 did
+// this with a fixed map, rows from the middle of the image outwards -- right for a centred object only).  The rows' work
+// is summed while the lists are built (wave_bin: one fire-and-forget atomic per entry); the LAST workgroup of the binning
+// launch to finish (a ticket) ranks each view's rows -- descending work, ties by row -- and writes the order.  Called by
+// every thread of every workgroup at the end of the kernel.
+__device__ __forceinline__ void sort_tile_rows(const Lists& L, int B) {
+  if (L.row_work == nullptr) return;  // (uniform)
+  __shared__ unsigned int s_last;
+  __shared__ unsigned int s_rw[ROW_ORDER_LDS];
+  __syncthreads();  // this workgroup's wavefronts have issued their atomics and waited for them
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_last = atomicAdd(L.ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+  }
+  __syncthreads();
+  if (s_last == 0u) return;
+  const int tiles_y = L.ntiles / L.tiles_x;
+  const int per_pass = ROW_ORDER_LDS / tiles_y;  // views ranked per pass (tiles_y <= ROW_ORDER_MAX_ROWS <= ROW_ORDER_LDS)
+  for (int b0 = 0; b0 < B; b0 += per_pass) {
+    const int nb = min(per_pass, B - b0), n = nb * tiles_y;
+    __syncthreads();
+    // (the sums were made by atomics of other workgroups, possibly on other XCDs: agent-scope loads, not cached ones)
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+      s_rw[i] = __hip_atomic_load(L.row_work + (size_t)b0 * tiles_y + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const int v = i / tiles_y, r = i - v * tiles_y;
+      const unsigned int mine = s_rw[i];
+      int rank = 0;
+      for (int q = 0; q < tiles_y; ++q) {
+        const unsigned int o = s_rw[v * tiles_y + q];
+        rank += (o > mine || (o == mine && q < r)) ? 1 : 0;
+      }
+      L.row_order[(size_t)(b0 + v) * tiles_y + rank] = (unsigned short)r;
+    }
+  }
+}
 
 #ifdef KAMD_PHASE_PROF
 static __device__ unsigned long long g_phase_bin[16];  // [0..7] phases, [10] longest wavefront, [11] > 1000 ticks (10 us at 100 MHz), [12] > 2500
@@ -543,6 +616,19 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(
     T v[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) v[i] = in.img[f * 6 + i] * in.mult;
+    // everything the record needs is requested up front, whether or not the face turns out to be kept: the kernel is bound
+    // by its dependent round trips, and `valid` / `front` -> (kept?) -> z would be two more of them
+    uint8_t valid_f = 1;
+    T front_f = 0, z0 = 0, z1 = 0, z2 = 0;
+    if (DO_R) {
+      if (in.valid != nullptr) valid_f = in.valid[f];
+      if (in.front != nullptr) front_f = in.front[f * in.lay.front_stride];
+      if (in.z != nullptr) {
+        z0 = in.z[f * in.lay.z_face + 0 * in.lay.z_vertex];
+        z1 = in.z[f * in.lay.z_face + 1 * in.lay.z_vertex];
+        z2 = in.z[f * in.lay.z_face + 2 * in.lay.z_vertex];
+      }
+    }
 #ifdef KAMD_PHASE_PROF
     asm volatile("s_waitcnt vmcnt(0)");
 #endif
@@ -550,9 +636,8 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(
     T xmin = nan_min<T>(nan_min<T>(v[0], v[2]), v[4]), xmax = nan_max<T>(nan_max<T>(v[0], v[2]), v[4]);
     T ymin = nan_min<T>(nan_min<T>(v[1], v[3]), v[5]), ymax = nan_max<T>(nan_max<T>(v[1], v[3]), v[5]);
     if (DO_R) {
-      bool keep = true;
-      if (in.valid != nullptr && in.valid[f] == 0) keep = false;
-      if (keep && in.front != nullptr && !(in.front[f * in.lay.front_stride] >= (T)0)) keep = false;
+      bool keep = valid_f != 0;
+      if (keep && in.front != nullptr && !(front_f >= (T)0)) keep = false;
       T bx0 = xmin, by0 = ymin, bx1 = xmax, by1 = ymax;
       if (in.bbox_r != nullptr) {
         bx0 = in.bbox_r[f * 4 + 0];
@@ -567,12 +652,6 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(
         // its record is never looked at nor written)
         r[0] = keep ? Rec4<T>{bx0, by0, bx1, by1} : Rec4<T>{(T)INFINITY, (T)INFINITY, -(T)INFINITY, -(T)INFINITY};
         if (keep) {
-          T z0 = 0, z1 = 0, z2 = 0;
-          if (in.z != nullptr) {
-            z0 = in.z[f * in.lay.z_face + 0 * in.lay.z_vertex];
-            z1 = in.z[f * in.lay.z_face + 1 * in.lay.z_vertex];
-            z2 = in.z[f * in.lay.z_face + 2 * in.lay.z_vertex];
-          }
           r[1] = Rec4<T>{v[0], v[1], v[2], v[3]};
           r[2] = Rec4<T>{v[4], v[5], z0, z1};
           T e7[7] = {0, 0, 1, 0, 0, 1, 3};
@@ -645,6 +724,7 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(
     if (DO_S) wave_bin<true>(act_s, big_s, b, first_b, f, sx0, sx1, sy0, sy1, pr_s.c_lo, pr_s.c_hi, pr_s.r_lo, pr_s.r_hi, LS);
   }
   PHASE_MARK(7);
+  if (DO_R) sort_tile_rows(LR, in.B);
   PHASE_FLUSH(g_phase_bin);
 #ifdef KAMD_PHASE_PROF
   if ((threadIdx.x & 63) == 0) {

@@ -234,20 +234,24 @@ DEFINE_SIDED_BWD(oracle_sided_distance_backward_f64, double)
 #define T float
 #define FN(n) n##_f32
 #define SQRTFN sqrtf
+#define FMAFN fmaf
 #define REF_TILE 1024
 #include "tridist_oracle.inc"
 #undef T
 #undef FN
 #undef SQRTFN
+#undef FMAFN
 #undef REF_TILE
 #define T double
 #define FN(n) n##_f64
 #define SQRTFN sqrt
+#define FMAFN fma
 #define REF_TILE 512
 #include "tridist_oracle.inc"
 #undef T
 #undef FN
 #undef SQRTFN
+#undef FMAFN
 #undef REF_TILE
 
 /* ---- mesh intersection (check_sign), instantiated for float and double ----------------- */
