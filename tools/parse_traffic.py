@@ -8,7 +8,7 @@ STEPS = 3
 # profile-table name (bench.py's "kernels" keys) -> pattern of the device symbol
 OURS = {'bin_faces_kernel': r'bin_faces_kernel2', 'raster_tile_kernel': r'raster_tile_kernel2', 'raster_backward_kernel': r'raster_backward_kernel',
         'soft_items_kernel': r'soft_items_kernel', 'soft_select_kernel': r'soft_select_kernel', 'soft_eval_kernel': r'soft_eval_kernel',
-        'soft_mask_backward_list_kernel': r'soft_mask_backward_list_kernel2', 'pv_forward_kernel': r'pv_forward_kernel',
+        'soft_mask_backward_list_kernel': r'soft_mask_backward_(list_kernel2|flat_kernel)', 'pv_forward_kernel': r'pv_forward_kernel',
         'pv_backward_kernel': r'pv_backward_kernel', 'fill_regions_kernel': r'fill_regions_kernel',
         'weighted_sum2_kernels': r'weighted_sum2_(partial|backward)_kernel'}   # (the forward's one-workgroup finish: 'other')
 
@@ -19,8 +19,35 @@ def rows(path, counter):
     return sorted(out)
 
 
+SECTIONS = ['chamfer_step', 'chamfer_operator', 'voxelgrid_256', 'point_to_mesh_1Mx50k']   # tools/pmc_traffic.py, in order
+
+
+def sections(path, counter):
+    """{section: {kernel: [values]}} of the launches behind each marker (a mask_iou call = forward + finish kernels)."""
+    rs = rows(path, counter)
+    out, cur, prev_marker = {}, None, False
+    idx = -1
+    for d, k, v in rs:
+        is_marker = 'mask_iou' in k
+        if is_marker:
+            if not prev_marker:
+                idx += 1
+                cur = SECTIONS[idx] if idx < len(SECTIONS) else None
+                if cur:
+                    out[cur] = collections.defaultdict(list)
+            prev_marker = True
+            continue
+        prev_marker = False
+        if cur:
+            out[cur][k].append(v)
+    return out
+
+
 def analyse(path, counter):
     rs = rows(path, counter)
+    first_marker = min((d for d, k, v in rs if 'mask_iou' in k), default=None)
+    if first_marker is not None:
+        rs = [r for r in rs if r[0] < first_marker]
     last_fill = max((d for d, k, v in rs if 'fill_regions_kernel' in k), default=-1)
     # the steps begin with prepare_vertices: everything from the first pv_forward_kernel after the calibration on
     marker = min((d for d, k, v in rs if 'pv_forward_kernel' in k and d > last_fill), default=last_fill + 1) - 1
@@ -61,5 +88,21 @@ ours = sum(v['hbm_bytes'] * v['launches_per_step'] for k, v in out.items() if no
 out['_step'] = {'our_kernels_hbm_bytes': ours, 'other_kernels_hbm_bytes': other_f + other_w,
                 'hbm_bytes': ours + other_f + other_w,
                 'other_kernels': sorted({re.sub(r'\(.*', '', k)[:80] for k in list(step_f) + list(step_w) if k not in claimed})}
+# ---- chamfer / C5 sections: per-kernel bytes per launch and per call
+sec_f, sec_w = sections(sys.argv[1], 'FETCH_SIZE'), sections(sys.argv[2], 'WRITE_SIZE')
+calls = {'chamfer_step': STEPS, 'chamfer_operator': STEPS, 'voxelgrid_256': STEPS, 'point_to_mesh_1Mx50k': 1}
+for sec in SECTIONS:
+    if sec not in sec_f and sec not in sec_w:
+        continue
+    kernels = {}
+    for k in sorted(set(sec_f.get(sec, {})) | set(sec_w.get(sec, {}))):
+        fv, wv = sec_f.get(sec, {}).get(k, []), sec_w.get(sec, {}).get(k, [])
+        name = re.sub(r'\(.*', '', k)[:70]
+        e = kernels.setdefault(name, {'fetch_bytes_per_call': 0.0, 'write_bytes_per_call': 0.0, 'launches_per_call': 0.0})
+        e['fetch_bytes_per_call'] += sum(fv) * (f_scale or 0) / calls[sec]
+        e['write_bytes_per_call'] += sum(wv) * (w_scale or 0) / calls[sec]
+        e['launches_per_call'] += max(len(fv), len(wv)) / calls[sec]
+    out['_' + sec] = {'hbm_bytes_per_call': sum(e['fetch_bytes_per_call'] + e['write_bytes_per_call'] for e in kernels.values()),
+                      'kernels': kernels}
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
 print(json.dumps(out, indent=1))

@@ -1,8 +1,11 @@
 """Workload for the HBM-traffic PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per pass):
 calibration launches of known size first (a 1 GiB torch clone = 16 B/lane streaming read+write; the K-buffer fill
 kernel = pure 16-B stores), then exactly STEPS steps of bench.py's DIB-R step (config C4, static features).
+Then, each section introduced by a marker launch (a tiny mask_iou call: kernel names nothing else here uses): STEPS chamfer
+steps at 100k x 100k (bench.py's: shared offset, .sum(), backward), STEPS calls of the chamfer operator alone, and config C5
+(STEPS voxelizer calls at 256^3, one point_to_mesh_distance of 1M queries on the 50k-face mesh).
 tools/parse_traffic.py turns the two CSVs into profiles/traffic.json; everything dispatched after the last
-fill_regions_kernel belongs to the steps."""
+fill_regions_kernel and before the first marker belongs to the DIB-R steps."""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -46,4 +49,55 @@ for _ in range(2):                     # reference-contract K-buffer operator: f
 torch.cuda.synchronize()
 for _ in range(STEPS):
     step()
+torch.cuda.synchronize()
+
+
+# ---- sections after the DIB-R steps, each behind a marker launch ------------------------------------------------------------
+_m = torch.rand(1, 8, 8, device=dev)
+
+
+def marker():
+    torch.cuda.synchronize()
+    kal.metrics.render.mask_iou(_m, _m)
+    torch.cuda.synchronize()
+
+
+n = 100000
+gen = torch.Generator().manual_seed(0)
+base = torch.rand((1, n, 3), generator=gen).to(dev)
+p2 = torch.rand((1, n, 3), generator=gen).to(dev).requires_grad_()
+offset = torch.zeros(3, device=dev, requires_grad=True)
+p1_leaf = base.clone().requires_grad_()
+upstream = torch.ones(1, device=dev)
+
+
+def chamfer_step():
+    offset.grad = None
+    p2.grad = None
+    kal.metrics.pointcloud.chamfer_distance(base + offset, p2).sum().backward()
+
+
+def chamfer_operator():
+    p1_leaf.grad = None
+    p2.grad = None
+    kal.metrics.pointcloud.chamfer_distance(p1_leaf, p2).backward(upstream)
+
+
+chamfer_step(); chamfer_operator()      # warm-up (before the marker)
+marker()
+for _ in range(STEPS):
+    chamfer_step()
+marker()
+for _ in range(STEPS):
+    chamfer_operator()
+v1 = verts.detach().unsqueeze(0)
+fv = v1[0][faces].unsqueeze(0).contiguous()
+q = (torch.rand((1, 1000000, 3), generator=torch.Generator().manual_seed(0)) * 1.2 - 0.6).to(dev)
+kal.ops.conversions.trianglemeshes_to_voxelgrids(v1, faces, 256)     # warm-up
+kal.metrics.trianglemesh.point_to_mesh_distance(q, fv)
+marker()
+for _ in range(STEPS):
+    kal.ops.conversions.trianglemeshes_to_voxelgrids(v1, faces, 256)
+marker()
+kal.metrics.trianglemesh.point_to_mesh_distance(q, fv)
 torch.cuda.synchronize()
