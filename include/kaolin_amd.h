@@ -228,15 +228,17 @@ int kamd_dibr_soft_mask_backward_f64(void* stream, int B, int H, int W, int F, i
 /*            tile * B + b) * 16 + sub-tile, owns the records [item*64*K,        */
 /*            item*64*K + item_count[item]), FACE-MAJOR (the pixels of one face  */
 /*            are consecutive);                                                   */
-/*  hit_rec / hit_prob  the evaluated hits as ONE flat list of work[8] records    */
-/*            (every item appended as one contiguous range): hit_rec = two int32  */
-/*            {(b*F + face) | which-of-six << 29, row << 16 | col}, hit_prob the   */
-/*            probability -- all the backward pass reads (it streams the list in   */
-/*            rounds of 256 records, no items).  Requires B*F < 2^29, H, W < 2^16. */
+/*  hit_rec / hit_prob  the evaluated hits as a flat list in 64 shards of equal    */
+/*            capacity (capacity / 64 records each; shard s holds work[16 + s]      */
+/*            records; an item appends one contiguous range to shard item % 64):    */
+/*            hit_rec = two int32 {(b*F + face) | which-of-six << 29, row << 16 |   */
+/*            col}, hit_prob the probability -- all the backward pass reads (it     */
+/*            streams the shards in rounds of 256 records, no items).               */
+/*            Requires B*F < 2^29, H, W < 2^16.                                     */
 /* item_count holds ceil(W/32)*ceil(H/32)*16*B ints.  `work`                      */
 /* (kamd_dibr_soft_mask_work_words 32-bit words) receives the worklist: 8 sharded */
-/* item counters, the flat list's record count (word 8), then the items {item,    */
-/* uncovered-pixel mask}.  The fused dibr_rasterization forward appends one byte  */
+/* item counters and the flat list's 64 shard counts in a 128-word header, then    */
+/* the items {item, uncovered-pixel mask}.  The fused dibr_rasterization forward appends one byte  */
 /* per (mesh, 16x16-pixel tile): does the tile hold a covered pixel (read by its  */
 /* backward).  Requires B*H*W < 2^31.                                             */
 /* Records each of the three hit arrays must hold (64*K per sub-tile slot).       */

@@ -232,7 +232,7 @@ def _size(query, *shape):
 
 def _work_buffer(batch_size, height, width, device):
     """The search's worklist: 8 sharded item counters (16-word header), then the items {item id, uncovered-pixel mask}."""
-    n = max(_size('kamd_dibr_soft_mask_work_words', batch_size, height, width), 16)
+    n = max(_size('kamd_dibr_soft_mask_work_words', batch_size, height, width), WORK_HEADER)
     return torch.empty(n, dtype=torch.int32, device=device)
 
 
@@ -240,7 +240,7 @@ def _hit_list(batch_size, height, width, knum, dtype, device, num_faces=0):
     """Storage of the hit lists: 64*K record slots per 16x4-pixel sub-tile slot (just the used parts are ever touched) for
     the segmented pair records the search leaves {face, pixel << 16 | rank} as (cap, 2) int32, and for the flat list of the
     evaluated hits -- probabilities and (cap, 2) int32 records {(b*F + face) | which << 29, row << 16 | col} --, one count
-    per sub-tile slot, and the worklist of the sub-tiles that were searched (word 8 of its header: the flat list's length)."""
+    per sub-tile slot, and the worklist of the sub-tiles that were searched (its header also holds the flat list's lengths)."""
     cap = max(_size('kamd_dibr_soft_mask_lean_capacity', batch_size, height, width, int(knum)), 1)
     n_sub = ((width + 31) // 32) * ((height + 31) // 32) * 16 * batch_size
     return (torch.empty((cap, 2), dtype=torch.int32, device=device),
@@ -249,29 +249,35 @@ def _hit_list(batch_size, height, width, knum, dtype, device, num_faces=0):
             _work_buffer(batch_size, height, width, device))
 
 
+WORK_HEADER = 128      # tile_lists.h WORK_HEADER: words 0..7 the worklist shards' item counts, 16..79 the flat hit list's shard counts
+FLAT_SHARDS = 64       # soft2.inc
+
+
 def work_items(work, batch_size, height, width):
-    """Item ids (int64, 1-D) recorded in a worklist buffer (tests / debugging; synchronises).  Layout (tile_lists.h): 16
-    header words (8 shard counters, the flat hit list's length), 8 shards x shard_cap items of 4 words, then one coverage
-    byte per 16 x 16 tile."""
+    """Item ids (int64, 1-D) recorded in a worklist buffer (tests / debugging; synchronises).  Layout (tile_lists.h): the
+    header, 8 shards x shard_cap items of 4 words, one coverage byte per 16 x 16 tile, the tile kernels' row order."""
     counts = work[:8].tolist()
     n_groups = batch_size * ((width + 15) // 16) * ((height + 15) // 16)
     shard_cap = 4 * ((n_groups + 7) // 8)
-    items = work[16:16 + 8 * shard_cap * 4].view(8, shard_cap, 4)
+    items = work[WORK_HEADER:WORK_HEADER + 8 * shard_cap * 4].view(8, shard_cap, 4)
     return torch.cat([items[s, :min(c, shard_cap), 0] for s, c in enumerate(counts)]).long()
 
 
 def hit_list_entries(hits, num_faces, batch_size, height, width):
     """The flat hit list -> (pix, face, prob, type) 1-D tensors of the recorded hits, pix = flat (b, row, col) index, face
-    mesh-relative, type = which-of-six + 1 as in the K-buffers (tests / debugging; synchronises)."""
+    mesh-relative, type = which-of-six + 1 as in the K-buffers (tests / debugging; synchronises).  The list is FLAT_SHARDS
+    lists of equal capacity; shard s holds work[16 + s] records."""
     hit_pair, hit_prob, hit_rec, item_count, work = hits
-    n = int(work[8])
-    rec = hit_rec[:n].long()
+    counts = work[16:16 + FLAT_SHARDS].tolist()
+    shard_cap = hit_rec.shape[0] // FLAT_SHARDS
+    sel = torch.cat([torch.arange(s * shard_cap, s * shard_cap + c, device=hit_rec.device) for s, c in enumerate(counts)])
+    rec = hit_rec[sel].long()
     key = rec[:, 0] & ((1 << 29) - 1)
     which = (rec[:, 0] >> 29) & 7
     b, face = key // int(num_faces), key % int(num_faces)
     row, col = (rec[:, 1] >> 16) & 0xFFFF, rec[:, 1] & 0xFFFF
     pix = (b * height + row) * width + col
-    return pix, face, hit_prob[:n], which + 1
+    return pix, face, hit_prob[sel], which + 1
 
 
 def dibr_soft_mask_forward_fused(face_vertices_image, selected_face_idx, sigmainv, boxlen, knum, multiplier):

@@ -241,6 +241,10 @@ __global__ __launch_bounds__(64) void soft_mask_backward_kernel(
 }
 
 // ---- launches ---------------------------------------------------------------------------------------------------------
+inline size_t flat_shard_cap_of(int B, int H, int W, int K) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  return flat_shard_cap((size_t)B * tl::pass_geom(H, W, tl::S_TILE).ntiles * tl::S_SUBS, K);
+}
 // what a flat hit record can address: (b * F + face) in 29 bits, row and column in 16 bits each
 inline bool flat_list_fits(int B, int H, int W, int F) {
   return (long long)B * (F > 0 ? F : 0) < (1ll << FLAT_KEY_BITS) && H <= 65535 && W <= 65535;
@@ -449,7 +453,7 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
   tl::Lists LR = tl::lists_of(workspace, lay.r, B, false);
   tl::Lists LS = tl::lists_of(workspace, lay.s, B, true);
   // the tile kernels' row order (heaviest rows first) is left in the `work` buffer: the backward pass follows it too
-  const bool row_order = total_faces > 0 && tl::row_order_supported(H) && kamd_env_int("KAMD_ROW_ORDER", 1) == 1;
+  const bool row_order = total_faces > 0 && tl::row_order_supported(H) && kamd_env_int("KAMD_ROW_ORDER", 1) == 1 /* 2: off */;
   if (row_order) tl::with_row_order(LR, workspace, lay.r, reinterpret_cast<unsigned short*>(work + tl::work_order_offset_words(B, H, W)));
   T* rec_r = (T*)((char*)workspace + lay.r.rec);
   T* rec_s = (T*)((char*)workspace + lay.s.rec);
@@ -540,7 +544,7 @@ int dibr_backward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K
   const unsigned char* tile_cov = kamd_env_int("KAMD_BWD_TILE_COV", 1) == 1  // (2: off, for A/B runs)
                                       ? reinterpret_cast<const unsigned char*>(work + tl::work_cov_offset_words(B, H, W))
                                       : nullptr;
-  const unsigned short* row_order = (F > 0 && tl::row_order_supported(H) && kamd_env_int("KAMD_ROW_ORDER", 1) == 1)
+  const unsigned short* row_order = (F > 0 && tl::row_order_supported(H) && kamd_env_int("KAMD_ROW_ORDER", 1) == 1 /* 2: off */)
                                         ? reinterpret_cast<const unsigned short*>(work + tl::work_order_offset_words(B, H, W))
                                         : nullptr;
   if (!use_side || kamd::prof_all()) {
@@ -593,8 +597,8 @@ extern "C" {
 size_t kamd_dibr_soft_mask_lean_capacity(int B, int H, int W, int K) {
   // records the segmented hit list must be able to hold: every 16x4-pixel sub-tile slot of every 32x32 tile owns 64*K
   if (B <= 0 || H <= 0 || W <= 0 || K <= 0) return 0;
-  const kamd::tl::PassGeom g = kamd::tl::pass_geom(H, W, kamd::tl::S_TILE);
-  return (size_t)B * g.ntiles * kamd::tl::S_SUBS * 64 * (size_t)K;
+  // (the flat list's FLAT_SHARDS equal shards together: at least 64*K per sub-tile slot, which is also what the segmented pairs need)
+  return (size_t)FLAT_SHARDS * flat_shard_cap_of(B, H, W, K);
 }
 size_t kamd_dibr_soft_mask_work_words(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
@@ -629,7 +633,7 @@ size_t kamd_dibr_rasterization_workspace(int B, int H, int W, int F, int K, int 
                                              float multiplier, T* soft_mask, int32_t* hit_pair, T* hit_prob,         \
                                              int32_t* hit_rec, int32_t* item_count, uint32_t* work,                 \
                                              void* workspace) {                                                       \
-    HitList2<T> l{(int2*)hit_pair, hit_prob, (uint2*)hit_rec, item_count, work + FLAT_COUNT_WORD};                                                  \
+    HitList2<T> l{(int2*)hit_pair, hit_prob, (uint2*)hit_rec, item_count, work + FLAT_COUNT_WORD, flat_shard_cap_of(B, H, W, K)};                                                  \
     return soft_mask_forward_launch<T>((hipStream_t)stream, B, H, W, F, K, img, large_bbox, sel_idx, sigmainv,       \
                                        multiplier, soft_mask, nullptr, nullptr, nullptr, workspace, nullptr, &l,     \
                                        work);                                                                         \
@@ -639,7 +643,7 @@ size_t kamd_dibr_rasterization_workspace(int B, int H, int W, int F, int K, int 
                                               const int32_t* hit_rec, const int32_t* item_count,                    \
                                               const uint32_t* work, const T* img, double img_scale, float sigmainv,   \
                                               float multiplier, T* g_img) {                                           \
-    HitList2<T> l{(int2*)hit_pair, (T*)hit_prob, (uint2*)hit_rec, (int*)item_count, (unsigned int*)work + FLAT_COUNT_WORD};                              \
+    HitList2<T> l{(int2*)hit_pair, (T*)hit_prob, (uint2*)hit_rec, (int*)item_count, (unsigned int*)work + FLAT_COUNT_WORD, flat_shard_cap_of(B, H, W, K)};                              \
     return soft_mask_backward_list_launch<T>((hipStream_t)stream, B, H, W, F, K, grad, soft_mask, l, work, img,      \
                                              img_scale, sigmainv, multiplier, g_img);                                 \
   }                                                                                                                   \
@@ -648,7 +652,7 @@ size_t kamd_dibr_rasterization_workspace(int B, int H, int W, int F, int K, int 
                                               float sigmainv, T* soft_mask, int32_t* hit_pair, T* hit_prob,          \
                                               int32_t* hit_rec, int32_t* item_count, uint32_t* work,                \
                                               void* workspace) {                                                      \
-    HitList2<T> l{(int2*)hit_pair, hit_prob, (uint2*)hit_rec, item_count, work + FLAT_COUNT_WORD};                                                  \
+    HitList2<T> l{(int2*)hit_pair, hit_prob, (uint2*)hit_rec, item_count, work + FLAT_COUNT_WORD, flat_shard_cap_of(B, H, W, K)};                                                  \
     return soft_mask_forward_launch<T>((hipStream_t)stream, B, H, W, F, K, img, nullptr, sel_idx, sigmainv,          \
                                        (float)multiplier, soft_mask, nullptr, nullptr, nullptr, workspace, nullptr,  \
                                        &l, work, true, multiplier, margin);                                           \
@@ -659,7 +663,7 @@ size_t kamd_dibr_rasterization_workspace(int B, int H, int W, int F, int K, int 
       int64_t front_stride, double multiplier, float eps, float sigmainv, double margin, T* interp, int64_t* face_idx, \
       T* weights, T* soft_mask, int32_t* hit_pair, T* hit_prob, int32_t* hit_rec, int32_t* item_count,               \
       uint32_t* work, void* workspace, T* grad_img_to_zero) {                                                         \
-    HitList2<T> l{(int2*)hit_pair, hit_prob, (uint2*)hit_rec, item_count, work + FLAT_COUNT_WORD};                                                   \
+    HitList2<T> l{(int2*)hit_pair, hit_prob, (uint2*)hit_rec, item_count, work + FLAT_COUNT_WORD, flat_shard_cap_of(B, H, W, K)};                                                   \
     return dibr_forward_fused<T>((hipStream_t)stream, B, H, W, F, D, K, z, z_face_stride, z_vertex_stride, img, feat,  \
                                  valid, front, front_stride, multiplier, eps, sigmainv, margin, interp, face_idx,     \
                                  weights, soft_mask, l, work, workspace, grad_img_to_zero);                           \
@@ -669,7 +673,7 @@ size_t kamd_dibr_rasterization_workspace(int B, int H, int W, int F, int K, int 
       const int64_t* face_idx, const T* weights, const T* soft_mask, const int32_t* hit_pair, const T* hit_prob,      \
       const int32_t* hit_rec, const int32_t* item_count, const uint32_t* work, const T* img, const T* feat,          \
       double multiplier, float eps, float sigmainv, T* g_img, T* g_feat) {                                            \
-    HitList2<T> l{(int2*)hit_pair, (T*)hit_prob, (uint2*)hit_rec, (int*)item_count, (unsigned int*)work + FLAT_COUNT_WORD};                               \
+    HitList2<T> l{(int2*)hit_pair, (T*)hit_prob, (uint2*)hit_rec, (int*)item_count, (unsigned int*)work + FLAT_COUNT_WORD, flat_shard_cap_of(B, H, W, K)};                               \
     return dibr_backward_fused<T>((hipStream_t)stream, B, H, W, F, D, K, grad_feat, grad_soft, face_idx, weights,     \
                                   soft_mask, l, work, img, feat, multiplier, eps, sigmainv, g_img, g_feat);           \
   }

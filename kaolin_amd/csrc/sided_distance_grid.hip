@@ -341,7 +341,15 @@ __device__ __forceinline__ float sdg_dist(float tx, float ty, float tz, float qx
 #ifndef KAMD_SDG_GROUP
 #define KAMD_SDG_GROUP 4  // build knob; 100k x 100k (profiles/r02y_sdg.txt): 2 lanes 60 us, 4: 56, 8: 61, 16: 85 for both directions
 #endif
-constexpr int SDG_GROUP = KAMD_SDG_GROUP;  // lanes cooperating on one query (rows of the cell cube are dealt round-robin)
+constexpr int SDG_GROUP = KAMD_SDG_GROUP;
+#ifndef KAMD_SDG_R0
+#define KAMD_SDG_R0 1     // first ring of the search: 1 = start with the 3 x 3 x 3 cube of cells (0: with the query's own cell, as in round 2)
+#endif
+#ifndef KAMD_SDG_BATCH
+#define KAMD_SDG_BATCH 3  // rows of a ring a lane takes at a time (their cell ranges are loaded together; 1: the round-2 loop)
+#endif
+constexpr int SDG_R0 = KAMD_SDG_R0;
+constexpr int SDG_BATCH = KAMD_SDG_BATCH;  // lanes cooperating on one query (rows of the cell cube are dealt round-robin)
 
 // the search for one query, shared by the one-direction and the two-direction kernels.  All SDG_GROUP lanes of a query
 // call it with the same (qx, qy, qz, c); on return every lane holds the query's (best, best_i).
@@ -362,15 +370,83 @@ __device__ __forceinline__ void sdg_search(const Box& s_box, int G, float qx, fl
 #pragma unroll
     for (int a = 0; a < 3; ++a) slack[a] = 4e-6f * (fabsf(q[a]) + fabsf(s_box.lo[a]) + s_box.size[a] * (float)G);
     const int cq[3] = {cx, cy, cz};
-    for (int r = 0; r < G; ++r) {
+    // The first ring visited is the 3 x 3 x 3 cube (SDG_R0 = 1): with ~2 targets per cell the single cell of ring 0 almost
+    // never settles a query (the nearest target is ~0.44 cells away, the cell's walls ~0.17), and every ring is a chain of
+    // dependent round trips (cell ranges -> targets -> merge).  Visiting more cells than needed changes nothing: the
+    // search is exact and ties are broken explicitly.
+    const int r_first = G >= 3 ? SDG_R0 : 0;
+    for (int r = r_first; r < G; ++r) {
       const int z0 = max(cz - r, 0), z1 = min(cz + r, G - 1);
       const int y0 = max(cy - r, 0), y1 = min(cy + r, G - 1);
       const int x0 = max(cx - r, 0), x1 = min(cx + r, G - 1);
       const int ny = y1 - y0 + 1, nrows = (z1 - z0 + 1) * ny;
+#if KAMD_SDG_BATCH > 1
+      // a lane's rows are taken SDG_BATCH at a time: the cell ranges of the whole batch are requested before any of its
+      // targets, the targets two at a time -- fewer dependent round trips per ring (was: range -> target -> target ... per row)
+      for (int j0 = sub; j0 < nrows; j0 += SDG_BATCH * SDG_GROUP) {
+        int k0[SDG_BATCH][2], k1[SDG_BATCH][2], nseg[SDG_BATCH];
+#pragma unroll
+        for (int u = 0; u < SDG_BATCH; ++u) {
+          const int j = j0 + u * SDG_GROUP;
+          nseg[u] = 0;
+          k0[u][0] = k0[u][1] = k1[u][0] = k1[u][1] = 0;
+          if (j < nrows) {
+            const int z = z0 + j / ny, y = y0 + j % ny;
+            const int row = (z * G + y) * G;
+            const bool shell_row = r == r_first || (abs(z - cz) == r) || (abs(y - cy) == r);
+            if (shell_row) {
+              k0[u][0] = start[row + x0];
+              k1[u][0] = start[row + x1 + 1];
+              nseg[u] = 1;
+            } else {
+              // (segment 0: the cell at cx - r, segment 1: the cell at cx + r; an absent one stays empty)
+              if (cx - r >= 0) {
+                k0[u][0] = start[row + cx - r];
+                k1[u][0] = start[row + cx - r + 1];
+              }
+              if (cx + r <= G - 1) {
+                k0[u][1] = start[row + cx + r];
+                k1[u][1] = start[row + cx + r + 1];
+              }
+              nseg[u] = 2;
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < SDG_BATCH; ++u)
+#pragma unroll
+          for (int sgm = 0; sgm < 2; ++sgm) {  // (compile-time indices: the arrays stay in registers)
+            const int kb = k0[u][sgm], ke = sgm < nseg[u] ? k1[u][sgm] : kb;
+            for (int k = kb; k < ke; k += 2) {
+              const bool two = k + 1 < ke;
+              const float4 ta = TS[k];
+              const float4 tb = TS[two ? k + 1 : k];
+              {
+                const float d = sdg_dist(ta.x, ta.y, ta.z, qx, qy, qz);
+                const int ti = __float_as_int(ta.w);
+                if (d < best || (d == best && ti < best_i)) {
+                  best = d;
+                  best_i = ti;
+                  if (TRACK) best_k = k;
+                }
+              }
+              if (two) {
+                const float d = sdg_dist(tb.x, tb.y, tb.z, qx, qy, qz);
+                const int ti = __float_as_int(tb.w);
+                if (d < best || (d == best && ti < best_i)) {
+                  best = d;
+                  best_i = ti;
+                  if (TRACK) best_k = k + 1;
+                }
+              }
+            }
+          }
+      }
+#else
       for (int j = sub; j < nrows; j += SDG_GROUP) {
         const int z = z0 + j / ny, y = y0 + j % ny;
         const int row = (z * G + y) * G;
-        const bool shell_row = (abs(z - cz) == r) || (abs(y - cy) == r);
+        const bool shell_row = r == r_first || (abs(z - cz) == r) || (abs(y - cy) == r);
         // cells are numbered x-fastest and targets are sorted by cell: the cells x0..x1 of a row own ONE contiguous
         // slice of the sorted targets.  On a shell row every x is new; elsewhere only the two end cells are.
         int k0[2], k1[2], nseg;
@@ -403,6 +479,7 @@ __device__ __forceinline__ void sdg_search(const Box& s_box, int G, float qx, fl
             }
           }
       }
+#endif
 #pragma unroll
       for (int m = 1; m < SDG_GROUP; m <<= 1) {  // lexicographic (dist, idx) minimum over the group
         const float od = __shfl_xor(best, m, 64);

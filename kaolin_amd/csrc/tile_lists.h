@@ -131,12 +131,16 @@ struct Lists {
   unsigned int* sub_touched;  // [B * ntiles]      zeroed; soft pass only: bit s = some enlarged box reaches sub-tile s
   int tiles_x, ntiles;
   // raster pass only (nullptr: none): the order in which the tile kernels visit a view's tile rows, heaviest first
-  unsigned int* row_work;     // [B * tiles_y]     zeroed; faces listed in the row's tiles, summed while the lists are built
-  unsigned int* ticket;       // zeroed; workgroups of the binning launch that have finished
+  unsigned int* row_work;     // [B * tiles_y]     zeroed; faces listed in the row's tiles (summed per workgroup in LDS, then added here)
+  unsigned int* ticket;       // zeroed; TICKET_GROUPS + 1 counters: workgroups of the binning launch that have finished
   unsigned short* row_order;  // [B * tiles_y]     written by the last workgroup: row_order[b * tiles_y + k] = k-th heaviest row of view b
 };
+// (same-address device atomics complete one at a time, ~50 ns each on this part: 1 563 workgroups taking ONE ticket counter
+// made the binning launch 90 us longer.  Workgroups therefore count in TICKET_GROUPS sub-counters, and only the last of each
+// group takes the top counter.)
+constexpr int TICKET_GROUPS = 64;
 constexpr int ROW_ORDER_MAX_ROWS = 256;      // tile rows per view (images up to 4096 pixels high) ...
-constexpr int ROW_ORDER_LDS = 2048;          // ... sorted in LDS, ROW_ORDER_LDS / tiles_y views at a time
+constexpr int ROW_ORDER_LDS = 1024;          // ... sorted in LDS, ROW_ORDER_LDS / tiles_y views at a time
 inline bool row_order_supported(int H) { return (H + R_TILE - 1) / R_TILE <= ROW_ORDER_MAX_ROWS; }
 
 inline size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -177,7 +181,7 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
     L.r.pool_top = off; off += 256;
     L.r.big_count = off; off += a256((size_t)B * 4);
     L.r.row_work = off; off += a256((size_t)B * L.r.g.tiles_y * 4);
-    L.r.ticket = off; off += 256;
+    L.r.ticket = off; off += a256((size_t)(TICKET_GROUPS + 1) * 4);
   }
   if (with_s) {
     L.s.count = off; off += a256(nts * 4);
@@ -210,7 +214,7 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
 }
 // the worklist lives in its own buffer (the autograd path keeps it for the backward pass): WORK_HEADER words of counters,
 // then WORK_SHARDS x shard_cap items of 16 bytes.  One 256-thread workgroup per 16 x 16 pixels appends at most 4 items.
-constexpr int WORK_HEADER = 16;
+constexpr int WORK_HEADER = 128;   // words 0..7: the shards' item counts; words 16..79: the flat hit list's per-shard record counts (soft2.inc)
 inline unsigned int work_shard_cap(int B, int H, int W) {
   const PassGeom g = pass_geom(H, W, R_TILE);
   const size_t n_groups = (size_t)B * g.ntiles;
@@ -248,11 +252,10 @@ inline Lists lists_of(void* ws, const PassLayout& p, int B, bool soft) {
   l.row_order = nullptr;
   return l;
 }
-// raster pass: sum the rows' work while binning and leave the row order at `order` (B * tiles_y u16)
+// raster pass: the binning launch's last workgroup leaves the tile kernels' row order at `order` (B * tiles_y u16)
 inline void with_row_order(Lists& l, void* ws, const PassLayout& p, unsigned short* order) {
-  char* c = (char*)ws;
-  l.row_work = (unsigned int*)(c + p.row_work);
-  l.ticket = (unsigned int*)(c + p.ticket);
+  l.row_work = (unsigned int*)((char*)ws + p.row_work);
+  l.ticket = (unsigned int*)((char*)ws + p.ticket);
   l.row_order = order;
 }
 
@@ -421,7 +424,9 @@ __device__ __forceinline__ void append_entry_pair(const PendingEntry& pa, const 
 template <bool SOFT>
 __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long first_b, long long f, int tx0, int tx1,
                                          int ty0, int ty1, int c_lo, int c_hi, int r_lo, int r_hi, const Lists& L,
-                                         PendingEntry* deferred = nullptr) {
+                                         PendingEntry* deferred = nullptr, unsigned int* s_rowacc = nullptr, int rowacc_b0 = 0) {
+  // `s_rowacc` (raster pass, optional): the workgroup's LDS table [2][tiles_y] of the faces its entries list per tile row, for
+  // the views rowacc_b0 and rowacc_b0 + 1 (a workgroup of 256 consecutive faces rarely spans more); other views: global atomics
   // `deferred`: the wavefront's LAST batch of entries is handed back instead of appended (the caller appends it together
   // with the other pass' last batch: append_entry_pair)
   if (deferred != nullptr) deferred->on = false;
@@ -449,16 +454,10 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
       const unsigned long long rows = h >= 8 ? ~0ull : ((1ull << (8 * h)) - 1ull);
       pending = (rowm * 0x0101010101010101ull) & rows;
     }
-    int my_t = -1, k = 0, my_row = 0;
+    int my_t = -1, k = 0;
     unsigned long long my_bal = 0ull;
     unsigned int my_sub = 0u;
-    // (raster pass: the faces an entry lists count as work of its tile row -- what the tile kernels' row order is made from)
-    auto note_row = [&]() {
-      if (!SOFT && L.row_work != nullptr && my_t >= 0)
-        atomicAdd(L.row_work + (size_t)bL * (L.ntiles / L.tiles_x) + my_row, (unsigned int)__popcll(my_bal));
-    };
     auto flush = [&]() {
-      note_row();
       const size_t ti = (size_t)bL * L.ntiles + (my_t >= 0 ? my_t : 0);
       // (soft pass: the entry also carries the sub-tiles its faces reach, so that a work item can skip whole entries)
       append_entry(my_t >= 0, L, ti, make_uint4(block, SOFT ? my_sub : 0u, (unsigned int)my_bal, (unsigned int)(my_bal >> 32)));
@@ -492,14 +491,19 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
       }
       if (lane == k) {
         my_t = ty * L.tiles_x + tx;
-        my_row = ty;
         my_bal = bal;
         my_sub = sub;
+      }
+      if (!SOFT && s_rowacc != nullptr && lane == 0) {  // (one LDS atomic per entry; same-address global atomics cost ~50 ns each)
+        const int tiles_y = L.ntiles / L.tiles_x, rel = bL - rowacc_b0;
+        if (rel < 2)
+          atomicAdd(&s_rowacc[rel * tiles_y + ty], (unsigned int)__popcll(bal));
+        else
+          atomicAdd(L.row_work + (size_t)bL * tiles_y + ty, (unsigned int)__popcll(bal));
       }
       if (++k == 64) flush();
     }
     if (deferred != nullptr && remaining == 0ull) {
-      note_row();
       deferred->on = my_t >= 0;
       deferred->ti = (size_t)bL * L.ntiles + (my_t >= 0 ? my_t : 0);
       deferred->entry = make_uint4(block, SOFT ? my_sub : 0u, (unsigned int)my_bal, (unsigned int)(my_bal >> 32));
@@ -540,18 +544,26 @@ struct BinIn {
 // ---- the tile kernels' row order ------------------------------------------------------------------------------------------
 // The workgroup of a tile with faces lives ~100x longer than a background tile's, so the tile kernels visit a view's tile
 // rows heaviest first: the long workgroups start first and the background rows stream out beside their tail (round 2 did
-// this with a fixed map, rows from the middle of the image outwards -- right for a centred object only).  The rows' work
-// is summed while the lists are built (wave_bin: one fire-and-forget atomic per entry); the LAST workgroup of the binning
-// launch to finish (a ticket) ranks each view's rows -- descending work, ties by row -- and writes the order.  Called by
-// every thread of every workgroup at the end of the kernel.
+// this with a fixed map, rows from the middle of the image outwards -- right for a centred object only).  Every binning
+// workgroup sums the faces its entries list per tile row in LDS and adds the few non-zero sums to row_work; the LAST
+// workgroup to finish (tickets, see TICKET_GROUPS) ranks each view's rows, descending work, ties by row, and writes the order.
+// Called by every thread of every workgroup at the end of the kernel.
 __device__ __forceinline__ void sort_tile_rows(const Lists& L, int B) {
-  if (L.row_work == nullptr) return;  // (uniform)
+  if (L.ticket == nullptr) return;  // (uniform)
   __shared__ unsigned int s_last;
   __shared__ unsigned int s_rw[ROW_ORDER_LDS];
   __syncthreads();  // this workgroup's wavefronts have issued their atomics and waited for them
   if (threadIdx.x == 0) {
     __threadfence();
-    s_last = atomicAdd(L.ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+    const unsigned int group = blockIdx.x % TICKET_GROUPS;
+    const unsigned int members = (gridDim.x - group + TICKET_GROUPS - 1) / TICKET_GROUPS;  // workgroups g with g % GROUPS == group
+    unsigned int last = 0u;
+    if (atomicAdd(L.ticket + 1 + group, 1u) == members - 1u) {
+      __threadfence();
+      const unsigned int groups = gridDim.x < (unsigned int)TICKET_GROUPS ? gridDim.x : (unsigned int)TICKET_GROUPS;
+      last = atomicAdd(L.ticket, 1u) == groups - 1u ? 1u : 0u;
+    }
+    s_last = last;
   }
   __syncthreads();
   if (s_last == 0u) return;
@@ -595,6 +607,13 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(
   const unsigned long long wall0 = wall_clock64();  // 100 MHz
 #endif
   const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+  // the tile kernels' row order (sort_tile_rows): this workgroup's entries per tile row, two views' worth
+  __shared__ unsigned int s_rowacc[DO_R ? 2 * ROW_ORDER_MAX_ROWS : 1];
+  const bool want_rows = DO_R && LR.row_work != nullptr;
+  if (want_rows) {
+    for (int i = threadIdx.x; i < 2 * ROW_ORDER_MAX_ROWS; i += 256) s_rowacc[i] = 0u;
+    __syncthreads();
+  }
   bool live = f < in.total_faces;
   int b = 0;
   long long first_b = 0;
@@ -712,19 +731,39 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(
     }
   }
   PHASE_MARK(5);
+  // (the view of the workgroup's first face: uniform)
+  int rowacc_b0 = 0;
+  if (want_rows) {
+    const long long f0 = (long long)blockIdx.x * 256;
+    if (in.first == nullptr) {
+      rowacc_b0 = (int)(f0 / in.F);
+    } else {
+      while (rowacc_b0 + 1 < in.B && in.first[rowacc_b0 + 1] <= f0) ++rowacc_b0;
+    }
+  }
+  unsigned int* rowacc = want_rows ? s_rowacc : nullptr;
   if (DO_R && DO_S) {
     PendingEntry er, es;
-    wave_bin<false>(act_r, big_r, b, first_b, f, rx0, rx1, ry0, ry1, 0, 0, 0, 0, LR, &er);
+    wave_bin<false>(act_r, big_r, b, first_b, f, rx0, rx1, ry0, ry1, 0, 0, 0, 0, LR, &er, rowacc, rowacc_b0);
     PHASE_MARK(6);
     wave_bin<true>(act_s, big_s, b, first_b, f, sx0, sx1, sy0, sy1, pr_s.c_lo, pr_s.c_hi, pr_s.r_lo, pr_s.r_hi, LS, &es);
     append_entry_pair(er, LR, es, LS);
   } else {
-    if (DO_R) wave_bin<false>(act_r, big_r, b, first_b, f, rx0, rx1, ry0, ry1, 0, 0, 0, 0, LR);
+    if (DO_R) wave_bin<false>(act_r, big_r, b, first_b, f, rx0, rx1, ry0, ry1, 0, 0, 0, 0, LR, nullptr, rowacc, rowacc_b0);
     PHASE_MARK(6);
     if (DO_S) wave_bin<true>(act_s, big_s, b, first_b, f, sx0, sx1, sy0, sy1, pr_s.c_lo, pr_s.c_hi, pr_s.r_lo, pr_s.r_hi, LS);
   }
   PHASE_MARK(7);
-  if (DO_R) sort_tile_rows(LR, in.B);
+  if (want_rows) {
+    __syncthreads();
+    const int tiles_y = LR.ntiles / LR.tiles_x;
+    for (int i = threadIdx.x; i < 2 * tiles_y; i += 256) {
+      const unsigned int v = s_rowacc[i];
+      const int bb = rowacc_b0 + i / tiles_y;
+      if (v != 0u && bb < in.B) atomicAdd(LR.row_work + (size_t)bb * tiles_y + (i % tiles_y), v);
+    }
+    sort_tile_rows(LR, in.B);
+  }
   PHASE_FLUSH(g_phase_bin);
 #ifdef KAMD_PHASE_PROF
   if ((threadIdx.x & 63) == 0) {

@@ -6,11 +6,11 @@
 set -u
 tag=${1:-r01x}; pmc=${2:-}
 repo=$(pwd); out=$repo/gpurun_out/$tag; mkdir -p $out
-timeout 300 python -m pytest tests -m gpu -q -x --durations=15 --timeout 120 > $out/pytest_gpu.log 2>&1; tail -2 $out/pytest_gpu.log
-timeout 200 python bench.py 2> $out/bench.err | tail -1 > $out/bench.json
+timeout 500 python -m pytest tests -m gpu -q --durations=15 --timeout 280 > $out/pytest_gpu.log 2>&1; tail -2 $out/pytest_gpu.log
+timeout 320 python bench.py 2> $out/bench.err | tail -1 > $out/bench.json
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 cd /tmp && export TMPDIR=/tmp
-timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python $repo/bench.py --no-cpu-baseline 2> $out/prof.err | tail -1 > $out/bench_under_rocprof.json
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python $repo/bench.py --no-cpu-baseline --no-contract-ops 2> $out/prof.err | tail -1 > $out/bench_under_rocprof.json
 find $out/prof -name '*kernel_stats.csv' -exec cp {} $out/kernel_stats.csv \;
 if [ -n "$pmc" ]; then
   timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_f -- python $repo/tools/pmc_traffic.py > /dev/null 2>&1
@@ -24,6 +24,14 @@ if [ -n "$pmc" ]; then
   timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM --output-format csv -d $out/pmc2 -- python $repo/tools/pmc_traffic.py > /dev/null 2>&1
   find $out/pmc2 -name '*counter_collection.csv' -exec cp {} $out/pmc_sq2.csv \;
   rm -rf $out/pmc1 $out/pmc2
+  # the tables kept under profiles/ (traffic.json: calibrated HBM bytes per launch of every kernel, the DIB-R step, the chamfer step /
+  # operator and config C5; raw per-kernel tables of the four passes)
+  python $repo/tools/parse_traffic.py $out/pmc_fetch.csv $out/pmc_write.csv $out/traffic.json "tools/round_profile.sh $tag pmc (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/pmc_traffic.py)" > /dev/null 2> $out/parse_traffic.err
+  python $repo/tools/pmc_table.py $out/pmc_fetch.csv $out/pmc_FETCH_SIZE.txt "rocprofv3 --pmc FETCH_SIZE --output-format csv -- python tools/pmc_traffic.py" > /dev/null 2>&1
+  python $repo/tools/pmc_table.py $out/pmc_write.csv $out/pmc_WRITE_SIZE.txt "rocprofv3 --pmc WRITE_SIZE --output-format csv -- python tools/pmc_traffic.py" > /dev/null 2>&1
+  python $repo/tools/pmc_table.py $out/pmc_sq1.csv $out/pmc_SQ_waves_insts.txt "rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -- python tools/pmc_traffic.py" > /dev/null 2>&1
+  python $repo/tools/pmc_table.py $out/pmc_sq2.csv $out/pmc_SQ_lds_vmem.txt "rocprofv3 --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM --output-format csv -- python tools/pmc_traffic.py" > /dev/null 2>&1
+  rm -f $out/pmc_fetch.csv $out/pmc_write.csv $out/pmc_sq1.csv $out/pmc_sq2.csv   # (tens of MB; the tables above are what is kept)
 fi
 rm -rf $out/prof
 cd $repo; ls -la $out; cat $out/bench.json | cut -c1-400
