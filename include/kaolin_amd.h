@@ -229,7 +229,7 @@ int kamd_dibr_soft_mask_backward_f64(void* stream, int B, int H, int W, int F, i
 /*            item*64*K + item_count[item]), FACE-MAJOR (the pixels of one face  */
 /*            are consecutive);                                                   */
 /*  hit_rec / hit_prob  the evaluated hits as a flat list in 64 shards of equal    */
-/*            capacity (capacity / 64 records each; shard s holds work[16 + s]      */
+/*            capacity (capacity / 64 records each; shard s holds work[256 + 32 s]   */
 /*            records; an item appends one contiguous range to shard item % 64):    */
 /*            hit_rec = two int32 {(b*F + face) | which-of-six << 29, row << 16 |   */
 /*            col}, hit_prob the probability -- all the backward pass reads (it     */
@@ -237,7 +237,8 @@ int kamd_dibr_soft_mask_backward_f64(void* stream, int B, int H, int W, int F, i
 /*            Requires B*F < 2^29, H, W < 2^16.                                     */
 /* item_count holds ceil(W/32)*ceil(H/32)*16*B ints.  `work`                      */
 /* (kamd_dibr_soft_mask_work_words 32-bit words) receives the worklist: 8 sharded */
-/* item counters and the flat list's 64 shard counts in a 128-word header, then    */
+/* item counters (words 32 s) and the flat list's 64 shard counts, one per 128-byte */
+/* line (same-line device atomics serialise), in a 2304-word header, then          */
 /* the items {item, uncovered-pixel mask}.  The fused dibr_rasterization forward appends one byte  */
 /* per (mesh, 16x16-pixel tile): does the tile hold a covered pixel (read by its  */
 /* backward).  Requires B*H*W < 2^31.                                             */

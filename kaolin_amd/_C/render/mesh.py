@@ -249,14 +249,16 @@ def _hit_list(batch_size, height, width, knum, dtype, device, num_faces=0):
             _work_buffer(batch_size, height, width, device))
 
 
-WORK_HEADER = 128      # tile_lists.h WORK_HEADER: words 0..7 the worklist shards' item counts, 16..79 the flat hit list's shard counts
-FLAT_SHARDS = 64       # soft2.inc
+COUNTER_STRIDE = 32                              # tile_lists.h: append counters sit one per 128-byte line
+WORK_FLAT_WORD = 8 * COUNTER_STRIDE              # the flat hit list's shard counters follow the worklist's 8
+FLAT_SHARDS = 64                                 # soft2.inc
+WORK_HEADER = WORK_FLAT_WORD + FLAT_SHARDS * COUNTER_STRIDE
 
 
 def work_items(work, batch_size, height, width):
     """Item ids (int64, 1-D) recorded in a worklist buffer (tests / debugging; synchronises).  Layout (tile_lists.h): the
     header, 8 shards x shard_cap items of 4 words, one coverage byte per 16 x 16 tile, the tile kernels' row order."""
-    counts = work[:8].tolist()
+    counts = work[:8 * COUNTER_STRIDE:COUNTER_STRIDE].tolist()
     n_groups = batch_size * ((width + 15) // 16) * ((height + 15) // 16)
     shard_cap = 4 * ((n_groups + 7) // 8)
     items = work[WORK_HEADER:WORK_HEADER + 8 * shard_cap * 4].view(8, shard_cap, 4)
@@ -266,9 +268,9 @@ def work_items(work, batch_size, height, width):
 def hit_list_entries(hits, num_faces, batch_size, height, width):
     """The flat hit list -> (pix, face, prob, type) 1-D tensors of the recorded hits, pix = flat (b, row, col) index, face
     mesh-relative, type = which-of-six + 1 as in the K-buffers (tests / debugging; synchronises).  The list is FLAT_SHARDS
-    lists of equal capacity; shard s holds work[16 + s] records."""
+    lists of equal capacity; shard s holds work[WORK_FLAT_WORD + s * COUNTER_STRIDE] records."""
     hit_pair, hit_prob, hit_rec, item_count, work = hits
-    counts = work[16:16 + FLAT_SHARDS].tolist()
+    counts = work[WORK_FLAT_WORD:WORK_FLAT_WORD + FLAT_SHARDS * COUNTER_STRIDE:COUNTER_STRIDE].tolist()
     shard_cap = hit_rec.shape[0] // FLAT_SHARDS
     sel = torch.cat([torch.arange(s * shard_cap, s * shard_cap + c, device=hit_rec.device) for s, c in enumerate(counts)])
     rec = hit_rec[sel].long()

@@ -346,7 +346,8 @@ constexpr int SDG_GROUP = KAMD_SDG_GROUP;
 #define KAMD_SDG_R0 1     // first ring of the search: 1 = start with the 3 x 3 x 3 cube of cells (0: with the query's own cell, as in round 2)
 #endif
 #ifndef KAMD_SDG_BATCH
-#define KAMD_SDG_BATCH 3  // rows of a ring a lane takes at a time (their cell ranges are loaded together; 1: the round-2 loop)
+#define KAMD_SDG_BATCH 1  // rows of a ring a lane takes at a time (> 1: their cell ranges are loaded together; measured at 100k x 100k: 62.9 us either way
+                          // on a uniform cloud, 131 (1) vs 139 us (3) on a sphere surface: more registers, lower occupancy)
 #endif
 constexpr int SDG_R0 = KAMD_SDG_R0;
 constexpr int SDG_BATCH = KAMD_SDG_BATCH;  // lanes cooperating on one query (rows of the cell cube are dealt round-robin)

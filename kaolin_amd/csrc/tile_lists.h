@@ -99,6 +99,14 @@ __device__ __forceinline__ void edge_coefficients(const float* v, float x0, floa
   out[6] = ok ? (float)K : 3.0f;
 }
 constexpr double SOFT_EPS = 1e-7;     // the reference's literal EPS (dibr_soft_mask_cuda.cu:23), a double
+// Append counters live one per 128-byte line (COUNTER_STRIDE words apart): device-scope atomics on one line complete one at a
+// time (measured on MI355X: ~33 ns each on one address, ~15 ns each on neighbouring words of a line), so counters that are hit
+// thousands of times per launch must not share lines.
+constexpr int COUNTER_STRIDE = 32;
+#ifndef KAMD_COUNT_STRIDE
+#define KAMD_COUNT_STRIDE 1  // words between the per-tile list counters (and sub-tile reach words): 32 = one 128-byte line per tile (build knob)
+#endif
+constexpr int TCS = KAMD_COUNT_STRIDE;
 constexpr int WORK_SHARDS = 8;        // worklist shards (one append counter each; workgroup id & 7 picks the shard)
 
 struct PassGeom {
@@ -132,12 +140,11 @@ struct Lists {
   int tiles_x, ntiles;
   // raster pass only (nullptr: none): the order in which the tile kernels visit a view's tile rows, heaviest first
   unsigned int* row_work;     // [B * tiles_y]     zeroed; faces listed in the row's tiles (summed per workgroup in LDS, then added here)
-  unsigned int* ticket;       // zeroed; TICKET_GROUPS + 1 counters: workgroups of the binning launch that have finished
+  unsigned int* ticket;       // zeroed; TICKET_GROUPS + 1 counters, COUNTER_STRIDE words apart: workgroups of the binning launch that have finished
   unsigned short* row_order;  // [B * tiles_y]     written by the last workgroup: row_order[b * tiles_y + k] = k-th heaviest row of view b
 };
-// (same-address device atomics complete one at a time, ~50 ns each on this part: 1 563 workgroups taking ONE ticket counter
-// made the binning launch 90 us longer.  Workgroups therefore count in TICKET_GROUPS sub-counters, and only the last of each
-// group takes the top counter.)
+// (same-address device atomics complete one at a time: workgroups count in TICKET_GROUPS sub-counters, each on a line of its
+// own, and only the last of each group takes the top counter)
 constexpr int TICKET_GROUPS = 64;
 constexpr int ROW_ORDER_MAX_ROWS = 256;      // tile rows per view (images up to 4096 pixels high) ...
 constexpr int ROW_ORDER_LDS = 1024;          // ... sorted in LDS, ROW_ORDER_LDS / tiles_y views at a time
@@ -176,19 +183,19 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
   L.s.C = 64; L.s.maxc = 32;    // 64 + 32 * 31 = 1056 entries per 32 x 32 tile
   const size_t ntr = (size_t)B * L.r.g.ntiles, nts = (size_t)B * L.s.g.ntiles;
   if (with_r) {
-    L.r.count = off; off += a256(ntr * 4);
+    L.r.count = off; off += a256(ntr * 4 * TCS);
     L.r.tab = off; off += a256(ntr * L.r.maxc * 4);
     L.r.pool_top = off; off += 256;
     L.r.big_count = off; off += a256((size_t)B * 4);
     L.r.row_work = off; off += a256((size_t)B * L.r.g.tiles_y * 4);
-    L.r.ticket = off; off += a256((size_t)(TICKET_GROUPS + 1) * 4);
+    L.r.ticket = off; off += a256((size_t)(TICKET_GROUPS + 1) * COUNTER_STRIDE * 4);
   }
   if (with_s) {
-    L.s.count = off; off += a256(nts * 4);
+    L.s.count = off; off += a256(nts * 4 * TCS);
     L.s.tab = off; off += a256(nts * L.s.maxc * 4);
     L.s.pool_top = off; off += 256;
     L.s.big_count = off; off += a256((size_t)B * 4);
-    L.s.sub_touched = off; off += a256(nts * 4);
+    L.s.sub_touched = off; off += a256(nts * 4 * TCS);
   }
   L.zero_bytes = off;
   if (with_r) {
@@ -214,7 +221,8 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
 }
 // the worklist lives in its own buffer (the autograd path keeps it for the backward pass): WORK_HEADER words of counters,
 // then WORK_SHARDS x shard_cap items of 16 bytes.  One 256-thread workgroup per 16 x 16 pixels appends at most 4 items.
-constexpr int WORK_HEADER = 128;   // words 0..7: the shards' item counts; words 16..79: the flat hit list's per-shard record counts (soft2.inc)
+constexpr int WORK_FLAT_WORD = 8 * COUNTER_STRIDE;                    // the flat hit list's shard counters (soft2.inc) follow the worklist's
+constexpr int WORK_HEADER = WORK_FLAT_WORD + 64 * COUNTER_STRIDE;     // words; all zeroed per call
 inline unsigned int work_shard_cap(int B, int H, int W) {
   const PassGeom g = pass_geom(H, W, R_TILE);
   const size_t n_groups = (size_t)B * g.ntiles;
@@ -318,7 +326,7 @@ __device__ __forceinline__ void append_entry(bool on, const Lists& L, size_t ti,
   unsigned int slot = 0, c = 0, i = 0, v = 0;
   bool pooled = false;
   if (on) {
-    slot = atomicAdd(L.count + ti, 1u) & ~BRUTE_BIT;
+    slot = atomicAdd(L.count + ti * TCS, 1u) & ~BRUTE_BIT;
     if (slot < (unsigned int)L.C) {
       L.inl[ti * L.C + slot] = entry;
     } else {
@@ -326,7 +334,7 @@ __device__ __forceinline__ void append_entry(bool on, const Lists& L, size_t ti,
       c = o / OVC_PAYLOAD;
       i = o - c * OVC_PAYLOAD;
       if (c >= (unsigned int)L.maxc)
-        atomicOr(L.count + ti, BRUTE_BIT);
+        atomicOr(L.count + ti * TCS, BRUTE_BIT);
       else
         pooled = true;
     }
@@ -345,7 +353,7 @@ __device__ __forceinline__ void append_entry(bool on, const Lists& L, size_t ti,
   }
   if (pooled) {            // step 3
     if (v == 0xFFFFFFFFu)
-      atomicOr(L.count + ti, BRUTE_BIT);
+      atomicOr(L.count + ti * TCS, BRUTE_BIT);
     else
       L.pool[(size_t)(v - 1u) * OVC + 1u + i] = entry;
   }
@@ -366,7 +374,7 @@ __device__ __forceinline__ void append_entry_pair(const PendingEntry& pa, const 
   bool pooled[2] = {false, false};
 #pragma unroll
   for (int q = 0; q < 2; ++q)
-    if (pe[q]->on) slot[q] = atomicAdd(Ls[q]->count + pe[q]->ti, 1u) & ~BRUTE_BIT;
+    if (pe[q]->on) slot[q] = atomicAdd(Ls[q]->count + pe[q]->ti * TCS, 1u) & ~BRUTE_BIT;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const Lists& L = *Ls[q];
@@ -378,7 +386,7 @@ __device__ __forceinline__ void append_entry_pair(const PendingEntry& pa, const 
         c[q] = o / OVC_PAYLOAD;
         i[q] = o - c[q] * OVC_PAYLOAD;
         if (c[q] >= (unsigned int)L.maxc)
-          atomicOr(L.count + pe[q]->ti, BRUTE_BIT);
+          atomicOr(L.count + pe[q]->ti * TCS, BRUTE_BIT);
         else
           pooled[q] = true;
       }
@@ -407,7 +415,7 @@ __device__ __forceinline__ void append_entry_pair(const PendingEntry& pa, const 
   for (int q = 0; q < 2; ++q)
     if (pooled[q]) {
       if (v[q] == 0xFFFFFFFFu)
-        atomicOr(Ls[q]->count + pe[q]->ti, BRUTE_BIT);
+        atomicOr(Ls[q]->count + pe[q]->ti * TCS, BRUTE_BIT);
       else
         Ls[q]->pool[(size_t)(v[q] - 1u) * OVC + 1u + i[q]] = pe[q]->entry;
     }
@@ -461,7 +469,7 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
       const size_t ti = (size_t)bL * L.ntiles + (my_t >= 0 ? my_t : 0);
       // (soft pass: the entry also carries the sub-tiles its faces reach, so that a work item can skip whole entries)
       append_entry(my_t >= 0, L, ti, make_uint4(block, SOFT ? my_sub : 0u, (unsigned int)my_bal, (unsigned int)(my_bal >> 32)));
-      if (SOFT && my_t >= 0 && my_sub != 0u) atomicOr(L.sub_touched + ti, my_sub);
+      if (SOFT && my_t >= 0 && my_sub != 0u) atomicOr(L.sub_touched + ti * TCS, my_sub);
       my_t = -1;
       k = 0;
     };
@@ -507,7 +515,7 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
       deferred->on = my_t >= 0;
       deferred->ti = (size_t)bL * L.ntiles + (my_t >= 0 ? my_t : 0);
       deferred->entry = make_uint4(block, SOFT ? my_sub : 0u, (unsigned int)my_bal, (unsigned int)(my_bal >> 32));
-      if (SOFT && my_t >= 0 && my_sub != 0u) atomicOr(L.sub_touched + deferred->ti, my_sub);
+      if (SOFT && my_t >= 0 && my_sub != 0u) atomicOr(L.sub_touched + deferred->ti * TCS, my_sub);
     } else {
       flush();
     }
@@ -554,12 +562,13 @@ __device__ __forceinline__ void sort_tile_rows(const Lists& L, int B) {
   __shared__ unsigned int s_rw[ROW_ORDER_LDS];
   __syncthreads();  // this workgroup's wavefronts have issued their atomics and waited for them
   if (threadIdx.x == 0) {
-    __threadfence();
+    // No fence: everything the last workgroup reads was produced by device-scope atomics, which the barrier above has seen
+    // acknowledged, and is read with agent-scope loads.  (A __threadfence() here is a release at agent scope = a write-back
+    // of the XCD's L2 -- full of this kernel's freshly written records -- per workgroup: it tripled the kernel's time.)
     const unsigned int group = blockIdx.x % TICKET_GROUPS;
     const unsigned int members = (gridDim.x - group + TICKET_GROUPS - 1) / TICKET_GROUPS;  // workgroups g with g % GROUPS == group
     unsigned int last = 0u;
-    if (atomicAdd(L.ticket + 1 + group, 1u) == members - 1u) {
-      __threadfence();
+    if (atomicAdd(L.ticket + (1 + group) * COUNTER_STRIDE, 1u) == members - 1u) {
       const unsigned int groups = gridDim.x < (unsigned int)TICKET_GROUPS ? gridDim.x : (unsigned int)TICKET_GROUPS;
       last = atomicAdd(L.ticket, 1u) == groups - 1u ? 1u : 0u;
     }
@@ -788,7 +797,7 @@ struct TileSrc {
 __device__ __forceinline__ TileSrc tile_src(const Lists& L, int b, int tile) {
   TileSrc s;
   s.ti = (size_t)b * L.ntiles + tile;
-  const unsigned int raw = L.count[s.ti];
+  const unsigned int raw = L.count[s.ti * TCS];
   s.brute = (raw & BRUTE_BIT) != 0u;
   s.n = raw & ~BRUTE_BIT;
   return s;
@@ -842,7 +851,7 @@ __device__ __forceinline__ void queue_items(unsigned long long unc, bool has_fac
     const int sy = tile_y + wave * SUB_H;
     const int st = (sy / S_TILE) * tiles_x_s + tile_x / S_TILE;
     const int ss = ((sy % S_TILE) / SUB_H) * (S_TILE / SUB_W) + (tile_x % S_TILE) / SUB_W;
-    item = ((sub_touched[(size_t)b * ntiles_s + st] >> ss) & 1u) != 0u || big_count_s[b] != 0u;
+    item = ((sub_touched[((size_t)b * ntiles_s + st) * TCS] >> ss) & 1u) != 0u || big_count_s[b] != 0u;
   }
   if (lane == 0) s_item_unc[wave] = item ? unc : 0ull;
   const int any_covered = __syncthreads_or(covered ? 1 : 0);
@@ -853,7 +862,7 @@ __device__ __forceinline__ void queue_items(unsigned long long unc, bool has_fac
     for (int w = 0; w < 4; ++w) n += s_item_unc[w] != 0ull ? 1 : 0;
     if (n > 0) {
       const unsigned int shard = blockIdx.x & (WORK_SHARDS - 1);
-      unsigned int pos = atomicAdd(work_counts + shard, (unsigned int)n);
+      unsigned int pos = atomicAdd(work_counts + shard * COUNTER_STRIDE, (unsigned int)n);
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
         const unsigned long long u = s_item_unc[w];

@@ -91,7 +91,7 @@ def test_forward_leaves_a_row_order_that_starts_where_the_object_is(shift):
     lib = kal._lib.load()
     assert work.numel() == lib.kamd_dibr_soft_mask_work_words(B, H, W)
     n_groups = B * tiles_x * tiles_y
-    off = 128 + 8 * (4 * ((n_groups + 7) // 8)) * 4 + (n_groups + 3) // 4         # header, items, coverage bytes (tile_lists.h)
+    off = kal._C.render.mesh.WORK_HEADER + 8 * (4 * ((n_groups + 7) // 8)) * 4 + (n_groups + 3) // 4         # header, items, coverage bytes (tile_lists.h)
     order = work[off:off + (B * tiles_y + 1) // 2].view(torch.int16)[:B * tiles_y].view(B, tiles_y).long().cpu()
     covered_rows = (face_idx >= 0).any(dim=2).cpu()                                  # (B, H)
     for b in range(B):
