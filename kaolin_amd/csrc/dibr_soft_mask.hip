@@ -452,9 +452,9 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
   const tl::Layout lay = tl::make_layout(B, H, W, total_faces, (int)sizeof(T), true, true, K);
   tl::Lists LR = tl::lists_of(workspace, lay.r, B, false);
   tl::Lists LS = tl::lists_of(workspace, lay.s, B, true);
-  // the tile kernels' row order (heaviest rows first) is left in the `work` buffer: the backward pass follows it too
-  const bool row_order = total_faces > 0 && tl::row_order_supported(H) && kamd_env_int("KAMD_ROW_ORDER", 1) == 1 /* 2: off */;
-  if (row_order) tl::with_row_order(LR, workspace, lay.r, reinterpret_cast<unsigned short*>(work + tl::work_order_offset_words(B, H, W)));
+  // (KAMD_ROW_ORDER=2: the tile kernels start from the middle of the image instead of the middle of the covered rows: A/B runs)
+  const bool row_span = kamd_env_int("KAMD_ROW_ORDER", 1) == 1;
+  if (!row_span) LR.row_span = nullptr;
   T* rec_r = (T*)((char*)workspace + lay.r.rec);
   T* rec_s = (T*)((char*)workspace + lay.s.rec);
   // one launch clears the list heads, the work-list header and (when the caller will differentiate) the buffer the backward
@@ -496,6 +496,7 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
   co.work_counts = work;
   co.shard_cap = tl::work_shard_cap(B, H, W);
   co.tile_cov = reinterpret_cast<unsigned char*>(work + tl::work_cov_offset_words(B, H, W));
+  co.row_centre_out = work + tl::work_centre_offset_words(B, H, W);  // (the backward's tile kernel starts from the same rows)
   KAMD_CHECK(kamd::raster2_draw<T>(st, B, H, W, D, F, (float)multiplier, eps, rec_r, LR, feat, interp, face_idx, weights, co,
                                    kamd_env_int("KAMD_DIBR_BG_WEIGHTS", 2) != 1));
   if (total_faces > 0)
@@ -544,14 +545,12 @@ int dibr_backward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K
   const unsigned char* tile_cov = kamd_env_int("KAMD_BWD_TILE_COV", 1) == 1  // (2: off, for A/B runs)
                                       ? reinterpret_cast<const unsigned char*>(work + tl::work_cov_offset_words(B, H, W))
                                       : nullptr;
-  const unsigned short* row_order = (F > 0 && tl::row_order_supported(H) && kamd_env_int("KAMD_ROW_ORDER", 1) == 1 /* 2: off */)
-                                        ? reinterpret_cast<const unsigned short*>(work + tl::work_order_offset_words(B, H, W))
-                                        : nullptr;
+  const unsigned int* row_centre = F > 0 ? work + tl::work_centre_offset_words(B, H, W) : nullptr;
   if (!use_side || kamd::prof_all()) {
     KAMD_CHECK(soft_mask_backward_list_launch<T>(st, B, H, W, F, K, grad_soft, soft_mask, list, work, img, multiplier, sigmainv,
                                                  (float)multiplier, g_img));
     return kamd::raster_backward_draw<T>(st, B, H, W, F, D, grad_feat, face_idx, weights, img, feat, eps, g_img, g_feat, tile_cov,
-                                         row_order);
+                                         row_centre);
   }
   std::lock_guard<std::mutex> lk(g_side_mu);
   SideStream* ss;
@@ -566,7 +565,7 @@ int dibr_backward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K
   if (rc == 0) rc = rc2;
   if (rc == 0)
     rc = kamd::raster_backward_draw<T>(st, B, H, W, F, D, grad_feat, face_idx, weights, img, feat, eps, g_img, g_feat, tile_cov,
-                                       row_order);
+                                       row_centre);
   rc2 = (int)hipStreamWaitEvent(st, ss->join, 0);
   return rc != 0 ? rc : rc2;
 }

@@ -103,10 +103,6 @@ constexpr double SOFT_EPS = 1e-7;     // the reference's literal EPS (dibr_soft_
 // time (measured on MI355X: ~33 ns each on one address, ~15 ns each on neighbouring words of a line), so counters that are hit
 // thousands of times per launch must not share lines.
 constexpr int COUNTER_STRIDE = 32;
-#ifndef KAMD_COUNT_STRIDE
-#define KAMD_COUNT_STRIDE 1  // words between the per-tile list counters (and sub-tile reach words): 32 = one 128-byte line per tile (build knob)
-#endif
-constexpr int TCS = KAMD_COUNT_STRIDE;
 constexpr int WORK_SHARDS = 8;        // worklist shards (one append counter each; workgroup id & 7 picks the shard)
 
 struct PassGeom {
@@ -138,17 +134,9 @@ struct Lists {
   unsigned int* big_list;     // [total_faces]     mesh b's segment starts at its first packed face
   unsigned int* sub_touched;  // [B * ntiles]      zeroed; soft pass only: bit s = some enlarged box reaches sub-tile s
   int tiles_x, ntiles;
-  // raster pass only (nullptr: none): the order in which the tile kernels visit a view's tile rows, heaviest first
-  unsigned int* row_work;     // [B * tiles_y]     zeroed; faces listed in the row's tiles (summed per workgroup in LDS, then added here)
-  unsigned int* ticket;       // zeroed; TICKET_GROUPS + 1 counters, COUNTER_STRIDE words apart: workgroups of the binning launch that have finished
-  unsigned short* row_order;  // [B * tiles_y]     written by the last workgroup: row_order[b * tiles_y + k] = k-th heaviest row of view b
+  // raster pass only (nullptr: none): the tile rows the mesh's boxes cover, per view -- where the tile kernels start
+  unsigned int* row_span;     // [B * COUNTER_STRIDE] zeroed; view b: word 0 = (last covered row + 1), word 1 = (tiles_y - first covered row); 0 = none
 };
-// (same-address device atomics complete one at a time: workgroups count in TICKET_GROUPS sub-counters, each on a line of its
-// own, and only the last of each group takes the top counter)
-constexpr int TICKET_GROUPS = 64;
-constexpr int ROW_ORDER_MAX_ROWS = 256;      // tile rows per view (images up to 4096 pixels high) ...
-constexpr int ROW_ORDER_LDS = 1024;          // ... sorted in LDS, ROW_ORDER_LDS / tiles_y views at a time
-inline bool row_order_supported(int H) { return (H + R_TILE - 1) / R_TILE <= ROW_ORDER_MAX_ROWS; }
 
 inline size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline unsigned int pool_chunks(long long total_faces, long long n_tiles_total) {
@@ -161,8 +149,7 @@ inline unsigned int pool_chunks(long long total_faces, long long n_tiles_total) 
 // Host-side layout of one pass inside a workspace.  All zeroed arrays of both passes are placed in ONE contiguous region
 // at the start of the workspace so that a single fill kernel clears them.
 struct PassLayout {
-  size_t count, tab, pool_top, big_count, sub_touched, row_work, ticket;  // inside the zero region
-  size_t row_order;                      // raster pass: (B * tiles_y) u16 (the fused operator keeps it in its `work` buffer instead)
+  size_t count, tab, pool_top, big_count, sub_touched, row_span;  // inside the zero region
   size_t inl, pool, big_list, rec;                      // after it
   size_t pixcnt, prob_pm;                // soft pass: hits per (item, pixel) (u16); pixel-major probabilities (knum > 128 only)
   unsigned int cap_chunks;
@@ -183,19 +170,18 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
   L.s.C = 64; L.s.maxc = 32;    // 64 + 32 * 31 = 1056 entries per 32 x 32 tile
   const size_t ntr = (size_t)B * L.r.g.ntiles, nts = (size_t)B * L.s.g.ntiles;
   if (with_r) {
-    L.r.count = off; off += a256(ntr * 4 * TCS);
+    L.r.count = off; off += a256(ntr * 4);
     L.r.tab = off; off += a256(ntr * L.r.maxc * 4);
     L.r.pool_top = off; off += 256;
     L.r.big_count = off; off += a256((size_t)B * 4);
-    L.r.row_work = off; off += a256((size_t)B * L.r.g.tiles_y * 4);
-    L.r.ticket = off; off += a256((size_t)(TICKET_GROUPS + 1) * COUNTER_STRIDE * 4);
+    L.r.row_span = off; off += a256((size_t)B * COUNTER_STRIDE * 4);
   }
   if (with_s) {
-    L.s.count = off; off += a256(nts * 4 * TCS);
+    L.s.count = off; off += a256(nts * 4);
     L.s.tab = off; off += a256(nts * L.s.maxc * 4);
     L.s.pool_top = off; off += 256;
     L.s.big_count = off; off += a256((size_t)B * 4);
-    L.s.sub_touched = off; off += a256(nts * 4 * TCS);
+    L.s.sub_touched = off; off += a256(nts * 4);
   }
   L.zero_bytes = off;
   if (with_r) {
@@ -204,7 +190,6 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
     L.r.pool = off; off += a256((size_t)L.r.cap_chunks * OVC * 16);
     L.r.big_list = off; off += a256((size_t)total_faces * 4);
     L.r.rec = off; off += a256((size_t)total_faces * REC_R * esz);
-    L.r.row_order = off; off += a256((size_t)B * L.r.g.tiles_y * 2);
   }
   if (with_s) {
     L.s.cap_chunks = pool_chunks(total_faces, (long long)nts);
@@ -231,13 +216,12 @@ inline unsigned int work_shard_cap(int B, int H, int W) {
 // ... then one byte per (mesh, 16 x 16 tile) [b * ntiles + tile]: does the tile hold a covered pixel?  (Written by the
 // rasterizer's tile kernel in the fused path; the rasterizer's backward kernel leaves a tile without one at once.)
 inline size_t work_cov_offset_words(int B, int H, int W) { return WORK_HEADER + (size_t)WORK_SHARDS * work_shard_cap(B, H, W) * 4; }
-// ... then the forward's tile-row order (B * tiles_y u16, Lists::row_order), which the rasterizer's backward kernel follows too
-inline size_t work_order_offset_words(int B, int H, int W) {
+// ... then, per view, the tile row the forward's tile kernel started from (B words), which the rasterizer's backward kernel
+// starts from too
+inline size_t work_centre_offset_words(int B, int H, int W) {
   return work_cov_offset_words(B, H, W) + ((size_t)B * pass_geom(H, W, R_TILE).ntiles + 3) / 4;
 }
-inline size_t work_words(int B, int H, int W) {
-  return work_order_offset_words(B, H, W) + ((size_t)B * pass_geom(H, W, R_TILE).tiles_y + 1) / 2;
-}
+inline size_t work_words(int B, int H, int W) { return work_centre_offset_words(B, H, W) + (size_t)B; }
 
 inline Lists lists_of(void* ws, const PassLayout& p, int B, bool soft) {
   char* c = (char*)ws;
@@ -255,16 +239,8 @@ inline Lists lists_of(void* ws, const PassLayout& p, int B, bool soft) {
   l.sub_touched = soft ? (unsigned int*)(c + p.sub_touched) : nullptr;
   l.tiles_x = p.g.tiles_x;
   l.ntiles = p.g.ntiles;
-  l.row_work = nullptr;   // (set by the launches that want the data-driven row order: with_row_order)
-  l.ticket = nullptr;
-  l.row_order = nullptr;
+  l.row_span = (!soft && p.row_span != 0) ? (unsigned int*)(c + p.row_span) : nullptr;
   return l;
-}
-// raster pass: the binning launch's last workgroup leaves the tile kernels' row order at `order` (B * tiles_y u16)
-inline void with_row_order(Lists& l, void* ws, const PassLayout& p, unsigned short* order) {
-  l.row_work = (unsigned int*)((char*)ws + p.row_work);
-  l.ticket = (unsigned int*)((char*)ws + p.ticket);
-  l.row_order = order;
 }
 
 // ---- conservative pixel range of a half-open box -----------------------------------------------------------------------
@@ -326,7 +302,7 @@ __device__ __forceinline__ void append_entry(bool on, const Lists& L, size_t ti,
   unsigned int slot = 0, c = 0, i = 0, v = 0;
   bool pooled = false;
   if (on) {
-    slot = atomicAdd(L.count + ti * TCS, 1u) & ~BRUTE_BIT;
+    slot = atomicAdd(L.count + ti, 1u) & ~BRUTE_BIT;
     if (slot < (unsigned int)L.C) {
       L.inl[ti * L.C + slot] = entry;
     } else {
@@ -334,7 +310,7 @@ __device__ __forceinline__ void append_entry(bool on, const Lists& L, size_t ti,
       c = o / OVC_PAYLOAD;
       i = o - c * OVC_PAYLOAD;
       if (c >= (unsigned int)L.maxc)
-        atomicOr(L.count + ti * TCS, BRUTE_BIT);
+        atomicOr(L.count + ti, BRUTE_BIT);
       else
         pooled = true;
     }
@@ -353,7 +329,7 @@ __device__ __forceinline__ void append_entry(bool on, const Lists& L, size_t ti,
   }
   if (pooled) {            // step 3
     if (v == 0xFFFFFFFFu)
-      atomicOr(L.count + ti * TCS, BRUTE_BIT);
+      atomicOr(L.count + ti, BRUTE_BIT);
     else
       L.pool[(size_t)(v - 1u) * OVC + 1u + i] = entry;
   }
@@ -374,7 +350,7 @@ __device__ __forceinline__ void append_entry_pair(const PendingEntry& pa, const 
   bool pooled[2] = {false, false};
 #pragma unroll
   for (int q = 0; q < 2; ++q)
-    if (pe[q]->on) slot[q] = atomicAdd(Ls[q]->count + pe[q]->ti * TCS, 1u) & ~BRUTE_BIT;
+    if (pe[q]->on) slot[q] = atomicAdd(Ls[q]->count + pe[q]->ti, 1u) & ~BRUTE_BIT;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const Lists& L = *Ls[q];
@@ -386,7 +362,7 @@ __device__ __forceinline__ void append_entry_pair(const PendingEntry& pa, const 
         c[q] = o / OVC_PAYLOAD;
         i[q] = o - c[q] * OVC_PAYLOAD;
         if (c[q] >= (unsigned int)L.maxc)
-          atomicOr(L.count + pe[q]->ti * TCS, BRUTE_BIT);
+          atomicOr(L.count + pe[q]->ti, BRUTE_BIT);
         else
           pooled[q] = true;
       }
@@ -415,7 +391,7 @@ __device__ __forceinline__ void append_entry_pair(const PendingEntry& pa, const 
   for (int q = 0; q < 2; ++q)
     if (pooled[q]) {
       if (v[q] == 0xFFFFFFFFu)
-        atomicOr(Ls[q]->count + pe[q]->ti * TCS, BRUTE_BIT);
+        atomicOr(Ls[q]->count + pe[q]->ti, BRUTE_BIT);
       else
         Ls[q]->pool[(size_t)(v[q] - 1u) * OVC + 1u + i[q]] = pe[q]->entry;
     }
@@ -432,9 +408,7 @@ __device__ __forceinline__ void append_entry_pair(const PendingEntry& pa, const 
 template <bool SOFT>
 __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long first_b, long long f, int tx0, int tx1,
                                          int ty0, int ty1, int c_lo, int c_hi, int r_lo, int r_hi, const Lists& L,
-                                         PendingEntry* deferred = nullptr, unsigned int* s_rowacc = nullptr, int rowacc_b0 = 0) {
-  // `s_rowacc` (raster pass, optional): the workgroup's LDS table [2][tiles_y] of the faces its entries list per tile row, for
-  // the views rowacc_b0 and rowacc_b0 + 1 (a workgroup of 256 consecutive faces rarely spans more); other views: global atomics
+                                         PendingEntry* deferred = nullptr) {
   // `deferred`: the wavefront's LAST batch of entries is handed back instead of appended (the caller appends it together
   // with the other pass' last batch: append_entry_pair)
   if (deferred != nullptr) deferred->on = false;
@@ -469,7 +443,7 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
       const size_t ti = (size_t)bL * L.ntiles + (my_t >= 0 ? my_t : 0);
       // (soft pass: the entry also carries the sub-tiles its faces reach, so that a work item can skip whole entries)
       append_entry(my_t >= 0, L, ti, make_uint4(block, SOFT ? my_sub : 0u, (unsigned int)my_bal, (unsigned int)(my_bal >> 32)));
-      if (SOFT && my_t >= 0 && my_sub != 0u) atomicOr(L.sub_touched + ti * TCS, my_sub);
+      if (SOFT && my_t >= 0 && my_sub != 0u) atomicOr(L.sub_touched + ti, my_sub);
       my_t = -1;
       k = 0;
     };
@@ -502,20 +476,13 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
         my_bal = bal;
         my_sub = sub;
       }
-      if (!SOFT && s_rowacc != nullptr && lane == 0) {  // (one LDS atomic per entry; same-address global atomics cost ~50 ns each)
-        const int tiles_y = L.ntiles / L.tiles_x, rel = bL - rowacc_b0;
-        if (rel < 2)
-          atomicAdd(&s_rowacc[rel * tiles_y + ty], (unsigned int)__popcll(bal));
-        else
-          atomicAdd(L.row_work + (size_t)bL * tiles_y + ty, (unsigned int)__popcll(bal));
-      }
       if (++k == 64) flush();
     }
     if (deferred != nullptr && remaining == 0ull) {
       deferred->on = my_t >= 0;
       deferred->ti = (size_t)bL * L.ntiles + (my_t >= 0 ? my_t : 0);
       deferred->entry = make_uint4(block, SOFT ? my_sub : 0u, (unsigned int)my_bal, (unsigned int)(my_bal >> 32));
-      if (SOFT && my_t >= 0 && my_sub != 0u) atomicOr(L.sub_touched + deferred->ti * TCS, my_sub);
+      if (SOFT && my_t >= 0 && my_sub != 0u) atomicOr(L.sub_touched + deferred->ti, my_sub);
     } else {
       flush();
     }
@@ -549,51 +516,75 @@ struct BinIn {
   T* rec_s;
 };
 
-// ---- the tile kernels' row order ------------------------------------------------------------------------------------------
+// ---- where the tile kernels start ------------------------------------------------------------------------------------------
 // The workgroup of a tile with faces lives ~100x longer than a background tile's, so the tile kernels visit a view's tile
-// rows heaviest first: the long workgroups start first and the background rows stream out beside their tail (round 2 did
-// this with a fixed map, rows from the middle of the image outwards -- right for a centred object only).  Every binning
-// workgroup sums the faces its entries list per tile row in LDS and adds the few non-zero sums to row_work; the LAST
-// workgroup to finish (tickets, see TICKET_GROUPS) ranks each view's rows, descending work, ties by row, and writes the order.
-// Called by every thread of every workgroup at the end of the kernel.
-__device__ __forceinline__ void sort_tile_rows(const Lists& L, int B) {
-  if (L.ticket == nullptr) return;  // (uniform)
-  __shared__ unsigned int s_last;
-  __shared__ unsigned int s_rw[ROW_ORDER_LDS];
-  __syncthreads();  // this workgroup's wavefronts have issued their atomics and waited for them
-  if (threadIdx.x == 0) {
-    // No fence: everything the last workgroup reads was produced by device-scope atomics, which the barrier above has seen
-    // acknowledged, and is read with agent-scope loads.  (A __threadfence() here is a release at agent scope = a write-back
-    // of the XCD's L2 -- full of this kernel's freshly written records -- per workgroup: it tripled the kernel's time.)
-    const unsigned int group = blockIdx.x % TICKET_GROUPS;
-    const unsigned int members = (gridDim.x - group + TICKET_GROUPS - 1) / TICKET_GROUPS;  // workgroups g with g % GROUPS == group
-    unsigned int last = 0u;
-    if (atomicAdd(L.ticket + (1 + group) * COUNTER_STRIDE, 1u) == members - 1u) {
-      const unsigned int groups = gridDim.x < (unsigned int)TICKET_GROUPS ? gridDim.x : (unsigned int)TICKET_GROUPS;
-      last = atomicAdd(L.ticket, 1u) == groups - 1u ? 1u : 0u;
+// rows outwards from the middle of the rows the mesh covers: the long workgroups start first and the background rows stream
+// out beside their tail (round 2 started from the middle of the IMAGE -- right for a centred object only).  The binning
+// kernel notes, per view, the first and the last tile row any kept face's box reaches: a wave reduction, one LDS slot per
+// wavefront, and per workgroup at most two device atomics (atomicMax on words of the view's own line), skipped when the
+// published span already holds the workgroup's.  (Measured and dropped: ranking the rows by the faces their tiles list --
+// a ticket per workgroup and a sort in the last one to finish cost the binning launch 8 us, and the ranked order a u16 load
+// per tile-kernel workgroup: 4 us more on 131 072 workgroups; a device-scope fence in that ticket wrote back the XCD's L2
+// per workgroup and tripled the launch.)
+// row k of the visiting order around centre c: c, c - 1, c + 1, c - 2, ... and, once one side is used up, on along the other
+__host__ __device__ inline int row_from_centre(int k, int c, int tiles_y) {
+  const int left = c, right = tiles_y - 1 - c, m = left < right ? left : right;
+  if (k <= 2 * m) return (k & 1) ? c - ((k + 1) >> 1) : c + (k >> 1);
+  return right > left ? k : tiles_y - 1 - k;
+}
+// the centre the tile kernels of view b start from (the middle row of the image when no face was binned)
+__device__ __forceinline__ int row_centre(const unsigned int* __restrict__ row_span, int b, int tiles_y) {
+  if (row_span == nullptr) return tiles_y >> 1;
+  const unsigned int hi1 = row_span[(size_t)b * COUNTER_STRIDE], lo_inv = row_span[(size_t)b * COUNTER_STRIDE + 1];
+  if (hi1 == 0u || lo_inv == 0u) return tiles_y >> 1;
+  const int lo = tiles_y - (int)lo_inv, hi = (int)hi1 - 1;
+  const int c = (lo + hi) >> 1;
+  return c < 0 ? 0 : (c > tiles_y - 1 ? tiles_y - 1 : c);
+}
+// called by every thread of the binning kernel: `act` = the lane's face is kept and reaches the image, rows [r0, r1]
+__device__ __forceinline__ void note_row_span(const Lists& L, bool act, int b, int r0, int r1) {
+  if (L.row_span == nullptr) return;  // (uniform)
+  __shared__ int s_span[4][4];        // per wavefront: {view, lo, hi} of its first view; lanes of other views go alone
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tiles_y = L.ntiles / L.tiles_x;
+  const unsigned long long am = __ballot(act);
+  int b0 = -1, lo = 0x7FFFFFFF, hi = -1;
+  if (am != 0ull) {
+    b0 = __builtin_amdgcn_readlane(b, __ffsll((long long)am) - 1);
+    const bool mine = act && b == b0;
+    lo = mine ? r0 : 0x7FFFFFFF;
+    hi = mine ? r1 : -1;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      lo = min(lo, __shfl_xor(lo, d, 64));
+      hi = max(hi, __shfl_xor(hi, d, 64));
     }
-    s_last = last;
+    if (act && b != b0) {  // (a wavefront that straddles views: meshes of fewer than 64 faces, or a view boundary)
+      atomicMax(L.row_span + (size_t)b * COUNTER_STRIDE, (unsigned int)(r1 + 1));
+      atomicMax(L.row_span + (size_t)b * COUNTER_STRIDE + 1, (unsigned int)(tiles_y - r0));
+    }
+  }
+  if (lane == 0) {
+    s_span[wave][0] = b0;
+    s_span[wave][1] = lo;
+    s_span[wave][2] = hi;
   }
   __syncthreads();
-  if (s_last == 0u) return;
-  const int tiles_y = L.ntiles / L.tiles_x;
-  const int per_pass = ROW_ORDER_LDS / tiles_y;  // views ranked per pass (tiles_y <= ROW_ORDER_MAX_ROWS <= ROW_ORDER_LDS)
-  for (int b0 = 0; b0 < B; b0 += per_pass) {
-    const int nb = min(per_pass, B - b0), n = nb * tiles_y;
-    __syncthreads();
-    // (the sums were made by atomics of other workgroups, possibly on other XCDs: agent-scope loads, not cached ones)
-    for (int i = threadIdx.x; i < n; i += blockDim.x)
-      s_rw[i] = __hip_atomic_load(L.row_work + (size_t)b0 * tiles_y + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      const int v = i / tiles_y, r = i - v * tiles_y;
-      const unsigned int mine = s_rw[i];
-      int rank = 0;
-      for (int q = 0; q < tiles_y; ++q) {
-        const unsigned int o = s_rw[v * tiles_y + q];
-        rank += (o > mine || (o == mine && q < r)) ? 1 : 0;
-      }
-      L.row_order[(size_t)(b0 + v) * tiles_y + rank] = (unsigned short)r;
+  if (threadIdx.x < 4) {
+    // wavefront w speaks for its view unless an earlier wavefront of the workgroup has the same view (then that one merges)
+    const int w = threadIdx.x, vb = s_span[w][0];
+    bool first = vb >= 0;
+    for (int q = 0; q < w; ++q) first = first && s_span[q][0] != vb;
+    if (first) {
+      int l = s_span[w][1], h = s_span[w][2];
+      for (int q = w + 1; q < 4; ++q)
+        if (s_span[q][0] == vb) {
+          l = min(l, s_span[q][1]);
+          h = max(h, s_span[q][2]);
+        }
+      unsigned int* p = L.row_span + (size_t)vb * COUNTER_STRIDE;
+      // (plain loads first: once the span has grown, most workgroups have nothing to add and issue no atomic)
+      if (p[0] < (unsigned int)(h + 1)) atomicMax(p, (unsigned int)(h + 1));
+      if (p[1] < (unsigned int)(tiles_y - l)) atomicMax(p + 1, (unsigned int)(tiles_y - l));
     }
   }
 }
@@ -616,13 +607,6 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(
   const unsigned long long wall0 = wall_clock64();  // 100 MHz
 #endif
   const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
-  // the tile kernels' row order (sort_tile_rows): this workgroup's entries per tile row, two views' worth
-  __shared__ unsigned int s_rowacc[DO_R ? 2 * ROW_ORDER_MAX_ROWS : 1];
-  const bool want_rows = DO_R && LR.row_work != nullptr;
-  if (want_rows) {
-    for (int i = threadIdx.x; i < 2 * ROW_ORDER_MAX_ROWS; i += 256) s_rowacc[i] = 0u;
-    __syncthreads();
-  }
   bool live = f < in.total_faces;
   int b = 0;
   long long first_b = 0;
@@ -740,39 +724,19 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(
     }
   }
   PHASE_MARK(5);
-  // (the view of the workgroup's first face: uniform)
-  int rowacc_b0 = 0;
-  if (want_rows) {
-    const long long f0 = (long long)blockIdx.x * 256;
-    if (in.first == nullptr) {
-      rowacc_b0 = (int)(f0 / in.F);
-    } else {
-      while (rowacc_b0 + 1 < in.B && in.first[rowacc_b0 + 1] <= f0) ++rowacc_b0;
-    }
-  }
-  unsigned int* rowacc = want_rows ? s_rowacc : nullptr;
+  if (DO_R) note_row_span(LR, act_r, b, ry0, ry1);
   if (DO_R && DO_S) {
     PendingEntry er, es;
-    wave_bin<false>(act_r, big_r, b, first_b, f, rx0, rx1, ry0, ry1, 0, 0, 0, 0, LR, &er, rowacc, rowacc_b0);
+    wave_bin<false>(act_r, big_r, b, first_b, f, rx0, rx1, ry0, ry1, 0, 0, 0, 0, LR, &er);
     PHASE_MARK(6);
     wave_bin<true>(act_s, big_s, b, first_b, f, sx0, sx1, sy0, sy1, pr_s.c_lo, pr_s.c_hi, pr_s.r_lo, pr_s.r_hi, LS, &es);
     append_entry_pair(er, LR, es, LS);
   } else {
-    if (DO_R) wave_bin<false>(act_r, big_r, b, first_b, f, rx0, rx1, ry0, ry1, 0, 0, 0, 0, LR, nullptr, rowacc, rowacc_b0);
+    if (DO_R) wave_bin<false>(act_r, big_r, b, first_b, f, rx0, rx1, ry0, ry1, 0, 0, 0, 0, LR);
     PHASE_MARK(6);
     if (DO_S) wave_bin<true>(act_s, big_s, b, first_b, f, sx0, sx1, sy0, sy1, pr_s.c_lo, pr_s.c_hi, pr_s.r_lo, pr_s.r_hi, LS);
   }
   PHASE_MARK(7);
-  if (want_rows) {
-    __syncthreads();
-    const int tiles_y = LR.ntiles / LR.tiles_x;
-    for (int i = threadIdx.x; i < 2 * tiles_y; i += 256) {
-      const unsigned int v = s_rowacc[i];
-      const int bb = rowacc_b0 + i / tiles_y;
-      if (v != 0u && bb < in.B) atomicAdd(LR.row_work + (size_t)bb * tiles_y + (i % tiles_y), v);
-    }
-    sort_tile_rows(LR, in.B);
-  }
   PHASE_FLUSH(g_phase_bin);
 #ifdef KAMD_PHASE_PROF
   if ((threadIdx.x & 63) == 0) {
@@ -797,7 +761,7 @@ struct TileSrc {
 __device__ __forceinline__ TileSrc tile_src(const Lists& L, int b, int tile) {
   TileSrc s;
   s.ti = (size_t)b * L.ntiles + tile;
-  const unsigned int raw = L.count[s.ti * TCS];
+  const unsigned int raw = L.count[s.ti];
   s.brute = (raw & BRUTE_BIT) != 0u;
   s.n = raw & ~BRUTE_BIT;
   return s;
@@ -820,6 +784,7 @@ struct ClassifyOut {
   unsigned int* work_counts;
   unsigned int shard_cap;
   unsigned char* tile_cov;          // [B * ntiles_r] (work_cov_offset_words), or nullptr
+  unsigned int* row_centre_out;     // [B] (work_centre_offset_words): the tile row the kernel started view b from, or nullptr
 };
 
 // exclusive prefix over the 256 threads of a workgroup; *total = sum.  `scratch`: 4 ints of LDS.
@@ -851,7 +816,7 @@ __device__ __forceinline__ void queue_items(unsigned long long unc, bool has_fac
     const int sy = tile_y + wave * SUB_H;
     const int st = (sy / S_TILE) * tiles_x_s + tile_x / S_TILE;
     const int ss = ((sy % S_TILE) / SUB_H) * (S_TILE / SUB_W) + (tile_x % S_TILE) / SUB_W;
-    item = ((sub_touched[((size_t)b * ntiles_s + st) * TCS] >> ss) & 1u) != 0u || big_count_s[b] != 0u;
+    item = ((sub_touched[(size_t)b * ntiles_s + st] >> ss) & 1u) != 0u || big_count_s[b] != 0u;
   }
   if (lane == 0) s_item_unc[wave] = item ? unc : 0ull;
   const int any_covered = __syncthreads_or(covered ? 1 : 0);

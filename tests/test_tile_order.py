@@ -1,30 +1,26 @@
 """The rasterizer kernels' workgroup -> tile map (kaolin_amd/csrc/raster2.inc KAMD_RASTER_ORDER, rasterize.hip
-KAMD_RBWD_ORDER): views interleaved, a view's tile rows heaviest first -- the order the binning launch leaves
-(tile_lists.h sort_tile_rows: rows ranked by the faces their tiles list, ties by row) -- or, without it, from the middle of
-the image outwards.  Restated in Python and checked for what correctness needs -- every (view, tile) exactly once -- and
-for what the order is for: heavy rows first whatever the object's position.  The GPU test reads the order a forward pass
-left behind."""
+KAMD_RBWD_ORDER): views interleaved, a view's tile rows visited outwards from a centre row -- the middle of the rows the
+mesh's boxes cover, which the binning launch leaves per view (tile_lists.h note_row_span / row_centre / row_from_centre), or
+the middle of the image.  Restated in Python and checked for what correctness needs -- every (view, tile) exactly once --
+and for what the order is for: the rows come in non-decreasing distance from the centre until one side of the image is
+used up.  The GPU test reads the centre a forward pass left behind."""
 import pytest
 import torch
 
 
-def rank_rows(row_work):
-    """sort_tile_rows for one view: order[rank] = row, rank = rows with more work (or as much and a smaller index)."""
-    n = len(row_work)
-    order = [None] * n
-    for r in range(n):
-        rank = sum(1 for q in range(n) if row_work[q] > row_work[r] or (row_work[q] == row_work[r] and q < r))
-        order[rank] = r
-    return order
+def row_from_centre(k, c, tiles_y):
+    """tile_lists.h row_from_centre: c, c - 1, c + 1, c - 2, ... and, once one side is used up, on along the other."""
+    left, right = c, tiles_y - 1 - c
+    m = min(left, right)
+    if k <= 2 * m:
+        return c - ((k + 1) >> 1) if k & 1 else c + (k >> 1)
+    return k if right > left else tiles_y - 1 - k
 
 
-def tile_of(block, B, tiles_x, tiles_y, columns_too=False, row_order=None):
+def tile_of(block, B, tiles_x, tiles_y, columns_too=False, centres=None):
     b, k = block % B, block // B
     kr, tx = k // tiles_x, k % tiles_x
-    mid = tiles_y >> 1
-    ty = mid - ((kr + 1) >> 1) if kr & 1 else mid + (kr >> 1)
-    if row_order is not None:
-        ty = row_order[b][kr]
+    ty = row_from_centre(kr, tiles_y >> 1 if centres is None else centres[b], tiles_y)
     if columns_too:
         midx = tiles_x >> 1
         tx = midx - ((tx + 1) >> 1) if tx & 1 else midx + (tx >> 1)
@@ -56,28 +52,25 @@ def test_rows_leave_the_middle_monotonically(tiles_y):
     assert [b for b, _ in first] == [0, 1, 0, 1] and first[0][1] == first[1][1] and first[2][1] == first[0][1] + 1
 
 
-@pytest.mark.parametrize('seed', [0, 1, 2])
-@pytest.mark.parametrize('B,tiles_x,tiles_y', [(1, 3, 1), (2, 4, 7), (8, 64, 64), (3, 5, 256)])
-def test_data_driven_row_order_is_a_bijection_heaviest_first(B, tiles_x, tiles_y, seed):
-    g = torch.Generator().manual_seed(seed)
-    work = torch.randint(0, 5, (B, tiles_y), generator=g) * torch.randint(0, 2, (B, tiles_y), generator=g)   # many ties and zeros
-    order = [rank_rows(work[b].tolist()) for b in range(B)]
-    for b in range(B):
-        assert sorted(order[b]) == list(range(tiles_y))
-        w = [int(work[b, r]) for r in order[b]]
-        assert w == sorted(w, reverse=True)
-        assert all(order[b][i] < order[b][i + 1] for i in range(tiles_y - 1) if w[i] == w[i + 1])    # ties keep the row order
-    n = tiles_x * tiles_y
-    seen = {tile_of(block, B, tiles_x, tiles_y, row_order=order) for block in range(B * n)}
-    assert len(seen) == B * n
+@pytest.mark.parametrize('tiles_y', [1, 2, 3, 8, 63, 64])
+def test_rows_from_any_centre_are_a_bijection_in_order_of_distance(tiles_y):
+    for c in range(tiles_y):
+        rows = [row_from_centre(k, c, tiles_y) for k in range(tiles_y)]
+        assert sorted(rows) == list(range(tiles_y)) and rows[0] == c
+        dist = [abs(r - c) for r in rows]
+        assert dist == sorted(dist)
+    B, tiles_x = 3, 5
+    centres = [0, tiles_y - 1, tiles_y // 3]
+    seen = {tile_of(block, B, tiles_x, tiles_y, centres=centres) for block in range(B * tiles_x * tiles_y)}
+    assert len(seen) == B * tiles_x * tiles_y
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('shift', [(0., 0.), (0.5, -0.55), (-0.3, 0.9)])
-def test_forward_leaves_a_row_order_that_starts_where_the_object_is(shift):
-    """dibr_rasterization's binning launch ranks every view's 16-pixel tile rows by the faces their tiles list and leaves
-    the order in the operator's work buffer (what raster_tile / raster_backward follow): a permutation per view, and every
-    row that holds a covered pixel comes before every row no face box reaches -- wherever the object sits."""
+def test_forward_starts_where_the_object_is(shift):
+    """dibr_rasterization's binning launch notes, per view, the tile rows the kept faces' boxes cover; the tile kernel starts
+    from the middle of them and leaves that row in the operator's work buffer for the backward pass.  Wherever the object
+    sits, the centre row must lie inside the rows that hold covered pixels (give or take the boxes' slack)."""
     import kaolin_amd as kal
     from kaolin_amd.utils import testing as T
     fz, fimg, feats, nz = T.sphere_scene(level=12, num_views=3, device='cuda')
@@ -91,24 +84,14 @@ def test_forward_leaves_a_row_order_that_starts_where_the_object_is(shift):
     lib = kal._lib.load()
     assert work.numel() == lib.kamd_dibr_soft_mask_work_words(B, H, W)
     n_groups = B * tiles_x * tiles_y
-    off = kal._C.render.mesh.WORK_HEADER + 8 * (4 * ((n_groups + 7) // 8)) * 4 + (n_groups + 3) // 4         # header, items, coverage bytes (tile_lists.h)
-    order = work[off:off + (B * tiles_y + 1) // 2].view(torch.int16)[:B * tiles_y].view(B, tiles_y).long().cpu()
+    off = kal._C.render.mesh.WORK_HEADER + 8 * (4 * ((n_groups + 7) // 8)) * 4 + (n_groups + 3) // 4   # header, items, coverage bytes
+    centres = work[off:off + B].tolist()
     covered_rows = (face_idx >= 0).any(dim=2).cpu()                                  # (B, H)
     for b in range(B):
-        assert sorted(order[b].tolist()) == list(range(tiles_y))
-        has_cov = [bool(covered_rows[b, r * 16:(r + 1) * 16].any()) for r in range(tiles_y)]
-        n_cov = sum(has_cov)
-        if n_cov == 0:
-            continue
-        # the scaled boxes of the faces: rows no box comes near have no work and must all come after the covered rows
-        first = set(order[b, :n_cov].tolist())
-        ys = fimg[b, :, :, 1]
-        lo, hi = float(ys.min()), float(ys.max())
-        reach = [r for r in range(tiles_y) if not ((H - 1 - (hi + 0.05) * H) / 2 > (r + 1) * 16 or (H - 1 - (lo - 0.05) * H) / 2 < r * 16 - 1)]
-        assert all(has_cov[r] or r in reach for r in first)
-        assert all(order[b, i] in reach for i in range(n_cov)), 'a row without any face ranked among the heaviest'
-        pos = {int(r): i for i, r in enumerate(order[b].tolist())}
-        unreached = [r for r in range(tiles_y) if r not in reach]
-        assert all(pos[c] < pos[u] for c in range(tiles_y) if has_cov[c] for u in unreached)
-    (out.sum() + soft.sum()).backward()          # the backward follows the same order: must simply work
+        assert 0 <= centres[b] < tiles_y
+        rows = [r for r in range(tiles_y) if bool(covered_rows[b, r * 16:(r + 1) * 16].any())]
+        if rows:
+            assert rows[0] - 1 <= centres[b] <= rows[-1] + 1, (centres[b], rows)
+            assert abs(centres[b] - (rows[0] + rows[-1]) / 2) <= 1.5
+    (out.sum() + soft.sum()).backward()          # the backward starts from the same rows: must simply work
     assert torch.isfinite(a.grad).all()
