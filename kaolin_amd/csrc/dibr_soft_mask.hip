@@ -122,28 +122,6 @@ inline int fill_edges(hipStream_t st, void* p, size_t bytes, int v, FillPlan* pl
 }
 
 #include "soft2.inc"
-#include "raster_backward.inc"
-
-// ---- the fused dibr_rasterization backward: both backward passes in ONE launch ------------------------------------------------
-// The rasterizer's backward (one workgroup per 16 x 16 tile, most of which leave at once) and the soft mask's (persistent
-// workgroups streaming the flat hit list) are independent and accumulate atomically into the same g_img.  As two launches
-// they run one after the other (48 + 55 us at C4; side by side on two streams the fork / join events cost what the overlap
-// saved).  Here every `period`-th workgroup is one of the n_flat streaming workgroups and the others take the tiles in
-// order, so that both kinds are resident together from the first wave of workgroups on.
-template <typename T, int DT, bool GF>
-__global__ __launch_bounds__(256) void dibr_backward_fused_kernel(RasterBwdArgs<T> ra, FlatBwdArgs<T> fa, unsigned int n_flat,
-                                                                  unsigned int period) {
-  const unsigned int i = blockIdx.x, mixed = n_flat * period;
-  if (i < mixed) {
-    const unsigned int g = i / period, r = i - g * period;
-    if (r == 0u)
-      soft_backward_flat_body<T>(g, n_flat, fa);
-    else
-      raster_backward_body<T, DT, GF>(g * (period - 1u) + (r - 1u), ra);
-  } else {
-    raster_backward_body<T, DT, GF>(n_flat * (period - 1u) + (i - mixed), ra);
-  }
-}
 
 // ---- K4 ---------------------------------------------------------------------------------------------------
 // One 64-lane workgroup per 16x4-pixel sub-tile.  The reference adds every (pixel, hit) contribution to the
@@ -432,9 +410,8 @@ int soft_mask_backward_list_launch(hipStream_t st, int B, int H, int W, int F, i
     kamd::ProfScope prof_(kamd::K_SOFT_BACKWARD_LIST, st);
     // persistent workgroups over the rounds of 256 hits (their number is known on the device only)
     static const int per_cu = kamd_env_int("KAMD_SOFT_BWD_PER_CU", 16);
-    const FlatBwdArgs<T> fa{H, W, F, 1.0f / (float)F, grad, soft_mask, list, img, (T)img_scale, sigmainv, multiplier, g_img,
-                            kamd_env_int("KAMD_BWD_MODE", 0)};
-    hipLaunchKernelGGL(soft_mask_backward_flat_kernel<T>, dim3(KAMD_NUM_CU * per_cu), dim3(256), 0, st, fa);
+    hipLaunchKernelGGL(soft_mask_backward_flat_kernel<T>, dim3(KAMD_NUM_CU * per_cu), dim3(256), 0, st, H, W, F, 1.0f / (float)F,
+                       grad, soft_mask, list, img, (T)img_scale, sigmainv, multiplier, g_img, kamd_env_int("KAMD_BWD_MODE", 0));
   }
   KAMD_RETURN_LAST_ERROR();
 }
@@ -569,32 +546,6 @@ int dibr_backward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K
                                       ? reinterpret_cast<const unsigned char*>(work + tl::work_cov_offset_words(B, H, W))
                                       : nullptr;
   const unsigned int* row_centre = F > 0 ? work + tl::work_centre_offset_words(B, H, W) : nullptr;
-  // one launch for both (KAMD_BWD_FUSED=2: two launches, for A/B runs and for timing each kernel alone)
-  if (kamd_env_int("KAMD_BWD_FUSED", 1) == 1 && !use_side && (long long)B * H * W > 0 && F > 0) {
-    static const int per_cu = kamd_env_int("KAMD_SOFT_BWD_PER_CU", 16);
-    const unsigned int n_flat = (unsigned int)(KAMD_NUM_CU * per_cu);
-    const unsigned int n_rb = (unsigned int)(B * ((W + 15) / 16) * ((H + 15) / 16));
-    const unsigned int period = n_rb / n_flat + 1u;  // n_flat * (period - 1) <= n_rb
-    const RasterBwdArgs<T> ra{B, H, W, F, D, grad_feat, face_idx, weights, img, feat, eps, g_img, g_feat, tile_cov, row_centre};
-    const FlatBwdArgs<T> fa{H, W, F, 1.0f / (float)F, grad_soft, soft_mask, list, img, (T)multiplier, sigmainv, (float)multiplier, g_img,
-                            kamd_env_int("KAMD_BWD_MODE", 0)};
-    const dim3 grid(n_rb + n_flat);
-    kamd::ProfScope prof_(kamd::K_DIBR_BACKWARD, st);
-#define KAMD_FB(DT)                                                                                                   \
-  if (g_feat != nullptr)                                                                                              \
-    hipLaunchKernelGGL((dibr_backward_fused_kernel<T, DT, true>), grid, dim3(256), 0, st, ra, fa, n_flat, period);   \
-  else                                                                                                                \
-    hipLaunchKernelGGL((dibr_backward_fused_kernel<T, DT, false>), grid, dim3(256), 0, st, ra, fa, n_flat, period)
-    switch (D) {
-      case 1: KAMD_FB(1); break;
-      case 2: KAMD_FB(2); break;
-      case 3: KAMD_FB(3); break;
-      case 4: KAMD_FB(4); break;
-      default: KAMD_FB(0); break;
-    }
-#undef KAMD_FB
-    KAMD_RETURN_LAST_ERROR();
-  }
   if (!use_side || kamd::prof_all()) {
     KAMD_CHECK(soft_mask_backward_list_launch<T>(st, B, H, W, F, K, grad_soft, soft_mask, list, work, img, multiplier, sigmainv,
                                                  (float)multiplier, g_img));

@@ -27,7 +27,186 @@ using namespace kamd;
 
 #include "raster2.inc"
 
-#include "raster_backward.inc"
+// ---- K2 -------------------------------------------------------------------------------------------------
+// Per covered pixel the reference issues 3*D + 6*D float atomics on addresses shared by every pixel of the same
+// face (rasterization_cuda.cu:283,391-398): the run time is atomic contention (measured 2.4 ms for C4).  Here a
+// workgroup owns a 16x16-pixel block: every lane computes its pixel's 6 + 3*D contributions, finds / creates its
+// face's slot in an LDS hash table (one compare-and-swap) and adds them there with non-returning LDS atomics
+// (ds_add_f32: nothing to wait for); at the end one global atomic per touched (face, value) is issued.
+constexpr int RB_HT = 256;  // hash slots = pixels per block: every face finds a slot (linear probing terminates)
+
+// numerators of d(w1)/d(.) and d(w2)/d(.) for the six vertex coordinates (ax, ay, bx, by, cx, cy), and k3
+// (rasterization_cuda.cu:287-371); the common 1/k3^2 is applied by the caller
+template <typename T>
+__device__ __forceinline__ T barycentric_jacobian(const T* v, T aw, T bw, T cw, float eps, T* dw1, T* dw2) {
+  const T ax = v[0], ay = v[1], bx = v[2], by = v[3], cx = v[4], cy = v[5];
+  const T x0 = aw * ax + bw * bx + cw * cx;
+  const T y0 = aw * ay + bw * by + cw * cy;
+  const T m = bx - ax, p = by - ay, n = cx - ax, q = cy - ay, s = x0 - ax, t = y0 - ay;
+  const T k1 = s * q - n * t;
+  const T k2 = m * t - s * p;
+  T k3 = m * q - n * p;
+  k3 = (T)((double)k3 + copysign((double)eps, (double)k3));
+  // dk_i * k3 - dk3 * k_i with the reference's explicit zero terms kept (0 * k3 - q * k1 ...)
+  const T zero = 0;
+  const T dw1dm = zero * k3 - q * k1, dw1dn = (-t) * k3 - (-p) * k1;
+  const T dw1dp = zero * k3 - (-n) * k1, dw1dq = s * k3 - m * k1;
+  const T dw1ds = q * k3 - zero * k1, dw1dt = (-n) * k3 - zero * k1;
+  const T dw2dm = t * k3 - q * k2, dw2dn = zero * k3 - (-p) * k2;
+  const T dw2dp = (-s) * k3 - (-n) * k2, dw2dq = zero * k3 - m * k2;
+  const T dw2ds = (-p) * k3 - zero * k2, dw2dt = m * k3 - zero * k2;
+  dw1[0] = -(dw1dm + dw1dn + dw1ds);
+  dw1[1] = -(dw1dp + dw1dq + dw1dt);
+  dw1[2] = dw1dm;
+  dw1[3] = dw1dp;
+  dw1[4] = dw1dn;
+  dw1[5] = dw1dq;
+  dw2[0] = -(dw2dm + dw2dn + dw2ds);
+  dw2[1] = -(dw2dp + dw2dq + dw2dt);
+  dw2[2] = dw2dm;
+  dw2[3] = dw2dp;
+  dw2[4] = dw2dn;
+  dw2[5] = dw2dq;
+  return k3;
+}
+
+#ifndef KAMD_RBWD_ORDER
+#define KAMD_RBWD_ORDER 1  // workgroup order of the backward: 1 = views interleaved, tile rows from the middle of the image outwards
+#endif                     // (as the forward's tile kernel; 0 = view-major, row-major: 49.4 vs 45.4 us at C4, 9 us of the step with feature gradients)
+// DT > 0: feature count known at compile time (block-merged through LDS); DT == 0: any D, per-lane global atomics.
+// GF = false: the caller does not need d/d(face_features) (static texture coordinates, the usual DIB-R set-up): only the
+// 6 image-coordinate values per face are merged instead of 6 + 3*D -- 2.5x fewer DPP merges and LDS atomics at D = 3.
+template <typename T, int DT, bool GF>
+__global__ __launch_bounds__(256) void raster_backward_kernel(
+    int B, int H, int W, int F, int D, const T* __restrict__ grad, const int64_t* __restrict__ face_idx,
+    const T* __restrict__ weights, const T* __restrict__ img, const T* __restrict__ feat, float eps,
+    T* __restrict__ g_img, T* __restrict__ g_feat, const unsigned char* __restrict__ tile_cov,
+    const unsigned int* __restrict__ row_centre) {
+  // (fused dibr_rasterization: the forward pass noted which tiles hold a covered pixel -- 85 % of C4's do not, and
+  // finding that out from face_idx costs a 2-KB read and a barrier per workgroup: 24 of this kernel's 60 us)
+  // workgroup = 16x16 pixels of one image; wavefront = 16x4
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+#if KAMD_RBWD_ORDER
+  // views interleaved, a view's tile rows in the forward pass' order (outwards from the middle of the covered rows; without
+  // it: of the image): the workgroups that find covered pixels start first
+  const int b = blockIdx.x % B, k_ = blockIdx.x / B, kr_ = k_ / tiles_x;
+  const int c_ = row_centre != nullptr ? min((int)row_centre[b], tiles_y - 1) : (tiles_y >> 1);
+  const int tile = tl::row_from_centre(kr_, c_, tiles_y) * tiles_x + (k_ - kr_ * tiles_x);
+#else
+  const int tile = blockIdx.x % (tiles_x * tiles_y), b = blockIdx.x / (tiles_x * tiles_y);
+#endif
+  if (tile_cov != nullptr && tile_cov[(size_t)b * (tiles_x * tiles_y) + tile] == 0) return;
+  constexpr int NV = (DT > 0 && GF) ? 6 + 3 * DT : 6;
+  __shared__ int s_key[DT > 0 ? RB_HT : 1];
+  __shared__ T s_acc[DT > 0 ? RB_HT * NV : 1];
+  __shared__ int s_used[DT > 0 ? 256 : 1];
+  __shared__ int s_nused;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = (tile % tiles_x) * 16 + (lane & 15), row = (tile / tiles_x) * 16 + wave * 4 + (lane >> 4);
+  const bool in_image = col < W && row < H;
+  const size_t tp = ((size_t)b * H + row) * W + col;
+  const int f = in_image ? (int)face_idx[tp] : -1;
+  if (DT > 0) {
+    if (!__syncthreads_or(f >= 0)) return;  // nothing covered in this block
+    for (int i = threadIdx.x; i < RB_HT; i += 256) s_key[i] = -1;
+    for (int i = threadIdx.x; i < RB_HT * NV; i += 256) s_acc[i] = 0;
+    if (threadIdx.x == 0) s_nused = 0;
+    __syncthreads();
+  }
+  T vals[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) vals[i] = 0;
+  if (f >= 0) {
+    const size_t tf = (size_t)b * F + (size_t)f;
+    const T aw = weights[tp * 3 + 0], bw = weights[tp * 3 + 1], cw = weights[tp * 3 + 2];
+    T dw1[6], dw2[6];
+    const T k3 = barycentric_jacobian<T>(img + tf * 6, aw, bw, cw, eps, dw1, dw2);
+    const T* ff = feat + tf * 3 * D;
+    const T* g = grad + tp * D;
+    const int nd = DT > 0 ? DT : D;
+    for (int d = 0; d < nd; ++d) {
+      const T gd = g[d];
+      const T c0 = ff[d], c1 = ff[D + d], c2 = ff[2 * D + d];
+      const T dldI = gd / (k3 * k3);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) vals[j] += (T)(dldI * ((c1 - c0) * dw1[j] + (c2 - c0) * dw2[j]));
+      if constexpr (!GF) {
+      } else if constexpr (DT > 0) {
+        vals[6 + d] = (T)(gd * aw);
+        vals[6 + DT + d] = (T)(gd * bw);
+        vals[6 + 2 * DT + d] = (T)(gd * cw);
+      } else {
+        kamd_atomic_add(g_feat + (tf * 3 + 0) * D + d, (T)(gd * aw));
+        kamd_atomic_add(g_feat + (tf * 3 + 1) * D + d, (T)(gd * bw));
+        kamd_atomic_add(g_feat + (tf * 3 + 2) * D + d, (T)(gd * cw));
+      }
+    }
+    if constexpr (DT == 0) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) kamd_atomic_add(g_img + tf * 6 + j, vals[j]);
+    }
+  }
+  if constexpr (DT > 0) {
+    // Pixels of one face are neighbours: in lane order (16 per row) they form runs.  A segmented inclusive scan sums
+    // every run (6 shuffle steps per value), and only the LAST lane of a run touches the LDS table: same-address LDS
+    // atomics were 56 % of this kernel's wave time (SQ_WAIT_INST_LDS) when every lane added on its own.
+    if (__ballot(f >= 0) != 0ull) {
+    // rows of 16 lanes = 16 horizontally adjacent pixels: runs are merged inside a row with DPP row shifts (register
+    // moves).  The 64-lane version went through ds_bpermute: 96 LDS-crossbar operations per wavefront, and this kernel
+    // spent 42 % of its wave cycles waiting on LDS (SQ_WAIT_INST_LDS).
+    const int rl = lane & 15;
+    const int prev_f = row_shr<1>(f);
+    const int next_f = row_shl<1>(f);
+    const bool run_start = rl == 0 || prev_f != f;
+    int start_lane = run_start ? rl : 0;
+    {
+      int o;
+      o = row_shr<1>(start_lane); if (rl >= 1) start_lane = max(start_lane, o);
+      o = row_shr<2>(start_lane); if (rl >= 2) start_lane = max(start_lane, o);
+      o = row_shr<4>(start_lane); if (rl >= 4) start_lane = max(start_lane, o);
+      o = row_shr<8>(start_lane); if (rl >= 8) start_lane = max(start_lane, o);
+    }
+#define KAMD_RB_STAGE(DD)                                        \
+    {                                                            \
+      const bool take = rl >= DD && start_lane <= rl - DD;       \
+      _Pragma("unroll") for (int i = 0; i < NV; ++i) {           \
+        const T o = row_shr<DD>(vals[i]);                        \
+        if (take) vals[i] += o;                                  \
+      }                                                          \
+    }
+    KAMD_RB_STAGE(1)
+    KAMD_RB_STAGE(2)
+    KAMD_RB_STAGE(4)
+    KAMD_RB_STAGE(8)
+#undef KAMD_RB_STAGE
+    const bool run_end = rl == 15 || next_f != f;
+    if (f >= 0 && run_end) {
+      int slot = (int)(((unsigned)f * 2654435761u) >> 24) & (RB_HT - 1);
+      for (;;) {  // at most 256 distinct faces for 256 slots: an empty slot always exists
+        const int k = atomicCAS(&s_key[slot], -1, f);
+        if (k == -1) s_used[atomicAdd(&s_nused, 1)] = slot;
+        if (k == -1 || k == f) break;
+        slot = (slot + 1) & (RB_HT - 1);
+      }
+#pragma unroll
+      for (int i = 0; i < NV; ++i) atomicAdd(&s_acc[slot * NV + i], vals[i]);
+    }
+    }
+  }
+  if constexpr (DT > 0) {
+    __syncthreads();
+    const int nused = s_nused;
+    for (int i = threadIdx.x; i < nused * NV; i += 256) {
+      const int slot = s_used[i / NV], v = i % NV;
+      const size_t tf = (size_t)b * F + (size_t)s_key[slot];
+      const T val = s_acc[slot * NV + v];
+      if (v < 6)
+        kamd_atomic_add(g_img + tf * 6 + v, val);
+      else if constexpr (GF)
+        kamd_atomic_add(g_feat + tf * 3 * D + (v - 6), val);
+    }
+  }
+}
 
 template <typename T>
 int rasterize_forward_launch(hipStream_t st, int B, int H, int W, int D, int64_t total_faces, const T* z, const T* img,
@@ -88,12 +267,13 @@ int rasterize_backward_launch(hipStream_t st, int B, int H, int W, int F, int D,
   if (total <= 0 || F <= 0) return 0;
   const dim3 grid((unsigned)(B * ((W + 15) / 16) * ((H + 15) / 16)));
   kamd::ProfScope prof_(kamd::K_RASTER_BACKWARD, st);
-  const RasterBwdArgs<T> ra{B, H, W, F, D, grad, face_idx, weights, img, feat, eps, g_img, g_feat, tile_cov, row_centre};
-#define KAMD_RB(DT)                                                                                  \
-  if (g_feat != nullptr)                                                                             \
-    hipLaunchKernelGGL((raster_backward_kernel<T, DT, true>), grid, dim3(256), 0, st, ra);           \
-  else                                                                                               \
-    hipLaunchKernelGGL((raster_backward_kernel<T, DT, false>), grid, dim3(256), 0, st, ra)
+#define KAMD_RB(DT)                                                                                                   \
+  if (g_feat != nullptr)                                                                                              \
+    hipLaunchKernelGGL((raster_backward_kernel<T, DT, true>), grid, dim3(256), 0, st, B, H, W, F, D, grad, face_idx,  \
+                       weights, img, feat, eps, g_img, g_feat, tile_cov, row_centre);                                 \
+  else                                                                                                                \
+    hipLaunchKernelGGL((raster_backward_kernel<T, DT, false>), grid, dim3(256), 0, st, B, H, W, F, D, grad, face_idx, \
+                       weights, img, feat, eps, g_img, g_feat, tile_cov, row_centre)
   switch (D) {
     case 1: KAMD_RB(1); break;
     case 2: KAMD_RB(2); break;

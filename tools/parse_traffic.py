@@ -10,7 +10,6 @@ OURS = {'bin_faces_kernel': r'bin_faces_kernel2', 'raster_tile_kernel': r'raster
         'soft_items_kernel': r'soft_items_kernel', 'soft_select_kernel': r'soft_select_kernel', 'soft_eval_kernel': r'soft_eval_kernel',
         'soft_mask_backward_list_kernel': r'soft_mask_backward_(list_kernel2|flat_kernel)', 'pv_forward_kernel': r'pv_forward_kernel',
         'pv_backward_kernel': r'pv_backward_kernel', 'fill_regions_kernel': r'fill_regions_kernel',
-        'dibr_backward_fused_kernel': r'dibr_backward_fused_kernel',
         'weighted_sum2_kernels': r'weighted_sum2_(partial|backward)_kernel'}   # (the forward's one-workgroup finish: 'other')
 
 
