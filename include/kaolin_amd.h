@@ -78,6 +78,10 @@ int kamd_sided_distance_pair_forward_f32(void* stream, int B, int N, int M,
                                          const float* p1, const float* p2,
                                          float* dist1, int64_t* idx1,
                                          float* dist2, int64_t* idx2, void* workspace);
+int kamd_sided_distance_pair_forward_f64(void* stream, int B, int N, int M,
+                                         const double* p1, const double* p2,
+                                         double* dist1, int64_t* idx1,
+                                         double* dist2, int64_t* idx2, void* workspace);
 
 /* Gradient of chamfer_distance (kaolin/metrics/pointcloud.py:120-136) w.r.t.   */
 /* both clouds in one launch: grad (B) is the gradient of the (B) result; the    */

@@ -49,7 +49,7 @@ def sided_distance_pair_forward(p1, p2):
     batch_size, num_p1, num_p2 = p1.size(0), p1.size(1), p2.size(1)
     check_size(fn, p1_arg, [batch_size, num_p1, 3])
     check_size(fn, p2_arg, [batch_size, num_p2, 3])
-    if p1.dtype != torch.float32:
+    if p1.dtype not in (torch.float32, torch.float64):
         return None
     lib = _lib.load()
     nbytes = lib.kamd_sided_distance_pair_forward_workspace(batch_size, num_p1, num_p2, p1.element_size())
@@ -61,7 +61,8 @@ def sided_distance_pair_forward(p1, p2):
         dist2 = torch.empty((batch_size, num_p2), dtype=p1.dtype, device=p1.device)
         idx2 = torch.empty((batch_size, num_p2), dtype=torch.long, device=p1.device)
         ws = _lib.workspace(nbytes, p1.device)
-        st = lib.kamd_sided_distance_pair_forward_f32(
+        run = lib.kamd_sided_distance_pair_forward_f32 if p1.dtype == torch.float32 else lib.kamd_sided_distance_pair_forward_f64
+        st = run(
             _lib.stream_ptr(p1.device), batch_size, num_p1, num_p2, _lib.ptr(p1), _lib.ptr(p2),
             _lib.ptr(dist1), _lib.ptr(idx1), _lib.ptr(dist2), _lib.ptr(idx2), _lib.ptr(ws))
     _lib.check(st, fn)

@@ -33,6 +33,7 @@ SIGNATURES = {
     'kamd_chamfer_distance_forward_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'kamd_chamfer_distance_backward_fused_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'kamd_sided_distance_pair_forward_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'kamd_sided_distance_pair_forward_f64': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'kamd_rasterize_forward_workspace': (_sz, [_i, _i, _i, _i64, _i]),
     'kamd_dibr_soft_mask_forward_workspace': (_sz, [_i, _i, _i, _i, _i, _i]),
     'kamd_triangle_distance_forward_workspace': (_sz, [_i, _i, _i]),

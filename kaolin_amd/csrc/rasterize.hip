@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(
   // views interleaved, a view's tile rows in the forward pass' order (outwards from the middle of the covered rows; without
   // it: of the image): the workgroups that find covered pixels start first
   const int b = blockIdx.x % B, k_ = blockIdx.x / B, kr_ = k_ / tiles_x;
-  const int c_ = row_centre != nullptr ? min((int)row_centre[b], tiles_y - 1) : (tiles_y >> 1);
+  const int c_ = row_centre != nullptr ? (int)min(row_centre[b], (unsigned int)(tiles_y - 1)) : (tiles_y >> 1);  // (any row in range gives a bijection)
   const int tile = tl::row_from_centre(kr_, c_, tiles_y) * tiles_x + (k_ - kr_ * tiles_x);
 #else
   const int tile = blockIdx.x % (tiles_x * tiles_y), b = blockIdx.x / (tiles_x * tiles_y);

@@ -407,8 +407,9 @@ inline bool sd_force_brute() {
 extern "C" {
 
 size_t kamd_sided_distance_forward_workspace(int B, int N, int M, int elem_size) {
-  if (elem_size != 4 || B <= 0 || N <= 0 || M <= 0) return 0;
-  if (kamd::sdgrid_applicable(B, N, M) && !sd_force_brute()) return kamd::sdgrid_workspace_bytes(B, N, M);
+  if ((elem_size != 4 && elem_size != 8) || B <= 0 || N <= 0 || M <= 0) return 0;
+  if (kamd::sdgrid_applicable(B, N, M) && !sd_force_brute()) return kamd::sdgrid_workspace_bytes(B, N, M, elem_size);
+  if (elem_size != 4) return 0;
   SdPlan p = sd_plan(B, N, M);
   if (!p.fast) return 0;
   return (size_t)p.S * B * N * (sizeof(float) + sizeof(int));
@@ -438,8 +439,13 @@ int kamd_sided_distance_forward_f32(void* stream, int B, int N, int M, const flo
 }
 
 size_t kamd_sided_distance_pair_forward_workspace(int B, int N, int M, int elem_size) {
-  if (elem_size != 4 || !kamd::sdgrid_pair_applicable(B, N, M) || sd_force_brute()) return 0;
-  return kamd::sdgrid_pair_workspace_bytes(B, N, M);
+  if ((elem_size != 4 && elem_size != 8) || !kamd::sdgrid_pair_applicable(B, N, M) || sd_force_brute()) return 0;
+  return kamd::sdgrid_pair_workspace_bytes(B, N, M, elem_size);
+}
+int kamd_sided_distance_pair_forward_f64(void* stream, int B, int N, int M, const double* p1, const double* p2,
+                                         double* dist1, int64_t* idx1, double* dist2, int64_t* idx2, void* workspace) {
+  if (workspace == nullptr || !kamd::sdgrid_pair_applicable(B, N, M)) return (int)hipErrorInvalidValue;
+  return kamd::sdgrid_pair_forward_f64((hipStream_t)stream, B, N, M, p1, p2, dist1, idx1, dist2, idx2, workspace);
 }
 
 int kamd_sided_distance_pair_forward_f32(void* stream, int B, int N, int M, const float* p1, const float* p2,
@@ -485,7 +491,10 @@ int kamd_chamfer_distance_backward_fused_f32(void* stream, int B, int N, int M, 
 
 int kamd_sided_distance_forward_f64(void* stream, int B, int N, int M, const double* p1, const double* p2,
                                     double* dist, int64_t* idx, void* workspace) {
-  (void)workspace;
+  if (B <= 0 || N <= 0 || M <= 0) return 0;
+  // large clouds: the exact grid search (the grid itself lives in float, distances are the reference's double expression)
+  if (workspace != nullptr && kamd::sdgrid_applicable(B, N, M) && !sd_force_brute())
+    return kamd::sdgrid_forward_f64((hipStream_t)stream, B, N, M, p1, p2, dist, idx, workspace);
   return sd_forward_generic_launch<double>((hipStream_t)stream, B, N, M, p1, p2, dist, idx);
 }
 

@@ -1,4 +1,4 @@
-// sided_distance forward, exact uniform-grid search (fp32) for MI355X (gfx950).
+// sided_distance forward, exact uniform-grid search (fp32 and fp64) for MI355X (gfx950).
 //
 // The reference (kaolin/csrc/metrics/sided_distance_cuda.cu:52-201) is an all-pairs search: N*M distance
 // evaluations against 24*(N+M) bytes of input, 8 300 FLOP/B at 100k x 100k -- VALU-bound by construction
@@ -26,6 +26,11 @@
 // (tests/test_sided_distance.py compares both with the oracle, incl. duplicates, NaNs, queries outside the box,
 // degenerate boxes).  Non-finite targets are binned at a clamped cell: they yield NaN/inf distances that can never win
 // against a finite one, as in the reference.
+// fp64 clouds (the reference dispatches half / float / double: sided_distance_cuda.cu:252) use the same pipeline: the GRID is
+// only an acceleration structure, so points are binned by their coordinates rounded to float (a monotone map: build and query
+// agree on every cell), the sorted copy keeps the doubles, every distance is the reference's double expression, and the
+// geometric bound's head-room (67 float ulps) covers the rounding of the coordinates it is computed from.  A query whose
+// coordinates do not fit a float walks all targets (exact, slow, rare).
 #include "common.h"
 #include "profile.h"
 #include "sided_distance_grid.h"
@@ -43,16 +48,41 @@ inline int sdg_cells_per_axis(int M) {
 }
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
+template <typename T> struct Vec4Of;
+template <> struct Vec4Of<float> { typedef float4 type; };
+template <> struct Vec4Of<double> { typedef double4 type; };
+// the original index travels in the fourth component of a sorted point
+__device__ __forceinline__ float sdg_pack_idx(int i, float) { return __int_as_float(i); }
+__device__ __forceinline__ double sdg_pack_idx(int i, double) { return __hiloint2double(0, i); }
+__device__ __forceinline__ int sdg_unpack_idx(float w) { return __float_as_int(w); }
+__device__ __forceinline__ int sdg_unpack_idx(double w) { return __double2loint(w); }
+
 // one cloud of the pipeline (kernel argument, by value)
-struct Cloud {
+template <typename T>
+struct CloudT {
+  typedef typename Vec4Of<T>::type V4;
   int n, G;             // points per batch item; cells per axis of the grid it is binned on
-  const float* pts;     // (B, n, 3)
-  unsigned int* box;    // (B, 8) encoded {lo[3], hi[3]} of the grid's box, 0 = no finite point yet
+  const T* pts;         // (B, n, 3)
+  unsigned int* box;    // (B, 8) encoded {lo[3], hi[3]} of the grid's box (floats), 0 = no finite point yet
   int* count;           // (B, G^3) zero before the build
   int* start;           // (B, G^3 + 1)
   int2* cellrank;       // (B, n) {cell, rank inside the cell}
-  float4* sorted;       // (B, n) {x, y, z, original index} in cell order
+  V4* sorted;           // (B, n) {x, y, z, original index} in cell order
 };
+typedef CloudT<float> Cloud;
+template <typename T>
+inline CloudT<T> cloud_as(const Cloud& c) {  // (the layout below is laid out by element size; the pointers are retyped)
+  CloudT<T> r;
+  r.n = c.n;
+  r.G = c.G;
+  r.pts = reinterpret_cast<const T*>(c.pts);
+  r.box = c.box;
+  r.count = c.count;
+  r.start = c.start;
+  r.cellrank = c.cellrank;
+  r.sorted = reinterpret_cast<typename Vec4Of<T>::type*>(c.sorted);
+  return r;
+}
 
 // what chamfer_distance adds to the search (SDG_VALUE / SDG_GRAD): everything the value and the gradient need is
 // produced by the query launch itself
@@ -84,14 +114,14 @@ constexpr int SDG_BUILD_THREADS = KAMD_SDG_BUILD_THREADS;  // workgroup of the b
 inline size_t sdg_partials(int B) { return (size_t)2 * B > 8192 ? (size_t)2 * B : 8192; }
 
 // pair = false: sided_distance(p1, p2): both clouds on p2's grid.  pair = true: each cloud on its own grid.
-inline SdgWs sdg_layout(void* base, int B, int N, int M, const float* p1, const float* p2, bool pair, int mode) {
+inline SdgWs sdg_layout(void* base, int B, int N, int M, const void* p1, const void* p2, bool pair, int mode, int esz = 4) {
   SdgWs w;
   w.b.n = M;
   w.b.G = sdg_cells_per_axis(M);
-  w.b.pts = p2;
+  w.b.pts = (const float*)p2;
   w.a.n = N;
   w.a.G = pair ? sdg_cells_per_axis(N) : w.b.G;
-  w.a.pts = p1;
+  w.a.pts = (const float*)p1;
   char* p = (char*)base;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -120,8 +150,8 @@ inline SdgWs sdg_layout(void* base, int B, int N, int M, const float* p1, const 
   w.a.start = (int*)take((size_t)B * (nca + 1) * 4);
   w.b.cellrank = (int2*)take((size_t)B * M * 8);
   w.a.cellrank = (int2*)take((size_t)B * N * 8);
-  w.b.sorted = (float4*)take((size_t)B * M * 16);
-  w.a.sorted = (float4*)take((size_t)B * N * 16);
+  w.b.sorted = (float4*)take((size_t)B * M * 4 * esz);
+  w.a.sorted = (float4*)take((size_t)B * N * 4 * esz);
   w.scan_blocks = (int)(((nca > ncb ? nca : ncb) + SDG_BUILD_THREADS - 1) / SDG_BUILD_THREADS);
   w.scan_sums = (int*)take((size_t)2 * B * w.scan_blocks * 4);
   w.total = off;
@@ -190,7 +220,8 @@ __device__ __forceinline__ Box sdg_box_decode(const unsigned int* w, int G) {
 }
 
 // X = the targets' cloud, Y = the other one; own_box_y: Y is binned on its own box (chamfer), else on X's (sided_distance)
-__global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(Cloud X, Cloud Y, int B, int own_box_y, int* sums, int scan_blocks,
+template <typename T>
+__global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(CloudT<T> X, CloudT<T> Y, int B, int own_box_y, int* sums, int scan_blocks,
                                                                unsigned int* barrier, int naps) {
   __shared__ float s_red[6][SDG_BUILD_THREADS / 64];
   __shared__ int s_wave[SDG_BUILD_THREADS / 64];
@@ -208,12 +239,12 @@ __global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(Cloud X, Cloud Y,
       const bool first = u < B;
       const int b = first ? u : u - B;
       const int n = first ? X.n : Y.n;
-      const float* Pt = (first ? X.pts : Y.pts) + (size_t)b * n * 3;
+      const T* Pt = (first ? X.pts : Y.pts) + (size_t)b * n * 3;
       float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
       for (int i = part * SDG_BUILD_THREADS + tid; i < n; i += P * SDG_BUILD_THREADS) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-          const float v = Pt[(size_t)i * 3 + a];
+          const float v = (float)Pt[(size_t)i * 3 + a];  // (the grid lives in float, whatever the points' type)
           if (isfinite(v)) {
             lo[a] = fminf(lo[a], v);
             hi[a] = fmaxf(hi[a], v);
@@ -263,10 +294,10 @@ __global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(Cloud X, Cloud Y,
     if (!first) i -= X.n;
     const int n = first ? X.n : Y.n, G = first ? X.G : Y.G;
     const Box bx = sdg_box_decode<true>((first ? X.box : Y.box) + (size_t)b * 8, G);
-    const float* Pt = (first ? X.pts : Y.pts) + ((size_t)b * n + i) * 3;
-    const int cx = sdg_axis_cell(Pt[0], bx.lo[0], bx.inv[0], G);
-    const int cy = sdg_axis_cell(Pt[1], bx.lo[1], bx.inv[1], G);
-    const int cz = sdg_axis_cell(Pt[2], bx.lo[2], bx.inv[2], G);
+    const T* Pt = (first ? X.pts : Y.pts) + ((size_t)b * n + i) * 3;
+    const int cx = sdg_axis_cell((float)Pt[0], bx.lo[0], bx.inv[0], G);
+    const int cy = sdg_axis_cell((float)Pt[1], bx.lo[1], bx.inv[1], G);
+    const int cz = sdg_axis_cell((float)Pt[2], bx.lo[2], bx.inv[2], G);
     const int c = (cz * G + cy) * G + cx;
     const int rank = atomicAdd((first ? X.count : Y.count) + (size_t)b * ((size_t)G * G * G) + c, 1);
     (first ? X.cellrank : Y.cellrank)[(size_t)b * n + i] = make_int2(c, rank);
@@ -327,8 +358,13 @@ __global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(Cloud X, Cloud Y,
     const int n = first ? X.n : Y.n, G = first ? X.G : Y.G;
     const int2 cr = (first ? X.cellrank : Y.cellrank)[(size_t)b * n + i];
     const int pos = sdg_ld((first ? X.start : Y.start) + (size_t)b * ((size_t)G * G * G + 1) + cr.x) + cr.y;
-    const float* Pt = (first ? X.pts : Y.pts) + ((size_t)b * n + i) * 3;
-    (first ? X.sorted : Y.sorted)[(size_t)b * n + pos] = make_float4(Pt[0], Pt[1], Pt[2], __int_as_float(i));
+    const T* Pt = (first ? X.pts : Y.pts) + ((size_t)b * n + i) * 3;
+    typename CloudT<T>::V4 rec;
+    rec.x = Pt[0];
+    rec.y = Pt[1];
+    rec.z = Pt[2];
+    rec.w = sdg_pack_idx(i, (T)0);
+    (first ? X.sorted : Y.sorted)[(size_t)b * n + pos] = rec;
   }
 }
 
@@ -336,6 +372,10 @@ __global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(Cloud X, Cloud Y,
 __device__ __forceinline__ float sdg_dist(float tx, float ty, float tz, float qx, float qy, float qz) {
   const float dx = tx - qx, dy = ty - qy, dz = tz - qz;
   return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+__device__ __forceinline__ double sdg_dist(double tx, double ty, double tz, double qx, double qy, double qz) {
+  const double dx = tx - qx, dy = ty - qy, dz = tz - qz;
+  return __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));  // (the same pin as the all-pairs kernel and the oracle)
 }
 
 #ifndef KAMD_SDG_GROUP
@@ -350,23 +390,52 @@ constexpr int SDG_GROUP = KAMD_SDG_GROUP;
                           // on a uniform cloud, 131 (1) vs 139 us (3) on a sphere surface: more registers, lower occupancy)
 #endif
 constexpr int SDG_R0 = KAMD_SDG_R0;
-constexpr int SDG_BATCH = KAMD_SDG_BATCH;  // lanes cooperating on one query (rows of the cell cube are dealt round-robin)
+[[maybe_unused]] constexpr int SDG_BATCH = KAMD_SDG_BATCH;
 
 // the search for one query, shared by the one-direction and the two-direction kernels.  All SDG_GROUP lanes of a query
 // call it with the same (qx, qy, qz, c); on return every lane holds the query's (best, best_i).
 // TRACK: best_k = the winner's position in the sorted targets (-1 while the seed holds: the caller then looks target 0 up).
-template <bool TRACK>
-__device__ __forceinline__ void sdg_search(const Box& s_box, int G, float qx, float qy, float qz, int c,
-                                           const float* __restrict__ T0, const int* __restrict__ start,
-                                           const float4* __restrict__ TS, int sub, float& best, int& best_i, int& best_k) {
+template <bool TRACK, typename T>
+__device__ __forceinline__ void sdg_search(const Box& s_box, int G, T qx, T qy, T qz, int c,
+                                           const T* __restrict__ T0, const int* __restrict__ start,
+                                           const typename Vec4Of<T>::type* __restrict__ TS, int nt, int sub, T& best, int& best_i,
+                                           int& best_k) {
+  typedef typename Vec4Of<T>::type V4;
   // the reference's seed: target 0 unconditionally (a NaN distance sticks)
   best = sdg_dist(T0[0], T0[1], T0[2], qx, qy, qz);
   best_i = 0;
   best_k = -1;
+  if (sizeof(T) == 8 && !(fabs((double)qx) < 1e30 && fabs((double)qy) < 1e30 && fabs((double)qz) < 1e30)) {
+    // a double query outside float's range (or not finite): the float grid says nothing about it -- walk every target
+    if (best == best) {
+      for (int k = sub; k < nt; k += SDG_GROUP) {
+        const V4 t = TS[k];
+        const T d = sdg_dist(t.x, t.y, t.z, qx, qy, qz);
+        const int ti = sdg_unpack_idx(t.w);
+        if (d < best || (d == best && ti < best_i)) {
+          best = d;
+          best_i = ti;
+          if (TRACK) best_k = k;
+        }
+      }
+#pragma unroll
+      for (int m = 1; m < SDG_GROUP; m <<= 1) {
+        const T od = __shfl_xor(best, m, 64);
+        const int oi = __shfl_xor(best_i, m, 64);
+        const int ok = TRACK ? __shfl_xor(best_k, m, 64) : 0;
+        if (od < best || (od == best && oi < best_i)) {
+          best = od;
+          best_i = oi;
+          if (TRACK) best_k = ok;
+        }
+      }
+    }
+    return;
+  }
   if (best == best) {  // uniform within the group (same query)
     const int cx = c % G, cy = (c / G) % G, cz = c / (G * G);
     // rounding head-room of the geometric bound: cell membership is decided by a rounded (v - lo) * inv
-    const float q[3] = {qx, qy, qz};
+    const float q[3] = {(float)qx, (float)qy, (float)qz};
     float slack[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) slack[a] = 4e-6f * (fabsf(q[a]) + fabsf(s_box.lo[a]) + s_box.size[a] * (float)G);
@@ -420,11 +489,11 @@ __device__ __forceinline__ void sdg_search(const Box& s_box, int G, float qx, fl
             const int kb = k0[u][sgm], ke = sgm < nseg[u] ? k1[u][sgm] : kb;
             for (int k = kb; k < ke; k += 2) {
               const bool two = k + 1 < ke;
-              const float4 ta = TS[k];
-              const float4 tb = TS[two ? k + 1 : k];
+              const V4 ta = TS[k];
+              const V4 tb = TS[two ? k + 1 : k];
               {
-                const float d = sdg_dist(ta.x, ta.y, ta.z, qx, qy, qz);
-                const int ti = __float_as_int(ta.w);
+                const T d = sdg_dist(ta.x, ta.y, ta.z, qx, qy, qz);
+                const int ti = sdg_unpack_idx(ta.w);
                 if (d < best || (d == best && ti < best_i)) {
                   best = d;
                   best_i = ti;
@@ -432,8 +501,8 @@ __device__ __forceinline__ void sdg_search(const Box& s_box, int G, float qx, fl
                 }
               }
               if (two) {
-                const float d = sdg_dist(tb.x, tb.y, tb.z, qx, qy, qz);
-                const int ti = __float_as_int(tb.w);
+                const T d = sdg_dist(tb.x, tb.y, tb.z, qx, qy, qz);
+                const int ti = sdg_unpack_idx(tb.w);
                 if (d < best || (d == best && ti < best_i)) {
                   best = d;
                   best_i = ti;
@@ -470,9 +539,9 @@ __device__ __forceinline__ void sdg_search(const Box& s_box, int G, float qx, fl
         }
         for (int sgm = 0; sgm < nseg; ++sgm)
           for (int k = k0[sgm]; k < k1[sgm]; ++k) {
-            const float4 t = TS[k];
-            const float d = sdg_dist(t.x, t.y, t.z, qx, qy, qz);
-            const int ti = __float_as_int(t.w);
+            const V4 t = TS[k];
+            const T d = sdg_dist(t.x, t.y, t.z, qx, qy, qz);
+            const int ti = sdg_unpack_idx(t.w);
             if (d < best || (d == best && ti < best_i)) {
               best = d;
               best_i = ti;
@@ -483,7 +552,7 @@ __device__ __forceinline__ void sdg_search(const Box& s_box, int G, float qx, fl
 #endif
 #pragma unroll
       for (int m = 1; m < SDG_GROUP; m <<= 1) {  // lexicographic (dist, idx) minimum over the group
-        const float od = __shfl_xor(best, m, 64);
+        const T od = __shfl_xor(best, m, 64);
         const int oi = __shfl_xor(best_i, m, 64);
         const int ok = TRACK ? __shfl_xor(best_k, m, 64) : 0;
         if (od < best || (od == best && oi < best_i)) {
@@ -507,7 +576,7 @@ __device__ __forceinline__ void sdg_search(const Box& s_box, int G, float qx, fl
         }
       }
       if (whole_grid) break;
-      if (bound > 0.f && best < bound * bound * 0.99999f) break;
+      if (bound > 0.f && best < (T)(bound * bound * 0.99999f)) break;
     }
   }
 }
@@ -521,18 +590,20 @@ __device__ __forceinline__ void sdg_search(const Box& s_box, int G, float qx, fl
 // w1 * mean1 + w2 * mean2.  MODE == SDG_GRAD: every query also leaves d value / d (its own point) and adds
 // d value / d (its nearest point) with float atomics, both already scaled by w / n [/ (2 sqrt(dist))]: the atomics ride in
 // a kernel that waits on dependent loads anyway, and the backward pass is one multiply by the upstream gradient.
-template <int MODE>
-__global__ __launch_bounds__(256) void sdg_query(Cloud A, Cloud T, float* __restrict__ dist1, int64_t* __restrict__ idx1,
-                                                 float* __restrict__ dist2, int64_t* __restrict__ idx2, Fuse fz) {
+template <int MODE, typename S>
+__global__ __launch_bounds__(256) void sdg_query(CloudT<S> A, CloudT<S> T, S* __restrict__ dist1, int64_t* __restrict__ idx1,
+                                                 S* __restrict__ dist2, int64_t* __restrict__ idx2, Fuse fz) {
+  static_assert(MODE == SDG_PLAIN || sizeof(S) == 4, "the chamfer modes are fp32");
+  typedef typename Vec4Of<S>::type V4;
   __shared__ Box s_box;
   __shared__ double s_sum[4];
   const int b = blockIdx.y;
   const bool fwd = blockIdx.z == 0;
   const int nq = fwd ? A.n : T.n, nt = fwd ? T.n : A.n, G = fwd ? T.G : A.G;
   const int NC = G * G * G;
-  const float* Tp = (fwd ? T.pts : A.pts) + (size_t)b * nt * 3;
+  const S* Tp = (fwd ? T.pts : A.pts) + (size_t)b * nt * 3;
   const int* Tstart = (fwd ? T.start : A.start) + (size_t)b * (NC + 1);
-  const float4* Tsorted = (fwd ? T.sorted : A.sorted) + (size_t)b * nt;
+  const V4* Tsorted = (fwd ? T.sorted : A.sorted) + (size_t)b * nt;
   if (threadIdx.x == 0) s_box = sdg_box_decode((fwd ? T.box : A.box) + (size_t)b * 8, G);
   __syncthreads();
   // 100k queries are only ~1.5 wavefronts per SIMD and every query is a chain of dependent loads (cell range ->
@@ -546,20 +617,20 @@ __global__ __launch_bounds__(256) void sdg_query(Cloud A, Cloud T, float* __rest
   for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
     const int slot = (chunk * 256 + threadIdx.x) / SDG_GROUP;
     const bool live = slot < nq;
-    const float4 q = (fwd ? A.sorted : T.sorted)[(size_t)b * nq + (live ? slot : 0)];
-    const int cx = sdg_axis_cell(q.x, s_box.lo[0], s_box.inv[0], G);
-    const int cy = sdg_axis_cell(q.y, s_box.lo[1], s_box.inv[1], G);
-    const int cz = sdg_axis_cell(q.z, s_box.lo[2], s_box.inv[2], G);
-    float best;
+    const V4 q = (fwd ? A.sorted : T.sorted)[(size_t)b * nq + (live ? slot : 0)];
+    const int cx = sdg_axis_cell((float)q.x, s_box.lo[0], s_box.inv[0], G);
+    const int cy = sdg_axis_cell((float)q.y, s_box.lo[1], s_box.inv[1], G);
+    const int cz = sdg_axis_cell((float)q.z, s_box.lo[2], s_box.inv[2], G);
+    S best;
     int best_i, best_k;
-    sdg_search<MODE == SDG_GRAD>(s_box, G, q.x, q.y, q.z, (cz * G + cy) * G + cx, Tp, Tstart, Tsorted, sub, best, best_i, best_k);
+    sdg_search<MODE == SDG_GRAD, S>(s_box, G, q.x, q.y, q.z, (cz * G + cy) * G + cx, Tp, Tstart, Tsorted, nt, sub, best, best_i, best_k);
     if (live && sub == 0) {
-      const size_t o = (size_t)b * nq + __float_as_int(q.w);
-      float* dist = fwd ? dist1 : dist2;
+      const size_t o = (size_t)b * nq + sdg_unpack_idx(q.w);
+      S* dist = fwd ? dist1 : dist2;
       int64_t* idx = fwd ? idx1 : idx2;
       if (dist != nullptr) dist[o] = best;
       if (idx != nullptr) idx[o] = best_i;
-      if (MODE >= SDG_VALUE) {
+      if constexpr (MODE >= SDG_VALUE) {
         const float root = fz.squared ? best : sqrtf(best);
         term += (double)root;
         if (MODE == SDG_GRAD) {
@@ -572,10 +643,10 @@ __global__ __launch_bounds__(256) void sdg_query(Cloud A, Cloud T, float* __rest
             const int2 cr = (fwd ? T.cellrank : A.cellrank)[(size_t)b * nt];
             best_k = Tstart[cr.x] + cr.y;
           }
-          const float4 t = Tsorted[best_k];
+          const V4 t = Tsorted[best_k];
           float* own = (fwd ? fz.own_a : fz.own_b) + ((size_t)b * nq + slot) * 3;
           float* scat = (fwd ? fz.scat_b : fz.scat_a) + ((size_t)b * nt + best_k) * 3;
-          const float qv[3] = {q.x, q.y, q.z}, tv[3] = {t.x, t.y, t.z};
+          const float qv[3] = {(float)q.x, (float)q.y, (float)q.z}, tv[3] = {(float)t.x, (float)t.y, (float)t.z};
 #pragma unroll
           for (int a = 0; a < 3; ++a) {
             own[a] = 2.f * (qv[a] - tv[a]) * k;
@@ -668,9 +739,11 @@ inline int sdg_num_cus() {
   return cached[dev];
 }
 
-int sdg_run(hipStream_t st, int B, int N, int M, const float* p1, const float* p2, float* dist1, int64_t* idx1,
-            float* dist2, int64_t* idx2, void* workspace, bool pair, int mode, float w1, float w2, int squared, float* out) {
-  SdgWs w = sdg_layout(workspace, B, N, M, p1, p2, pair, mode);
+template <typename S>
+int sdg_run(hipStream_t st, int B, int N, int M, const S* p1, const S* p2, S* dist1, int64_t* idx1,
+            S* dist2, int64_t* idx2, void* workspace, bool pair, int mode, float w1, float w2, int squared, float* out) {
+  SdgWs w = sdg_layout(workspace, B, N, M, p1, p2, pair, mode, (int)sizeof(S));
+  const CloudT<S> ca = cloud_as<S>(w.a), cb = cloud_as<S>(w.b);
   KAMD_CHECK(kamd_zero_async(workspace, w.zero_bytes, st));
   {
     ProfScope p(K_SDG_BUILD, st);
@@ -683,7 +756,7 @@ int sdg_run(hipStream_t st, int B, int N, int M, const float* p1, const float* p
     const int cap = kamd_env_int("KAMD_SDG_WGS", 128);
     if (nwg > cap) nwg = cap;
     const int naps = kamd_env_int("KAMD_SDG_NAPS", 4);
-    hipLaunchKernelGGL(sdg_build, dim3(nwg), dim3(SDG_BUILD_THREADS), 0, st, w.b, w.a, B, pair ? 1 : 0, w.scan_sums,
+    hipLaunchKernelGGL(sdg_build<S>, dim3(nwg), dim3(SDG_BUILD_THREADS), 0, st, cb, ca, B, pair ? 1 : 0, w.scan_sums,
                        w.scan_blocks, w.barrier, naps);
   }
   KAMD_CHECK(hipGetLastError());
@@ -701,12 +774,17 @@ int sdg_run(hipStream_t st, int B, int N, int M, const float* p1, const float* p
     w.fuse.c1 = w1 * (1.f / (float)N);
     w.fuse.c2 = w2 * (1.f / (float)M);
     w.fuse.squared = squared;
-    if (mode == SDG_PLAIN)
-      hipLaunchKernelGGL(sdg_query<SDG_PLAIN>, grid, dim3(256), 0, st, w.a, w.b, dist1, idx1, dist2, idx2, w.fuse);
-    else if (mode == SDG_VALUE)
-      hipLaunchKernelGGL(sdg_query<SDG_VALUE>, grid, dim3(256), 0, st, w.a, w.b, dist1, idx1, dist2, idx2, w.fuse);
-    else
-      hipLaunchKernelGGL(sdg_query<SDG_GRAD>, grid, dim3(256), 0, st, w.a, w.b, dist1, idx1, dist2, idx2, w.fuse);
+    if constexpr (sizeof(S) == 4) {
+      if (mode == SDG_PLAIN)
+        hipLaunchKernelGGL((sdg_query<SDG_PLAIN, S>), grid, dim3(256), 0, st, ca, cb, dist1, idx1, dist2, idx2, w.fuse);
+      else if (mode == SDG_VALUE)
+        hipLaunchKernelGGL((sdg_query<SDG_VALUE, S>), grid, dim3(256), 0, st, ca, cb, dist1, idx1, dist2, idx2, w.fuse);
+      else
+        hipLaunchKernelGGL((sdg_query<SDG_GRAD, S>), grid, dim3(256), 0, st, ca, cb, dist1, idx1, dist2, idx2, w.fuse);
+    } else {
+      if (mode != SDG_PLAIN) return (int)hipErrorInvalidValue;
+      hipLaunchKernelGGL((sdg_query<SDG_PLAIN, S>), grid, dim3(256), 0, st, ca, cb, dist1, idx1, dist2, idx2, w.fuse);
+    }
     if (mode != SDG_PLAIN)
       hipLaunchKernelGGL(sdg_chamfer_value, dim3(B), dim3(256), 0, st, B, gx, N, M, (const double*)w.fuse.sums, w1, w2, out);
   }
@@ -719,22 +797,30 @@ bool sdgrid_applicable(int B, int N, int M) {
   // below this the brute-force kernels are as fast as the launches of the grid pipeline
   return B >= 1 && B <= 65535 && M >= 8192 && N >= 2048 && (long long)B * (long long)(M > N ? M : N) < (1ll << 30);
 }
-size_t sdgrid_workspace_bytes(int B, int N, int M) {
-  return sdg_layout(nullptr, B, N, M, nullptr, nullptr, false, SDG_PLAIN).total;
+size_t sdgrid_workspace_bytes(int B, int N, int M, int elem_size) {
+  return sdg_layout(nullptr, B, N, M, nullptr, nullptr, false, SDG_PLAIN, elem_size).total;
+}
+int sdgrid_forward_f64(hipStream_t st, int B, int N, int M, const double* p1, const double* p2, double* dist, int64_t* idx,
+                       void* workspace) {
+  return sdg_run<double>(st, B, N, M, p1, p2, dist, idx, nullptr, nullptr, workspace, false, SDG_PLAIN, 1.f, 1.f, 1, nullptr);
 }
 
 int sdgrid_forward_f32(hipStream_t st, int B, int N, int M, const float* p1, const float* p2, float* dist, int64_t* idx,
                        void* workspace) {
-  return sdg_run(st, B, N, M, p1, p2, dist, idx, nullptr, nullptr, workspace, false, SDG_PLAIN, 1.f, 1.f, 1, nullptr);
+  return sdg_run<float>(st, B, N, M, p1, p2, dist, idx, nullptr, nullptr, workspace, false, SDG_PLAIN, 1.f, 1.f, 1, nullptr);
 }
 
 bool sdgrid_pair_applicable(int B, int N, int M) { return sdgrid_applicable(B, N, M) && sdgrid_applicable(B, M, N); }
-size_t sdgrid_pair_workspace_bytes(int B, int N, int M) {
-  return sdg_layout(nullptr, B, N, M, nullptr, nullptr, true, SDG_PLAIN).total;
+size_t sdgrid_pair_workspace_bytes(int B, int N, int M, int elem_size) {
+  return sdg_layout(nullptr, B, N, M, nullptr, nullptr, true, SDG_PLAIN, elem_size).total;
+}
+int sdgrid_pair_forward_f64(hipStream_t st, int B, int N, int M, const double* p1, const double* p2, double* dist1,
+                            int64_t* idx1, double* dist2, int64_t* idx2, void* workspace) {
+  return sdg_run<double>(st, B, N, M, p1, p2, dist1, idx1, dist2, idx2, workspace, true, SDG_PLAIN, 1.f, 1.f, 1, nullptr);
 }
 int sdgrid_pair_forward_f32(hipStream_t st, int B, int N, int M, const float* p1, const float* p2, float* dist1,
                             int64_t* idx1, float* dist2, int64_t* idx2, void* workspace) {
-  return sdg_run(st, B, N, M, p1, p2, dist1, idx1, dist2, idx2, workspace, true, SDG_PLAIN, 1.f, 1.f, 1, nullptr);
+  return sdg_run<float>(st, B, N, M, p1, p2, dist1, idx1, dist2, idx2, workspace, true, SDG_PLAIN, 1.f, 1.f, 1, nullptr);
 }
 
 size_t sdgrid_chamfer_workspace_bytes(int B, int N, int M, bool with_grad) {
@@ -743,7 +829,7 @@ size_t sdgrid_chamfer_workspace_bytes(int B, int N, int M, bool with_grad) {
 int sdgrid_chamfer_forward_f32(hipStream_t st, int B, int N, int M, const float* p1, const float* p2, float w1, float w2,
                                int squared, bool with_grad, float* out, float* dist1, int64_t* idx1, float* dist2,
                                int64_t* idx2, void* workspace) {
-  return sdg_run(st, B, N, M, p1, p2, dist1, idx1, dist2, idx2, workspace, true, with_grad ? SDG_GRAD : SDG_VALUE, w1, w2,
+  return sdg_run<float>(st, B, N, M, p1, p2, dist1, idx1, dist2, idx2, workspace, true, with_grad ? SDG_GRAD : SDG_VALUE, w1, w2,
                  squared, out);
 }
 int sdgrid_chamfer_backward_f32(hipStream_t st, int B, int N, int M, const float* grad, void* workspace, float* g1,

@@ -103,6 +103,8 @@ constexpr double SOFT_EPS = 1e-7;     // the reference's literal EPS (dibr_soft_
 // time (measured on MI355X: ~33 ns each on one address, ~15 ns each on neighbouring words of a line), so counters that are hit
 // thousands of times per launch must not share lines.
 constexpr int COUNTER_STRIDE = 32;
+constexpr int SPAN_SHARDS = 1;        // copies of a view's covered-row span (workgroup id picks one; readers take their union).  One is enough: workgroups read the span
+                                      // before they add to it, so only the first finishers and the few that extend it issue atomics at all
 constexpr int WORK_SHARDS = 8;        // worklist shards (one append counter each; workgroup id & 7 picks the shard)
 
 struct PassGeom {
@@ -135,7 +137,7 @@ struct Lists {
   unsigned int* sub_touched;  // [B * ntiles]      zeroed; soft pass only: bit s = some enlarged box reaches sub-tile s
   int tiles_x, ntiles;
   // raster pass only (nullptr: none): the tile rows the mesh's boxes cover, per view -- where the tile kernels start
-  unsigned int* row_span;     // [B * COUNTER_STRIDE] zeroed; view b: word 0 = (last covered row + 1), word 1 = (tiles_y - first covered row); 0 = none
+  unsigned int* row_span;     // [B * 2 * SPAN_SHARDS] zeroed; view b: SPAN_SHARDS x (last covered row + 1), then SPAN_SHARDS x (tiles_y - first covered row); 0 = none
 };
 
 inline size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -174,7 +176,7 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
     L.r.tab = off; off += a256(ntr * L.r.maxc * 4);
     L.r.pool_top = off; off += 256;
     L.r.big_count = off; off += a256((size_t)B * 4);
-    L.r.row_span = off; off += a256((size_t)B * COUNTER_STRIDE * 4);
+    L.r.row_span = off; off += a256((size_t)B * 2 * SPAN_SHARDS * 4);
   }
   if (with_s) {
     L.s.count = off; off += a256(nts * 4);
@@ -520,31 +522,41 @@ struct BinIn {
 // The workgroup of a tile with faces lives ~100x longer than a background tile's, so the tile kernels visit a view's tile
 // rows outwards from the middle of the rows the mesh covers: the long workgroups start first and the background rows stream
 // out beside their tail (round 2 started from the middle of the IMAGE -- right for a centred object only).  The binning
-// kernel notes, per view, the first and the last tile row any kept face's box reaches: a wave reduction, one LDS slot per
-// wavefront, and per workgroup at most two device atomics (atomicMax on words of the view's own line), skipped when the
-// published span already holds the workgroup's.  (Measured and dropped: ranking the rows by the faces their tiles list --
-// a ticket per workgroup and a sort in the last one to finish cost the binning launch 8 us, and the ranked order a u16 load
-// per tile-kernel workgroup: 4 us more on 131 072 workgroups; a device-scope fence in that ticket wrote back the XCD's L2
-// per workgroup and tripled the launch.)
+// kernel notes, per view, the first and the last tile row any kept face's box reaches.  Everything about it is arranged to
+// stay off the kernel's critical path (every wavefront of the launch is resident, the launch lasts one wavefront's life):
+// the lanes' rows are reduced per wavefront, merged per workgroup in LDS behind the LAST barrier of the kernel, and leave
+// as at most two fire-and-forget atomicMax per workgroup and view, on one of SPAN_SHARDS copies of the span -- and only when
+// the copy, read first, does not hold the workgroup's rows yet (behind the last barrier nobody waits for that load; once the
+// span has grown most workgroups add nothing: same-line device atomics complete one at a time, and a view's copies share
+// one 64-byte line so that a tile-kernel workgroup reads them with one scalar load).
+// Measured and dropped on the way: ranking the rows by the faces their tiles list (a ticket per workgroup + a sort in the
+// last one to finish: +8 us in the binning launch, and a u16 load per tile-kernel workgroup: +4 us on 131 072 workgroups;
+// with a device-scope fence in the ticket -- an L2 write-back per workgroup -- the launch tripled); a workgroup merge in
+// the middle of the kernel with a read-before-update of the span (+9 us: a barrier and a dependent load in every wavefront's life).
 // row k of the visiting order around centre c: c, c - 1, c + 1, c - 2, ... and, once one side is used up, on along the other
 __host__ __device__ inline int row_from_centre(int k, int c, int tiles_y) {
   const int left = c, right = tiles_y - 1 - c, m = left < right ? left : right;
   if (k <= 2 * m) return (k & 1) ? c - ((k + 1) >> 1) : c + (k >> 1);
   return right > left ? k : tiles_y - 1 - k;
 }
-// the centre the tile kernels of view b start from (the middle row of the image when no face was binned)
+// the centre the tile kernels of view b start from (the middle row of the image when no face was binned); uniform loads
 __device__ __forceinline__ int row_centre(const unsigned int* __restrict__ row_span, int b, int tiles_y) {
   if (row_span == nullptr) return tiles_y >> 1;
-  const unsigned int hi1 = row_span[(size_t)b * COUNTER_STRIDE], lo_inv = row_span[(size_t)b * COUNTER_STRIDE + 1];
+  unsigned int hi1 = 0u, lo_inv = 0u;
+  const unsigned int* __restrict__ v = row_span + (size_t)b * (2 * SPAN_SHARDS);  // 64 bytes, 64-byte aligned
+#pragma unroll
+  for (int s = 0; s < SPAN_SHARDS; ++s) {
+    hi1 = max(hi1, v[s]);
+    lo_inv = max(lo_inv, v[SPAN_SHARDS + s]);
+  }
   if (hi1 == 0u || lo_inv == 0u) return tiles_y >> 1;
   const int lo = tiles_y - (int)lo_inv, hi = (int)hi1 - 1;
   const int c = (lo + hi) >> 1;
   return c < 0 ? 0 : (c > tiles_y - 1 ? tiles_y - 1 : c);
 }
-// called by every thread of the binning kernel: `act` = the lane's face is kept and reaches the image, rows [r0, r1]
-__device__ __forceinline__ void note_row_span(const Lists& L, bool act, int b, int r0, int r1) {
-  if (L.row_span == nullptr) return;  // (uniform)
-  __shared__ int s_span[4][4];        // per wavefront: {view, lo, hi} of its first view; lanes of other views go alone
+// A wavefront's contribution: {view of its first kept face, first row, last row} -> s_span[wave]; kept faces of other views
+// (a wavefront that straddles a view boundary, meshes of fewer than 64 faces) go straight to memory.
+__device__ __forceinline__ void span_of_wave(const Lists& L, bool act, int b, int r0, int r1, int (*s_span)[4]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tiles_y = L.ntiles / L.tiles_x;
   const unsigned long long am = __ballot(act);
   int b0 = -1, lo = 0x7FFFFFFF, hi = -1;
@@ -558,9 +570,10 @@ __device__ __forceinline__ void note_row_span(const Lists& L, bool act, int b, i
       lo = min(lo, __shfl_xor(lo, d, 64));
       hi = max(hi, __shfl_xor(hi, d, 64));
     }
-    if (act && b != b0) {  // (a wavefront that straddles views: meshes of fewer than 64 faces, or a view boundary)
-      atomicMax(L.row_span + (size_t)b * COUNTER_STRIDE, (unsigned int)(r1 + 1));
-      atomicMax(L.row_span + (size_t)b * COUNTER_STRIDE + 1, (unsigned int)(tiles_y - r0));
+    if (act && b != b0) {
+      unsigned int* p = L.row_span + (size_t)b * (2 * SPAN_SHARDS) + (blockIdx.x % SPAN_SHARDS);
+      atomicMax(p, (unsigned int)(r1 + 1));
+      atomicMax(p + SPAN_SHARDS, (unsigned int)(tiles_y - r0));
     }
   }
   if (lane == 0) {
@@ -568,10 +581,13 @@ __device__ __forceinline__ void note_row_span(const Lists& L, bool act, int b, i
     s_span[wave][1] = lo;
     s_span[wave][2] = hi;
   }
+}
+// ... merged per workgroup and published; called by every thread at the very end of the kernel
+__device__ __forceinline__ void publish_row_span(const Lists& L, int (*s_span)[4]) {
   __syncthreads();
   if (threadIdx.x < 4) {
     // wavefront w speaks for its view unless an earlier wavefront of the workgroup has the same view (then that one merges)
-    const int w = threadIdx.x, vb = s_span[w][0];
+    const int w = threadIdx.x, vb = s_span[w][0], tiles_y = L.ntiles / L.tiles_x;
     bool first = vb >= 0;
     for (int q = 0; q < w; ++q) first = first && s_span[q][0] != vb;
     if (first) {
@@ -581,10 +597,11 @@ __device__ __forceinline__ void note_row_span(const Lists& L, bool act, int b, i
           l = min(l, s_span[q][1]);
           h = max(h, s_span[q][2]);
         }
-      unsigned int* p = L.row_span + (size_t)vb * COUNTER_STRIDE;
-      // (plain loads first: once the span has grown, most workgroups have nothing to add and issue no atomic)
-      if (p[0] < (unsigned int)(h + 1)) atomicMax(p, (unsigned int)(h + 1));
-      if (p[1] < (unsigned int)(tiles_y - l)) atomicMax(p + 1, (unsigned int)(tiles_y - l));
+      unsigned int* p = L.row_span + (size_t)vb * (2 * SPAN_SHARDS) + (blockIdx.x % SPAN_SHARDS);
+      const unsigned int have_hi = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int have_lo = __hip_atomic_load(p + SPAN_SHARDS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (have_hi < (unsigned int)(h + 1)) atomicMax(p, (unsigned int)(h + 1));
+      if (have_lo < (unsigned int)(tiles_y - l)) atomicMax(p + SPAN_SHARDS, (unsigned int)(tiles_y - l));
     }
   }
 }
@@ -724,7 +741,9 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(
     }
   }
   PHASE_MARK(5);
-  if (DO_R) note_row_span(LR, act_r, b, ry0, ry1);
+  __shared__ int s_span[4][4];
+  const bool want_span = DO_R && LR.row_span != nullptr;
+  if (want_span) span_of_wave(LR, act_r, b, ry0, ry1, s_span);
   if (DO_R && DO_S) {
     PendingEntry er, es;
     wave_bin<false>(act_r, big_r, b, first_b, f, rx0, rx1, ry0, ry1, 0, 0, 0, 0, LR, &er);
@@ -737,6 +756,7 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(
     if (DO_S) wave_bin<true>(act_s, big_s, b, first_b, f, sx0, sx1, sy0, sy1, pr_s.c_lo, pr_s.c_hi, pr_s.r_lo, pr_s.r_hi, LS);
   }
   PHASE_MARK(7);
+  if (want_span) publish_row_span(LR, s_span);
   PHASE_FLUSH(g_phase_bin);
 #ifdef KAMD_PHASE_PROF
   if ((threadIdx.x & 63) == 0) {

@@ -125,8 +125,8 @@ def _chamfer_value(to_p2, to_p1, w1, w2, squared):
 
 
 def _nearest_both_ways(p1, p2):
-    """(distances p1 -> p2, distances p2 -> p1).  Large fp32 clouds on the GPU are binned once for both searches."""
-    if p1.is_cuda and p1.dtype == torch.float32 and p2.dtype == torch.float32 and p1.dim() == 3 and p2.dim() == 3:
+    """(distances p1 -> p2, distances p2 -> p1).  Large fp32 / fp64 clouds on the GPU are binned once for both searches."""
+    if p1.is_cuda and p1.dtype in (torch.float32, torch.float64) and p2.dtype == p1.dtype and p1.dim() == 3 and p2.dim() == 3:
         return _SidedDistancePairFunction.apply(p1, p2)
     return sided_distance(p1, p2)[0], sided_distance(p2, p1)[0]
 
