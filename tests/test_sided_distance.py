@@ -285,6 +285,68 @@ def test_grid_search_bit_exact_vs_oracle(kind, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['uniform', 'clustered', 'surface', 'flat'])
+@pytest.mark.parametrize('shape', [(1, 20000, 30011), (2, 2048, 8192)])
+def test_grid_search_fp64_bit_exact_vs_oracle(kind, shape):
+    """fp64 clouds of the same sizes take the grid search too (the reference dispatches half / float / double:
+    sided_distance_cuda.cu:252; tests/python/kaolin/metrics/test_pointcloud.py:24): the grid is built from the coordinates
+    rounded to float, every distance is the double expression -- dist and idx bit-identical to the fp64 all-pairs oracle and
+    to the all-pairs kernel (KAMD_SIDED_DISTANCE=brute); both directions from one binning pass as well."""
+    from kaolin_amd import _C
+    pc = _pc()
+    B, N, M = shape
+    p1, p2 = _clouds(kind, B, N, M, seed=N + M + 2)
+    p1, p2 = p1.double() + 1e-9 * torch.rand(p1.shape, dtype=torch.double), p2.double() + 1e-9 * torch.rand(p2.shape, dtype=torch.double)
+    if kind == 'flat':       # exact duplicates (ties by index) survive the perturbation only if it is shared
+        p2 = torch.cat([p2[:, :M // 2], p2[:, :M // 2]], dim=1)
+    assert _lib_ws(B, N, M, 8) > 0, 'these shapes must take the grid path'
+    d_ref, i_ref = oracle.sided_distance_forward(p1, p2, omp=True)
+    d, i = pc.sided_distance(p1.cuda(), p2.cuda())
+    assert d.dtype == torch.double
+    assert torch.equal(i.cpu(), i_ref) and torch.equal(d.cpu(), d_ref)
+    os.environ['KAMD_SIDED_DISTANCE'] = 'brute'
+    try:
+        d2, i2 = pc.sided_distance(p1.cuda(), p2.cuda())
+    finally:
+        del os.environ['KAMD_SIDED_DISTANCE']
+    assert torch.equal(i2, i) and torch.equal(d2, d)
+    if N >= 8192:
+        both = _C.metrics.sided_distance_pair_forward(p1.cuda(), p2.cuda())
+        assert both is not None
+        d21, i21 = oracle.sided_distance_forward(p2, p1, omp=True)
+        assert torch.equal(both[1].cpu(), i_ref) and torch.equal(both[0].cpu(), d_ref)
+        assert torch.equal(both[3].cpu(), i21) and torch.equal(both[2].cpu(), d21)
+
+
+def _lib_ws(B, N, M, esz):
+    from kaolin_amd import _lib
+    return _lib.load().kamd_sided_distance_forward_workspace(B, N, M, esz)
+
+
+@pytest.mark.gpu
+def test_grid_search_fp64_queries_beyond_float_range_and_nonfinite():
+    """The fp64 grid lives in float: a query whose coordinates do not fit a float (1e39, 1e300, inf, NaN) walks every target
+    instead; targets beyond float range are binned at clamped cells and found by the rings.  Results equal the oracle's."""
+    pc = _pc()
+    g = torch.Generator().manual_seed(9)
+    p1 = torch.rand(1, 4000, 3, generator=g, dtype=torch.double)
+    p2 = torch.rand(1, 9000, 3, generator=g, dtype=torch.double)
+    p1[0, 0] = torch.tensor([1e39, 0.5, 0.5], dtype=torch.double)       # beyond float, finite in double
+    p1[0, 1] = torch.tensor([1e300, -1e300, 0.], dtype=torch.double)    # squared distance overflows to inf
+    p1[0, 2, 1] = float('inf')
+    p1[0, 3, 2] = float('nan')
+    p1[0, 4] = torch.tensor([5e38, 0.1, 0.2], dtype=torch.double)
+    p2[0, 100] = torch.tensor([6e38, 0.1, 0.2], dtype=torch.double)     # a target beyond float range, nearest to query 4
+    p2[0, 200] = torch.tensor([1.0000000001e39, 0.5, 0.5], dtype=torch.double)   # ... and one next to query 0
+    p2[0, 300, 0] = float('nan')
+    d_ref, i_ref = oracle.sided_distance_forward(p1, p2, omp=True)
+    assert int(i_ref[0, 4]) == 100 and int(i_ref[0, 0]) == 200           # (the case is what it claims)
+    d, i = pc.sided_distance(p1.cuda(), p2.cuda())
+    assert torch.equal(i.cpu(), i_ref)
+    assert torch.equal(torch.isnan(d.cpu()), torch.isnan(d_ref)) and torch.equal(torch.nan_to_num(d.cpu()), torch.nan_to_num(d_ref))
+
+
+@pytest.mark.gpu
 def test_grid_search_nonfinite_and_brute_force_switch():
     """NaN / inf handling of the grid path equals the reference's seed semantics; KAMD_SIDED_DISTANCE=brute keeps the
     all-pairs kernels, and both paths agree bit for bit."""
