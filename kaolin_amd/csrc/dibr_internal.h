@@ -9,10 +9,10 @@ int raster2_draw(hipStream_t st, int B, int H, int W, int D, int F_dense, float 
                  const tl::Lists& LR, const T* feat, T* interp, int64_t* sel_idx, T* weights, const tl::ClassifyOut& co,
                  bool weights_internal);  // background tiles leave `weights` unwritten (read only where face_idx >= 0)
 // rasterize.hip: the rasterizer's backward kernel; tile_cov (one byte per (mesh, 16 x 16 tile), tl::work_cov_offset_words)
-// lets workgroups of tiles without a covered pixel leave at once (nullptr: found out from face_idx); row_centre: per view the
-// tile row the forward's tile kernel started from (tl::work_centre_offset_words; nullptr: the middle of the image)
+// lets workgroups of tiles without a covered pixel leave at once (nullptr: found out from face_idx); row_span: the forward's
+// covered-row spans (tl::work_span_offset_words; nullptr: start from the middle of the image)
 template <typename T>
 int raster_backward_draw(hipStream_t st, int B, int H, int W, int F, int D, const T* grad, const int64_t* face_idx, const T* weights,
                          const T* img, const T* feat, float eps, T* g_img, T* g_feat, const unsigned char* tile_cov,
-                         const unsigned int* row_centre);
+                         const unsigned int* row_span);
 }  // namespace kamd

@@ -256,7 +256,8 @@ template <typename T>
 int soft2_search_launch(hipStream_t st, int B, int H, int W, int F, int K, float sigmainv, float multiplier, const T* rec,
                         const tl::Lists& LS, const unsigned int* work, T* soft_mask, T* prob, int64_t* idx, uint8_t* type,
                         uint8_t* hit_count, const HitList2<T>* lean, unsigned short* pixcnt, T* prob_pm,
-                        void* zero_p = nullptr, size_t zero_bytes = 0) {  // (a 16-byte aligned range the eval launch clears)
+                        void* zero_p = nullptr, size_t zero_bytes = 0,  // (a 16-byte aligned range the eval launch clears)
+                        const unsigned int* span_src = nullptr, unsigned int* span_dst = nullptr, int span_n = 0) {
   const unsigned int shard_cap = tl::work_shard_cap(B, H, W);
   const long long n_sub = (long long)B * LS.ntiles * tl::S_SUBS;
   Select2Args<T> sa{};
@@ -296,6 +297,9 @@ int soft2_search_launch(hipStream_t st, int B, int H, int W, int F, int K, float
   ea.prob_pm = prob_pm;
   ea.zero_p = (uint4*)zero_p;
   ea.zero_n16 = zero_bytes / 16;
+  ea.span_src = span_src;
+  ea.span_dst = span_dst;
+  ea.span_n = span_n;
   // one wavefront (select) / workgroup (eval) per work item; the number of items is known on the device only, so the
   // grids cover the worklist round-robin
   static const int sel_per_cu = kamd_env_int("KAMD_SOFT_SELECT_PER_CU", 32);
@@ -496,7 +500,6 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
   co.work_counts = work;
   co.shard_cap = tl::work_shard_cap(B, H, W);
   co.tile_cov = reinterpret_cast<unsigned char*>(work + tl::work_cov_offset_words(B, H, W));
-  co.row_centre_out = work + tl::work_centre_offset_words(B, H, W);  // (the backward's tile kernel starts from the same rows)
   KAMD_CHECK(kamd::raster2_draw<T>(st, B, H, W, D, F, (float)multiplier, eps, rec_r, LR, feat, interp, face_idx, weights, co,
                                    kamd_env_int("KAMD_DIBR_BG_WEIGHTS", 2) != 1));
   if (total_faces > 0)
@@ -504,7 +507,7 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
                                       (int64_t*)nullptr, (uint8_t*)nullptr, (uint8_t*)nullptr, &list,
                                       (unsigned short*)((char*)workspace + lay.s.pixcnt),
                                       (T*)((char*)workspace + lay.s.prob_pm), zero_in_eval ? (void*)g_img_zero : nullptr,
-                                      zero_in_eval ? g_bytes : 0));
+                                      zero_in_eval ? g_bytes : 0, LR.row_span, work + tl::work_span_offset_words(B, H, W), 2 * B));
   KAMD_RETURN_LAST_ERROR();
 }
 
@@ -545,7 +548,7 @@ int dibr_backward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K
   const unsigned char* tile_cov = kamd_env_int("KAMD_BWD_TILE_COV", 1) == 1  // (2: off, for A/B runs)
                                       ? reinterpret_cast<const unsigned char*>(work + tl::work_cov_offset_words(B, H, W))
                                       : nullptr;
-  const unsigned int* row_centre = F > 0 ? work + tl::work_centre_offset_words(B, H, W) : nullptr;
+  const unsigned int* row_centre = F > 0 ? work + tl::work_span_offset_words(B, H, W) : nullptr;  // (copied there by the forward's eval launch)
   if (!use_side || kamd::prof_all()) {
     KAMD_CHECK(soft_mask_backward_list_launch<T>(st, B, H, W, F, K, grad_soft, soft_mask, list, work, img, multiplier, sigmainv,
                                                  (float)multiplier, g_img));

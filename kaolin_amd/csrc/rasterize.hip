@@ -81,17 +81,16 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(
     int B, int H, int W, int F, int D, const T* __restrict__ grad, const int64_t* __restrict__ face_idx,
     const T* __restrict__ weights, const T* __restrict__ img, const T* __restrict__ feat, float eps,
     T* __restrict__ g_img, T* __restrict__ g_feat, const unsigned char* __restrict__ tile_cov,
-    const unsigned int* __restrict__ row_centre) {
+    const unsigned int* __restrict__ row_span) {
   // (fused dibr_rasterization: the forward pass noted which tiles hold a covered pixel -- 85 % of C4's do not, and
   // finding that out from face_idx costs a 2-KB read and a barrier per workgroup: 24 of this kernel's 60 us)
   // workgroup = 16x16 pixels of one image; wavefront = 16x4
   const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
 #if KAMD_RBWD_ORDER
-  // views interleaved, a view's tile rows in the forward pass' order (outwards from the middle of the covered rows; without
-  // it: of the image): the workgroups that find covered pixels start first
+  // views interleaved, a view's tile rows in the forward pass' order (from the middle outwards, shifted to start in the middle
+  // of the covered rows): the workgroups that find covered pixels start first
   const int b = blockIdx.x % B, k_ = blockIdx.x / B, kr_ = k_ / tiles_x;
-  const int c_ = row_centre != nullptr ? (int)min(row_centre[b], (unsigned int)(tiles_y - 1)) : (tiles_y >> 1);  // (any row in range gives a bijection)
-  const int tile = tl::row_from_centre(kr_, c_, tiles_y) * tiles_x + (k_ - kr_ * tiles_x);
+  const int tile = tl::row_of_order(kr_, tl::row_centre(row_span, b, tiles_y), tiles_y) * tiles_x + (k_ - kr_ * tiles_x);
 #else
   const int tile = blockIdx.x % (tiles_x * tiles_y), b = blockIdx.x / (tiles_x * tiles_y);
 #endif
@@ -262,7 +261,7 @@ int rasterize_forward_fused_launch(hipStream_t st, int B, int H, int W, int F, i
 template <typename T>
 int rasterize_backward_launch(hipStream_t st, int B, int H, int W, int F, int D, const T* grad, const int64_t* face_idx,
                               const T* weights, const T* img, const T* feat, float eps, T* g_img, T* g_feat,
-                              const unsigned char* tile_cov = nullptr, const unsigned int* row_centre = nullptr) {
+                              const unsigned char* tile_cov = nullptr, const unsigned int* row_span = nullptr) {
   const long long total = (long long)B * H * W;
   if (total <= 0 || F <= 0) return 0;
   const dim3 grid((unsigned)(B * ((W + 15) / 16) * ((H + 15) / 16)));
@@ -270,10 +269,10 @@ int rasterize_backward_launch(hipStream_t st, int B, int H, int W, int F, int D,
 #define KAMD_RB(DT)                                                                                                   \
   if (g_feat != nullptr)                                                                                              \
     hipLaunchKernelGGL((raster_backward_kernel<T, DT, true>), grid, dim3(256), 0, st, B, H, W, F, D, grad, face_idx,  \
-                       weights, img, feat, eps, g_img, g_feat, tile_cov, row_centre);                                 \
+                       weights, img, feat, eps, g_img, g_feat, tile_cov, row_span);                                   \
   else                                                                                                                \
     hipLaunchKernelGGL((raster_backward_kernel<T, DT, false>), grid, dim3(256), 0, st, B, H, W, F, D, grad, face_idx, \
-                       weights, img, feat, eps, g_img, g_feat, tile_cov, row_centre)
+                       weights, img, feat, eps, g_img, g_feat, tile_cov, row_span)
   switch (D) {
     case 1: KAMD_RB(1); break;
     case 2: KAMD_RB(2); break;
@@ -302,8 +301,8 @@ int raster2_draw(hipStream_t st, int B, int H, int W, int D, int F_dense, float 
 template <typename T>
 int raster_backward_draw(hipStream_t st, int B, int H, int W, int F, int D, const T* grad, const int64_t* face_idx, const T* weights,
                          const T* img, const T* feat, float eps, T* g_img, T* g_feat, const unsigned char* tile_cov,
-                         const unsigned int* row_centre) {
-  return rasterize_backward_launch<T>(st, B, H, W, F, D, grad, face_idx, weights, img, feat, eps, g_img, g_feat, tile_cov, row_centre);
+                         const unsigned int* row_span) {
+  return rasterize_backward_launch<T>(st, B, H, W, F, D, grad, face_idx, weights, img, feat, eps, g_img, g_feat, tile_cov, row_span);
 }
 template int raster_backward_draw<float>(hipStream_t, int, int, int, int, int, const float*, const int64_t*, const float*,
                                          const float*, const float*, float, float*, float*, const unsigned char*, const unsigned int*);

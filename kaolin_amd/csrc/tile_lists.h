@@ -103,8 +103,7 @@ constexpr double SOFT_EPS = 1e-7;     // the reference's literal EPS (dibr_soft_
 // time (measured on MI355X: ~33 ns each on one address, ~15 ns each on neighbouring words of a line), so counters that are hit
 // thousands of times per launch must not share lines.
 constexpr int COUNTER_STRIDE = 32;
-constexpr int SPAN_SHARDS = 1;        // copies of a view's covered-row span (workgroup id picks one; readers take their union).  One is enough: workgroups read the span
-                                      // before they add to it, so only the first finishers and the few that extend it issue atomics at all
+constexpr int SPAN_SAMPLE = 16;       // every SPAN_SAMPLE-th workgroup of the binning launch reports the tile rows its faces cover (note_row_span)
 constexpr int WORK_SHARDS = 8;        // worklist shards (one append counter each; workgroup id & 7 picks the shard)
 
 struct PassGeom {
@@ -137,7 +136,7 @@ struct Lists {
   unsigned int* sub_touched;  // [B * ntiles]      zeroed; soft pass only: bit s = some enlarged box reaches sub-tile s
   int tiles_x, ntiles;
   // raster pass only (nullptr: none): the tile rows the mesh's boxes cover, per view -- where the tile kernels start
-  unsigned int* row_span;     // [B * 2 * SPAN_SHARDS] zeroed; view b: SPAN_SHARDS x (last covered row + 1), then SPAN_SHARDS x (tiles_y - first covered row); 0 = none
+  unsigned int* row_span;     // [B * 2] zeroed; view b: (last covered row + 1), (tiles_y - first covered row); 0 = none
 };
 
 inline size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -176,7 +175,7 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
     L.r.tab = off; off += a256(ntr * L.r.maxc * 4);
     L.r.pool_top = off; off += 256;
     L.r.big_count = off; off += a256((size_t)B * 4);
-    L.r.row_span = off; off += a256((size_t)B * 2 * SPAN_SHARDS * 4);
+    L.r.row_span = off; off += a256((size_t)B * 2 * 4);
   }
   if (with_s) {
     L.s.count = off; off += a256(nts * 4);
@@ -218,12 +217,12 @@ inline unsigned int work_shard_cap(int B, int H, int W) {
 // ... then one byte per (mesh, 16 x 16 tile) [b * ntiles + tile]: does the tile hold a covered pixel?  (Written by the
 // rasterizer's tile kernel in the fused path; the rasterizer's backward kernel leaves a tile without one at once.)
 inline size_t work_cov_offset_words(int B, int H, int W) { return WORK_HEADER + (size_t)WORK_SHARDS * work_shard_cap(B, H, W) * 4; }
-// ... then, per view, the tile row the forward's tile kernel started from (B words), which the rasterizer's backward kernel
-// starts from too
-inline size_t work_centre_offset_words(int B, int H, int W) {
+// ... then a copy of the forward's covered-row spans (Lists::row_span, 2 B words): the rasterizer's backward kernel starts from
+// the same rows as the forward's tile kernel
+inline size_t work_span_offset_words(int B, int H, int W) {
   return work_cov_offset_words(B, H, W) + ((size_t)B * pass_geom(H, W, R_TILE).ntiles + 3) / 4;
 }
-inline size_t work_words(int B, int H, int W) { return work_centre_offset_words(B, H, W) + (size_t)B; }
+inline size_t work_words(int B, int H, int W) { return work_span_offset_words(B, H, W) + (size_t)2 * B; }
 
 inline Lists lists_of(void* ws, const PassLayout& p, int B, bool soft) {
   char* c = (char*)ws;
@@ -521,88 +520,49 @@ struct BinIn {
 // ---- where the tile kernels start ------------------------------------------------------------------------------------------
 // The workgroup of a tile with faces lives ~100x longer than a background tile's, so the tile kernels visit a view's tile
 // rows outwards from the middle of the rows the mesh covers: the long workgroups start first and the background rows stream
-// out beside their tail (round 2 started from the middle of the IMAGE -- right for a centred object only).  The binning
-// kernel notes, per view, the first and the last tile row any kept face's box reaches.  Everything about it is arranged to
-// stay off the kernel's critical path (every wavefront of the launch is resident, the launch lasts one wavefront's life):
-// the lanes' rows are reduced per wavefront, merged per workgroup in LDS behind the LAST barrier of the kernel, and leave
-// as at most two fire-and-forget atomicMax per workgroup and view, on one of SPAN_SHARDS copies of the span -- and only when
-// the copy, read first, does not hold the workgroup's rows yet (behind the last barrier nobody waits for that load; once the
-// span has grown most workgroups add nothing: same-line device atomics complete one at a time, and a view's copies share
-// one 64-byte line so that a tile-kernel workgroup reads them with one scalar load).
-// Measured and dropped on the way: ranking the rows by the faces their tiles list (a ticket per workgroup + a sort in the
-// last one to finish: +8 us in the binning launch, and a u16 load per tile-kernel workgroup: +4 us on 131 072 workgroups;
-// with a device-scope fence in the ticket -- an L2 write-back per workgroup -- the launch tripled); a workgroup merge in
-// the middle of the kernel with a read-before-update of the span (+9 us: a barrier and a dependent load in every wavefront's life).
-// row k of the visiting order around centre c: c, c - 1, c + 1, c - 2, ... and, once one side is used up, on along the other
-__host__ __device__ inline int row_from_centre(int k, int c, int tiles_y) {
-  const int left = c, right = tiles_y - 1 - c, m = left < right ? left : right;
-  if (k <= 2 * m) return (k & 1) ? c - ((k + 1) >> 1) : c + (k >> 1);
-  return right > left ? k : tiles_y - 1 - k;
+// out beside their tail (round 2 started from the middle of the IMAGE -- right for a centred object only).  The span of
+// covered rows is an ESTIMATE (any order is correct) and has to cost nothing, because everything that was tried to get it
+// exactly did: every wavefront of the binning launch is resident and they all finish together, so ANY per-workgroup
+// publication -- two atomicMax per workgroup on a view's line, even behind the last barrier and skipped when a read shows the
+// span already covered -- queues ~3 000 same-line atomics (~25 ns each) at the end of the launch: +9 to +17 us; ranking the
+// rows by the faces their tiles list (a ticket per workgroup, a sort in the last one) +8 us, and with a device-scope fence in
+// the ticket (an L2 write-back per workgroup) the launch tripled.  So only every SPAN_SAMPLE-th workgroup reports -- ~100
+// groups of 256 consecutive faces, spread evenly over the face list -- and the tile kernels shift their fixed visiting order
+// (rows from the middle of the image outwards) cyclically so that it starts in the middle of the reported span: one scalar
+// load and three scalar instructions per workgroup (a closed-form "outwards from c" map and a ranked row table were measured
+// too: they pushed raster_tile, which sits at its 64-VGPR limit, into spilling -- 98 -> 121-150 us).
+// row k of the visiting order: rows from the middle of the image outwards, shifted cyclically to start at row `centre`
+__host__ __device__ inline int row_of_order(int k, int centre, int tiles_y) {
+  const int mid = tiles_y >> 1;
+  int ty = ((k & 1) ? mid - ((k + 1) >> 1) : mid + (k >> 1)) + (centre - mid);
+  return ty < 0 ? ty + tiles_y : (ty >= tiles_y ? ty - tiles_y : ty);
 }
-// the centre the tile kernels of view b start from (the middle row of the image when no face was binned); uniform loads
+// the middle of view b's reported span (the middle of the image when nothing was reported); uniform loads
 __device__ __forceinline__ int row_centre(const unsigned int* __restrict__ row_span, int b, int tiles_y) {
   if (row_span == nullptr) return tiles_y >> 1;
-  unsigned int hi1 = 0u, lo_inv = 0u;
-  const unsigned int* __restrict__ v = row_span + (size_t)b * (2 * SPAN_SHARDS);  // 64 bytes, 64-byte aligned
-#pragma unroll
-  for (int s = 0; s < SPAN_SHARDS; ++s) {
-    hi1 = max(hi1, v[s]);
-    lo_inv = max(lo_inv, v[SPAN_SHARDS + s]);
-  }
+  const unsigned int hi1 = row_span[2 * b], lo_inv = row_span[2 * b + 1];
   if (hi1 == 0u || lo_inv == 0u) return tiles_y >> 1;
-  const int lo = tiles_y - (int)lo_inv, hi = (int)hi1 - 1;
-  const int c = (lo + hi) >> 1;
+  const int c = (tiles_y - (int)lo_inv + (int)hi1 - 1) >> 1;
   return c < 0 ? 0 : (c > tiles_y - 1 ? tiles_y - 1 : c);
 }
-// A wavefront's contribution: {view of its first kept face, first row, last row} -> s_span[wave]; kept faces of other views
-// (a wavefront that straddles a view boundary, meshes of fewer than 64 faces) go straight to memory.
-__device__ __forceinline__ void span_of_wave(const Lists& L, bool act, int b, int r0, int r1, int (*s_span)[4]) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tiles_y = L.ntiles / L.tiles_x;
+// called by every thread of a REPORTING workgroup of the binning kernel (uniform per workgroup): `act` = the lane's face is
+// kept and reaches the image, tile rows [r0, r1]
+__device__ __forceinline__ void note_row_span(const Lists& L, bool act, int b, int r0, int r1) {
+  const int tiles_y = L.ntiles / L.tiles_x;
   const unsigned long long am = __ballot(act);
-  int b0 = -1, lo = 0x7FFFFFFF, hi = -1;
-  if (am != 0ull) {
-    b0 = __builtin_amdgcn_readlane(b, __ffsll((long long)am) - 1);
-    const bool mine = act && b == b0;
-    lo = mine ? r0 : 0x7FFFFFFF;
-    hi = mine ? r1 : -1;
+  if (am == 0ull) return;
+  // the wavefront's first view is reduced (a wavefront of 64 consecutive faces rarely straddles two)
+  const int b0 = __builtin_amdgcn_readlane(b, __ffsll((long long)am) - 1);
+  const bool mine = act && b == b0;
+  int lo = mine ? r0 : 0x7FFFFFFF, hi = mine ? r1 : -1;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      lo = min(lo, __shfl_xor(lo, d, 64));
-      hi = max(hi, __shfl_xor(hi, d, 64));
-    }
-    if (act && b != b0) {
-      unsigned int* p = L.row_span + (size_t)b * (2 * SPAN_SHARDS) + (blockIdx.x % SPAN_SHARDS);
-      atomicMax(p, (unsigned int)(r1 + 1));
-      atomicMax(p + SPAN_SHARDS, (unsigned int)(tiles_y - r0));
-    }
+  for (int d = 32; d >= 1; d >>= 1) {
+    lo = min(lo, __shfl_xor(lo, d, 64));
+    hi = max(hi, __shfl_xor(hi, d, 64));
   }
-  if (lane == 0) {
-    s_span[wave][0] = b0;
-    s_span[wave][1] = lo;
-    s_span[wave][2] = hi;
-  }
-}
-// ... merged per workgroup and published; called by every thread at the very end of the kernel
-__device__ __forceinline__ void publish_row_span(const Lists& L, int (*s_span)[4]) {
-  __syncthreads();
-  if (threadIdx.x < 4) {
-    // wavefront w speaks for its view unless an earlier wavefront of the workgroup has the same view (then that one merges)
-    const int w = threadIdx.x, vb = s_span[w][0], tiles_y = L.ntiles / L.tiles_x;
-    bool first = vb >= 0;
-    for (int q = 0; q < w; ++q) first = first && s_span[q][0] != vb;
-    if (first) {
-      int l = s_span[w][1], h = s_span[w][2];
-      for (int q = w + 1; q < 4; ++q)
-        if (s_span[q][0] == vb) {
-          l = min(l, s_span[q][1]);
-          h = max(h, s_span[q][2]);
-        }
-      unsigned int* p = L.row_span + (size_t)vb * (2 * SPAN_SHARDS) + (blockIdx.x % SPAN_SHARDS);
-      const unsigned int have_hi = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned int have_lo = __hip_atomic_load(p + SPAN_SHARDS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (have_hi < (unsigned int)(h + 1)) atomicMax(p, (unsigned int)(h + 1));
-      if (have_lo < (unsigned int)(tiles_y - l)) atomicMax(p + SPAN_SHARDS, (unsigned int)(tiles_y - l));
-    }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(L.row_span + 2 * b0, (unsigned int)(hi + 1));
+    atomicMax(L.row_span + 2 * b0 + 1, (unsigned int)(tiles_y - lo));
   }
 }
 
@@ -741,9 +701,7 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(
     }
   }
   PHASE_MARK(5);
-  __shared__ int s_span[4][4];
-  const bool want_span = DO_R && LR.row_span != nullptr;
-  if (want_span) span_of_wave(LR, act_r, b, ry0, ry1, s_span);
+  if (DO_R && LR.row_span != nullptr && blockIdx.x % SPAN_SAMPLE == 0) note_row_span(LR, act_r, b, ry0, ry1);
   if (DO_R && DO_S) {
     PendingEntry er, es;
     wave_bin<false>(act_r, big_r, b, first_b, f, rx0, rx1, ry0, ry1, 0, 0, 0, 0, LR, &er);
@@ -756,7 +714,6 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(
     if (DO_S) wave_bin<true>(act_s, big_s, b, first_b, f, sx0, sx1, sy0, sy1, pr_s.c_lo, pr_s.c_hi, pr_s.r_lo, pr_s.r_hi, LS);
   }
   PHASE_MARK(7);
-  if (want_span) publish_row_span(LR, s_span);
   PHASE_FLUSH(g_phase_bin);
 #ifdef KAMD_PHASE_PROF
   if ((threadIdx.x & 63) == 0) {
@@ -804,7 +761,6 @@ struct ClassifyOut {
   unsigned int* work_counts;
   unsigned int shard_cap;
   unsigned char* tile_cov;          // [B * ntiles_r] (work_cov_offset_words), or nullptr
-  unsigned int* row_centre_out;     // [B] (work_centre_offset_words): the tile row the kernel started view b from, or nullptr
 };
 
 // exclusive prefix over the 256 threads of a workgroup; *total = sum.  `scratch`: 4 ints of LDS.

@@ -428,7 +428,11 @@ def test_pair_search_nonfinite_fallback_and_one_sided_grad():
         assert torch.equal(torch.isnan(d.cpu()), torch.isnan(d_ref))
         assert torch.equal(torch.nan_to_num(d.cpu()), torch.nan_to_num(d_ref))
     assert _C.metrics.sided_distance_pair_forward(p1[:, :100].cuda().contiguous(), p2.cuda()) is None
-    assert _C.metrics.sided_distance_pair_forward(p1.double().cuda(), p2.double().cuda()) is None
+    both64 = _C.metrics.sided_distance_pair_forward(p1.double().cuda(), p2.double().cuda())      # fp64 takes the shared grid too
+    for (q, t), (d, i) in zip([(p1.double(), p2.double()), (p2.double(), p1.double())], [both64[:2], both64[2:]]):
+        d_ref, i_ref = oracle.sided_distance_forward(q, t, omp=True)
+        assert torch.equal(i.cpu(), i_ref) and torch.equal(torch.nan_to_num(d.cpu()), torch.nan_to_num(d_ref))
+    assert _C.metrics.sided_distance_pair_forward(p1.half().cuda(), p2.half().cuda()) is None    # fp16: the two all-pairs calls
     small = pc.chamfer_distance(p1[:1, 1:200].cuda(), p2[:1, 1:300].cuda())
     ref = oracle.sided_distance_forward(p1[:1, 1:200], p2[:1, 1:300])[0].mean(-1) + \
         oracle.sided_distance_forward(p2[:1, 1:300], p1[:1, 1:200])[0].mean(-1)

@@ -1,26 +1,24 @@
 """The rasterizer kernels' workgroup -> tile map (kaolin_amd/csrc/raster2.inc KAMD_RASTER_ORDER, rasterize.hip
-KAMD_RBWD_ORDER): views interleaved, a view's tile rows visited outwards from a centre row -- the middle of the rows the
-mesh's boxes cover, which the binning launch leaves per view (tile_lists.h note_row_span / row_centre / row_from_centre), or
-the middle of the image.  Restated in Python and checked for what correctness needs -- every (view, tile) exactly once --
-and for what the order is for: the rows come in non-decreasing distance from the centre until one side of the image is
-used up.  The GPU test reads the centre a forward pass left behind."""
+KAMD_RBWD_ORDER): views interleaved, a view's tile rows visited from the middle of the image outwards, the whole order shifted
+cyclically so that it starts at a centre row -- the middle of the rows the mesh covers, estimated by the binning launch
+(tile_lists.h note_row_span / row_centre / row_of_order).  Restated in Python and checked for what correctness needs -- every
+(view, tile) exactly once -- and for what the order is for: it starts at the centre and leaves it monotonically until it
+wraps.  The GPU test reads the span a forward pass left behind."""
 import pytest
 import torch
 
 
-def row_from_centre(k, c, tiles_y):
-    """tile_lists.h row_from_centre: c, c - 1, c + 1, c - 2, ... and, once one side is used up, on along the other."""
-    left, right = c, tiles_y - 1 - c
-    m = min(left, right)
-    if k <= 2 * m:
-        return c - ((k + 1) >> 1) if k & 1 else c + (k >> 1)
-    return k if right > left else tiles_y - 1 - k
+def row_of_order(k, centre, tiles_y):
+    """tile_lists.h row_of_order: the k-th row of mid, mid - 1, mid + 1, ... shifted cyclically by (centre - mid)."""
+    mid = tiles_y >> 1
+    ty = (mid - ((k + 1) >> 1) if k & 1 else mid + (k >> 1)) + (centre - mid)
+    return ty + tiles_y if ty < 0 else (ty - tiles_y if ty >= tiles_y else ty)
 
 
 def tile_of(block, B, tiles_x, tiles_y, columns_too=False, centres=None):
     b, k = block % B, block // B
     kr, tx = k // tiles_x, k % tiles_x
-    ty = row_from_centre(kr, tiles_y >> 1 if centres is None else centres[b], tiles_y)
+    ty = row_of_order(kr, tiles_y >> 1 if centres is None else centres[b], tiles_y)
     if columns_too:
         midx = tiles_x >> 1
         tx = midx - ((tx + 1) >> 1) if tx & 1 else midx + (tx >> 1)
@@ -53,11 +51,13 @@ def test_rows_leave_the_middle_monotonically(tiles_y):
 
 
 @pytest.mark.parametrize('tiles_y', [1, 2, 3, 8, 63, 64])
-def test_rows_from_any_centre_are_a_bijection_in_order_of_distance(tiles_y):
+def test_rows_from_any_centre_are_a_bijection_leaving_the_centre(tiles_y):
     for c in range(tiles_y):
-        rows = [row_from_centre(k, c, tiles_y) for k in range(tiles_y)]
+        rows = [row_of_order(k, c, tiles_y) for k in range(tiles_y)]
         assert sorted(rows) == list(range(tiles_y)) and rows[0] == c
-        dist = [abs(r - c) for r in rows]
+        # until the shifted order wraps around an image edge, the rows come in non-decreasing distance from the centre
+        reach = min(c, tiles_y - 1 - c)
+        dist = [abs(r - c) for r in rows[:2 * reach + 1]]
         assert dist == sorted(dist)
     B, tiles_x = 3, 5
     centres = [0, tiles_y - 1, tiles_y // 3]
@@ -68,12 +68,13 @@ def test_rows_from_any_centre_are_a_bijection_in_order_of_distance(tiles_y):
 @pytest.mark.gpu
 @pytest.mark.parametrize('shift', [(0., 0.), (0.5, -0.55), (-0.3, 0.9)])
 def test_forward_starts_where_the_object_is(shift):
-    """dibr_rasterization's binning launch notes, per view, the tile rows the kept faces' boxes cover; the tile kernel starts
-    from the middle of them and leaves that row in the operator's work buffer for the backward pass.  Wherever the object
-    sits, the centre row must lie inside the rows that hold covered pixels (give or take the boxes' slack)."""
+    """dibr_rasterization's binning launch reports, per view, tile rows its kept faces' boxes cover (a sample of its
+    workgroups: an estimate); the tile kernel starts from the middle of them, and the span is left next to the operator's
+    worklist for the backward pass.  Wherever the object sits, the reported rows must lie inside the rows that hold covered
+    pixels (give or take the boxes' slack), and so must their middle."""
     import kaolin_amd as kal
     from kaolin_amd.utils import testing as T
-    fz, fimg, feats, nz = T.sphere_scene(level=12, num_views=3, device='cuda')
+    fz, fimg, feats, nz = T.sphere_scene(level=24, num_views=3, device='cuda')      # 11 520 faces: 45 binning workgroups per view
     fimg = (fimg + torch.tensor(shift, device='cuda')).contiguous()
     H, W = 272, 200
     feat = torch.cat(feats, -1).contiguous()
@@ -85,13 +86,17 @@ def test_forward_starts_where_the_object_is(shift):
     assert work.numel() == lib.kamd_dibr_soft_mask_work_words(B, H, W)
     n_groups = B * tiles_x * tiles_y
     off = kal._C.render.mesh.WORK_HEADER + 8 * (4 * ((n_groups + 7) // 8)) * 4 + (n_groups + 3) // 4   # header, items, coverage bytes
-    centres = work[off:off + B].tolist()
+    span = work[off:off + 2 * B].view(B, 2).tolist()
     covered_rows = (face_idx >= 0).any(dim=2).cpu()                                  # (B, H)
     for b in range(B):
-        assert 0 <= centres[b] < tiles_y
         rows = [r for r in range(tiles_y) if bool(covered_rows[b, r * 16:(r + 1) * 16].any())]
-        if rows:
-            assert rows[0] - 1 <= centres[b] <= rows[-1] + 1, (centres[b], rows)
-            assert abs(centres[b] - (rows[0] + rows[-1]) / 2) <= 1.5
+        hi1, lo_inv = span[b]
+        if not rows:
+            continue
+        assert hi1 > 0 and lo_inv > 0, 'no workgroup reported for a view with covered pixels'
+        lo, hi = tiles_y - lo_inv, hi1 - 1
+        assert rows[0] - 1 <= lo <= hi <= rows[-1] + 1, (lo, hi, rows)
+        assert rows[0] <= (lo + hi) // 2 <= rows[-1]
+        assert hi - lo >= (rows[-1] - rows[0]) // 2, 'the sample misses most of the object'
     (out.sum() + soft.sum()).backward()          # the backward starts from the same rows: must simply work
     assert torch.isfinite(a.grad).all()
