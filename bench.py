@@ -403,7 +403,9 @@ def main():
 
     # ---------------- the same step replayed as a HIP graph (N = 1: no host in it)
     graph_replay = None
-    if world == 1 and not args.quick:
+    # (not under a process group, even of one rank: the collective backend's watchdog thread polls events, which HIP refuses
+    # while another thread is capturing)
+    if world == 1 and not D.is_distributed() and not args.quick:
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -515,7 +517,7 @@ def main():
                                     'value': round(pairs / odt / 1e6, 1),
                                     'note': 'chamfer_distance fwd + bwd (gradients to both clouds) from a given upstream '
                                             'gradient; no shared parameter, no collective'}
-        if world == 1:
+        if world == 1 and not D.is_distributed():
             try:
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
