@@ -383,25 +383,35 @@ def dibr_rasterization_forward_fused(height, width, face_vertices_z, face_vertic
     front = None
     if valid_faces is not None and valid_faces.is_floating_point():
         front, valid_faces = valid_faces, None
-    args = [Arg(face_vertices_z, 'face_vertices_z', 3), Arg(face_vertices_image, 'face_vertices_image', 4),
-            Arg(face_features, 'face_features', 5)]
-    if valid_faces is not None:
-        args.append(Arg(valid_faces, 'valid_faces', 6))
-    if front is not None:
-        args.append(Arg(front, 'face_normals_z', 6))
-    check_all_same_gpu(fn, args)
-    check_all_contiguous(fn, args[1:3] + ([args[3]] if valid_faces is not None else []))
     batch_size, num_faces, feat_dim = face_vertices_z.size(0), face_vertices_z.size(1), face_features.size(3)
-    check_size(fn, args[0], [batch_size, num_faces, 3])
-    check_size(fn, args[1], [batch_size, num_faces, 3, 2])
-    check_size(fn, args[2], [batch_size, num_faces, 3, feat_dim])
-    if len(args) > 3:
-        check_size(fn, args[3], [batch_size, num_faces])
+    extra = valid_faces if valid_faces is not None else front
+    # (a hot host path -- the DIB-R step is enqueued from here: one inline test for the usual case, the reference-style checks
+    # with their messages only when it fails)
+    dev = face_vertices_z.device
+    if not (face_vertices_z.is_cuda and face_vertices_image.device == dev and face_features.device == dev and
+            face_vertices_image.is_contiguous() and face_features.is_contiguous() and
+            face_vertices_z.shape == (batch_size, num_faces, 3) and face_vertices_image.shape == (batch_size, num_faces, 3, 2) and
+            face_features.shape == (batch_size, num_faces, 3, feat_dim) and
+            (extra is None or (extra.device == dev and extra.shape == (batch_size, num_faces) and
+                               (front is not None or extra.is_contiguous())))):
+        args = [Arg(face_vertices_z, 'face_vertices_z', 3), Arg(face_vertices_image, 'face_vertices_image', 4),
+                Arg(face_features, 'face_features', 5)]
+        if valid_faces is not None:
+            args.append(Arg(valid_faces, 'valid_faces', 6))
+        if front is not None:
+            args.append(Arg(front, 'face_normals_z', 6))
+        check_all_same_gpu(fn, args)
+        check_all_contiguous(fn, args[1:3] + ([args[3]] if valid_faces is not None else []))
+        check_size(fn, args[0], [batch_size, num_faces, 3])
+        check_size(fn, args[1], [batch_size, num_faces, 3, 2])
+        check_size(fn, args[2], [batch_size, num_faces, 3, feat_dim])
+        if len(args) > 3:
+            check_size(fn, args[3], [batch_size, num_faces])
     dtype, device = face_vertices_z.dtype, face_vertices_z.device
     sfx = _lib.dtype_suffix(dtype, fn)
-    for a in args[1:3] + ([args[3]] if front is not None else []):
-        if a.t.dtype != dtype:
-            raise RuntimeError(f'expected scalar type {_lib._PRETTY[dtype]} but found {_lib._PRETTY.get(a.t.dtype, a.t.dtype)}')
+    for t in (face_vertices_image, face_features, front):
+        if t is not None and t.dtype != dtype:
+            raise RuntimeError(f'expected scalar type {_lib._PRETTY[dtype]} but found {_lib._PRETTY.get(t.dtype, t.dtype)}')
     lib = _lib.load()
     esz = face_vertices_z.element_size()
     z, z_face, z_vertex = _face_strides(face_vertices_z, True)
@@ -436,18 +446,25 @@ def dibr_rasterization_backward_fused(grad_features, grad_soft_mask, face_idx, o
     ``need_feature_grad=False`` (static features: autograd's ``needs_input_grad``) skips the second one -> None.
     ``zeroed_grad_image``: the buffer the forward cleared for this call (accumulated into and returned)."""
     fn = 'dibr_rasterization_backward_fused'
-    args = [Arg(grad_features, 'grad_features', 1), Arg(grad_soft_mask, 'grad_soft_mask', 2), Arg(face_idx, 'face_idx', 3),
-            Arg(output_weights, 'output_weights', 4), Arg(soft_mask, 'soft_mask', 5),
-            Arg(face_vertices_image, 'face_vertices_image', 7), Arg(face_features, 'face_features', 8)]
-    check_all_same_gpu(fn, args)
-    check_all_contiguous(fn, args)
     batch_size, height, width, feat_dim = grad_features.shape
     num_faces = face_vertices_image.size(1)
-    check_size(fn, args[1], [batch_size, height, width])
-    check_size(fn, args[2], [batch_size, height, width])
-    check_size(fn, args[3], [batch_size, height, width, 3])
-    check_size(fn, args[5], [batch_size, num_faces, 3, 2])
-    check_size(fn, args[6], [batch_size, num_faces, 3, feat_dim])
+    dev = face_vertices_image.device
+    tensors = (grad_features, grad_soft_mask, face_idx, output_weights, soft_mask, face_vertices_image, face_features)
+    if not (face_vertices_image.is_cuda and all(t.device == dev and t.is_contiguous() for t in tensors) and
+            grad_soft_mask.shape == (batch_size, height, width) and face_idx.shape == (batch_size, height, width) and
+            output_weights.shape == (batch_size, height, width, 3) and
+            face_vertices_image.shape == (batch_size, num_faces, 3, 2) and
+            face_features.shape == (batch_size, num_faces, 3, feat_dim)):
+        args = [Arg(grad_features, 'grad_features', 1), Arg(grad_soft_mask, 'grad_soft_mask', 2), Arg(face_idx, 'face_idx', 3),
+                Arg(output_weights, 'output_weights', 4), Arg(soft_mask, 'soft_mask', 5),
+                Arg(face_vertices_image, 'face_vertices_image', 7), Arg(face_features, 'face_features', 8)]
+        check_all_same_gpu(fn, args)
+        check_all_contiguous(fn, args)
+        check_size(fn, args[1], [batch_size, height, width])
+        check_size(fn, args[2], [batch_size, height, width])
+        check_size(fn, args[3], [batch_size, height, width, 3])
+        check_size(fn, args[5], [batch_size, num_faces, 3, 2])
+        check_size(fn, args[6], [batch_size, num_faces, 3, feat_dim])
     dtype, device = face_vertices_image.dtype, face_vertices_image.device
     sfx = _lib.dtype_suffix(dtype, fn)
     lib = _lib.load()
@@ -464,16 +481,15 @@ def dibr_rasterization_backward_fused(grad_features, grad_soft_mask, face_idx, o
     return g_img, g_feat
 
 
-_ADJ_CACHE = {}
+_ADJ_CACHE = {}     # id(faces) -> (faces, version, num_vertices, offsets, entries): the entry pins `faces`, so its id stays unique
 
 
 def vertex_face_adjacency(faces, num_vertices):
     """CSR list of the (face, corner) incidences of every vertex: (offsets (V+1) int32, entries (3F) int32 = face*3+k).
     Built with three torch ops the first time a `faces` tensor is seen and cached (mesh topology is static in training)."""
-    key = (faces.data_ptr(), tuple(faces.shape), faces._version, int(num_vertices), str(faces.device))
-    hit = _ADJ_CACHE.get(key)
-    if hit is not None:
-        return hit
+    hit = _ADJ_CACHE.get(id(faces))
+    if hit is not None and hit[0] is faces and hit[1] == faces._version and hit[2] == num_vertices:
+        return hit[3], hit[4], faces
     flat = faces.reshape(-1)
     entries = torch.argsort(flat, stable=True).to(torch.int32)
     counts = torch.bincount(flat, minlength=num_vertices)
@@ -481,30 +497,37 @@ def vertex_face_adjacency(faces, num_vertices):
     offsets[1:] = torch.cumsum(counts, 0).to(torch.int32)
     if len(_ADJ_CACHE) > 8:
         _ADJ_CACHE.clear()
-    _ADJ_CACHE[key] = (offsets, entries, faces)   # keep `faces` alive so that its data_ptr stays unique
-    return _ADJ_CACHE[key]
+    _ADJ_CACHE[id(faces)] = (faces, faces._version, int(num_vertices), offsets, entries)
+    return offsets, entries, faces
 
 
-_FACES_OK = {}
+_FACES_OK = {}      # id(faces) -> (faces, version, num_vertices, ok)
 
 
 def faces_in_range(faces, num_vertices):
     """True when every index of `faces` addresses a vertex (the reference's index_select would raise otherwise; the fused
     kernels read unchecked).  One reduction and one host read per `faces` tensor, cached like the adjacency (mesh topology
-    is static); the entry keeps `faces` alive, so that its data_ptr cannot be handed to another tensor of the same shape
-    while the entry exists (a recycled address would hit a stale answer)."""
-    key = (faces.data_ptr(), tuple(faces.shape), faces._version, int(num_vertices), str(faces.device))
-    hit = _FACES_OK.get(key)
-    if hit is None:
-        if faces.numel() == 0:
-            ok = True
-        else:
-            lo, hi = torch.stack(torch.aminmax(faces)).tolist()     # min and max in one pass, one synchronising read
-            ok = lo >= 0 and hi < num_vertices
-        if len(_FACES_OK) > 16:
-            _FACES_OK.clear()
-        hit = _FACES_OK[key] = (ok, faces)
-    return hit[0]
+    is static); the entry keeps `faces` alive, so that neither its id nor its data_ptr can be handed to another tensor
+    while the entry exists (a recycled address would hit a stale answer); an in-place edit bumps the version."""
+    hit = _FACES_OK.get(id(faces))
+    if hit is not None and hit[0] is faces and hit[1] == faces._version and hit[2] == num_vertices:
+        return hit[3]
+    if faces.numel() == 0:
+        ok = True
+    else:
+        lo, hi = torch.stack(torch.aminmax(faces)).tolist()     # min and max in one pass, one synchronising read
+        ok = lo >= 0 and hi < num_vertices
+    if len(_FACES_OK) > 16:
+        _FACES_OK.clear()
+    _FACES_OK[id(faces)] = (faces, faces._version, int(num_vertices), ok)
+    return ok
+
+
+def _as(t, dtype):
+    """`t` as a contiguous tensor of `dtype` (itself when it already is: the usual case, and a hot host path)."""
+    if t is None or (t.dtype == dtype and t.is_contiguous()):
+        return t
+    return t.to(dtype).contiguous()
 
 
 def _pv_common(vertices, faces, camera_proj, camera_rot, camera_trans, camera_transform):
@@ -526,9 +549,9 @@ def prepare_vertices_forward_fused(vertices, faces, camera_proj, camera_rot, cam
     sfx = _lib.dtype_suffix(dtype, fn)
     V, F = v.size(1), faces.size(0)
     lib = _lib.load()
-    c = lambda t: None if t is None else t.to(dtype).contiguous()  # noqa: E731
-    proj, rot, trans, tf = c(camera_proj.reshape(-1)), c(camera_rot), c(camera_trans), c(camera_transform)
-    faces = faces.contiguous()
+    proj, rot, trans, tf = _as(camera_proj.reshape(-1), dtype), _as(camera_rot, dtype), _as(camera_trans, dtype), _as(camera_transform, dtype)
+    if not faces.is_contiguous():
+        faces = faces.contiguous()
     with _lib.on_device(device):
         fv_cam = torch.empty((B, F, 3, 3), dtype=dtype, device=device)
         fv_img = torch.empty((B, F, 3, 2), dtype=dtype, device=device)
@@ -548,11 +571,11 @@ def prepare_vertices_backward_fused(vertices, faces, camera_proj, camera_rot, ca
     sfx = _lib.dtype_suffix(dtype, fn)
     V, F = v.size(1), faces.size(0)
     lib = _lib.load()
-    c = lambda t: None if t is None else t.to(dtype).contiguous()  # noqa: E731
-    proj, rot, trans, tf = c(camera_proj.reshape(-1)), c(camera_rot), c(camera_trans), c(camera_transform)
-    faces = faces.contiguous()
+    proj, rot, trans, tf = _as(camera_proj.reshape(-1), dtype), _as(camera_rot, dtype), _as(camera_trans, dtype), _as(camera_transform, dtype)
+    if not faces.is_contiguous():
+        faces = faces.contiguous()
     offsets, entries, _ = vertex_face_adjacency(faces, V)
-    g = [None if t is None else t.contiguous() for t in (grad_cam, grad_img, grad_nrm)]
+    g = [t if (t is None or t.is_contiguous()) else t.contiguous() for t in (grad_cam, grad_img, grad_nrm)]
     with _lib.on_device(device):
         g_vertices = torch.empty((B, V, 3), dtype=dtype, device=device)
         st = getattr(lib, f'kamd_prepare_vertices_backward_{sfx}')(
