@@ -97,7 +97,7 @@ for sec in SECTIONS:
     kernels = {}
     for k in sorted(set(sec_f.get(sec, {})) | set(sec_w.get(sec, {}))):
         fv, wv = sec_f.get(sec, {}).get(k, []), sec_w.get(sec, {}).get(k, [])
-        name = re.sub(r'\(.*', '', k)[:70]
+        name = re.sub(r'[(<].*', '', k.replace('(anonymous namespace)::', '').replace('void ', '').replace('kamd::', ''))[:70]
         e = kernels.setdefault(name, {'fetch_bytes_per_call': 0.0, 'write_bytes_per_call': 0.0, 'launches_per_call': 0.0})
         e['fetch_bytes_per_call'] += sum(fv) * (f_scale or 0) / calls[sec]
         e['write_bytes_per_call'] += sum(wv) * (w_scale or 0) / calls[sec]
