@@ -291,8 +291,9 @@ template <typename T>
 int raster2_draw(hipStream_t st, int B, int H, int W, int D, int F_dense, float multiplier, float eps, const T* rec,
                  const tl::Lists& LR, const T* feat, T* interp, int64_t* sel_idx, T* weights, const tl::ClassifyOut& co,
                  bool weights_internal) {
+  if (!raster2_grid_fits(H, W)) return (int)hipErrorInvalidValue;
   kamd::ProfScope prof_(kamd::K_RASTER_TILE, st);
-  hipLaunchKernelGGL((raster_tile_kernel2<T, true>), dim3(LR.ntiles * B), dim3(256), 0, st, B, F_dense,
+  hipLaunchKernelGGL((raster_tile_kernel2<T, true>), raster2_grid(LR, B), dim3(256), 0, st, B, F_dense,
                      (const int64_t*)nullptr, H, W, D, pixel_scale(multiplier, H, W), eps,
                      raster2_wide_ok(W, interp, sel_idx, weights, co.soft_mask) | (weights_internal ? 2 : 0),
                      kamd_env_int("KAMD_RASTER_MODE", 0), rec, LR, feat, interp, sel_idx, weights, co);

@@ -820,5 +820,65 @@ __device__ __forceinline__ void queue_items(unsigned long long unc, bool has_fac
   }
 }
 
+// The rasterizer's tile kernel reads what queue_items needs at its start, next to the tile's list head (one round trip
+// instead of a second one at the tail).  Result: bit 2 w = some enlarged box reaches the 16 x 4 sub-tile of wavefront w of
+// rasterizer tile (tx, ty) (the soft tile's word, shifted: its sub-tiles are numbered row by row, two per row).  Every
+// operand is uniform over the workgroup: scalar loads.
+static_assert(R_TILE == SUB_W && R_TILE == 4 * SUB_H && S_TILE == 2 * R_TILE, "reach_of_tile: four sub-tiles per rasterizer tile, 2 x 2 rasterizer tiles per soft tile");
+constexpr unsigned int REACH_ALL = 0x55u;
+__device__ __forceinline__ unsigned int reach_of_tile(const unsigned int* __restrict__ sub_touched, const unsigned int* __restrict__ big_count_s,
+                                                      int tiles_x_s, int ntiles_s, int b, int tx, int ty) {
+  const unsigned int big = big_count_s[b];
+  const unsigned int w = sub_touched[(size_t)b * ntiles_s + (ty >> 1) * tiles_x_s + (tx >> 1)];
+  return big != 0u ? REACH_ALL : (w >> ((ty & 1) * 8 + (tx & 1))) & REACH_ALL;
+}
+__device__ __forceinline__ bool reached(unsigned int reach, int w) { return ((reach >> (2 * w)) & 1u) != 0u; }
+__device__ __forceinline__ unsigned int item_id_of(int B, int b, int tx, int ty, int tiles_x_s, int w) {
+  const int st = (ty >> 1) * tiles_x_s + (tx >> 1), ss = (ty & 1) * 8 + 2 * w + (tx & 1);
+  return (unsigned int)((st * B + b) * S_SUBS + ss);
+}
+// queue_items with the reach bits in hand (`shard`: the workgroup's worklist shard)
+__device__ __forceinline__ void queue_items_reached(unsigned long long unc, unsigned int reach, int B, int b, int tx, int ty, int tiles_x_s,
+                                                    int wave, int lane, unsigned int shard, uint4* __restrict__ work_items,
+                                                    unsigned int* __restrict__ work_counts, unsigned int shard_cap,
+                                                    unsigned long long* s_item_unc, bool covered, unsigned char* __restrict__ tile_cov,
+                                                    size_t cov_index) {
+  const bool item = unc != 0ull && reached(reach, wave);
+  if (lane == 0) s_item_unc[wave] = item ? unc : 0ull;
+  const int any_covered = __syncthreads_or(covered ? 1 : 0);
+  if (threadIdx.x == 0) {
+    if (tile_cov != nullptr) tile_cov[cov_index] = any_covered ? 1 : 0;
+    int n = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) n += s_item_unc[w] != 0ull ? 1 : 0;
+    if (n > 0) {
+      unsigned int pos = atomicAdd(work_counts + shard * COUNTER_STRIDE, (unsigned int)n);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const unsigned long long u = s_item_unc[w];
+        if (u == 0ull) continue;
+        if (pos < shard_cap)
+          work_items[(size_t)shard * shard_cap + pos] = make_uint4(item_id_of(B, b, tx, ty, tiles_x_s, w), (unsigned int)u, (unsigned int)(u >> 32), 0u);
+        ++pos;
+      }
+    }
+  }
+}
+// A background tile that lies fully inside the image: every pixel of every sub-tile is uncovered, so ONE lane can queue
+// the tile's items without hearing from the other wavefronts (no LDS, no barrier).  Called by one lane.
+__device__ __forceinline__ void queue_items_background(unsigned int reach, int B, int b, int tx, int ty, int tiles_x_s, unsigned int shard,
+                                                       uint4* __restrict__ work_items, unsigned int* __restrict__ work_counts,
+                                                       unsigned int shard_cap, unsigned char* __restrict__ tile_cov, size_t cov_index) {
+  if (tile_cov != nullptr) tile_cov[cov_index] = 0;
+  if (reach == 0u) return;
+  unsigned int pos = atomicAdd(work_counts + shard * COUNTER_STRIDE, (unsigned int)__popc(reach));
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (!reached(reach, w)) continue;
+    if (pos < shard_cap) work_items[(size_t)shard * shard_cap + pos] = make_uint4(item_id_of(B, b, tx, ty, tiles_x_s, w), ~0u, ~0u, 0u);
+    ++pos;
+  }
+}
+
 }  // namespace tl
 }  // namespace kamd

@@ -16,6 +16,8 @@ def row_of_order(k, centre, tiles_y):
 
 
 def tile_of(block, B, tiles_x, tiles_y, columns_too=False, centres=None):
+    """`block`: the workgroup's place in dispatch order.  raster_backward's grid is linear; raster_tile's is (B, tiles_x,
+    tiles_y) -- the dispatcher walks x fastest, then y, then z: the same order without the index arithmetic."""
     b, k = block % B, block // B
     kr, tx = k // tiles_x, k % tiles_x
     ty = row_of_order(kr, tiles_y >> 1 if centres is None else centres[b], tiles_y)
