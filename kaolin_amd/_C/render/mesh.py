@@ -252,7 +252,21 @@ def _hit_list(batch_size, height, width, knum, dtype, device, num_faces=0):
 COUNTER_STRIDE = 32                              # tile_lists.h: append counters sit one per 128-byte line
 WORK_FLAT_WORD = 8 * COUNTER_STRIDE              # the flat hit list's shard counters follow the worklist's 8
 FLAT_SHARDS = 64                                 # soft2.inc
-WORK_HEADER = WORK_FLAT_WORD + FLAT_SHARDS * COUNTER_STRIDE
+COV_SHARDS = 32                                  # the covered-tile list's shard counters follow the flat list's
+WORK_COV_WORD = WORK_FLAT_WORD + FLAT_SHARDS * COUNTER_STRIDE
+WORK_HEADER = WORK_COV_WORD + COV_SHARDS * COUNTER_STRIDE
+
+
+def covered_tiles(work, batch_size, height, width):
+    """Indices b * ntiles + tile (sorted, 1-D int64) of the 16 x 16 tiles the forward pass found a covered pixel in: the list the
+    rasterizer's backward pass walks (tile_lists.h work_covlist_offset_words; tests / debugging; synchronises)."""
+    n_groups = batch_size * ((height + 15) // 16) * ((width + 15) // 16)
+    cap = ((batch_size + 7) // 8) * ((n_groups // batch_size + 3) // 4)
+    off = WORK_HEADER + 8 * (4 * ((n_groups + 7) // 8)) * 4 + (n_groups + 3) // 4 + 2 * batch_size
+    counts = work[WORK_COV_WORD:WORK_COV_WORD + COV_SHARDS * COUNTER_STRIDE:COUNTER_STRIDE].tolist()
+    lists = work[off:off + COV_SHARDS * cap].view(COV_SHARDS, cap)
+    out = [lists[s, :c] for s, c in enumerate(counts) if c]
+    return torch.sort(torch.cat(out).long())[0] if out else torch.zeros(0, dtype=torch.long)
 
 
 def work_items(work, batch_size, height, width):

@@ -15,4 +15,10 @@ template <typename T>
 int raster_backward_draw(hipStream_t st, int B, int H, int W, int F, int D, const T* grad, const int64_t* face_idx, const T* weights,
                          const T* img, const T* feat, float eps, T* g_img, T* g_feat, const unsigned char* tile_cov,
                          const unsigned int* row_span);
+// rasterize.hip: the same over the forward's list of covered tiles (tl::work_covlist_offset_words; counters at
+// work[tl::WORK_COV_WORD + s * COUNTER_STRIDE]): a persistent grid, no workgroup for a tile without a covered pixel
+template <typename T>
+int raster_backward_draw_list(hipStream_t st, int B, int H, int W, int F, int D, const T* grad, const int64_t* face_idx, const T* weights,
+                              const T* img, const T* feat, float eps, T* g_img, T* g_feat, const unsigned int* cov_counts,
+                              const unsigned int* cov_list, unsigned int cov_cap);
 }  // namespace kamd

@@ -549,9 +549,15 @@ int dibr_backward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K
                                       ? reinterpret_cast<const unsigned char*>(work + tl::work_cov_offset_words(B, H, W))
                                       : nullptr;
   const unsigned int* row_centre = F > 0 ? work + tl::work_span_offset_words(B, H, W) : nullptr;  // (copied there by the forward's eval launch)
+  // the rasterizer's backward walks the forward's list of covered tiles (KAMD_BWD_COV_LIST=2: one workgroup per tile, for A/B runs)
+  static const bool cov_list = kamd_env_int("KAMD_BWD_COV_LIST", 1) == 1;
   if (!use_side || kamd::prof_all()) {
     KAMD_CHECK(soft_mask_backward_list_launch<T>(st, B, H, W, F, K, grad_soft, soft_mask, list, work, img, multiplier, sigmainv,
                                                  (float)multiplier, g_img));
+    if (cov_list && tile_cov != nullptr)
+      return kamd::raster_backward_draw_list<T>(st, B, H, W, F, D, grad_feat, face_idx, weights, img, feat, eps, g_img, g_feat,
+                                                work + tl::WORK_COV_WORD, work + tl::work_covlist_offset_words(B, H, W),
+                                                tl::cov_shard_cap((size_t)B, (size_t)tl::pass_geom(H, W, tl::R_TILE).ntiles));
     return kamd::raster_backward_draw<T>(st, B, H, W, F, D, grad_feat, face_idx, weights, img, feat, eps, g_img, g_feat, tile_cov,
                                          row_centre);
   }

@@ -70,58 +70,93 @@ __device__ __forceinline__ T barycentric_jacobian(const T* v, T aw, T bw, T cw, 
   return k3;
 }
 
+#ifndef KAMD_RBWD_DIRECT
+#define KAMD_RBWD_DIRECT 0  // 0 = a tile's run totals are merged per face in an LDS hash table, one global atomic request (24 contiguous bytes in six
+                            // lanes) per face and tile; 1 = no table: every wavefront stages its runs' totals in LDS rows of its own and sends one
+                            // request per run.  Measured at C4 (r03n / r03o): global float atomics cost ~60 ps per REQUEST (a line touched by an
+                            // instruction) chip-wide, whatever the lanes in it -- run-end lanes adding value by value: 219 us; staged, one request per
+                            // run (20 per wavefront): 53 us; the table (14 requests per wavefront, but a CAS probe + 6 LDS float atomics per run:
+                            // 20 us of LDS pipe): 50 us.  Ablations of the table kernel (r03m): list walk + face_idx + barrier 11 us, table clear +
+                            // barriers + arithmetic + DPP merges 13, gathers 5, table inserts 20, flush 2.
+#endif
+#ifndef KAMD_RBWD_ABL
+#define KAMD_RBWD_ABL 0  // ablations for timing experiments (wrong results): 1 = no per-face gathers, 2 = no per-pixel loads besides face_idx
+#endif
+#ifndef KAMD_RBWD_FLUSH
+#define KAMD_RBWD_FLUSH 1  // 1 = the tile's per-face sums leave as global atomics; 0 / 2: no flush / plain stores (timing experiments, wrong results)
+#endif
 #ifndef KAMD_RBWD_ORDER
 #define KAMD_RBWD_ORDER 1  // workgroup order of the backward: 1 = views interleaved, tile rows from the middle of the image outwards
 #endif                     // (as the forward's tile kernel; 0 = view-major, row-major: 49.4 vs 45.4 us at C4, 9 us of the step with feature gradients)
 // DT > 0: feature count known at compile time (block-merged through LDS); DT == 0: any D, per-lane global atomics.
 // GF = false: the caller does not need d/d(face_features) (static texture coordinates, the usual DIB-R set-up): only the
 // 6 image-coordinate values per face are merged instead of 6 + 3*D -- 2.5x fewer DPP merges and LDS atomics at D = 3.
-template <typename T, int DT, bool GF>
-__global__ __launch_bounds__(256) void raster_backward_kernel(
-    int B, int H, int W, int F, int D, const T* __restrict__ grad, const int64_t* __restrict__ face_idx,
-    const T* __restrict__ weights, const T* __restrict__ img, const T* __restrict__ feat, float eps,
-    T* __restrict__ g_img, T* __restrict__ g_feat, const unsigned char* __restrict__ tile_cov,
-    const unsigned int* __restrict__ row_span) {
-  // (fused dibr_rasterization: the forward pass noted which tiles hold a covered pixel -- 85 % of C4's do not, and
-  // finding that out from face_idx costs a 2-KB read and a barrier per workgroup: 24 of this kernel's 60 us)
-  // workgroup = 16x16 pixels of one image; wavefront = 16x4
-  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
-#if KAMD_RBWD_ORDER
-  // views interleaved, a view's tile rows in the forward pass' order (from the middle outwards, shifted to start in the middle
-  // of the covered rows): the workgroups that find covered pixels start first
-  const int b = blockIdx.x % B, k_ = blockIdx.x / B, kr_ = k_ / tiles_x;
-  const int tile = tl::row_of_order(kr_, tl::row_centre(row_span, b, tiles_y), tiles_y) * tiles_x + (k_ - kr_ * tiles_x);
+PHASE_TABLE(g_phase_rbwd)
+#ifdef KAMD_PHASE_PROF
+#define RBWD_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")  // (profiling builds: a phase ends when its memory operations have)
 #else
-  const int tile = blockIdx.x % (tiles_x * tiles_y), b = blockIdx.x / (tiles_x * tiles_y);
+#define RBWD_DRAIN()
 #endif
-  if (tile_cov != nullptr && tile_cov[(size_t)b * (tiles_x * tiles_y) + tile] == 0) return;
+
+// one 16 x 16-pixel tile of image b: workgroup = the tile, wavefront = 16 x 4 pixels.  Called by every thread of the workgroup
+// (barriers inside); may be called for one tile after another (its LDS tables are re-initialised behind a barrier).
+template <typename T, int DT, bool GF>
+__device__ __forceinline__ void raster_backward_tile(
+    int b, int tile, int tiles_x, int H, int W, int F, int D, const T* __restrict__ grad, const int64_t* __restrict__ face_idx,
+    const T* __restrict__ weights, const T* __restrict__ img, const T* __restrict__ feat, float eps,
+    T* __restrict__ g_img, T* __restrict__ g_feat) {
   constexpr int NV = (DT > 0 && GF) ? 6 + 3 * DT : 6;
-  __shared__ int s_key[DT > 0 ? RB_HT : 1];
-  __shared__ T s_acc[DT > 0 ? RB_HT * NV : 1];
-  __shared__ int s_used[DT > 0 ? 256 : 1];
+  constexpr bool TABLE = DT > 0 && !KAMD_RBWD_DIRECT;  // per-tile LDS hash table of the faces' sums
+  __shared__ int s_key[TABLE ? RB_HT : 1];
+  __shared__ T s_acc[TABLE ? RB_HT * NV : 1];
+  __shared__ int s_used[TABLE ? 256 : 1];
   __shared__ int s_nused;
+  constexpr bool STAGED = DT > 0 && !TABLE;                    // run totals go to global memory through per-wavefront staging rows
+  __shared__ int s_runf[STAGED ? 4 : 1][STAGED ? 64 : 1];      // the runs' faces ...
+  __shared__ T s_runv[STAGED ? 4 : 1][STAGED ? 64 * NV : 1];   // ... and their NV sums
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = (tile % tiles_x) * 16 + (lane & 15), row = (tile / tiles_x) * 16 + wave * 4 + (lane >> 4);
   const bool in_image = col < W && row < H;
+  PHASE_DECL;
   const size_t tp = ((size_t)b * H + row) * W + col;
   const int f = in_image ? (int)face_idx[tp] : -1;
-  if (DT > 0) {
+  if (DT > 0 && !TABLE) {
+    if (__ballot(f >= 0) == 0ull) return;  // nothing covered in this wavefront's 16 x 4 pixels (no workgroup-wide state: wavefronts are on their own)
+  }
+  if (TABLE) {
     if (!__syncthreads_or(f >= 0)) return;  // nothing covered in this block
+    PHASE_MARK(0);
+#if KAMD_RBWD_ABL & 4   // (timing experiments only: the tile ends here)
+    if (f != -12345) return;
+#endif
     for (int i = threadIdx.x; i < RB_HT; i += 256) s_key[i] = -1;
     for (int i = threadIdx.x; i < RB_HT * NV; i += 256) s_acc[i] = 0;
     if (threadIdx.x == 0) s_nused = 0;
     __syncthreads();
+    PHASE_MARK(1);
   }
   T vals[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) vals[i] = 0;
   if (f >= 0) {
     const size_t tf = (size_t)b * F + (size_t)f;
+#if KAMD_RBWD_ABL & 2   // (timing experiments only: no per-pixel loads besides face_idx)
+    const T aw = (T)0.25 + (T)(f & 3) * (T)0.01, bw = (T)0.5, cw = (T)0.25 - (T)(f & 3) * (T)0.01;
+    const T gfake[4] = {(T)(f & 7), (T)1, (T)2, (T)3};
+    const T* g = gfake;
+#else
     const T aw = weights[tp * 3 + 0], bw = weights[tp * 3 + 1], cw = weights[tp * 3 + 2];
+    const T* g = grad + tp * D;
+#endif
     T dw1[6], dw2[6];
+#if KAMD_RBWD_ABL & 1   // (timing experiments only: no per-face gathers)
+    const T fake[12] = {(T)(f & 15), (T)1, (T)3, (T)(f & 7), (T)5, (T)9, (T)1, (T)2, (T)(f & 3), (T)4, (T)5, (T)6};
+    const T k3 = barycentric_jacobian<T>(fake, aw, bw, cw, eps, dw1, dw2);
+    const T* ff = fake + 3;
+#else
     const T k3 = barycentric_jacobian<T>(img + tf * 6, aw, bw, cw, eps, dw1, dw2);
     const T* ff = feat + tf * 3 * D;
-    const T* g = grad + tp * D;
+#endif
     const int nd = DT > 0 ? DT : D;
     for (int d = 0; d < nd; ++d) {
       const T gd = g[d];
@@ -145,6 +180,8 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(
       for (int j = 0; j < 6; ++j) kamd_atomic_add(g_img + tf * 6 + j, vals[j]);
     }
   }
+  RBWD_DRAIN();
+  PHASE_MARK(2);
   if constexpr (DT > 0) {
     // Pixels of one face are neighbours: in lane order (16 per row) they form runs.  A segmented inclusive scan sums
     // every run (6 shuffle steps per value), and only the LAST lane of a run touches the LDS table: same-address LDS
@@ -178,8 +215,38 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(
     KAMD_RB_STAGE(4)
     KAMD_RB_STAGE(8)
 #undef KAMD_RB_STAGE
+    PHASE_MARK(3);
     const bool run_end = rl == 15 || next_f != f;
+    if constexpr (!TABLE) {
+      // The run totals leave through a per-wavefront LDS staging row so that ONE atomic instruction carries all the values of a
+      // face in consecutive lanes (24 contiguous bytes = one L2 atomic request per face; issued value by value from the
+      // run-end lanes, every instruction touches a different line per lane: 219 us, r03n).  No workgroup-wide state: no
+      // table to clear, no barrier, no LDS atomics (the round-2 table's cost 20 of the kernel's 49 us).
+      const unsigned long long ends = __ballot(f >= 0 && run_end);
+      const int n_ends = __popcll(ends);
+      wave_lds_fence();  // (the previous tile's readers of this wavefront's rows are done)
+      if (f >= 0 && run_end) {
+        const int q = __popcll(ends & ((1ull << lane) - 1ull));
+        s_runf[wave][q] = f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s_runv[wave][q * NV + i] = vals[i];
+      }
+      wave_lds_fence();
+      for (int j = lane; j < n_ends * NV; j += 64) {
+        const int q = j / NV, c = j - q * NV;
+        const size_t tf = (size_t)b * F + (size_t)s_runf[wave][q];
+        const T v = s_runv[wave][j];
+        if (c < 6)
+          kamd_atomic_add(g_img + tf * 6 + c, v);
+        else if constexpr (GF)
+          kamd_atomic_add(g_feat + tf * 3 * D + (c - 6), v);
+      }
+    } else
+#if KAMD_RBWD_ABL & 8   // (timing experiments only: no hash insert / LDS adds)
+    if (f == -12345) {
+#else
     if (f >= 0 && run_end) {
+#endif
       int slot = (int)(((unsigned)f * 2654435761u) >> 24) & (RB_HT - 1);
       for (;;) {  // at most 256 distinct faces for 256 slots: an empty slot always exists
         const int k = atomicCAS(&s_key[slot], -1, f);
@@ -192,18 +259,90 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(
     }
     }
   }
-  if constexpr (DT > 0) {
+  if constexpr (TABLE) {
+    RBWD_DRAIN();
+    PHASE_MARK(4);
     __syncthreads();
+    PHASE_MARK(5);
     const int nused = s_nused;
     for (int i = threadIdx.x; i < nused * NV; i += 256) {
       const int slot = s_used[i / NV], v = i % NV;
       const size_t tf = (size_t)b * F + (size_t)s_key[slot];
       const T val = s_acc[slot * NV + v];
+#if KAMD_RBWD_FLUSH == 0      // (timing experiments only: wrong results)
+      if (val == (T)123456.0) g_img[tf * 6 + v] = val;
+#elif KAMD_RBWD_FLUSH == 2    // (timing experiments only: plain stores)
+      if (v < 6) g_img[tf * 6 + v] = val;
+#else
       if (v < 6)
         kamd_atomic_add(g_img + tf * 6 + v, val);
       else if constexpr (GF)
         kamd_atomic_add(g_feat + tf * 3 * D + (v - 6), val);
+#endif
     }
+    PHASE_MARK(6);
+    RBWD_DRAIN();
+    PHASE_MARK(7);
+  }
+  PHASE_FLUSH(g_phase_rbwd);
+}
+
+template <typename T, int DT, bool GF>
+__global__ __launch_bounds__(256) void raster_backward_kernel(
+    int B, int H, int W, int F, int D, const T* __restrict__ grad, const int64_t* __restrict__ face_idx,
+    const T* __restrict__ weights, const T* __restrict__ img, const T* __restrict__ feat, float eps,
+    T* __restrict__ g_img, T* __restrict__ g_feat, const unsigned char* __restrict__ tile_cov,
+    const unsigned int* __restrict__ row_span) {
+  // (fused dibr_rasterization: the forward pass noted which tiles hold a covered pixel -- 85 % of C4's do not, and
+  // finding that out from face_idx costs a 2-KB read and a barrier per workgroup: 24 of this kernel's 60 us)
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+#if KAMD_RBWD_ORDER
+  // views interleaved, a view's tile rows in the forward pass' order (from the middle outwards, shifted to start in the middle
+  // of the covered rows): the workgroups that find covered pixels start first
+  const int b = blockIdx.x % B, k_ = blockIdx.x / B, kr_ = k_ / tiles_x;
+  const int tile = tl::row_of_order(kr_, tl::row_centre(row_span, b, tiles_y), tiles_y) * tiles_x + (k_ - kr_ * tiles_x);
+#else
+  const int tile = blockIdx.x % (tiles_x * tiles_y), b = blockIdx.x / (tiles_x * tiles_y);
+#endif
+  if (tile_cov != nullptr && tile_cov[(size_t)b * (tiles_x * tiles_y) + tile] == 0) return;
+  raster_backward_tile<T, DT, GF>(b, tile, tiles_x, H, W, F, D, grad, face_idx, weights, img, feat, eps, g_img, g_feat);
+}
+
+// The fused operator's backward: the forward's tile kernel left the list of the tiles that hold a covered pixel (15 % of C4's
+// tiles; tl::queue_items_reached, COV_SHARDS shards) -- a persistent grid walks it, workgroup w taking entries w, w + grid, ...
+// The one-workgroup-per-tile launch above spent ~45 % of its wavefront time on the 26k workgroups whose only act is to
+// find their tile's coverage byte clear (index arithmetic, two dependent loads, exit): 49 -> xx us at C4.
+template <typename T, int DT, bool GF>
+__global__ __launch_bounds__(256) void raster_backward_list_kernel(
+    int B, int H, int W, int F, int D, const T* __restrict__ grad, const int64_t* __restrict__ face_idx,
+    const T* __restrict__ weights, const T* __restrict__ img, const T* __restrict__ feat, float eps,
+    T* __restrict__ g_img, T* __restrict__ g_feat, const unsigned int* __restrict__ cov_counts,
+    const unsigned int* __restrict__ cov_list, unsigned int cov_cap, int grouped) {
+  __shared__ unsigned int s_end[tl::COV_SHARDS];  // inclusive prefix of the shards' entry counts
+  const int tiles_x = (W + 15) / 16, ntiles = tiles_x * ((H + 15) / 16);
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x < 64) {
+    static_assert(tl::COV_SHARDS <= 64, "one wavefront scans the shard counts");
+    unsigned int c = lane < tl::COV_SHARDS ? min(cov_counts[lane * tl::COUNTER_STRIDE], cov_cap) : 0u;
+    c = (unsigned int)wave_inclusive_scan((int)c);
+    if (lane < tl::COV_SHARDS) s_end[lane] = c;
+  }
+  __syncthreads();
+  // workgroup w runs on XCD w % 8 (round-robin dispatch) and takes the entries of group w % 8 (shards 4 (w % 8) .. + 3: with 8 or
+  // more views, the views b % 8 == w % 8 -- a view's gradient lines stay in one XCD's L2), every (grid / 8)-th of them
+  // (grouped == 0, an A/B knob: every workgroup strides over the whole list -- a view's lines then bounce between the XCDs' L2s)
+  const unsigned int grp = blockIdx.x & 7u, first = !grouped ? 0u : (grp ? s_end[4 * grp - 1] : 0u);
+  const unsigned int last = !grouped ? s_end[tl::COV_SHARDS - 1] : s_end[4 * grp + 3];
+  const unsigned int step = grouped ? gridDim.x >> 3 : gridDim.x;
+  for (unsigned int i = first + (grouped ? blockIdx.x >> 3 : blockIdx.x); i < last; i += step) {
+    // the shard that holds entry i: the first whose inclusive prefix exceeds i (one ballot)
+    const unsigned int e = s_end[lane & (tl::COV_SHARDS - 1)];
+    const unsigned long long m = __ballot(lane < tl::COV_SHARDS && e > i);
+    const int sh = __ffsll((long long)m) - 1;
+    const unsigned int start = sh > 0 ? s_end[sh - 1] : 0u;
+    const unsigned int id = cov_list[(size_t)sh * cov_cap + (i - start)];
+    const int b = (int)(id / (unsigned int)ntiles), tile = (int)(id - (unsigned int)b * (unsigned int)ntiles);
+    raster_backward_tile<T, DT, GF>(b, tile, tiles_x, H, W, F, D, grad, face_idx, weights, img, feat, eps, g_img, g_feat);
   }
 }
 
@@ -284,9 +423,48 @@ int rasterize_backward_launch(hipStream_t st, int B, int H, int W, int F, int D,
   return (int)hipGetLastError();
 }
 
+// the fused operator's backward over the forward's covered-tile list (persistent grid)
+template <typename T>
+int rasterize_backward_list_launch(hipStream_t st, int B, int H, int W, int F, int D, const T* grad, const int64_t* face_idx,
+                                   const T* weights, const T* img, const T* feat, float eps, T* g_img, T* g_feat,
+                                   const unsigned int* cov_counts, const unsigned int* cov_list, unsigned int cov_cap) {
+  const long long n_groups = (long long)B * ((W + 15) / 16) * ((H + 15) / 16);
+  if (n_groups <= 0 || F <= 0) return 0;
+  static const int per_cu = kamd_env_int("KAMD_RBWD_PER_CU", 8);
+  static const int grouped = kamd_env_int("KAMD_RBWD_GROUPED", 1) == 1 ? 1 : 0;  // (2: off, for A/B runs)
+  const dim3 grid((unsigned)(((std::min<long long>(n_groups, (long long)KAMD_NUM_CU * per_cu) + 7) / 8) * 8));  // (a multiple of 8: every group served)
+  kamd::ProfScope prof_(kamd::K_RASTER_BACKWARD, st);
+#define KAMD_RBL(DT)                                                                                                       \
+  if (g_feat != nullptr)                                                                                                   \
+    hipLaunchKernelGGL((raster_backward_list_kernel<T, DT, true>), grid, dim3(256), 0, st, B, H, W, F, D, grad, face_idx,  \
+                       weights, img, feat, eps, g_img, g_feat, cov_counts, cov_list, cov_cap, grouped);                    \
+  else                                                                                                                     \
+    hipLaunchKernelGGL((raster_backward_list_kernel<T, DT, false>), grid, dim3(256), 0, st, B, H, W, F, D, grad, face_idx, \
+                       weights, img, feat, eps, g_img, g_feat, cov_counts, cov_list, cov_cap, grouped)
+  switch (D) {
+    case 1: KAMD_RBL(1); break;
+    case 2: KAMD_RBL(2); break;
+    case 3: KAMD_RBL(3); break;
+    case 4: KAMD_RBL(4); break;
+    default: KAMD_RBL(0); break;
+  }
+#undef KAMD_RBL
+  return (int)hipGetLastError();
+}
+
 }  // namespace
 
 namespace kamd {
+template <typename T>
+int raster_backward_draw_list(hipStream_t st, int B, int H, int W, int F, int D, const T* grad, const int64_t* face_idx, const T* weights,
+                              const T* img, const T* feat, float eps, T* g_img, T* g_feat, const unsigned int* cov_counts,
+                              const unsigned int* cov_list, unsigned int cov_cap) {
+  return rasterize_backward_list_launch<T>(st, B, H, W, F, D, grad, face_idx, weights, img, feat, eps, g_img, g_feat, cov_counts, cov_list, cov_cap);
+}
+template int raster_backward_draw_list<float>(hipStream_t, int, int, int, int, int, const float*, const int64_t*, const float*, const float*,
+                                              const float*, float, float*, float*, const unsigned int*, const unsigned int*, unsigned int);
+template int raster_backward_draw_list<double>(hipStream_t, int, int, int, int, int, const double*, const int64_t*, const double*, const double*,
+                                               const double*, float, double*, double*, const unsigned int*, const unsigned int*, unsigned int);
 template <typename T>
 int raster2_draw(hipStream_t st, int B, int H, int W, int D, int F_dense, float multiplier, float eps, const T* rec,
                  const tl::Lists& LR, const T* feat, T* interp, int64_t* sel_idx, T* weights, const tl::ClassifyOut& co,
@@ -316,6 +494,14 @@ template int raster2_draw<double>(hipStream_t, int, int, int, int, int, float, f
 }  // namespace kamd
 
 #ifdef KAMD_PHASE_PROF
+extern "C" int kamd_debug_phase_cycles_rbwd(unsigned long long* out16, int reset) {
+  int rc = (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_rbwd), 16 * sizeof(unsigned long long));
+  if (reset) {
+    unsigned long long z[16] = {0};
+    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_rbwd), z, sizeof(z));
+  }
+  return rc;
+}
 extern "C" int kamd_debug_phase_cycles_raster(unsigned long long* out16, int reset) {
   int rc = (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_raster), 16 * sizeof(unsigned long long));
   if (reset) {

@@ -208,7 +208,9 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
 // the worklist lives in its own buffer (the autograd path keeps it for the backward pass): WORK_HEADER words of counters,
 // then WORK_SHARDS x shard_cap items of 16 bytes.  One 256-thread workgroup per 16 x 16 pixels appends at most 4 items.
 constexpr int WORK_FLAT_WORD = 8 * COUNTER_STRIDE;                    // the flat hit list's shard counters (soft2.inc) follow the worklist's
-constexpr int WORK_HEADER = WORK_FLAT_WORD + 64 * COUNTER_STRIDE;     // words; all zeroed per call
+constexpr int COV_SHARDS = 32;                                        // shards of the list of tiles that hold a covered pixel
+constexpr int WORK_COV_WORD = WORK_FLAT_WORD + 64 * COUNTER_STRIDE;   // ... whose counters follow the flat list's
+constexpr int WORK_HEADER = WORK_COV_WORD + COV_SHARDS * COUNTER_STRIDE;  // words; all zeroed per call
 inline unsigned int work_shard_cap(int B, int H, int W) {
   const PassGeom g = pass_geom(H, W, R_TILE);
   const size_t n_groups = (size_t)B * g.ntiles;
@@ -222,7 +224,26 @@ inline size_t work_cov_offset_words(int B, int H, int W) { return WORK_HEADER + 
 inline size_t work_span_offset_words(int B, int H, int W) {
   return work_cov_offset_words(B, H, W) + ((size_t)B * pass_geom(H, W, R_TILE).ntiles + 3) / 4;
 }
-inline size_t work_words(int B, int H, int W) { return work_span_offset_words(B, H, W) + (size_t)2 * B; }
+// ... then the list of the tiles that hold a covered pixel ([b * ntiles + tile], COV_SHARDS shards of equal capacity, appended
+// by the rasterizer's tile kernel in dispatch order): the rasterizer's backward pass walks it with a persistent grid instead
+// of launching one workgroup per tile of the image to find out that 85 % of them have nothing to do
+// Shard of tile `tile_order` (its place in the tile kernel's order of tiles) of view b: 8 groups x 4.  With 8 or more views the
+// group is the view's (b % 8): the backward's workgroups of XCD x take group x, so that a view's gradient lines are updated
+// through one XCD's L2 (as in the forward, whose consecutive workgroups are the views of one tile); with fewer views the
+// groups just spread the tiles.  Capacity: no shard receives more than ceil(B / 8) views' quarter of the tiles.
+static_assert(COV_SHARDS == 32, "8 groups x 4");
+__host__ __device__ inline unsigned int cov_shard_of(int B, int b, unsigned int tile_order) {
+  const unsigned int order = tile_order * (unsigned int)B + (unsigned int)b;
+  return B >= 8 ? (((unsigned int)b & 7u) << 2) | (tile_order & 3u) : ((order & 7u) << 2) | ((order >> 3) & 3u);
+}
+__host__ __device__ inline unsigned int cov_shard_cap(size_t B, size_t ntiles) { return (unsigned int)(((B + 7) / 8) * ((ntiles + 3) / 4)); }
+__host__ __device__ inline size_t cov_list_words_after_cov(size_t B, size_t n_groups) { return (n_groups + 3) / 4 + 2 * B; }
+inline size_t work_covlist_offset_words(int B, int H, int W) {
+  return work_cov_offset_words(B, H, W) + cov_list_words_after_cov((size_t)B, (size_t)B * pass_geom(H, W, R_TILE).ntiles);
+}
+inline size_t work_words(int B, int H, int W) {
+  return work_covlist_offset_words(B, H, W) + (size_t)COV_SHARDS * cov_shard_cap((size_t)B, (size_t)pass_geom(H, W, R_TILE).ntiles);
+}
 
 inline Lists lists_of(void* ws, const PassLayout& p, int B, bool soft) {
   char* c = (char*)ws;
@@ -838,16 +859,28 @@ __device__ __forceinline__ unsigned int item_id_of(int B, int b, int tx, int ty,
   return (unsigned int)((st * B + b) * S_SUBS + ss);
 }
 // queue_items with the reach bits in hand (`shard`: the workgroup's worklist shard)
+// (`tile_order`: the tile's place in the kernel's order of tiles; the workgroup's place in dispatch order is tile_order * B + b
+// -- its shard of the worklist is that % WORK_SHARDS: no shard receives more than its share of the tiles, which is what the
+// capacities assume; cov_shard_of picks the covered-tile list's)
 __device__ __forceinline__ void queue_items_reached(unsigned long long unc, unsigned int reach, int B, int b, int tx, int ty, int tiles_x_s,
-                                                    int wave, int lane, unsigned int shard, uint4* __restrict__ work_items,
+                                                    int wave, int lane, unsigned int tile_order, uint4* __restrict__ work_items,
                                                     unsigned int* __restrict__ work_counts, unsigned int shard_cap,
                                                     unsigned long long* s_item_unc, bool covered, unsigned char* __restrict__ tile_cov,
-                                                    size_t cov_index) {
+                                                    size_t cov_index, size_t ntiles_r) {
+  const unsigned int shard = (tile_order * (unsigned int)B + (unsigned int)b) & (WORK_SHARDS - 1);
   const bool item = unc != 0ull && reached(reach, wave);
   if (lane == 0) s_item_unc[wave] = item ? unc : 0ull;
   const int any_covered = __syncthreads_or(covered ? 1 : 0);
   if (threadIdx.x == 0) {
-    if (tile_cov != nullptr) tile_cov[cov_index] = any_covered ? 1 : 0;
+    if (tile_cov != nullptr) {
+      tile_cov[cov_index] = any_covered ? 1 : 0;
+      if (any_covered) {  // the covered-tile list lives behind the coverage bytes and the span copy (work_covlist_offset_words)
+        const unsigned int cs = cov_shard_of(B, b, tile_order);
+        const unsigned int pos = atomicAdd(work_counts + WORK_COV_WORD + cs * COUNTER_STRIDE, 1u);
+        unsigned int* list = reinterpret_cast<unsigned int*>(tile_cov) + cov_list_words_after_cov((size_t)B, (size_t)B * ntiles_r);
+        list[(size_t)cs * cov_shard_cap((size_t)B, ntiles_r) + pos] = (unsigned int)cov_index;
+      }
+    }
     int n = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) n += s_item_unc[w] != 0ull ? 1 : 0;
@@ -866,9 +899,10 @@ __device__ __forceinline__ void queue_items_reached(unsigned long long unc, unsi
 }
 // A background tile that lies fully inside the image: every pixel of every sub-tile is uncovered, so ONE lane can queue
 // the tile's items without hearing from the other wavefronts (no LDS, no barrier).  Called by one lane.
-__device__ __forceinline__ void queue_items_background(unsigned int reach, int B, int b, int tx, int ty, int tiles_x_s, unsigned int shard,
+__device__ __forceinline__ void queue_items_background(unsigned int reach, int B, int b, int tx, int ty, int tiles_x_s, unsigned int tile_order,
                                                        uint4* __restrict__ work_items, unsigned int* __restrict__ work_counts,
                                                        unsigned int shard_cap, unsigned char* __restrict__ tile_cov, size_t cov_index) {
+  const unsigned int shard = (tile_order * (unsigned int)B + (unsigned int)b) & (WORK_SHARDS - 1);
   if (tile_cov != nullptr) tile_cov[cov_index] = 0;
   if (reach == 0u) return;
   unsigned int pos = atomicAdd(work_counts + shard * COUNTER_STRIDE, (unsigned int)__popc(reach));

@@ -102,3 +102,35 @@ def test_forward_starts_where_the_object_is(shift):
         assert hi - lo >= (rows[-1] - rows[0]) // 2, 'the sample misses most of the object'
     (out.sum() + soft.sum()).backward()          # the backward starts from the same rows: must simply work
     assert torch.isfinite(a.grad).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,W,views', [(272, 200, 3), (35, 31, 2), (512, 512, 8)])
+def test_forward_lists_exactly_the_tiles_with_covered_pixels(H, W, views):
+    """The fused forward leaves, next to its worklist, the list of the 16 x 16 tiles that hold a covered pixel (sharded, in
+    dispatch order); the rasterizer's backward pass walks that list instead of launching a workgroup per tile.  The list
+    must be the set of tiles face_idx says are covered -- each once -- and the backward over it must equal the backward that
+    visits every tile (KAMD_BWD_COV_LIST=2 is read once per process, so the comparison is against the plain operators)."""
+    import kaolin_amd as kal
+    from kaolin_amd.utils import testing as T
+    fz, fimg, feats, nz = T.sphere_scene(level=16, num_views=views, device='cuda')
+    feat = torch.cat(feats, -1).contiguous()
+    a = fimg.clone().requires_grad_()
+    fg = feat.clone().requires_grad_()
+    out, soft, face_idx = kal.render.mesh.dibr_rasterization(H, W, fz, a, fg, nz)
+    work = out.grad_fn.saved_tensors[-1]
+    got = kal._C.render.mesh.covered_tiles(work, views, H, W).cpu()
+    tiles_x, tiles_y = (W + 15) // 16, (H + 15) // 16
+    cov = torch.nn.functional.pad(face_idx >= 0, (0, tiles_x * 16 - W, 0, tiles_y * 16 - H))
+    cov = cov.view(views, tiles_y, 16, tiles_x, 16).any(dim=4).any(dim=2).reshape(-1)      # [b * ntiles + tile]
+    assert torch.equal(got, cov.nonzero().flatten().cpu())
+    g = torch.Generator().manual_seed(1)
+    go = torch.rand(out.shape, generator=g).cuda()
+    out.backward(go)
+    # the same gradients through the unfused operators (rasterize's own backward visits every tile)
+    a2 = fimg.clone().requires_grad_()
+    f2 = feat.clone().requires_grad_()
+    out2, idx2 = kal.render.mesh.rasterize(H, W, fz, a2, f2, nz >= 0)
+    assert torch.equal(idx2, face_idx) and torch.equal(out2, out)
+    out2.backward(go)
+    assert torch.allclose(a.grad, a2.grad, rtol=1e-4, atol=1e-6) and torch.allclose(fg.grad, f2.grad, rtol=1e-4, atol=1e-6)
