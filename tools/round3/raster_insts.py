@@ -11,7 +11,7 @@ lib = _lib.load()
 V, H, W = 8, 1024, 1024
 fz, fimg, feats, nz = T.sphere_scene(level=50, num_views=V, device='cuda')
 feat = torch.cat(feats, -1).contiguous()
-MODES = [0, 32, 8, 1, 3, 7]
+MODES = [int(x) for x in os.environ.get('RI_MODES', '0,32,8,1,3,7').split(',') if x != '']   # (the ablation modes need a library built with -DKAMD_RASTER_DEBUG)
 what = sys.argv[1] if len(sys.argv) > 1 else 'time'
 
 
