@@ -241,11 +241,14 @@ int kamd_dibr_soft_mask_backward_f64(void* stream, int B, int H, int W, int F, i
 /*            Requires B*F < 2^29, H, W < 2^16.                                     */
 /* item_count holds ceil(W/32)*ceil(H/32)*16*B ints.  `work`                      */
 /* (kamd_dibr_soft_mask_work_words 32-bit words) receives the worklist: 8 sharded */
-/* item counters (words 32 s) and the flat list's 64 shard counts, one per 128-byte */
-/* line (same-line device atomics serialise), in a 2304-word header, then          */
-/* the items {item, uncovered-pixel mask}.  The fused dibr_rasterization forward appends one byte  */
-/* per (mesh, 16x16-pixel tile): does the tile hold a covered pixel (read by its  */
-/* backward).  Requires B*H*W < 2^31.                                             */
+/* item counters (words 32 s), the flat list's 64 shard counts and the covered-tile */
+/* list's 32, one per 128-byte line (same-line device atomics serialise), in a    */
+/* 3328-word header, then the items {item, uncovered-pixel mask (2 words), pairs  */
+/* the search accepted}.  The fused dibr_rasterization forward appends one byte   */
+/* per (mesh, 16x16-pixel tile): does the tile hold a covered pixel; a copy of    */
+/* the covered tile rows per view (2 words each); and the list of the tiles that  */
+/* hold a covered pixel (32 shards of ceil(B/8)*ceil(tiles/4) words), which the   */
+/* rasterizer's backward walks.  Requires B*H*W < 2^31.                            */
 /* Records each of the three hit arrays must hold (64*K per sub-tile slot).       */
 size_t kamd_dibr_soft_mask_lean_capacity(int B, int H, int W, int K);
 size_t kamd_dibr_soft_mask_work_words(int B, int H, int W);
