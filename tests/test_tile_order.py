@@ -134,3 +134,33 @@ def test_forward_lists_exactly_the_tiles_with_covered_pixels(H, W, views):
     assert torch.equal(idx2, face_idx) and torch.equal(out2, out)
     out2.backward(go)
     assert torch.allclose(a.grad, a2.grad, rtol=1e-4, atol=1e-6) and torch.allclose(fg.grad, f2.grad, rtol=1e-4, atol=1e-6)
+
+
+def cov_shard_of(B, b, tile_order):
+    """tile_lists.h cov_shard_of: 8 groups x 4 -- the view's group (b % 8) with 8 or more views, else the place in dispatch order."""
+    order = tile_order * B + b
+    return ((b & 7) << 2) | (tile_order & 3) if B >= 8 else ((order & 7) << 2) | ((order >> 3) & 3)
+
+
+@pytest.mark.parametrize('B', [1, 2, 3, 7, 8, 9, 12, 16, 17])
+@pytest.mark.parametrize('ntiles', [1, 2, 3, 4, 5, 6, 63, 64, 65, 4096])
+def test_covered_tile_shards_never_outgrow_their_capacity(B, ntiles):
+    """The covered-tile list has no overflow path: shard capacity ceil(B / 8) * ceil(ntiles / 4) (tile_lists.h cov_shard_cap) must
+    hold every tile the shard map can send to a shard, for any number of views and tiles -- and likewise the worklist's eight
+    shards (4 * ceil(B * ntiles / 8) items, at most four per tile) under (tile_order * B + b) % 8."""
+    cap = ((B + 7) // 8) * ((ntiles + 3) // 4)
+    counts = [0] * 32
+    work = [0] * 8
+    for t in range(ntiles):
+        for b in range(B):
+            s = cov_shard_of(B, b, t)
+            assert 0 <= s < 32
+            counts[s] += 1
+            work[(t * B + b) & 7] += 4
+    assert max(counts) <= cap, (max(counts), cap)
+    assert max(work) <= 4 * ((B * ntiles + 7) // 8)
+    # with 8 or more views a shard's tiles all belong to views of one residue class mod 8 (one XCD's share of the backward)
+    if B >= 8:
+        for t in range(min(ntiles, 8)):
+            for b in range(B):
+                assert cov_shard_of(B, b, t) >> 2 == b % 8
