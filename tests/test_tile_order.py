@@ -105,7 +105,7 @@ def test_forward_starts_where_the_object_is(shift):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('H,W,views', [(272, 200, 3), (35, 31, 2), (512, 512, 8)])
+@pytest.mark.parametrize('H,W,views', [(272, 200, 3), (35, 31, 2), (512, 512, 8), (96, 80, 9), (64, 48, 17)])
 def test_forward_lists_exactly_the_tiles_with_covered_pixels(H, W, views):
     """The fused forward leaves, next to its worklist, the list of the 16 x 16 tiles that hold a covered pixel (sharded, in
     dispatch order); the rasterizer's backward pass walks that list instead of launching a workgroup per tile.  The list
