@@ -21,6 +21,7 @@ of every kernel comes from a separate, fully instrumented pass of the same step 
 oracle (OpenMP) timed on a bounded sample on this box's host cores (rank 0, N = 1 only).
 """
 import argparse
+import gc
 import json
 import math
 import os
@@ -42,8 +43,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)   # (0.045 s of timed region: a single host hiccup is 0.3 % of it, not 2 %)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--views-per-gpu', type=int, default=8)
     ap.add_argument('--res', type=int, default=1024)
     ap.add_argument('--sphere-frequency', type=int, default=50, help='20*f^2 triangles (50 -> 50 000)')
@@ -317,6 +318,8 @@ def main():
     def timed(fn, steps, warmup):
         for _ in range(warmup):
             fn()
+        gc.collect()
+        gc.disable()     # (no collector pause inside the timed region: the step allocates a few hundred Python objects)
         D.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -326,6 +329,7 @@ def main():
         torch.cuda.synchronize()
         D.barrier()
         dt = time.perf_counter() - t0
+        gc.enable()
         if D.is_distributed():
             t = torch.tensor([dt], device=dev, dtype=torch.double)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
