@@ -905,7 +905,8 @@ __device__ __forceinline__ void queue_items_reached(unsigned long long unc, unsi
         const unsigned int cs = cov_shard_of(B, b, tile_order);
         const unsigned int pos = atomicAdd(work_counts + WORK_COV_WORD + cs * COUNTER_STRIDE, 1u);
         unsigned int* list = reinterpret_cast<unsigned int*>(tile_cov) + cov_list_words_after_cov((size_t)B, (size_t)B * ntiles_r);
-        list[(size_t)cs * cov_shard_cap((size_t)B, ntiles_r) + pos] = (unsigned int)cov_index;
+        const unsigned int cap = cov_shard_cap((size_t)B, ntiles_r);
+        if (pos < cap) list[(size_t)cs * cap + pos] = (unsigned int)cov_index;  // (always: cov_shard_of sends no shard more; the consumer clamps too)
       }
     }
     int n = 0;
