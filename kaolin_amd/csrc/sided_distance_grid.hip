@@ -378,6 +378,9 @@ __device__ __forceinline__ double sdg_dist(double tx, double ty, double tz, doub
   return __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));  // (the same pin as the all-pairs kernel and the oracle)
 }
 
+#ifndef KAMD_SDG_QUERY_WAVES
+#define KAMD_SDG_QUERY_WAVES 7  // waves per SIMD the search kernel is compiled for (72 VGPRs): the search is a chain of dependent loads, occupancy is what hides it
+#endif
 #ifndef KAMD_SDG_GROUP
 #define KAMD_SDG_GROUP 4  // build knob; 100k x 100k (profiles/r02y_sdg.txt): 2 lanes 60 us, 4: 56, 8: 61, 16: 85 for both directions
 #endif
@@ -591,7 +594,7 @@ __device__ __forceinline__ void sdg_search(const Box& s_box, int G, T qx, T qy, 
 // d value / d (its nearest point) with float atomics, both already scaled by w / n [/ (2 sqrt(dist))]: the atomics ride in
 // a kernel that waits on dependent loads anyway, and the backward pass is one multiply by the upstream gradient.
 template <int MODE, typename S>
-__global__ __launch_bounds__(256) void sdg_query(CloudT<S> A, CloudT<S> T, S* __restrict__ dist1, int64_t* __restrict__ idx1,
+__global__ __launch_bounds__(256, (MODE == SDG_GRAD ? KAMD_SDG_QUERY_WAVES : 1)) void sdg_query(CloudT<S> A, CloudT<S> T, S* __restrict__ dist1, int64_t* __restrict__ idx1,
                                                  S* __restrict__ dist2, int64_t* __restrict__ idx2, Fuse fz) {
   static_assert(MODE == SDG_PLAIN || sizeof(S) == 4, "the chamfer modes are fp32");
   typedef typename Vec4Of<S>::type V4;
@@ -624,15 +627,23 @@ __global__ __launch_bounds__(256) void sdg_query(CloudT<S> A, CloudT<S> T, S* __
     S best;
     int best_i, best_k;
     sdg_search<MODE == SDG_GRAD, S>(s_box, G, q.x, q.y, q.z, (cz * G + cy) * G + cx, Tp, Tstart, Tsorted, nt, sub, best, best_i, best_k);
-    if (live && sub == 0) {
-      const size_t o = (size_t)b * nq + sdg_unpack_idx(q.w);
-      S* dist = fwd ? dist1 : dist2;
-      int64_t* idx = fwd ? idx1 : idx2;
-      if (dist != nullptr) dist[o] = best;
-      if (idx != nullptr) idx[o] = best_i;
+    // Results leave from the first lanes of the query's group (every lane holds the merged result): lane 0 writes distance and
+    // index and adds the term; in the chamfer gradient mode lanes 0..2 take one coordinate each -- the 12 bytes of the query's own
+    // term are then consecutive lanes of ONE store instruction and the nearest target's three atomics ONE request (a global
+    // float atomic costs per line touched by an instruction, ~60 ps chip-wide: lane 0 adding x, y, z in turn made 600k
+    // requests per call at 100k x 100k, 36 us of this launch's 63)
+    constexpr int OUT_LANES = (MODE == SDG_GRAD && SDG_GROUP >= 3) ? 3 : 1;
+    if (live && sub < OUT_LANES) {
+      if (sub == 0) {
+        const size_t o = (size_t)b * nq + sdg_unpack_idx(q.w);
+        S* dist = fwd ? dist1 : dist2;
+        int64_t* idx = fwd ? idx1 : idx2;
+        if (dist != nullptr) dist[o] = best;
+        if (idx != nullptr) idx[o] = best_i;
+      }
       if constexpr (MODE >= SDG_VALUE) {
         const float root = fz.squared ? best : sqrtf(best);
-        term += (double)root;
+        if (sub == 0) term += (double)root;
         if (MODE == SDG_GRAD) {
           // value = sum_b up_b * (w1 / N * sum_i f(dist1_i) + w2 / M * sum_j f(dist2_j)); d dist / d q = 2 (q - t)
           // Both gradient arrays are laid out in the SORTED order of the cloud they belong to: this query's own term is a
@@ -646,11 +657,18 @@ __global__ __launch_bounds__(256) void sdg_query(CloudT<S> A, CloudT<S> T, S* __
           const V4 t = Tsorted[best_k];
           float* own = (fwd ? fz.own_a : fz.own_b) + ((size_t)b * nq + slot) * 3;
           float* scat = (fwd ? fz.scat_b : fz.scat_a) + ((size_t)b * nt + best_k) * 3;
-          const float qv[3] = {(float)q.x, (float)q.y, (float)q.z}, tv[3] = {(float)t.x, (float)t.y, (float)t.z};
+          if (OUT_LANES == 3) {
+            const float qa = sub == 0 ? (float)q.x : (sub == 1 ? (float)q.y : (float)q.z);
+            const float ta = sub == 0 ? (float)t.x : (sub == 1 ? (float)t.y : (float)t.z);
+            own[sub] = 2.f * (qa - ta) * k;
+            kamd_atomic_add(scat + sub, 2.f * (ta - qa) * k);
+          } else {
+            const float qv[3] = {(float)q.x, (float)q.y, (float)q.z}, tv[3] = {(float)t.x, (float)t.y, (float)t.z};
 #pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            own[a] = 2.f * (qv[a] - tv[a]) * k;
-            kamd_atomic_add(scat + a, 2.f * (tv[a] - qv[a]) * k);
+            for (int a = 0; a < 3; ++a) {
+              own[a] = 2.f * (qv[a] - tv[a]) * k;
+              kamd_atomic_add(scat + a, 2.f * (tv[a] - qv[a]) * k);
+            }
           }
         }
       }
