@@ -709,14 +709,117 @@ int dt_forward_fused(hipStream_t st, int B, int F, int P, int K, int D, const T*
   KAMD_RETURN_LAST_ERROR();
 }
 
+// The same arithmetic with the number of features known at compile time, and the results leaving through per-wavefront LDS
+// rows: a hit's 3 DT feature gradients and its 6 image-coordinate gradients then sit in consecutive LANES of the atomic
+// instructions -- two requests per hit (one line of g_feat, one of g_img) instead of 3 DT + 6.  Global float atomics cost
+// per request (a line touched by an instruction), ~60 ps chip-wide on MI355X, whatever the lanes in it (measured
+// on the rasterizer's backward): the lane-per-value form above made 15 requests per hit at D = 3.
+template <typename T, int DT>
+__global__ __launch_bounds__(256) void dt_backward_staged_kernel(int B, int F, int P, int K, const T* __restrict__ grad,
+                                                                 const int64_t* __restrict__ face_idx,
+                                                                 const T* __restrict__ weights, const T* __restrict__ fimg,
+                                                                 const T* __restrict__ feat, float eps, T* __restrict__ g_img,
+                                                                 T* __restrict__ g_feat) {
+  constexpr int D = DT, NF = 3 * DT, NV = NF + 6;
+  __shared__ T s_val[4][64 * NV];
+  __shared__ long long s_g[4][64];  // b * F + face of the lane's hit, -1: none
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t total = (size_t)B * P * K;
+  const size_t rounds = (total + 255) / 256;
+  for (size_t r = blockIdx.x; r < rounds; r += gridDim.x) {  // (uniform per workgroup; a wavefront never waits for another)
+    const size_t i = r * 256 + threadIdx.x;
+    const int64_t f = i < total ? face_idx[i] : -1;
+    long long g = -1;
+    T vals[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) vals[e] = 0;
+    if (f >= 0) {
+      const int b = (int)(i / ((size_t)P * K));
+      g = (long long)b * F + (long long)f;
+      const T wa = weights[i * 3], wb = weights[i * 3 + 1], wc = weights[i * 3 + 2];
+      const T* go = grad + i * D;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const T v = go[d];
+        vals[d] = v * wa;
+        vals[D + d] = v * wb;
+        vals[2 * D + d] = v * wc;
+      }
+      const T* v = fimg + (size_t)g * 6;
+      const T ax = v[0], ay = v[1], bx = v[2], by = v[3], cx = v[4], cy = v[5];
+      const T x0 = wa * ax + wb * bx + wc * cx;
+      const T y0 = wa * ay + wb * by + wc * cy;
+      const T m = bx - ax, p = by - ay, n = cx - ax, q = cy - ay, s = x0 - ax, t = y0 - ay;
+      const T k1 = s * q - n * t;
+      const T k2 = m * t - s * p;
+      T k3 = m * q - n * p;
+      k3 = (T)((double)k3 + copysign((double)eps, (double)k3));
+      const T z = 0;
+      const T dw1dm = z * k3 - q * k1, dw1dn = (-t) * k3 - (-p) * k1, dw1dp = z * k3 - (-n) * k1;
+      const T dw1dq = s * k3 - m * k1, dw1ds = q * k3 - z * k1, dw1dt = (-n) * k3 - z * k1;
+      const T dw2dm = t * k3 - q * k2, dw2dn = z * k3 - (-p) * k2, dw2dp = (-s) * k3 - (-n) * k2;
+      const T dw2dq = z * k3 - m * k2, dw2ds = (-p) * k3 - z * k2, dw2dt = m * k3 - z * k2;
+      const T dw1[6] = {-(dw1dm + dw1dn + dw1ds), -(dw1dp + dw1dq + dw1dt), dw1dm, dw1dp, dw1dn, dw1dq};
+      const T dw2[6] = {-(dw2dm + dw2dn + dw2ds), -(dw2dp + dw2dq + dw2dt), dw2dm, dw2dp, dw2dn, dw2dq};
+      const T* c = feat + (size_t)g * 3 * D;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const T c0 = c[d], c1 = c[D + d], c2 = c[2 * D + d];
+        const T dldI = go[d] / (k3 * k3);
+#pragma unroll
+        for (int e = 0; e < 6; ++e) vals[NF + e] += dldI * ((c1 - c0) * dw1[e] + (c2 - c0) * dw2[e]);
+      }
+    }
+    // (wavefront-level ordering is all that is needed: every wavefront owns its rows)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // the wavefront's hits, compacted (a pixel's K slots are mostly empty: a wavefront holds a handful of hits)
+    const unsigned long long act = __ballot(g >= 0);
+    const int n_act = __popcll(act);
+    if (g >= 0) {
+      const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)act, 0u));
+      s_g[wave][pos] = g;
+#pragma unroll
+      for (int e = 0; e < NV; ++e) s_val[wave][pos * NV + e] = vals[e];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int j = lane; j < n_act * NV; j += 64) {
+      const int q = j / NV, e = j - q * NV;
+      const long long gq = s_g[wave][q];
+      const T v = s_val[wave][j];
+      if (e < NF)
+        kamd_atomic_add(g_feat + (size_t)gq * NF + e, v);
+      else
+        kamd_atomic_add(g_img + (size_t)gq * 6 + (e - NF), v);
+    }
+  }
+}
+
 template <typename T>
 int dt_backward(hipStream_t st, int B, int F, int P, int K, int D, const T* grad, const int64_t* face_idx,
                 const T* weights, const T* fimg, const T* feat, float eps, T* g_img, T* g_feat) {
   const size_t n = (size_t)B * P * K;
   if (n == 0 || F <= 0) return 0;
   kamd::ProfScope prof_(kamd::K_DEFTET_BACKWARD, st);
-  hipLaunchKernelGGL(dt_backward_kernel<T>, dim3(dt_grid_for(n)), dim3(256), 0, st, B, F, P, K, D, grad, face_idx,
-                     weights, fimg, feat, eps, g_img, g_feat);
+  static const bool staged = kamd_env_int("KAMD_DEFTET_BWD_STAGED", 1) == 1;  // (2: a lane per value, for A/B runs)
+#define KAMD_DTB(DT)                                                                                                      \
+  hipLaunchKernelGGL((dt_backward_staged_kernel<T, DT>), dim3(dt_grid_for(n)), dim3(256), 0, st, B, F, P, K, grad, face_idx, \
+                     weights, fimg, feat, eps, g_img, g_feat)
+  if (staged && D >= 1 && D <= 4 && sizeof(T) == 4) {
+    switch (D) {
+      case 1: KAMD_DTB(1); break;
+      case 2: KAMD_DTB(2); break;
+      case 3: KAMD_DTB(3); break;
+      default: KAMD_DTB(4); break;
+    }
+  } else {
+    hipLaunchKernelGGL(dt_backward_kernel<T>, dim3(dt_grid_for(n)), dim3(256), 0, st, B, F, P, K, D, grad, face_idx,
+                       weights, fimg, feat, eps, g_img, g_feat);
+  }
+#undef KAMD_DTB
   KAMD_RETURN_LAST_ERROR();
 }
 
