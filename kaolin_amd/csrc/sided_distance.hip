@@ -314,6 +314,9 @@ int sd_forward_generic_launch(hipStream_t st, int B, int N, int M, const T* p1, 
 }
 
 // ---- backward (K6) ------------------------------------------------------------
+// One thread per (point, coordinate): consecutive lanes read and write consecutive scalars of p1 / g1, and the three atomics a
+// point sends to its nearest target sit in three consecutive lanes of ONE instruction -- one request per point (global float
+// atomics cost per request, ~60 ps chip-wide on MI355X: a thread per point adding x, y, z in turn made three).
 template <typename T>
 __global__ __launch_bounds__(256) void sd_backward(
     int N, int M, const T* __restrict__ grad, const T* __restrict__ p1, const T* __restrict__ p2,
@@ -321,23 +324,18 @@ __global__ __launch_bounds__(256) void sd_backward(
   using A = SdArith<T>;
   using acc_t = typename A::acc_t;
   const int b = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;  // scalar index into the item's (N, 3) arrays
+  if (e >= (long long)N * 3) return;
+  const int i = (int)(e / 3), a = (int)(e - (long long)i * 3);
   const size_t main_id = (size_t)b * N + i;
-  const acc_t x1 = A::load(p1 + main_id * 3), y1 = A::load(p1 + main_id * 3 + 1), z1 = A::load(p1 + main_id * 3 + 2);
+  const acc_t c1 = A::load(p1 + main_id * 3 + a);
   const size_t t = ((size_t)idx[main_id] + (size_t)b * M) * 3;
-  const acc_t x2 = A::load(p2 + t), y2 = A::load(p2 + t + 1), z2 = A::load(p2 + t + 2);
+  const acc_t c2 = A::load(p2 + t + a);
   const acc_t g = A::load(grad + main_id);
-  A::store(g1 + main_id * 3 + 0, A::grad(x1, x2, g));
-  A::store(g1 + main_id * 3 + 1, A::grad(y1, y2, g));
-  A::store(g1 + main_id * 3 + 2, A::grad(z1, z2, g));
-  T rx, ry, rz;
-  A::store(&rx, A::grad(x2, x1, g));
-  A::store(&ry, A::grad(y2, y1, g));
-  A::store(&rz, A::grad(z2, z1, g));
-  kamd_atomic_add(g2 + t + 0, rx);
-  kamd_atomic_add(g2 + t + 1, ry);
-  kamd_atomic_add(g2 + t + 2, rz);
+  A::store(g1 + main_id * 3 + a, A::grad(c1, c2, g));
+  T r;
+  A::store(&r, A::grad(c2, c1, g));
+  kamd_atomic_add(g2 + t + a, r);
 }
 
 template <typename T>
@@ -347,7 +345,7 @@ int sd_backward_launch(hipStream_t st, int B, int N, int M, const T* grad, const
   kamd::ProfScope prof_(kamd::K_SD_BACKWARD, st);
   for (int b0 = 0; b0 < B; b0 += 65535) {
     const int nb = B - b0 < 65535 ? B - b0 : 65535;
-    dim3 grid(kamd_cdiv(N, 256), nb);
+    dim3 grid(kamd_cdiv((long long)N * 3, 256), nb);
     hipLaunchKernelGGL(sd_backward<T>, grid, dim3(256), 0, st, N, M, grad + (size_t)b0 * N, p1 + (size_t)b0 * N * 3,
                        p2 + (size_t)b0 * M * 3, idx + (size_t)b0 * N, g1 + (size_t)b0 * N * 3, g2 + (size_t)b0 * M * 3);
   }
@@ -370,9 +368,12 @@ __global__ __launch_bounds__(256) void sd_chamfer_backward(int N, int M, const f
                                                            const float* __restrict__ dist1,
                                                            const float* __restrict__ dist2, float* __restrict__ g1,
                                                            float* __restrict__ g2) {
+  // (one thread per (point, coordinate), as sd_backward: coalesced scalars, one atomic request per point)
   const int b = blockIdx.y;
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N + M) return;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= ((long long)N + M) * 3) return;
+  int i = (int)(e / 3);
+  const int a = (int)(e - (long long)i * 3);
   const bool fwd = i < N;
   if (!fwd) i -= N;
   const int nq = fwd ? N : M, nt = fwd ? M : N;
@@ -386,14 +387,11 @@ __global__ __launch_bounds__(256) void sd_chamfer_backward(int N, int M, const f
   if (!squared) g = g / (2.f * sqrtf((fwd ? dist1 : dist2)[(size_t)b * nq + i]));
   float* GQ = (fwd ? g1 : g2) + ((size_t)b * nq + i) * 3;
   float* GT = (fwd ? g2 : g1) + t * 3;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const float q = Q[a], x = T[a];
-    if (SCATTER)
-      kamd_atomic_add(GT + a, 2.f * (x - q) * g);
-    else
-      GQ[a] = 2.f * (q - x) * g;
-  }
+  const float q = Q[a], x = T[a];
+  if (SCATTER)
+    kamd_atomic_add(GT + a, 2.f * (x - q) * g);
+  else
+    GQ[a] = 2.f * (q - x) * g;
 }
 
 // KAMD_SIDED_DISTANCE=brute keeps the all-pairs kernels for every size (A/B timing, tests of both paths)
@@ -461,7 +459,7 @@ int kamd_chamfer_distance_backward_f32(void* stream, int B, int N, int M, const 
   if (B <= 0 || N <= 0 || M <= 0) return 0;
   {
     kamd::ProfScope prof_(kamd::K_SD_BACKWARD, st);
-    const dim3 grid(kamd_cdiv((long long)N + M, 256), B);
+    const dim3 grid(kamd_cdiv(((long long)N + M) * 3, 256), B);  // (a thread per (point, coordinate))
     hipLaunchKernelGGL(sd_chamfer_backward<false>, grid, dim3(256), 0, st, N, M, grad, w1, w2, 1.f / (float)N,
                        1.f / (float)M, squared, p1, p2, idx1, idx2, dist1, dist2, g1, g2);
     hipLaunchKernelGGL(sd_chamfer_backward<true>, grid, dim3(256), 0, st, N, M, grad, w1, w2, 1.f / (float)N,
