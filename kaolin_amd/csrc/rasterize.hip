@@ -71,13 +71,17 @@ __device__ __forceinline__ T barycentric_jacobian(const T* v, T aw, T bw, T cw, 
 }
 
 #ifndef KAMD_RBWD_DIRECT
-#define KAMD_RBWD_DIRECT 0  // 0 = a tile's run totals are merged per face in an LDS hash table, one global atomic request (24 contiguous bytes in six
-                            // lanes) per face and tile; 1 = no table: every wavefront stages its runs' totals in LDS rows of its own and sends one
-                            // request per run.  Measured at C4 (r03n / r03o): global float atomics cost ~60 ps per REQUEST (a line touched by an
-                            // instruction) chip-wide, whatever the lanes in it -- run-end lanes adding value by value: 219 us; staged, one request per
-                            // run (20 per wavefront): 53 us; the table (14 requests per wavefront, but a CAS probe + 6 LDS float atomics per run:
-                            // 20 us of LDS pipe): 50 us.  Ablations of the table kernel (r03m): list walk + face_idx + barrier 11 us, table clear +
-                            // barriers + arithmetic + DPP merges 13, gathers 5, table inserts 20, flush 2.
+#define KAMD_RBWD_DIRECT 1  // 1 = no per-tile table: every wavefront stages its runs' totals in LDS rows of its own and sends one atomic request (a
+                            // face's values in consecutive lanes) per run; 0 = runs are first merged per face in a per-tile LDS hash table.
+                            // Measured at C4 (r03n / r03o / call 35-36): global float atomics cost ~60 ps per REQUEST (a line touched by an
+                            // instruction) chip-wide, whatever the lanes in it -- run-end lanes adding value by value: 219 us; staged, rows merged
+                            // only (20 requests per wavefront): 53 us; the table (14 per wavefront, but a CAS probe + 6 LDS float atomics per run:
+                            // 20 us of LDS pipe): 50; with the columns merged down the rows first (KAMD_RBWD_VERTICAL) the table 46 and the
+                            // staged form 42-43 -- the default.  Ablations of the table kernel (r03m): list walk + face_idx + barrier 11 us,
+                            // table clear + barriers + arithmetic + DPP merges 13, gathers 5, table inserts 20, flush 2.
+#endif
+#ifndef KAMD_RBWD_VERTICAL
+#define KAMD_RBWD_VERTICAL 1  // a column's sums of one face are merged down the wavefront's 4 rows before the rows' runs are merged (0: rows only)
 #endif
 #ifndef KAMD_RBWD_ABL
 #define KAMD_RBWD_ABL 0  // ablations for timing experiments (wrong results): 1 = no per-face gathers, 2 = no per-pixel loads besides face_idx
@@ -191,9 +195,31 @@ __device__ __forceinline__ void raster_backward_tile(
     // moves).  The 64-lane version went through ds_bpermute: 96 LDS-crossbar operations per wavefront, and this kernel
     // spent 42 % of its wave cycles waiting on LDS (SQ_WAIT_INST_LDS).
     const int rl = lane & 15;
-    const int prev_f = row_shr<1>(f);
-    const int next_f = row_shl<1>(f);
-    const bool run_start = rl == 0 || prev_f != f;
+    int fm = f;  // the face this lane's sums still belong to (-1 once they have been handed to the lane below)
+#if KAMD_RBWD_VERTICAL
+    {
+      // A face covers a few pixels in each of two or three rows: before the rows' runs are merged, every COLUMN of the
+      // wavefront's 4 rows is merged downwards -- row r takes over the sums of row r - 1 where both hold the same face
+      // (three steps of one ds_bpermute per value), and a lane whose sums moved down drops out.  A compact blob then ends
+      // as ONE run in its lowest row instead of one per row: fewer table inserts / atomic requests per wavefront.
+      const int wr = lane >> 4;
+      const int up_f = __shfl_up(f, 16, 64);
+      const bool same_up = wr >= 1 && f >= 0 && up_f == f;
+#pragma unroll
+      for (int step = 1; step <= 3; ++step) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const T o = __shfl_up(vals[i], 16, 64);
+          if (wr == step && same_up) vals[i] += o;
+        }
+      }
+      const int down_f = __shfl_down(f, 16, 64);
+      if (wr < 3 && f >= 0 && down_f == f) fm = -1;
+    }
+#endif
+    const int prev_f = row_shr<1>(fm);
+    const int next_f = row_shl<1>(fm);
+    const bool run_start = rl == 0 || prev_f != fm;
     int start_lane = run_start ? rl : 0;
     {
       int o;
@@ -216,18 +242,18 @@ __device__ __forceinline__ void raster_backward_tile(
     KAMD_RB_STAGE(8)
 #undef KAMD_RB_STAGE
     PHASE_MARK(3);
-    const bool run_end = rl == 15 || next_f != f;
+    const bool run_end = rl == 15 || next_f != fm;
     if constexpr (!TABLE) {
       // The run totals leave through a per-wavefront LDS staging row so that ONE atomic instruction carries all the values of a
       // face in consecutive lanes (24 contiguous bytes = one L2 atomic request per face; issued value by value from the
       // run-end lanes, every instruction touches a different line per lane: 219 us, r03n).  No workgroup-wide state: no
       // table to clear, no barrier, no LDS atomics (the round-2 table's cost 20 of the kernel's 49 us).
-      const unsigned long long ends = __ballot(f >= 0 && run_end);
+      const unsigned long long ends = __ballot(fm >= 0 && run_end);
       const int n_ends = __popcll(ends);
       wave_lds_fence();  // (the previous tile's readers of this wavefront's rows are done)
-      if (f >= 0 && run_end) {
+      if (fm >= 0 && run_end) {
         const int q = __popcll(ends & ((1ull << lane) - 1ull));
-        s_runf[wave][q] = f;
+        s_runf[wave][q] = fm;
 #pragma unroll
         for (int i = 0; i < NV; ++i) s_runv[wave][q * NV + i] = vals[i];
       }
@@ -245,13 +271,13 @@ __device__ __forceinline__ void raster_backward_tile(
 #if KAMD_RBWD_ABL & 8   // (timing experiments only: no hash insert / LDS adds)
     if (f == -12345) {
 #else
-    if (f >= 0 && run_end) {
+    if (fm >= 0 && run_end) {
 #endif
-      int slot = (int)(((unsigned)f * 2654435761u) >> 24) & (RB_HT - 1);
+      int slot = (int)(((unsigned)fm * 2654435761u) >> 24) & (RB_HT - 1);
       for (;;) {  // at most 256 distinct faces for 256 slots: an empty slot always exists
-        const int k = atomicCAS(&s_key[slot], -1, f);
+        const int k = atomicCAS(&s_key[slot], -1, fm);
         if (k == -1) s_used[atomicAdd(&s_nused, 1)] = slot;
-        if (k == -1 || k == f) break;
+        if (k == -1 || k == fm) break;
         slot = (slot + 1) & (RB_HT - 1);
       }
 #pragma unroll
@@ -430,7 +456,7 @@ int rasterize_backward_list_launch(hipStream_t st, int B, int H, int W, int F, i
                                    const unsigned int* cov_counts, const unsigned int* cov_list, unsigned int cov_cap) {
   const long long n_groups = (long long)B * ((W + 15) / 16) * ((H + 15) / 16);
   if (n_groups <= 0 || F <= 0) return 0;
-  static const int per_cu = kamd_env_int("KAMD_RBWD_PER_CU", 8);
+  static const int per_cu = kamd_env_int("KAMD_RBWD_PER_CU", 16);
   static const int grouped = kamd_env_int("KAMD_RBWD_GROUPED", 1) == 1 ? 1 : 0;  // (2: off, for A/B runs)
   const dim3 grid((unsigned)(((std::min<long long>(n_groups, (long long)KAMD_NUM_CU * per_cu) + 7) / 8) * 8));  // (a multiple of 8: every group served)
   kamd::ProfScope prof_(kamd::K_RASTER_BACKWARD, st);
