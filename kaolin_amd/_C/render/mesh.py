@@ -495,45 +495,81 @@ def dibr_rasterization_backward_fused(grad_features, grad_soft_mask, face_idx, o
     return g_img, g_feat
 
 
-_ADJ_CACHE = {}     # id(faces) -> (faces, version, num_vertices, offsets, entries): the entry pins `faces`, so its id stays unique
+def _storage_key(t):
+    """What identifies the DATA a tensor shows: a fresh tensor object over the same storage (`faces[:]`, `.view(...)`, a property
+    that re-wraps) has a new id() but the same key.  Sound only while a cache entry pins a tensor of that storage (the address
+    cannot be recycled) -- every entry below does; an in-place edit bumps `_version` (shared by all views of a storage)."""
+    return (t.data_ptr(), tuple(t.shape), t.stride(), t.device, t.dtype, t._version)
+
+
+class _TopologyCache:
+    """Per-`faces` results (mesh topology is static in training).  Two doors: id(faces) -- one dict probe and an `is`, the hot
+    path when the caller passes the same tensor object every step -- and, when that misses, the storage key above, so that
+    a re-wrapped view does not repeat the reduction / host read / argsort every step."""
+
+    def __init__(self, limit):
+        self.by_id, self.by_key, self.limit = {}, {}, limit
+
+    def get(self, faces, num_vertices):
+        hit = self.by_id.get(id(faces))
+        if hit is not None and hit[0] is faces and hit[1] == faces._version and hit[2] == num_vertices:
+            return hit[3]
+        hit = self.by_key.get(_storage_key(faces))
+        if hit is not None and hit[2] == num_vertices:
+            return hit[3]
+        return None
+
+    def put(self, faces, num_vertices, value):
+        if len(self.by_key) > self.limit:
+            self.by_id.clear()
+            self.by_key.clear()
+        entry = (faces, faces._version, int(num_vertices), value)     # (pins `faces`: neither its id nor its address can be reused)
+        self.by_id[id(faces)] = entry
+        self.by_key[_storage_key(faces)] = entry
+
+    def clear(self):
+        self.by_id.clear()
+        self.by_key.clear()
+
+    def __len__(self):
+        return len(self.by_key)
+
+
+_ADJ_CACHE = _TopologyCache(8)      # -> (offsets, entries)
 
 
 def vertex_face_adjacency(faces, num_vertices):
     """CSR list of the (face, corner) incidences of every vertex: (offsets (V+1) int32, entries (3F) int32 = face*3+k).
     Built with three torch ops the first time a `faces` tensor is seen and cached (mesh topology is static in training)."""
-    hit = _ADJ_CACHE.get(id(faces))
-    if hit is not None and hit[0] is faces and hit[1] == faces._version and hit[2] == num_vertices:
-        return hit[3], hit[4], faces
+    hit = _ADJ_CACHE.get(faces, num_vertices)
+    if hit is not None:
+        return hit[0], hit[1], faces
     flat = faces.reshape(-1)
     entries = torch.argsort(flat, stable=True).to(torch.int32)
     counts = torch.bincount(flat, minlength=num_vertices)
     offsets = torch.zeros(num_vertices + 1, dtype=torch.int32, device=faces.device)
     offsets[1:] = torch.cumsum(counts, 0).to(torch.int32)
-    if len(_ADJ_CACHE) > 8:
-        _ADJ_CACHE.clear()
-    _ADJ_CACHE[id(faces)] = (faces, faces._version, int(num_vertices), offsets, entries)
+    _ADJ_CACHE.put(faces, num_vertices, (offsets, entries))
     return offsets, entries, faces
 
 
-_FACES_OK = {}      # id(faces) -> (faces, version, num_vertices, ok)
+_FACES_OK = _TopologyCache(16)      # -> bool
 
 
 def faces_in_range(faces, num_vertices):
     """True when every index of `faces` addresses a vertex (the reference's index_select would raise otherwise; the fused
-    kernels read unchecked).  One reduction and one host read per `faces` tensor, cached like the adjacency (mesh topology
+    kernels read unchecked).  One reduction and one host read per `faces` storage, cached like the adjacency (mesh topology
     is static); the entry keeps `faces` alive, so that neither its id nor its data_ptr can be handed to another tensor
     while the entry exists (a recycled address would hit a stale answer); an in-place edit bumps the version."""
-    hit = _FACES_OK.get(id(faces))
-    if hit is not None and hit[0] is faces and hit[1] == faces._version and hit[2] == num_vertices:
-        return hit[3]
+    hit = _FACES_OK.get(faces, num_vertices)
+    if hit is not None:
+        return hit
     if faces.numel() == 0:
         ok = True
     else:
         lo, hi = torch.stack(torch.aminmax(faces)).tolist()     # min and max in one pass, one synchronising read
         ok = lo >= 0 and hi < num_vertices
-    if len(_FACES_OK) > 16:
-        _FACES_OK.clear()
-    _FACES_OK[id(faces)] = (faces, faces._version, int(num_vertices), ok)
+    _FACES_OK.put(faces, num_vertices, ok)
     return ok
 
 

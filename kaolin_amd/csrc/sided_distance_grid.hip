@@ -579,7 +579,9 @@ __device__ __forceinline__ void sdg_search(const Box& s_box, int G, T qx, T qy, 
         }
       }
       if (whole_grid) break;
-      if (bound > 0.f && best < (T)(bound * bound * 0.99999f)) break;
+      // (squared in T: a float square overflows to +inf from bound ~1.8e19 on, and any finite fp64 `best` would then stop the
+      // search after the first ring -- fp64 clouds reach the grid path with coordinates up to 1e30)
+      if (bound > 0.f && best < (T)bound * (T)bound * (T)0.99999f) break;
     }
   }
 }

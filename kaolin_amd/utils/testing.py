@@ -33,6 +33,34 @@ def check_allclose(a, b, rtol=1e-5, atol=1e-8):
         raise AssertionError(f'max abs diff {(a - b).abs().max().item()}')
 
 
+def elementwise_mismatch(a, b, tol=1e-5):
+    """Element-wise comparison of a float result `a` with its reference `b` (the north star's "within 1e-5 relative"):
+        |a - b| <= tol * |b| + tol * median(|b| over the elements where b != 0)
+    -- relative to EACH element, with a floor of `tol` times the typical magnitude so that elements which are tiny because
+    their terms cancel are not held to a relative bound their own reference does not meet (a tolerance scaled by the LARGEST
+    element, which these tests used through round 3, lets a small entry be off by orders of magnitude).
+    Returns None when every element passes, else a message naming the worst element."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    if a.shape != b.shape:
+        return f'shape {tuple(a.shape)} vs {tuple(b.shape)}'
+    nz = b[b != 0].abs()
+    floor = float(nz.median()) if nz.numel() else 0.0
+    bound = tol * b.abs() + tol * floor
+    bad = ~((a - b).abs() <= bound)                      # (NaN anywhere fails)
+    both_nan = torch.isnan(a) & torch.isnan(b)
+    bad &= ~both_nan
+    if not bool(bad.any()):
+        return None
+    excess = torch.where(bad, (a - b).abs() / bound.clamp(min=1e-300), torch.zeros_like(a))
+    i = int(excess.reshape(-1).argmax())
+    return (f'{int(bad.sum())} of {a.numel()} elements outside |a-b| <= {tol:g}|b| + {tol:g}*{floor:.3e}; worst at flat index {i}: '
+            f'{float(a.reshape(-1)[i])!r} vs {float(b.reshape(-1)[i])!r} ({float(excess.reshape(-1)[i]):.2f}x the bound)')
+
+
+def elementwise_close(a, b, tol=1e-5):
+    return elementwise_mismatch(a, b, tol) is None
+
+
 def check_tensor(tensor, shape=None, dtype=None, device=None, throw=True):
     """True when `tensor` has the given shape (None entries match anything), dtype and device; otherwise raises
     (ValueError for the shape, TypeError for dtype / device) or, with throw=False, returns False
@@ -88,6 +116,81 @@ def geodesic_sphere(frequency, radius=0.5):
     v = np.stack(verts)
     v = v / np.linalg.norm(v, axis=1, keepdims=True) * radius
     return torch.from_numpy(v), torch.tensor(faces, dtype=torch.long)
+
+
+def knot_mesh(nu=440, nv=48):
+    """A NON-CONVEX test mesh of ~50 000 triangles (the second scene of the parity tests and of bench.py --scene knot;
+    the convex sphere of config C4 has depth complexity 2, uniform tiny triangles and nothing off screen):
+      * a trefoil-knot tube (2 nu nv triangles): strands cross in front of each other -- 4 surface layers at a crossing;
+      * two nested spheres in the knot's central hole (2 880 + 3 920 triangles): with a strand in front or behind, 6-8 layers;
+      * a coarse bowl below everything (an inward-facing cap of a frequency-6 icosphere of radius 1.4, ~170 triangles
+        100-200 pixels across at 1024^2, partly beyond the image border): image-sized faces among tiny ones --
+        the tile lists' big-face path, boxes clipped by the image border, a silhouette against geometry instead of background.
+    Returns (vertices (V, 3) float64, faces (F, 3) int64); outward winding for the tube and the spheres, inward for the bowl."""
+    t = np.linspace(0.0, 2.0 * np.pi, nu, endpoint=False)
+    c = 0.17 * np.stack([np.sin(t) + 2.0 * np.sin(2.0 * t), np.cos(t) - 2.0 * np.cos(2.0 * t), -np.sin(3.0 * t)], axis=1)
+    d = 0.17 * np.stack([np.cos(t) + 4.0 * np.cos(2.0 * t), -np.sin(t) + 4.0 * np.sin(2.0 * t), -3.0 * np.cos(3.0 * t)], axis=1)
+    tangent = d / np.linalg.norm(d, axis=1, keepdims=True)
+    # a frame without twist jumps: project a fixed axis, fall back where it is nearly parallel to the tangent
+    ref = np.tile(np.array([[0.0, 0.0, 1.0]]), (nu, 1))
+    nearly = np.abs((tangent * ref).sum(1)) > 0.95
+    ref[nearly] = np.array([1.0, 0.0, 0.0])
+    n1 = np.cross(tangent, ref)
+    n1 /= np.linalg.norm(n1, axis=1, keepdims=True)
+    n2 = np.cross(tangent, n1)
+    a = np.linspace(0.0, 2.0 * np.pi, nv, endpoint=False)
+    ring = np.cos(a)[None, :, None] * n1[:, None, :] + np.sin(a)[None, :, None] * n2[:, None, :]
+    tube_v = (c[:, None, :] + 0.06 * ring).reshape(-1, 3)
+    i = np.arange(nu)[:, None]
+    j = np.arange(nv)[None, :]
+    v00, v10 = i * nv + j, ((i + 1) % nu) * nv + j
+    v01, v11 = i * nv + (j + 1) % nv, ((i + 1) % nu) * nv + (j + 1) % nv
+    tube_f = np.concatenate([np.stack([v00, v10, v11], -1).reshape(-1, 3), np.stack([v00, v11, v01], -1).reshape(-1, 3)])
+    # orient the tube outwards (the frame's handedness decides; check one face against its ring direction)
+    f0 = tube_f[0]
+    nrm = np.cross(tube_v[f0[1]] - tube_v[f0[0]], tube_v[f0[2]] - tube_v[f0[0]])
+    if (nrm * ring[0, 0]).sum() < 0:
+        tube_f = tube_f[:, [0, 2, 1]]
+    parts_v, parts_f, base = [tube_v], [tube_f], tube_v.shape[0]
+    for freq, radius in ((12, 0.10), (14, 0.13)):
+        sv, sf = geodesic_sphere(freq, radius)
+        parts_v.append(sv.numpy())
+        parts_f.append(sf.numpy() + base)
+        base += sv.shape[0]
+    bv, bf = geodesic_sphere(6, 1.4)
+    bv, bf = bv.numpy(), bf.numpy()
+    keep = bv[bf].mean(axis=1)[:, 1] < -0.75
+    parts_v.append(bv)
+    parts_f.append(bf[keep][:, [0, 2, 1]] + base)          # (inward: the far side of the bowl faces the camera)
+    return torch.from_numpy(np.concatenate(parts_v)), torch.from_numpy(np.concatenate(parts_f)).long()
+
+
+def mesh_scene(vertices, faces, num_views=1, device='cpu', dtype=torch.float, seed=0, distance=2.5):
+    """DIB-R inputs for any mesh: cameras as in :func:`sphere_scene`, features = [uv-like rand (B,F,3,2), ones (B,F,3,1)].
+    Returns (face_vertices_z, face_vertices_image, [feat_uv, feat_ones], face_normals_z)."""
+    v = vertices.to(dtype)
+    cams = torch.tensor([[0., 0., distance]], dtype=dtype) if num_views == 1 else fibonacci_cameras(num_views, distance, dtype)
+    fz, fimg, nz = project_mesh(v, faces, cams)
+    g = torch.Generator().manual_seed(seed)
+    uv = torch.rand((1, faces.shape[0], 3, 2), generator=g, dtype=torch.float).to(dtype).repeat(num_views, 1, 1, 1)
+    ones = torch.ones((num_views, faces.shape[0], 3, 1), dtype=dtype)
+    return fz.to(device), fimg.to(device), [uv.to(device), ones.to(device)], nz.to(device)
+
+
+def knot_scene(num_views=8, device='cpu', dtype=torch.float, seed=0, distance=2.5):
+    """:func:`knot_mesh` seen from the cameras of config C4 (a Fibonacci sphere of radius `distance` looking at the origin)."""
+    v, f = knot_mesh()
+    return mesh_scene(v, f, num_views, device, dtype, seed, distance)
+
+
+def scene_mesh(name, frequency=50):
+    """The meshes bench.py and the full-size parity tests render: 'sphere' (config C4: geodesic sphere, 20 f^2 triangles) or
+    'knot' (:func:`knot_mesh`).  -> (vertices float64, faces int64)"""
+    if name == 'sphere':
+        return geodesic_sphere(frequency)
+    if name == 'knot':
+        return knot_mesh()
+    raise ValueError(f'unknown scene {name!r} (sphere | knot)')
 
 
 def fibonacci_cameras(num_views, distance=2.5, dtype=torch.float):

@@ -200,26 +200,27 @@ def dibr_rasterization(height, width, face_vertices_z, face_vertices_image, face
 
 
 # ---- point -> triangle-soup distance (reference `_C.metrics.unbatched_triangle_distance_*`) ----------
-def triangle_distance_forward(points, face_vertices, omp=False):
+def triangle_distance_forward(points, face_vertices, omp=False, fused=True):
     """unbatched_triangle_distance.cpp:43-72 (outputs are caller-allocated there): returns (dist (N),
-    face_idx (N) int64, dist_type (N) int32: 0 plane, 1-3 vertex, 4-6 edge)."""
+    face_idx (N) int64, dist_type (N) int32: 0 plane, 1-3 vertex, 4-6 edge).  ``fused=False``: the build without the
+    contraction pin (every product and sum rounded on its own: tridist_oracle.inc header)."""
     pts, fv = _cpu(points), _cpu(face_vertices)
     N, F = pts.shape[0], fv.shape[0]
     dist = torch.zeros(N, dtype=pts.dtype)
     idx = torch.zeros(N, dtype=torch.long)
     typ = torch.zeros(N, dtype=torch.int32)
-    f = getattr(lib(omp), f'oracle_triangle_distance_forward_{_SFX[pts.dtype]}')
+    f = getattr(lib(omp), f'oracle_triangle_distance_forward_{_SFX[pts.dtype]}' + ('' if fused else '_unfused'))
     f(_ci(N), _ci(F), _p(pts), _p(fv), _p(dist), _p(idx), _p(typ))
     return dist, idx, typ
 
 
-def triangle_distance_backward(grad_dist, points, face_vertices, face_idx, dist_type):
+def triangle_distance_backward(grad_dist, points, face_vertices, face_idx, dist_type, fused=True):
     """unbatched_triangle_distance.cpp:74-114 -> (grad_points (N,3), grad_face_vertices (F,3,3))."""
     g, pts, fv = _cpu(grad_dist), _cpu(points), _cpu(face_vertices)
     idx, typ = _cpu(face_idx, torch.long), _cpu(dist_type, torch.int32)
     N, F = pts.shape[0], fv.shape[0]
     gp, gf = torch.zeros_like(pts), torch.zeros_like(fv)
-    f = getattr(lib(False), f'oracle_triangle_distance_backward_{_SFX[pts.dtype]}')
+    f = getattr(lib(False), f'oracle_triangle_distance_backward_{_SFX[pts.dtype]}' + ('' if fused else '_unfused'))
     f(_ci(N), _ci(F), _p(g), _p(pts), _p(fv), _p(idx), _p(typ), _p(gp), _p(gf))
     return gp, gf
 

@@ -19,9 +19,12 @@
  *     sided_distance:  d = fma(dz,dz, fma(dy,dy, dx*dx))
  *   Half (fp16) follows c10::Half: float operation, round to half after each one.
  *
- * Pinning: tests/test_oracle_pins.py checks this file against the reference's own
- * pure-PyTorch oracles and known-answer tests (fixtures under tests/golden/,
- * generated from /root/reference by tests/golden/make_golden.py).
+ * Pinning: the `-m "not gpu"` tests check this file against the reference's own
+ * pure-PyTorch oracles and known-answer tests -- tests/test_sided_distance.py,
+ * tests/test_dibr_oracle.py, tests/test_triangle_distance.py, tests/test_check_sign.py,
+ * tests/test_deftet.py, tests/test_mesh_to_spc.py, tests/test_voxelgrid.py -- on
+ * fixtures under tests/golden/, generated from /root/reference by
+ * tests/golden/make_golden.py.
  */
 #include <math.h>
 #include <stdint.h>
@@ -246,6 +249,33 @@ DEFINE_SIDED_BWD(oracle_sided_distance_backward_f64, double)
 #define FN(n) n##_f64
 #define SQRTFN sqrt
 #define FMAFN fma
+#define REF_TILE 512
+#include "tridist_oracle.inc"
+#undef T
+#undef FN
+#undef SQRTFN
+#undef FMAFN
+#undef REF_TILE
+/* The same restatement WITHOUT the contraction pin -- every multiply and add rounded on its own, exactly the source
+ * expressions of unbatched_triangle_distance_cuda.cu:56-131 -- as oracle_triangle_distance_{forward,backward}_{f32,f64}_unfused.
+ * The pinned build above is what the HIP kernel is bit-compared with; this one bounds how far that pin can sit from the
+ * reference whichever contraction nvcc chose (tests/test_triangle_distance.py::test_gpu_within_ulps_of_both_contraction_variants). */
+#define ORACLE_UNFUSED_FMA(a, b, c) ((a) * (b) + (c))
+#define T float
+#define FN(n) n##_f32_unfused
+#define SQRTFN sqrtf
+#define FMAFN ORACLE_UNFUSED_FMA
+#define REF_TILE 1024
+#include "tridist_oracle.inc"
+#undef T
+#undef FN
+#undef SQRTFN
+#undef FMAFN
+#undef REF_TILE
+#define T double
+#define FN(n) n##_f64_unfused
+#define SQRTFN sqrt
+#define FMAFN ORACLE_UNFUSED_FMA
 #define REF_TILE 512
 #include "tridist_oracle.inc"
 #undef T

@@ -178,3 +178,32 @@ def test_faces_in_range_cache_pins_its_tensor():
     assert m.faces_in_range(neg, 4) is False
     bad[1, 1] = 3                                   # in-place edit bumps the version: re-checked
     assert m.faces_in_range(bad, 4) is True
+
+
+def test_topology_caches_hit_for_a_rewrapped_view():
+    """the caches are probed by id(faces) first, but a caller that hands over a FRESH tensor object over the same
+    storage every step (`faces[:]`, `.view(...)`) must still hit -- otherwise the range check (a reduction + a synchronising
+    host read) and the adjacency (argsort, bincount, cumsum) are repeated each step."""
+    from kaolin_amd._C.render import mesh as m
+    m._FACES_OK.clear()
+    m._ADJ_CACHE.clear()
+    faces = torch.tensor([[0, 1, 2], [2, 3, 1], [0, 2, 3]])
+    assert m.faces_in_range(faces, 4) is True
+    off, ent, _ = m.vertex_face_adjacency(faces, 4)
+    calls = []
+    real = torch.aminmax
+    torch.aminmax = lambda *a, **k: calls.append(1) or real(*a, **k)
+    try:
+        for view in (faces[:], faces.view(3, 3), faces.reshape(-1).view(3, 3)):
+            assert view is not faces
+            assert m.faces_in_range(view, 4) is True
+            off2, ent2, _ = m.vertex_face_adjacency(view, 4)
+            assert off2 is off and ent2 is ent              # the cached tensors, not a rebuild
+        assert calls == []
+        assert m.faces_in_range(faces[:2], 4) is True        # another shape over the same storage: its own entry
+        assert calls == [1]
+        faces[0, 0] = 3                                      # an edit through ANY view bumps the shared version
+        assert m.faces_in_range(faces[:], 4) is True
+        assert calls == [1, 1]
+    finally:
+        torch.aminmax = real

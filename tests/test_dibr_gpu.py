@@ -32,6 +32,18 @@ def g_dibr():
 
 
 def rel_close(a, b, tol=1e-5):
+    """ELEMENT-WISE: |a - b| <= tol |b| + tol median|b != 0| (kaolin_amd.utils.testing.elementwise_mismatch; through round 3
+    this scaled the tolerance by the largest element of `b`, which let small entries be off by orders of magnitude)."""
+    from kaolin_amd.utils.testing import elementwise_mismatch
+    msg = elementwise_mismatch(a, b, tol)
+    assert msg is None, msg
+    return True
+
+
+def same_sum_other_order(a, b, tol):
+    """Two GPU paths that add the SAME float terms in a different (atomic) order: compared against the largest element -- an
+    element whose terms cancel carries the rounding noise of their magnitude in either path (oracle comparisons use the
+    element-wise rel_close above)."""
     a, b = a.double().cpu(), b.double().cpu()
     scale = max(float(b.abs().max()), 1e-30)
     return float((a - b).abs().max()) <= tol * scale
@@ -353,7 +365,7 @@ def test_backward_with_and_without_hit_count():
     g = torch.rand(soft.shape, device='cuda')
     a = m.dibr_soft_mask_backward_cuda(g, soft, face_idx, prob, idx, typ, scaled, 7000., 1000.)
     b = m.dibr_soft_mask_backward_cuda(g, soft, face_idx, prob, idx, typ, scaled, 7000., 1000., _hit_count=hits)
-    assert rel_close(a, b, 1e-6)
+    assert same_sum_other_order(a, b, 1e-6)
 
 
 @pytest.mark.parametrize('dtype', [torch.float, torch.double])
@@ -385,7 +397,7 @@ def test_kbuffer_operators_match_lean_autograd_path(dtype):
     g = torch.rand(soft.shape, device='cuda', dtype=dtype)
     ga = m.dibr_soft_mask_backward_cuda(g, soft, face_idx, prob, idx, typ, scaled, 7000., 1000.)
     gb = m.dibr_soft_mask_backward_lean(g, soft2, hits, scaled, 7000., 30, 1000.)
-    assert rel_close(ga, gb, 1e-6 if dtype == torch.float else 1e-12)
+    assert same_sum_other_order(ga, gb, 1e-6 if dtype == torch.float else 1e-12)
 
 
 @pytest.mark.parametrize('dtype', [torch.float, torch.double])
@@ -411,7 +423,7 @@ def test_fused_front_door_equals_reference_glue_plus_contract_operator(dtype, wi
     g = torch.rand(s1.shape, device='cuda', dtype=dtype)
     g1 = m.dibr_soft_mask_backward_lean(g, s1, h1, scaled, 7000, 30, 1000.)
     g2 = m.dibr_soft_mask_backward_lean(g, s2, h2, fimg.cuda(), 7000, 30, 1000., img_scale=1000.)
-    assert rel_close(g1, g2, 1e-6 if dtype == torch.float else 1e-12)
+    assert same_sum_other_order(g1, g2, 1e-6 if dtype == torch.float else 1e-12)
 
 
 @pytest.mark.gpu
@@ -466,7 +478,7 @@ def test_static_features_skip_their_gradient(D):
                 ((out * up).sum() + (soft * up_soft).sum()).backward()
             assert (f.grad is not None) == needs
             grads.append(a.grad.clone())
-        assert rel_close(grads[1], grads[0], 1e-5), name
+        assert same_sum_other_order(grads[1], grads[0], 1e-5), name
 
 
 def test_gradient_buffer_cleared_by_the_forward_is_used_once():
@@ -483,7 +495,7 @@ def test_gradient_buffer_cleared_by_the_forward_is_used_once():
     first = a.grad.clone()
     a.grad = None
     loss.backward()
-    assert rel_close(a.grad, first, 1e-5)
+    assert same_sum_other_order(a.grad, first, 1e-5)
     f = feat.clone().requires_grad_()
     out2, soft2, _ = kal().render.mesh.dibr_rasterization(H, W, fz.cuda(), fimg.cuda(), f, nz.cuda())
     assert out2.grad_fn.zeroed_grad is None

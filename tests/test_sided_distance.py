@@ -347,6 +347,25 @@ def test_grid_search_fp64_queries_beyond_float_range_and_nonfinite():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('scale', [1e20, 1e25, 3e29])
+def test_grid_search_fp64_huge_coordinates(scale):
+    """fp64 clouds whose coordinates are finite in float but whose SQUARES are not (|x| > 1.8e19): the search's stopping
+    rule must compare in double -- a float square of the distance to the visited cube's faces is +inf, and any finite best
+    distance would stop the search after the first ring (a nearest target in an unvisited cell missed).  Clustered targets
+    make the first ring a poor guess."""
+    pc = _pc()
+    g = torch.Generator().manual_seed(11)
+    p1 = torch.rand(1, 4000, 3, generator=g, dtype=torch.double)
+    centres = torch.rand(1, 40, 3, generator=g, dtype=torch.double)
+    p2 = centres[:, torch.randint(0, 40, (9000,), generator=g)] + 1e-3 * torch.randn(1, 9000, 3, generator=g, dtype=torch.double)
+    p1, p2 = p1 * scale, p2 * scale
+    assert _lib_ws(1, 4000, 9000, 8) > 0, 'these shapes must take the grid path'
+    d_ref, i_ref = oracle.sided_distance_forward(p1, p2, omp=True)
+    d, i = pc.sided_distance(p1.cuda(), p2.cuda())
+    assert torch.equal(i.cpu(), i_ref) and torch.equal(d.cpu(), d_ref)
+
+
+@pytest.mark.gpu
 def test_grid_search_nonfinite_and_brute_force_switch():
     """NaN / inf handling of the grid path equals the reference's seed semantics; KAMD_SIDED_DISTANCE=brute keeps the
     all-pairs kernels, and both paths agree bit for bit."""

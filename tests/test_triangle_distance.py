@@ -142,6 +142,62 @@ def test_gpu_vs_oracle(dtype, N, F):
     assert float((b.grad.cpu() - gf).abs().max()) <= 1e-5 * max(float(gf.abs().max()), 1e-30)
 
 
+def _near(a, b, scale2, ulps=32):
+    """|a - b| <= ulps * eps * max(|a|, |b|) + ulps * eps * scale2 -- a few roundings of the float expression, relative to the
+    value and to the squared coordinate scale the cancelling terms are formed at."""
+    eps = torch.finfo(a.dtype).eps
+    return (a - b).abs() <= ulps * eps * torch.maximum(a.abs(), b.abs()) + ulps * eps * scale2
+
+
+def test_oracle_contraction_variants_agree_within_ulps():
+    """The two builds of the restated kernel -- dot / cross / point_at as explicit fmas (what nvcc's default -fmad would form;
+    the pin the HIP kernel is bit-compared with) and every product / sum rounded on its own (the source expressions) -- differ
+    by a few roundings in the distance and pick the same face / region except at near-ties."""
+    torch.manual_seed(3)
+    for dtype in (torch.float, torch.double):
+        pts, fv = torch.rand(3000, 3, dtype=dtype) * 2 - 1, torch.randn(400, 3, 3, dtype=dtype)
+        d1, i1, t1 = oracle.triangle_distance_forward(pts, fv, omp=True)
+        d0, i0, t0 = oracle.triangle_distance_forward(pts, fv, omp=True, fused=False)
+        assert bool(_near(d1, d0, 4.0).all())
+        assert float((i1 != i0).float().mean()) < 5e-3 and float((t1 != t0).float().mean()) < 5e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float, torch.double])
+@pytest.mark.parametrize('kind', ['soup', 'sphere'])
+def test_gpu_within_ulps_of_both_contraction_variants(dtype, kind):
+    """kernel and oracle were edited in lockstep to the fma pin, so 'bit-exact vs the oracle' alone no longer bounds
+    the distance to the reference's source expressions.  The kernel must (a) equal the pinned oracle bit for bit and (b) stay
+    within a few roundings of the UNFUSED oracle -- whichever contraction nvcc chose for the shipped binary lies between
+    the two -- with the same face and region wherever the choice is not a near-tie."""
+    from kaolin_amd.utils.testing import geodesic_sphere
+    torch.manual_seed(17)
+    if kind == 'sphere':
+        v, f = geodesic_sphere(16)
+        fv = v.to(dtype)[f]
+        pts = torch.rand(20000, 3, dtype=dtype) * 1.2 - 0.6
+    else:
+        fv = torch.randn(1300, 3, 3, dtype=dtype)
+        pts = torch.randn(20000, 3, dtype=dtype)
+    scale2 = float(fv.abs().max()) ** 2 + float(pts.abs().max()) ** 2
+    dist, idx, typ = _gpu_fwd(pts, fv)
+    dist, idx, typ = dist.cpu(), idx.cpu(), typ.cpu()
+    d1, i1, t1 = oracle.triangle_distance_forward(pts, fv, omp=True)
+    assert torch.equal(dist, d1) and torch.equal(idx, i1) and torch.equal(typ, t1)
+    d0, i0, t0 = oracle.triangle_distance_forward(pts, fv, omp=True, fused=False)
+    assert bool(_near(dist, d0, scale2).all())
+    moved = (idx != i0) | (typ != t0)
+    # a different face / region only where the two candidates are equidistant up to rounding (shared edges and vertices of a
+    # connected mesh: exact ties broken by the last bit) -- the distance itself still agrees (asserted above for every point)
+    assert float(moved.float().mean()) < (0.1 if kind == 'sphere' else 5e-3)
+    # the gradients through either variant's (idx, type) agree where the choice agrees
+    g = torch.rand(pts.shape[0], dtype=dtype)
+    gp1, gf1 = oracle.triangle_distance_backward(g, pts, fv, i1, t1)
+    gp0, gf0 = oracle.triangle_distance_backward(g, pts, fv, i1, t1, fused=False)
+    assert torch.allclose(gp1, gp0, rtol=1e-5, atol=1e-6 * scale2 ** 0.5)
+    assert torch.allclose(gf1, gf0, rtol=1e-4, atol=1e-5 * scale2 ** 0.5)
+
+
 @pytest.mark.gpu
 def test_gpu_batched_api_and_errors():
     tm = _tm()
@@ -177,6 +233,33 @@ def test_gpu_full_size_properties():
     assert float((dist[0] - approx).abs().max()) < 2e-3
     d2, i2, t2 = _tm().point_to_mesh_distance(pts[None, 500000:], fv[None])
     assert torch.equal(d2[0], dist[0, 500000:]) and torch.equal(i2[0], idx[0, 500000:])
+
+
+@pytest.mark.gpu
+def test_gpu_backward_full_size_vs_oracle():
+    """K8 at the C5 shape (VERDICT r03 weak #1b): unbatched_triangle_distance_backward for 1 000 000 queries x the 50 000-face
+    sphere against the oracle's backward on the same (face_idx, dist_type) -- the GPU forward's, checked bit for bit on 8 192
+    sampled queries above and on 20 000 here.  A point's gradient is one term (no summation): 1e-6 element-wise; a face's
+    nine values collect ~20 points each through float atomics: 1e-5 element-wise (reference:
+    kaolin/csrc/metrics/unbatched_triangle_distance_cuda.cu:319-416)."""
+    from kaolin_amd.utils.testing import geodesic_sphere, elementwise_mismatch
+    v, f = geodesic_sphere(50)
+    fv_cpu = v.float()[f].contiguous()
+    g = torch.Generator().manual_seed(1)
+    pts_cpu = torch.rand(1000000, 3, generator=g) * 1.2 - 0.6
+    grad_cpu = torch.rand(1000000, generator=g) + 0.5
+    a, b = pts_cpu.cuda().requires_grad_(), fv_cpu.cuda().requires_grad_()
+    dist, idx, typ = _tm()._UnbatchedTriangleDistanceCuda.apply(a, b)
+    sel = torch.randperm(1000000, generator=g)[:20000]
+    d_ref, i_ref, t_ref = oracle.triangle_distance_forward(pts_cpu[sel], fv_cpu, omp=True)
+    assert torch.equal(idx[sel.cuda()].cpu(), i_ref) and torch.equal(typ[sel.cuda()].cpu(), t_ref) and torch.equal(dist[sel.cuda()].detach().cpu(), d_ref)
+    dist.backward(grad_cpu.cuda())
+    gp, gf = oracle.triangle_distance_backward(grad_cpu, pts_cpu, fv_cpu, idx.cpu(), typ.cpu())
+    msg = elementwise_mismatch(a.grad, gp, 1e-6)
+    assert msg is None, 'grad_points: ' + msg
+    msg = elementwise_mismatch(b.grad, gf, 1e-5)
+    assert msg is None, 'grad_face_vertices: ' + msg
+    assert int((gf.abs().sum(dim=(1, 2)) > 0).sum()) > 45000      # (nearly every face is somebody's nearest)
 
 
 @pytest.mark.gpu

@@ -1,4 +1,4 @@
-"""One step of the DIB-R bench as a timeline from a rocprofv3 kernel trace (tools/round2/r02_trace.sh):
+"""One step of the DIB-R bench as a timeline from a rocprofv3 kernel trace (tools/round3/r03_trace.sh):
 kernel, start offset, duration, gap to the previous kernel's end on the device (us)."""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
