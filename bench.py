@@ -61,21 +61,35 @@ def parse():
     ap.add_argument('--quick', action='store_true',
                     help='development probe: the headline step and its kernel table only (no variants, graph replay, contract '
                          'operators, chamfer, C5, CPU baseline)')
+    ap.add_argument('--scene', choices=['sphere', 'knot'], default='sphere',
+                    help='the mesh of the headline step: sphere = config C4 (BASELINE.json; the default and the only one `value` may be '
+                         'quoted on), knot = the non-convex ~49k-triangle scene of kaolin_amd.utils.testing.knot_mesh (depth complexity up '
+                         'to 8-11, image-sized triangles, geometry leaving the image); the default run also times the knot scene and reports '
+                         'it under "scene_variants"')
+    ap.add_argument('--no-scene-variants', action='store_true', help='skip the timing of the other scene')
+    ap.add_argument('--dump-vertex-grad', default=None, metavar='FILE',
+                    help='tests: after the timed steps run one more step and save rank 0\'s (all-reduced) vertex gradient with torch.save')
     ap.add_argument('--look-at', type=float, nargs=3, default=[0., 0., 0.],
                     help='point the cameras look at (default: the mesh centre; e.g. 0.35 -0.3 0 renders the object off-centre)')
     return ap.parse_args()
 
 
-def algorithmic_bytes(kernel, B, P, F, Fv, D, K, esz=4):
+def algorithmic_bytes(kernel, B, P, F, Fv, D, K, esz=4, P_cov=None):
     """Contract bytes per launch: every operator input the kernel consumes read once, every operator
-    output it produces written once (intermediate records / lists are NOT counted: they are this design's own traffic)."""
+    output it produces written once (intermediate records / lists are NOT counted: they are this design's own traffic).
+    `P_cov` (pixels of the 16 x 16 tiles that hold a covered pixel, per view; None = every pixel): the fused operator's
+    backward walks the forward's list of those tiles and never reads the others -- charging it every pixel put it at 0.97 of
+    HBM peak in round 3's line, above what any kernel reaches."""
+    Pb = P if P_cov is None else P_cov
     per = {
         # SURVEY 8(d) K1: P (20 + 4D) out -- face_idx (i64), 3 weights, D features -- + F' (52 + 12D) in -- the front faces'
         # 13 scalars + 3 D feature scalars: 32 B/pixel + 88 B/front face at D = 3.  (The fused operator's launch also writes
         # the soft mask of the pixels it settles, 4 B/pixel, and skips the 12 B/pixel of background weights: see
-        # roofline.bytes_note)
+        # roofline.bytes_note / roofline.launch_bytes)
         'raster_tile_kernel': P * (8 + 3 * esz + D * esz) + Fv * (13 * esz + 3 * D * esz),
-        'raster_backward_kernel': P * (8 + 3 * esz + D * esz) + F * (6 * esz * 2 + 3 * D * esz * 2),
+        # K2 in the fused operator (static features: no feature gradient): face_idx, weights and the upstream gradient of the
+        # covered tiles in; per front face 6 image coordinates in, 6 gradient values out
+        'raster_backward_kernel': Pb * (8 + 3 * esz + D * esz) + Fv * (6 * esz * 2),
         'fill_regions_kernel': P * K * (esz + 8 + 1),
         # select reads face_idx of the uncovered pixels' tiles and the faces' 6 coordinates + 4 box scalars
         'soft_select_kernel': P * 8 + F * 10 * esz,
@@ -84,6 +98,9 @@ def algorithmic_bytes(kernel, B, P, F, Fv, D, K, esz=4):
         'bin_faces_kernel': F * (13 * esz),
     }
     return B * per[kernel] if kernel in per else None
+
+
+STREAM_COPY_GBS = 6300.0   # what a streaming copy reaches on MI355X (HBM_PEAK_GBS note): no kernel moves its bytes faster
 
 
 # kernels of the fused DIB-R operator that share the GPU with a concurrent launch in the timed region (backward: the
@@ -199,17 +216,25 @@ def time_contract_operators(verts, faces, proj, rot, trans, feats3, G1, G2, H, W
     P = V * H * W
 
     def ev_time(fn):
-        out = fn()
+        """median of `reps` event-bracketed calls after three warm-up calls; the previous call's outputs are dropped BEFORE the
+        next call allocates its own (dibr_soft_mask_forward_cuda returns 3.3 GB of K-buffers at C4: with two sets alive the
+        timed call paid for allocator growth -- 6.5 ms on the driver's box against 0.8-0.96 ms everywhere else in round 3)"""
+        out = None
+        for _ in range(3):
+            del out
+            out = fn()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        tot = 0.0
+        times = []
         for _ in range(reps):
+            del out
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = fn()
             e1.record()
             e1.synchronize()
-            tot += e0.elapsed_time(e1)
-        return tot / reps, out
+            times.append(e0.elapsed_time(e1))
+        times.sort()
+        return times[len(times) // 2], out
 
     t_k1, (interp, sel, wts) = ev_time(lambda: m.packed_rasterize_forward_cuda(H, W, packed_z, packed_img, bboxes, packed_feat,
                                                                               first_idx, 1000., 1e-8))
@@ -235,7 +260,7 @@ def time_contract_operators(verts, faces, proj, rot, trans, feats3, G1, G2, H, W
             'Mpixels_per_s': round(P / (tot_ms * 1e-3) / 1e6, 1),
             'note': 'the four reference-contract operators called one after the other as the reference\'s autograd Functions call '
                     'them (K-buffers materialised: 390 B/pixel written by K3, read by K4); operator calls only, the torch glue '
-                    'around them is outside the events'}
+                    'around them is outside the events; ms = median of the event-bracketed calls after 3 warm-up calls'}
 
 
 def main():
@@ -252,35 +277,44 @@ def main():
     lib = _lib.load()
     H = W = args.res
     V = args.views_per_gpu
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')   # HBM bytes per launch from the PMC passes (tools/pmc_traffic.py)
 
     # ---------------- synthetic scene (config C4): shared mesh, this rank's slice of the camera ring
-    verts, faces = T.geodesic_sphere(args.sphere_frequency)
-    verts = verts.float().to(dev).requires_grad_()
-    faces = faces.to(dev)
-    F = faces.shape[0]
-    cams = D.shard_views(T.fibonacci_cameras(V * world, 2.5)).to(dev)     # this rank's views of the shared mesh
-    look_at = torch.tensor([args.look_at], device=dev, dtype=torch.float).repeat(V, 1)
-    up = torch.tensor([[0., 1., 0.]], device=dev).repeat(V, 1)
-    rot, trans = kal.render.camera.generate_rotate_translate_matrices(cams, look_at, up)
+    def build_scene(name):
+        verts, faces = T.scene_mesh(name, args.sphere_frequency)
+        sc = {'name': name, 'verts': verts.float().to(dev).requires_grad_(), 'faces': faces.to(dev), 'F': faces.shape[0]}
+        cams = D.shard_views(T.fibonacci_cameras(V * world, 2.5)).to(dev)     # this rank's views of the shared mesh
+        look_at = torch.tensor([args.look_at], device=dev, dtype=torch.float).repeat(V, 1)
+        up = torch.tensor([[0., 1., 0.]], device=dev).repeat(V, 1)
+        sc['rot'], sc['trans'] = kal.render.camera.generate_rotate_translate_matrices(cams, look_at, up)
+        g = torch.Generator().manual_seed(0)
+        uv = torch.rand((1, sc['F'], 3, 2), generator=g).to(dev).expand(V, -1, -1, -1).contiguous()
+        ones = torch.ones((V, sc['F'], 3, 1), device=dev)
+        sc['feats3'] = torch.cat([uv, ones], dim=-1).contiguous()   # D = 3 (uv + mask channel, as in the tutorial), static input
+        # The vertex gradient is shared by every view: its all-reduce is posted from autograd's accumulate hook and awaited
+        # before the step ends; with one process this is a no-op.
+        sc['reducer'] = D.SharedGradientReducer([sc['verts']])
+        return sc
+
     proj = kal.render.camera.generate_perspective_projection(math.pi / 4).to(dev)
     g = torch.Generator().manual_seed(0)
-    uv = torch.rand((1, F, 3, 2), generator=g).to(dev).expand(V, -1, -1, -1).contiguous()
-    ones = torch.ones((V, F, 3, 1), device=dev)
-    feats3 = torch.cat([uv, ones], dim=-1).contiguous()   # D = 3 (uv + mask channel, as in the tutorial), static input
+    torch.rand((1, T.scene_mesh('sphere', args.sphere_frequency)[1].shape[0], 3, 2), generator=g)   # (keeps G1 / G2 what they were in rounds 1-3)
     G1 = torch.rand((V, H, W, 3), generator=g).to(dev)
     G2 = torch.rand((V, H, W), generator=g).to(dev)
     G1f, G2f = G1.reshape(-1), G2.reshape(-1)
+    target_mask = (G2 > 0.5).float()
+    scene = build_scene(args.scene)
+    verts, faces, F, rot, trans, feats3, reducer = (scene[k] for k in ('verts', 'faces', 'F', 'rot', 'trans', 'feats3', 'reducer'))
     feats3_grad = feats3.clone().requires_grad_()          # variant: learnable per-face features (a texture atlas per view)
-    # The vertex gradient is shared by every view: its all-reduce is posted from autograd's accumulate hook and awaited
-    # before the step ends; with one process this is a no-op.
-    reducer = D.SharedGradientReducer([verts])
 
-    def make_step(features, tutorial_loss=False, torch_loss=False):
+    def make_step(sc, features, tutorial_loss=False, torch_loss=False):
+        verts_, faces_, rot_, trans_, reducer_ = sc['verts'], sc['faces'], sc['rot'], sc['trans'], sc['reducer']
+
         def step():
-            verts.grad = None
+            verts_.grad = None
             features.grad = None
             fv_cam, fv_img, normals = kal.render.mesh.prepare_vertices(
-                verts.unsqueeze(0).expand(V, -1, -1), faces, proj, camera_rot=rot, camera_trans=trans)
+                verts_.unsqueeze(0).expand(V, -1, -1), faces_, proj, camera_rot=rot_, camera_trans=trans_)
             feat, soft, face_idx = kal.render.mesh.dibr_rasterization(
                 H, W, fv_cam[..., 2], fv_img, features, normals[..., 2])
             if tutorial_loss:
@@ -293,14 +327,13 @@ def main():
                 # (features * G1).sum() + (soft_mask * G2).sum(): one fused pass over both G-buffers each way
                 loss = kal.metrics.render.weighted_sum(feat, G1, soft, G2)
             loss.backward()
-            reducer.wait()
+            reducer_.wait()
             return face_idx
         return step
-    target_mask = (G2 > 0.5).float()
-    dibr_step = make_step(feats3)
-    dibr_step_tutorial = make_step(feats3, tutorial_loss=True)
-    dibr_step_torch_loss = make_step(feats3, torch_loss=True)
-    dibr_step_feature_grad = make_step(feats3_grad)
+    dibr_step = make_step(scene, feats3)
+    dibr_step_tutorial = make_step(scene, feats3, tutorial_loss=True)
+    dibr_step_torch_loss = make_step(scene, feats3, torch_loss=True)
+    dibr_step_feature_grad = make_step(scene, feats3_grad)
 
     def per_step_ms(fn, steps):
         """Duration of every step of one more pass (events between steps on the launch stream, no host sync inside)."""
@@ -336,28 +369,54 @@ def main():
             dt = float(t.item())
         return dt
 
+    def covered_tile_pixels(face_idx):
+        """pixels of the 16 x 16 tiles that hold a covered pixel, per view on average (what the fused backward's tile walk reads)"""
+        c = (face_idx >= 0)
+        Hp, Wp = (H + 15) // 16 * 16, (W + 15) // 16 * 16
+        c = torch.nn.functional.pad(c, (0, Wp - W, 0, Hp - H))
+        tiles = c.reshape(V, Hp // 16, 16, Wp // 16, 16).any(dim=4).any(dim=2)
+        return float(tiles.float().sum()) * 256.0 / V
+
+    def kernel_table(step, sc, steps):
+        """One fully instrumented pass (HIP events around every launch of the library): per-kernel average durations."""
+        lib.kamd_profile_reset()
+        lib.kamd_profile_select(-1)
+        lib.kamd_profile_enable(1)
+        inst_dt = timed(step, steps, 0)
+        lib.kamd_profile_enable(0)
+        prof = _lib.kernel_profile(reset=True)
+        inst_ms = inst_dt / steps * 1e3
+        face_idx = step()
+        front = sc['front_faces']
+        p_cov = covered_tile_pixels(face_idx)
+        table, over = {}, []
+        for name, (ms, n) in prof.items():
+            avg_us = ms / n * 1e3
+            ab = algorithmic_bytes(name, V, H * W, sc['F'], front, 3, 30, P_cov=p_cov)
+            gbps = None if ab is None else round(ab / (avg_us * 1e-6) / 1e9, 1)
+            if gbps is not None and gbps > STREAM_COPY_GBS:
+                over.append(name)      # (a byte model that charges a kernel bytes it does not move: reported, never silently kept)
+            table[name] = {'avg_us': round(avg_us, 2), 'launches_per_step': round(n / steps, 2),
+                           'share_of_instrumented_step': round(ms / steps / inst_ms, 4), 'algorithmic_GBps': gbps}
+        return table, inst_ms, face_idx, p_cov, over
+
+    def front_faces(sc):
+        """front-facing faces per view on average (what K1 / K2 read): counted from the scene, not assumed"""
+        with torch.no_grad():
+            _, _, normals = kal.render.mesh.prepare_vertices(sc['verts'].detach().unsqueeze(0).expand(V, -1, -1), sc['faces'], proj,
+                                                            camera_rot=sc['rot'], camera_trans=sc['trans'])
+        return float((normals[..., 2] >= 0).float().sum()) / V
+
     # ---------------- DIB-R.  Two event records around a launch cost a few microseconds of stream time, and timing every
     # kernel also keeps the operator's two concurrent launches (side stream) on one stream.  So: (1) an instrumented
     # pass outside the timed region gives the per-kernel table and names the dominant kernel; (2) the timed region runs
     # the step as users run it, with HIP events around the dominant kernel only (the roofline line's duration).
+    scene['front_faces'] = front_faces(scene)
+    Fv = scene['front_faces']
     for _ in range(args.warmup):
         face_idx = dibr_step()
     kernel_ids = {lib.kamd_profile_kernel_name(k).decode(): k for k in range(lib.kamd_profile_num_kernels())}
-    lib.kamd_profile_reset()
-    lib.kamd_profile_select(-1)
-    lib.kamd_profile_enable(1)
-    inst_dt = timed(dibr_step, args.steps, 0)
-    lib.kamd_profile_enable(0)
-    prof = _lib.kernel_profile(reset=True)
-    inst_ms_per_step = inst_dt / args.steps * 1e3
-    Fv = F // 2  # front-facing faces of a closed convex mesh
-    kernels = {}
-    for name, (ms, n) in prof.items():
-        avg_us = ms / n * 1e3
-        ab = algorithmic_bytes(name, V, H * W, F, Fv, 3, 30)
-        kernels[name] = {'avg_us': round(avg_us, 2), 'launches_per_step': round(n / args.steps, 2),
-                         'share_of_instrumented_step': round(ms / args.steps / inst_ms_per_step, 4),
-                         'algorithmic_GBps': None if ab is None else round(ab / (avg_us * 1e-6) / 1e9, 1)}
+    kernels, inst_ms_per_step, face_idx, p_cov, over_peak = kernel_table(dibr_step, scene, args.steps)
     dom = pick_dominant(kernels)
 
     lib.kamd_profile_reset()
@@ -374,6 +433,11 @@ def main():
     mpix = world * V * H * W * args.steps / dt / 1e6
 
     step_stats = per_step_ms(dibr_step, max(args.steps, 20))
+    if args.dump_vertex_grad:
+        dibr_step()
+        torch.cuda.synchronize()
+        if rank == 0:
+            torch.save(verts.grad.detach().cpu(), args.dump_vertex_grad)
     feature_grad = tutorial = torch_loss = None
     if not args.quick:
         # variant with gradients w.r.t. the face features as well (raster_backward adds its feature-gradient atomics)
@@ -385,13 +449,50 @@ def main():
 
         tl_dt = timed(dibr_step_tutorial, args.steps, args.warmup)
         tutorial = {'ms_per_step': round(tl_dt / args.steps * 1e3, 4), 'per_step_ms': per_step_ms(dibr_step_tutorial, max(args.steps, 20)),
+                    'value': round(world * V * H * W * args.steps / tl_dt / 1e6, 2), 'unit': 'Mpixels/s',
                     'note': 'same step with the tutorial\'s objective: torch L1 image loss + kaolin.metrics.render.mask_iou (one fused '
                             'pass each way) instead of the two dot products'}
 
         tq_dt = timed(dibr_step_torch_loss, args.steps, args.warmup)
         torch_loss = {'ms_per_step': round(tq_dt / args.steps * 1e3, 4), 'per_step_ms': per_step_ms(dibr_step_torch_loss, max(args.steps, 20)),
+                      'value': round(world * V * H * W * args.steps / tq_dt / 1e6, 2), 'unit': 'Mpixels/s',
                       'note': 'same step with the linear loss written in torch (two rocBLAS dots, an add, two full-size products '
-                              'backward) instead of kaolin_amd.metrics.render.weighted_sum'}
+                              'backward) instead of kaolin_amd.metrics.render.weighted_sum: what a drop-in user of the reference\'s '
+                              'API gets without touching the loss'}
+
+    # ---------------- the other scene: the same step on the non-convex knot (or, with --scene knot, on the
+    # sphere), timed over fewer steps, with its own kernel table -- no kernel should be much slower than on the sphere
+    # without an explanation in DESIGN.md
+    scene_variants = None
+    if not args.quick and not args.no_scene_variants:
+        scene_variants = {}
+        for other in ('sphere', 'knot'):
+            if other == args.scene:
+                continue
+            try:
+                sc = build_scene(other)
+                sc['front_faces'] = front_faces(sc)
+                step_o = make_step(sc, sc['feats3'])
+                for _ in range(max(args.warmup // 2, 3)):
+                    fi = step_o()
+                n_o = max(min(args.steps, 30), 10)
+                table_o, inst_o, fi, p_cov_o, over_o = kernel_table(step_o, sc, n_o)
+                dt_o = timed(step_o, n_o, 2)
+                st_o = per_step_ms(step_o, max(n_o, 20))
+                scene_variants[other] = {
+                    'faces': sc['F'], 'front_faces_per_view': round(sc['front_faces'], 1),
+                    'covered_pixel_fraction': round(float((fi >= 0).float().mean()), 4),
+                    'covered_tile_pixel_fraction': round(p_cov_o / (H * W), 4),
+                    'ms_per_step': round(dt_o / n_o * 1e3, 4), 'per_step_ms': st_o,
+                    'value': round(world * V * H * W * n_o / dt_o / 1e6, 2), 'unit': 'Mpixels/s',
+                    'kernels_avg_us': {k: v['avg_us'] for k, v in table_o.items()},
+                    'vs_headline_scene_kernel_ratio': {k: round(v['avg_us'] / kernels[k]['avg_us'], 2) for k, v in table_o.items()
+                                                       if k in kernels and kernels[k]['avg_us'] > 0},
+                    'kernels_over_stream_copy_rate': over_o}
+                del sc, step_o
+            except Exception as exc:                    # (must not cost the run its headline line)
+                scene_variants[other] = {'error': f'{type(exc).__name__}: {str(exc)[:200]}'}
+                torch.cuda.synchronize()
 
     # ---------------- the reference-contract operators at C4 (the eight `_C` entry points; here the four of the
     # DIB-R path with their K-buffers): the only place where 8(d)'s contract bytes -- 872 B/pixel + 296 B/face -- are
@@ -432,8 +533,7 @@ def main():
 
     covered = float((face_idx >= 0).float().mean())
     traffic, step_traffic = None, None
-    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if dom and os.path.exists(tpath):
+    if dom and os.path.exists(tpath) and args.scene == 'sphere':   # (the counters were collected on config C4's scene)
         # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, calibrated on launches of
         # known size: tools/pmc_traffic.py, tools/parse_traffic.py, raw tables in profiles/r02*_pmc_*.txt)
         tj = json.load(open(tpath))
@@ -450,19 +550,26 @@ def main():
     roofline = None
     if dom and dom_n:
         dom_us = dom_ms / dom_n * 1e3                        # measured inside the timed region
-        dom_bytes = algorithmic_bytes(dom, V, H * W, F, Fv, 3, 30)
+        dom_bytes = int(round(algorithmic_bytes(dom, V, H * W, F, Fv, 3, 30, P_cov=p_cov)))
         dom_gbps = dom_bytes / (dom_us * 1e-6) / 1e9
         roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': round(dom_gbps, 1), 'peak': HBM_PEAK_GBS,
                     'unit': 'GB/s', 'frac': round(dom_gbps / HBM_PEAK_GBS, 4),
-                    'traffic': traffic, 'avg_launch_us': round(dom_us, 2),
+                    'traffic': traffic if args.scene == 'sphere' else None, 'avg_launch_us': round(dom_us, 2),
                     'algorithmic_bytes_per_launch': dom_bytes}
-        if traffic:
+        if traffic and args.scene == 'sphere':
             # the same duration against the bytes the PMC counters saw the kernel move (FETCH_SIZE + WRITE_SIZE)
             roofline['frac_on_counter_bytes'] = round(traffic / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
         if dom == 'raster_tile_kernel':
-            roofline['bytes_note'] = ('algorithmic bytes = SURVEY 8(d) K1: 32 B/pixel (face_idx i64 + 3 weights + 3 features) + 88 B '
+            # what THIS launch has to move: face_idx 8 + features 4 D + soft mask 4 bytes for every pixel,
+            # the 12 bytes of weights only in the tiles that hold a covered pixel (background tiles leave them unwritten), the
+            # front faces' 88 bytes
+            launch_bytes = int(round(V * (H * W * (8 + 4 * 3 + 4) + p_cov * 12 + Fv * 88)))
+            roofline['launch_bytes'] = launch_bytes
+            roofline['frac_on_launch_bytes'] = round(launch_bytes / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            roofline['bytes_note'] = ('algorithmic bytes (achieved / frac) = SURVEY 8(d) K1: 32 B/pixel (face_idx i64 + 3 weights + 3 features) + 88 B '
                                       'per front face; the fused launch also writes 4 B/pixel of soft mask and leaves the 12 B/pixel of '
-                                      'background weights unwritten (internal to the autograd node)')
+                                      'weights unwritten in tiles without a covered pixel (internal to the autograd node): launch_bytes / '
+                                      'frac_on_launch_bytes count exactly what it writes and reads; frac_on_counter_bytes = the PMC bytes')
     # whole-step figure against the contract bytes of SURVEY.md 8(d): 872 B/pixel + 296 B/face (D=3, K=30, fp32)
     contract = V * (H * W * 872 + F * 296)
     lean = V * (H * W * 48 + F * 136)
@@ -503,6 +610,27 @@ def main():
                    'host_enqueue_ms_per_step': round(chamfer_enqueue_ms, 4),
                    'kernels_avg_us': {k: round(v[0] / v[1] * 1e3, 2) for k, v in cprof.items()},
                    'hbm_frac_of_8TBps': round(192.0 * n / (cdt / args.steps) / 1e9 / HBM_PEAK_GBS, 6)}
+        # roofline of the search launch (the largest kernel of the chamfer step): SURVEY 8(d)'s forward bytes -- 36 B per point and
+        # direction -- over its event-bracketed duration, and the PMC bytes of the same launch (profiles/traffic.json, section
+        # _chamfer_step; collected on the C3 size only)
+        q_us = chamfer['kernels_avg_us'].get('sdg_query')
+        if q_us:
+            q_bytes = 2 * 36 * n
+            tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+            sec = (tj.get('_chamfer_step') or {}) if n == 100000 else {}
+            q_cnt = (sec.get('kernels') or {}).get('sdg_query')
+            q_traffic = (q_cnt['fetch_bytes_per_call'] + q_cnt['write_bytes_per_call']) / max(q_cnt['launches_per_call'], 1) if q_cnt else None
+            chamfer['roofline'] = {'kernel': 'sdg_query', 'bound': 'hbm', 'achieved': round(q_bytes / (q_us * 1e-6) / 1e9, 1), 'peak': HBM_PEAK_GBS,
+                                   'unit': 'GB/s', 'frac': round(q_bytes / (q_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                                   'avg_launch_us': q_us, 'algorithmic_bytes_per_launch': q_bytes,
+                                   'traffic': None if q_traffic is None else int(q_traffic),
+                                   'frac_on_counter_bytes': None if q_traffic is None else round(q_traffic / (q_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                                   'step_counter_bytes': int(sec['hbm_bytes_per_call']) if sec.get('hbm_bytes_per_call') else None,
+                                   'step_frac_on_counter_bytes': (round(sec['hbm_bytes_per_call'] / (cdt / args.steps) / 1e9 / HBM_PEAK_GBS, 5)
+                                                                  if sec.get('hbm_bytes_per_call') else None),
+                                   'note': 'an exact nearest-neighbour search is a latency chain over ~60 candidate targets per query, not a '
+                                           'stream: the HBM fraction says how far from memory-bound it is (SURVEY 8(d): brute force is VALU-bound '
+                                           'at 8 300 FLOP/B)'}
         # The step above wraps the operator in torch glue for the shared parameter (base + offset, .sum(), their backward
         # nodes and the reduction to 3 floats): ~10 small host-bound torch calls.  Two more readings of the same work:
         # (a) the operator alone -- chamfer_distance forward + backward to both clouds from a given upstream gradient,
@@ -582,12 +710,26 @@ def main():
         c5 = {'voxelgrid_256_us': round(vox_ms * 1e3, 1), 'voxelgrid_write_GBps': round(256 ** 3 * 4 / (vox_ms * 1e-3) / 1e9, 1),
               'voxelgrid_kernels_avg_us': vox_kernels,
               'voxelgrid_kernels_sum_frac_of_write_bound': round(256 ** 3 * 4 / 8e12 * 1e6 / max(sum(vox_kernels.values()), 1e-3), 3),
+              'roofline': None,
               'point_to_mesh_1Mx50k_ms': round(p2m_ms, 3),
               'point_to_mesh_kernels_avg_us': {k: v for k, v in kprof.items() if k.startswith('td_')},
               'point_to_mesh_Gpairs_per_s': round(1e6 * F / (p2m_ms * 1e-3) / 1e9, 1),
               # the all-pairs kernel issues 11 VALU lane-ops per (point, face) sphere test at 58 T lane-ops/s measured
               # (profiles/r01_ubench_valu.txt): > 1 means the exact search evaluated that much less than all pairs
               'point_to_mesh_allpairs_equiv_valu_frac': round(11.0 * 1e6 * F / (p2m_ms * 1e-3) / 58e12, 3)}
+        # roofline of the voxelizer (genuinely HBM-write-bound: SURVEY 8(d)): the dense grid's bytes over the two launches' summed
+        # durations, and the PMC bytes of one call (profiles/traffic.json, section _voxelgrid_256)
+        vox_us = sum(vox_kernels.values())
+        if vox_us > 0:
+            tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+            sec = tj.get('_voxelgrid_256') or {}
+            vb = 256 ** 3 * 4 + verts.shape[0] * 12 + F * 24
+            c5['roofline'] = {'kernel': 'vox_clear_extent_kernel + vox_mark_kernel', 'bound': 'hbm', 'achieved': round(vb / (vox_us * 1e-6) / 1e9, 1),
+                              'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(vb / (vox_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                              'avg_launch_us': round(vox_us, 1), 'algorithmic_bytes_per_launch': vb,
+                              'traffic': int(sec['hbm_bytes_per_call']) if sec.get('hbm_bytes_per_call') else None,
+                              'frac_on_counter_bytes': (round(sec['hbm_bytes_per_call'] / (vox_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                                                        if sec.get('hbm_bytes_per_call') else None)}
         # deftet_sparse_render fwd+bwd, view 0 of the same mesh, knum 30, free pixel coordinates
         with torch.no_grad():
             d_cam, d_img, _ = kal.render.mesh.prepare_vertices(
@@ -667,15 +809,26 @@ def main():
             'metric': 'Mpixels/s DIB-R fwd+bwd @1024^2', 'value': round(mpix, 2), 'unit': 'Mpixels/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'C4: dibr_rasterization fwd+bwd, {V} views/GPU at {H}x{W} of a {F}-triangle geodesic '
-                                   f'sphere (shared vertices), D=3 static face features (uv + mask channel; gradient w.r.t. the vertices only), '
+            # beside the K-step mean of the contract: the per-step MEDIAN of one more pass (SURVEY 8(d) asks for the median; a
+            # 20-step driver run is otherwise at the mercy of one outlier) and the same step with the loss written in plain torch
+            # (what a drop-in user of the reference's API gets: kaolin has no fused weighted_sum)
+            'median_ms_per_step': step_stats['median'],
+            'value_at_median_ms_per_step': round(world * V * H * W / (step_stats['median'] * 1e-3) / 1e6, 2),
+            'torch_loss_value': torch_loss['value'] if torch_loss else None,
+            'torch_loss_median_ms_per_step': torch_loss['per_step_ms']['median'] if torch_loss else None,
+            'config': {'workload': f'{"C4" if args.scene == "sphere" else "C4 shape, scene " + args.scene}: dibr_rasterization fwd+bwd, {V} views/GPU at {H}x{W} of a {F}-triangle '
+                                   f'{"geodesic sphere" if args.scene == "sphere" else "non-convex knot scene (kaolin_amd.utils.testing.knot_mesh)"} '
+                                   f'(shared vertices), D=3 static face features (uv + mask channel; gradient w.r.t. the vertices only), '
                                    f'knum=30, sigmainv=7000, boxlen=0.02, loss = sum(features*G1) + sum(soft_mask*G2) (fused weighted_sum), '
                                    f'prepare_vertices + vertex-gradient all-reduce (posted from the autograd hook) inside the step',
                        'views_per_gpu': V, 'global_views': V * world, 'height': H, 'width': W, 'faces': F,
-                       'covered_pixel_fraction': round(covered, 4), 'parallelism': f'views sharded {world}-way',
-                       'look_at': list(args.look_at)},
+                       'scene': args.scene, 'front_faces_per_view': round(Fv, 1),
+                       'covered_pixel_fraction': round(covered, 4), 'covered_tile_pixel_fraction': round(p_cov / (H * W), 4),
+                       'parallelism': f'views sharded {world}-way', 'look_at': list(args.look_at)},
             'per_step_ms': step_stats, 'feature_grad_variant': feature_grad, 'tutorial_loss_variant': tutorial, 'torch_loss_variant': torch_loss,
+            'scene_variants': scene_variants,
             'roofline': roofline, 'step_roofline': step_roofline, 'step_traffic': step_traffic, 'kernels': kernels,
+            'kernels_over_stream_copy_rate': over_peak,    # (algorithmic_GBps above what a streaming copy reaches = a byte model that is wrong)
             'kernels_note': f'per-kernel table: separate pass of {args.steps} steps with HIP events around every launch '
                             f'({inst_ms_per_step:.4f} ms/step: the events and the single-stream order they need cost the '
                             f'difference); the timed region brackets the roofline kernel only',

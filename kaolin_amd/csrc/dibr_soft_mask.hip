@@ -257,7 +257,8 @@ int soft2_search_launch(hipStream_t st, int B, int H, int W, int F, int K, float
                         const tl::Lists& LS, const unsigned int* work, T* soft_mask, T* prob, int64_t* idx, uint8_t* type,
                         uint8_t* hit_count, const HitList2<T>* lean, unsigned short* pixcnt, T* prob_pm,
                         void* zero_p = nullptr, size_t zero_bytes = 0,  // (a 16-byte aligned range the eval launch clears)
-                        const unsigned int* span_src = nullptr, unsigned int* span_dst = nullptr, int span_n = 0) {
+                        const unsigned int* span_src = nullptr, unsigned int* span_dst = nullptr, int span_n = 0,
+                        unsigned int* magic_dst = nullptr) {
   const unsigned int shard_cap = tl::work_shard_cap(B, H, W);
   const long long n_sub = (long long)B * LS.ntiles * tl::S_SUBS;
   Select2Args<T> sa{};
@@ -284,6 +285,7 @@ int soft2_search_launch(hipStream_t st, int B, int H, int W, int F, int K, float
   ea.K = K;
   ea.sigmainv = sigmainv;
   ea.multiplier = multiplier;
+  ea.inv_mult2 = 1.0 / ((double)multiplier * (double)multiplier);
   ea.rec = rec;
   ea.tiles_x_s = LS.tiles_x;
   ea.work = work;
@@ -300,6 +302,8 @@ int soft2_search_launch(hipStream_t st, int B, int H, int W, int F, int K, float
   ea.span_src = span_src;
   ea.span_dst = span_dst;
   ea.span_n = span_n;
+  ea.magic_dst = magic_dst;
+  ea.magic = tl::work_magic(B, H, W);
   // one wavefront (select) / workgroup (eval) per work item; the number of items is known on the device only, so the
   // grids cover the worklist round-robin
   static const int sel_per_cu = kamd_env_int("KAMD_SOFT_SELECT_PER_CU", 32);
@@ -414,8 +418,8 @@ int soft_mask_backward_list_launch(hipStream_t st, int B, int H, int W, int F, i
     kamd::ProfScope prof_(kamd::K_SOFT_BACKWARD_LIST, st);
     // persistent workgroups over the rounds of 256 hits (their number is known on the device only)
     static const int per_cu = kamd_env_int("KAMD_SOFT_BWD_PER_CU", 16);
-    hipLaunchKernelGGL(soft_mask_backward_flat_kernel<T>, dim3(KAMD_NUM_CU * per_cu), dim3(256), 0, st, H, W, F, 1.0f / (float)F,
-                       grad, soft_mask, list, img, (T)img_scale, sigmainv, multiplier, g_img, kamd_env_int("KAMD_BWD_MODE", 0));
+    hipLaunchKernelGGL(soft_mask_backward_flat_kernel<T>, dim3(KAMD_NUM_CU * per_cu), dim3(256), 0, st, H, W, F, flat_view_magic(F),
+                       grad, soft_mask, list, img, (T)img_scale, sigmainv, multiplier, 1.0 / (double)multiplier, g_img);
   }
   KAMD_RETURN_LAST_ERROR();
 }
@@ -507,7 +511,8 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
                                       (int64_t*)nullptr, (uint8_t*)nullptr, (uint8_t*)nullptr, &list,
                                       (unsigned short*)((char*)workspace + lay.s.pixcnt),
                                       (T*)((char*)workspace + lay.s.prob_pm), zero_in_eval ? (void*)g_img_zero : nullptr,
-                                      zero_in_eval ? g_bytes : 0, LR.row_span, work + tl::work_span_offset_words(B, H, W), 2 * B));
+                                      zero_in_eval ? g_bytes : 0, LR.row_span, work + tl::work_span_offset_words(B, H, W), 2 * B,
+                                      work + tl::WORK_MAGIC_WORD));
   KAMD_RETURN_LAST_ERROR();
 }
 
@@ -557,7 +562,8 @@ int dibr_backward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K
     if (cov_list && tile_cov != nullptr)
       return kamd::raster_backward_draw_list<T>(st, B, H, W, F, D, grad_feat, face_idx, weights, img, feat, eps, g_img, g_feat,
                                                 work + tl::WORK_COV_WORD, work + tl::work_covlist_offset_words(B, H, W),
-                                                tl::cov_shard_cap((size_t)B, (size_t)tl::pass_geom(H, W, tl::R_TILE).ntiles));
+                                                tl::cov_shard_cap((size_t)B, (size_t)tl::pass_geom(H, W, tl::R_TILE).ntiles),
+                                                work + tl::WORK_MAGIC_WORD);
     return kamd::raster_backward_draw<T>(st, B, H, W, F, D, grad_feat, face_idx, weights, img, feat, eps, g_img, g_feat, tile_cov,
                                          row_centre);
   }

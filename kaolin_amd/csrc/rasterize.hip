@@ -343,10 +343,22 @@ __global__ __launch_bounds__(256) void raster_backward_list_kernel(
     int B, int H, int W, int F, int D, const T* __restrict__ grad, const int64_t* __restrict__ face_idx,
     const T* __restrict__ weights, const T* __restrict__ img, const T* __restrict__ feat, float eps,
     T* __restrict__ g_img, T* __restrict__ g_feat, const unsigned int* __restrict__ cov_counts,
-    const unsigned int* __restrict__ cov_list, unsigned int cov_cap, int grouped) {
+    const unsigned int* __restrict__ cov_list, unsigned int cov_cap, int grouped, const unsigned int* __restrict__ magic_word,
+    unsigned int magic) {
   __shared__ unsigned int s_end[tl::COV_SHARDS];  // inclusive prefix of the shards' entry counts
   const int tiles_x = (W + 15) / 16, ntiles = tiles_x * ((H + 15) / 16);
   const int lane = threadIdx.x & 63;
+  // The list is trusted only with the forward's signature in the header (tl::WORK_MAGIC_WORD: a work buffer of another
+  // operator / build / shape would otherwise be read as tile indices); without it every tile is visited -- each wavefront
+  // finds out from face_idx whether it has anything to do, as the one-workgroup-per-tile launch does.  (Uniform: a scalar load.)
+  if (magic_word == nullptr || *magic_word != magic) {
+    const unsigned int all = (unsigned int)B * (unsigned int)ntiles;
+    for (unsigned int id = blockIdx.x; id < all; id += gridDim.x) {
+      const int b = (int)(id / (unsigned int)ntiles), tile = (int)(id - (unsigned int)b * (unsigned int)ntiles);
+      raster_backward_tile<T, DT, GF>(b, tile, tiles_x, H, W, F, D, grad, face_idx, weights, img, feat, eps, g_img, g_feat);
+    }
+    return;
+  }
   if (threadIdx.x < 64) {
     static_assert(tl::COV_SHARDS <= 64, "one wavefront scans the shard counts");
     unsigned int c = lane < tl::COV_SHARDS ? min(cov_counts[lane * tl::COUNTER_STRIDE], cov_cap) : 0u;
@@ -368,6 +380,7 @@ __global__ __launch_bounds__(256) void raster_backward_list_kernel(
     const unsigned int start = sh > 0 ? s_end[sh - 1] : 0u;
     const unsigned int id = cov_list[(size_t)sh * cov_cap + (i - start)];
     const int b = (int)(id / (unsigned int)ntiles), tile = (int)(id - (unsigned int)b * (unsigned int)ntiles);
+    if (b >= B) continue;  // (never with a list the forward wrote: belt and braces behind the signature check)
     raster_backward_tile<T, DT, GF>(b, tile, tiles_x, H, W, F, D, grad, face_idx, weights, img, feat, eps, g_img, g_feat);
   }
 }
@@ -453,8 +466,10 @@ int rasterize_backward_launch(hipStream_t st, int B, int H, int W, int F, int D,
 template <typename T>
 int rasterize_backward_list_launch(hipStream_t st, int B, int H, int W, int F, int D, const T* grad, const int64_t* face_idx,
                                    const T* weights, const T* img, const T* feat, float eps, T* g_img, T* g_feat,
-                                   const unsigned int* cov_counts, const unsigned int* cov_list, unsigned int cov_cap) {
+                                   const unsigned int* cov_counts, const unsigned int* cov_list, unsigned int cov_cap,
+                                   const unsigned int* magic_word) {
   const long long n_groups = (long long)B * ((W + 15) / 16) * ((H + 15) / 16);
+  const unsigned int magic = tl::work_magic(B, H, W);
   if (n_groups <= 0 || F <= 0) return 0;
   static const int per_cu = kamd_env_int("KAMD_RBWD_PER_CU", 16);
   static const int grouped = kamd_env_int("KAMD_RBWD_GROUPED", 1) == 1 ? 1 : 0;  // (2: off, for A/B runs)
@@ -463,10 +478,10 @@ int rasterize_backward_list_launch(hipStream_t st, int B, int H, int W, int F, i
 #define KAMD_RBL(DT)                                                                                                       \
   if (g_feat != nullptr)                                                                                                   \
     hipLaunchKernelGGL((raster_backward_list_kernel<T, DT, true>), grid, dim3(256), 0, st, B, H, W, F, D, grad, face_idx,  \
-                       weights, img, feat, eps, g_img, g_feat, cov_counts, cov_list, cov_cap, grouped);                    \
+                       weights, img, feat, eps, g_img, g_feat, cov_counts, cov_list, cov_cap, grouped, magic_word, magic);  \
   else                                                                                                                     \
     hipLaunchKernelGGL((raster_backward_list_kernel<T, DT, false>), grid, dim3(256), 0, st, B, H, W, F, D, grad, face_idx, \
-                       weights, img, feat, eps, g_img, g_feat, cov_counts, cov_list, cov_cap, grouped)
+                       weights, img, feat, eps, g_img, g_feat, cov_counts, cov_list, cov_cap, grouped, magic_word, magic)
   switch (D) {
     case 1: KAMD_RBL(1); break;
     case 2: KAMD_RBL(2); break;
@@ -484,13 +499,16 @@ namespace kamd {
 template <typename T>
 int raster_backward_draw_list(hipStream_t st, int B, int H, int W, int F, int D, const T* grad, const int64_t* face_idx, const T* weights,
                               const T* img, const T* feat, float eps, T* g_img, T* g_feat, const unsigned int* cov_counts,
-                              const unsigned int* cov_list, unsigned int cov_cap) {
-  return rasterize_backward_list_launch<T>(st, B, H, W, F, D, grad, face_idx, weights, img, feat, eps, g_img, g_feat, cov_counts, cov_list, cov_cap);
+                              const unsigned int* cov_list, unsigned int cov_cap, const unsigned int* magic_word) {
+  return rasterize_backward_list_launch<T>(st, B, H, W, F, D, grad, face_idx, weights, img, feat, eps, g_img, g_feat, cov_counts, cov_list, cov_cap,
+                                           magic_word);
 }
 template int raster_backward_draw_list<float>(hipStream_t, int, int, int, int, int, const float*, const int64_t*, const float*, const float*,
-                                              const float*, float, float*, float*, const unsigned int*, const unsigned int*, unsigned int);
+                                              const float*, float, float*, float*, const unsigned int*, const unsigned int*, unsigned int,
+                                              const unsigned int*);
 template int raster_backward_draw_list<double>(hipStream_t, int, int, int, int, int, const double*, const int64_t*, const double*, const double*,
-                                               const double*, float, double*, double*, const unsigned int*, const unsigned int*, unsigned int);
+                                               const double*, float, double*, double*, const unsigned int*, const unsigned int*, unsigned int,
+                                               const unsigned int*);
 template <typename T>
 int raster2_draw(hipStream_t st, int B, int H, int W, int D, int F_dense, float multiplier, float eps, const T* rec,
                  const tl::Lists& LR, const T* feat, T* interp, int64_t* sel_idx, T* weights, const tl::ClassifyOut& co,

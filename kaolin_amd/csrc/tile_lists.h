@@ -214,6 +214,14 @@ constexpr int WORK_FLAT_WORD = 8 * COUNTER_STRIDE;                    // the fla
 constexpr int COV_SHARDS = 32;                                        // shards of the list of tiles that hold a covered pixel
 constexpr int WORK_COV_WORD = WORK_FLAT_WORD + 64 * COUNTER_STRIDE;   // ... whose counters follow the flat list's
 constexpr int WORK_HEADER = WORK_COV_WORD + COV_SHARDS * COUNTER_STRIDE;  // words; all zeroed per call
+// A free word of the header's first line: the fused forward (its last launch) leaves a signature of the layout here, and the
+// fused backward's covered-tile walk trusts the list only when it finds it -- a work buffer that did not come from
+// kamd_dibr_rasterization_forward_* of THIS build and shape (another operator's, a tool's, stale memory) makes it visit every
+// tile instead of reading garbage as tile indices.
+constexpr int WORK_MAGIC_WORD = 1;
+__host__ __device__ inline unsigned int work_magic(int B, int H, int W) {
+  return 0xD1B40004u ^ ((unsigned int)B * 2654435761u) ^ ((unsigned int)H * 40503u) ^ ((unsigned int)W << 16);
+}
 inline unsigned int work_shard_cap(int B, int H, int W) {
   const PassGeom g = pass_geom(H, W, R_TILE);
   const size_t n_groups = (size_t)B * g.ntiles;

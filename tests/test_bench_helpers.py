@@ -37,6 +37,19 @@ def test_algorithmic_bytes_follow_the_survey_per_unit_figures():
     assert bench.algorithmic_bytes('soft_eval_kernel', B, P, F, Fv, 3, 30) is None
     assert bench.algorithmic_bytes('fill_regions_kernel', B, P, F, Fv, 3, 30) == B * P * 30 * 13
     assert bench.algorithmic_bytes('pv_forward_kernel', B, P, F, Fv, 3, 30) is None
+    # the fused backward walks the covered tiles only: charged the pixels of those tiles, not of the image (VERDICT r03 weak #7b)
+    p_cov = 0.2 * P
+    assert bench.algorithmic_bytes('raster_backward_kernel', B, P, F, Fv, 3, 30, P_cov=p_cov) == B * (p_cov * 32 + Fv * 48)
+    assert bench.algorithmic_bytes('raster_backward_kernel', B, P, F, Fv, 3, 30) == B * (P * 32 + Fv * 48)
+
+
+def test_traffic_parser_knows_the_list_walking_backward():
+    """VERDICT r03 weak #7b: the PMC parser's pattern for the rasterizer's backward did not match raster_backward_list_kernel."""
+    import re
+    src = open(os.path.join(ROOT, 'tools', 'parse_traffic.py')).read()
+    pat = re.search(r"'raster_backward_kernel': r'([^']+)'", src).group(1)
+    assert re.search(pat, 'void (anonymous namespace)::raster_backward_list_kernel<float, 3, false>(int, int)')
+    assert re.search(pat, 'void (anonymous namespace)::raster_backward_kernel<float, 3, false>(int, int)')
 
 
 def test_cpu_reference_extras_small_sample():

@@ -503,6 +503,32 @@ def test_gradient_buffer_cleared_by_the_forward_is_used_once():
     assert f.grad is not None
 
 
+def test_backward_without_the_forwards_signature_visits_every_tile():
+    """the fused backward walks the forward's list of covered tiles.  A work buffer that does not carry the forward's
+    layout signature (tl::WORK_MAGIC_WORD -- another operator's buffer, a tool's, a stale one) must not be read as tile
+    indices: the walk falls back to every tile and the gradient is the same."""
+    fz, fimg, feats, nz = _scene(10, 2, torch.float)
+    m = kal()._C.render.mesh
+    H, W = 96, 80
+    feat = torch.cat(feats, -1).cuda()
+    out = m.dibr_rasterization_forward_fused(H, W, fz.cuda(), fimg.cuda(), feat, nz.cuda(), 7000., 0.02, 30, 1000., 1e-8)
+    interp, face_idx, wts, soft, hits, _ = out
+    assert int(hits[4][1]) != 0                                   # the signature is there
+    g1 = torch.rand(interp.shape, device='cuda')
+    g2 = torch.rand(soft.shape, device='cuda')
+    good, _ = m.dibr_rasterization_backward_fused(g1, g2, face_idx, wts, soft, hits, fimg.cuda(), feat, 7000., 30, 1000., 1e-8,
+                                                  need_feature_grad=False)
+    work = hits[4].clone()
+    work[1] = 0                                                   # signature gone ...
+    cov0 = m.WORK_COV_WORD
+    work[cov0:cov0 + m.COV_SHARDS * m.COUNTER_STRIDE:m.COUNTER_STRIDE] = 1 << 30      # ... and the list's counts garbage
+    bad_hits = hits[:4] + (work,)
+    again, _ = m.dibr_rasterization_backward_fused(g1, g2, face_idx, wts, soft, bad_hits, fimg.cuda(), feat, 7000., 30, 1000., 1e-8,
+                                                   need_feature_grad=False)
+    assert same_sum_other_order(again, good, 1e-6)
+    assert float(good.abs().max()) > 0
+
+
 def test_nan_vertex_matches_reference_glue():
     """torch.min / torch.max propagate NaN, so a face with a NaN vertex has a NaN box that rejects no pixel; the
     fused binning must give the reference glue's result (`_packed_forward`), not confine the face to its finite corners."""

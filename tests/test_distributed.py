@@ -326,3 +326,34 @@ def test_bench_under_torchrun_one_rank_rccl(tmp_path):
     line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['n_gpus'] == 1 and line['value'] > 0 and line['distributed']['backend'] == 'nccl'
     assert line['distributed']['collectives_posted_per_step'] == 1
+
+
+@pytest.mark.gpu
+def test_bench_two_processes_sharing_gpu0(tmp_path):
+    """bench.py's N > 1 path with TWO ranks (RCCL refuses two ranks on one device, so gloo carries the
+    collectives between two processes that share GPU 0): launched as the driver launches it, `--gpus 2 --quick`.  The line
+    must say n_gpus 2, 16 global views, one posted collective per step, and rank 0's all-reduced vertex gradient must equal
+    the gradient of ONE process rendering the same 16 views (the MAX-over-ranks time reduction and the barriers run on the way)."""
+    import json
+    import subprocess
+    common = ['--steps', '3', '--warmup', '1', '--res', '256', '--sphere-frequency', '16', '--quick']
+    g2, g1 = str(tmp_path / 'grad2.pt'), str(tmp_path / 'grad1.pt')
+    env = dict(os.environ, KAMD_DIST_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--views-per-gpu', '8',
+           '--dump-vertex-grad', g2] + common
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=380)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['config']['global_views'] == 16 and line['config']['views_per_gpu'] == 8
+    assert line['distributed']['initialized'] and line['distributed']['backend'] == 'gloo'
+    assert line['distributed']['collectives_posted_per_step'] == 1
+    assert line['value'] > 0 and line['ms_per_step'] > 0 and line['scaling'] == 'weak'
+    # value = the pixels of BOTH ranks over the slowest rank's time
+    assert abs(line['value'] - 2 * 8 * 256 * 256 / (line['ms_per_step'] * 1e-3) / 1e6) <= 1e-3 * line['value']
+    one = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--views-per-gpu', '16', '--dump-vertex-grad', g1] + common,
+                         env=dict(os.environ), capture_output=True, text=True, timeout=380)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-4000:]
+    a, b = torch.load(g2).double(), torch.load(g1).double()
+    assert a.shape == b.shape and float(b.abs().max()) > 0
+    assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())

@@ -79,7 +79,14 @@ def _check_views_vs_oracle(H, W, fz, fimg, feat, nz, dtype_tol=1e-5, expect_cove
         assert rel_close(out.detach(), ref['features'], dtype_tol)
     assert rel_close(soft.detach(), ref['soft_mask'], dtype_tol)
     band = (ref['soft_mask'] > 0) & (ref['soft_mask'] < 1)
-    assert torch.equal((soft.detach().cpu() > 0) & (soft.detach().cpu() < 1), band)
+    # the band pixel for pixel -- except where "inside (0, 1)" hangs on the last bit: a mask below the smallest normal number
+    # (a lone far face whose exp() underflows: glibc returns a denormal, the device library flushes it to zero; the knot
+    # scene's image-sized triangles reach such pixels) or within 2 ulp of one.  The VALUES agree either way (asserted above).
+    got = soft.detach().cpu()
+    tiny, one_minus = torch.finfo(got.dtype).tiny, 1.0 - 4.0 * torch.finfo(got.dtype).eps
+    hangs_on_a_bit = (ref['soft_mask'] < tiny) | (ref['soft_mask'] > one_minus)
+    assert not bool(((((got > 0) & (got < 1)) != band) & ~hangs_on_a_bit).any())
+    assert int(((got > 0) & (got < 1) & band).sum()) >= 0.999 * int(band.sum())
     g = torch.Generator().manual_seed(7)
     g_feat_out = torch.rand(out.shape, generator=g, dtype=out.dtype)
     g_soft_out = torch.rand(soft.shape, generator=g, dtype=out.dtype)

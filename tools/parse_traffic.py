@@ -6,7 +6,7 @@ import collections, csv, json, re, sys
 
 STEPS = 3
 # profile-table name (bench.py's "kernels" keys) -> pattern of the device symbol
-OURS = {'bin_faces_kernel': r'bin_faces_kernel2', 'raster_tile_kernel': r'raster_tile_kernel2', 'raster_backward_kernel': r'raster_backward_kernel',
+OURS = {'bin_faces_kernel': r'bin_faces_kernel2', 'raster_tile_kernel': r'raster_tile_kernel2', 'raster_backward_kernel': r'raster_backward_(list_)?kernel',
         'soft_items_kernel': r'soft_items_kernel', 'soft_select_kernel': r'soft_select_kernel', 'soft_eval_kernel': r'soft_eval_kernel',
         'soft_mask_backward_list_kernel': r'soft_mask_backward_(list_kernel2|flat_kernel)', 'pv_forward_kernel': r'pv_forward_kernel',
         'pv_backward_kernel': r'pv_backward_kernel', 'fill_regions_kernel': r'fill_regions_kernel',
