@@ -297,10 +297,11 @@ def main():
         return sc
 
     proj = kal.render.camera.generate_perspective_projection(math.pi / 4).to(dev)
-    g = torch.Generator().manual_seed(0)
-    torch.rand((1, T.scene_mesh('sphere', args.sphere_frequency)[1].shape[0], 3, 2), generator=g)   # (keeps G1 / G2 what they were in rounds 1-3)
-    G1 = torch.rand((V, H, W, 3), generator=g).to(dev)
-    G2 = torch.rand((V, H, W), generator=g).to(dev)
+    # the loss weights of a view depend on its GLOBAL index only: N ranks of 8 views compute exactly the loss one process would
+    # compute on the same 8 N views (tests/test_distributed.py compares the all-reduced vertex gradient of the two)
+    first_view = D.shard_range(V * world)[0]
+    G1 = torch.stack([torch.rand((H, W, 3), generator=torch.Generator().manual_seed(1000 + first_view + v)) for v in range(V)]).to(dev)
+    G2 = torch.stack([torch.rand((H, W), generator=torch.Generator().manual_seed(5000 + first_view + v)) for v in range(V)]).to(dev)
     G1f, G2f = G1.reshape(-1), G2.reshape(-1)
     target_mask = (G2 > 0.5).float()
     scene = build_scene(args.scene)

@@ -637,6 +637,12 @@ int kamd_profile_num_kernels(void);
 const char* kamd_profile_kernel_name(int id);
 int kamd_profile_read(int id, double* total_ms, int64_t* launches);
 
+/* ---- self-test hook (no reference counterpart) ------------------------------------------------------------------ */
+/* The 64 x 64 bit transpose of the soft mask's select kernel (csrc/tile_bins.h wave_transpose64: gfx950 lane-swap and DPP      */
+/* instructions, no LDS) applied to `n_matrices` matrices of 64 uint64 rows each: out[m][j] = column j of matrix m.  With       */
+/* reference != 0 the same through __shfl_xor, the form the fast one replaced.  tests/test_dibr_gpu.py checks both against numpy. */
+int kamd_debug_transpose64(void* stream, int n_matrices, const uint64_t* in, uint64_t* out, int reference);
+
 #ifdef __cplusplus
 }
 #endif

@@ -269,6 +269,15 @@ def covered_tiles(work, batch_size, height, width):
     return torch.sort(torch.cat(out).long())[0] if out else torch.zeros(0, dtype=torch.long)
 
 
+def covered_row_spans(work, batch_size, height, width):
+    """(B, 2) int tensor: per view (last covered tile row + 1, tiles_y - first covered tile row) as the binning launch reported them
+    (0 = nothing reported); the copy the forward leaves next to the worklist for the backward pass (tile_lists.h
+    work_span_offset_words; tests / debugging; synchronises)."""
+    n_groups = batch_size * ((height + 15) // 16) * ((width + 15) // 16)
+    off = WORK_HEADER + 8 * (4 * ((n_groups + 7) // 8)) * 4 + (n_groups + 3) // 4
+    return work[off:off + 2 * batch_size].view(batch_size, 2)
+
+
 def work_items(work, batch_size, height, width):
     """Item ids (int64, 1-D) recorded in a worklist buffer (tests / debugging; synchronises).  Layout (tile_lists.h): the
     header, 8 shards x shard_cap items of 4 words, one coverage byte per 16 x 16 tile, the tile kernels' row order."""

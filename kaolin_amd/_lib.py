@@ -57,6 +57,7 @@ SIGNATURES = {
     'kamd_profile_num_kernels': (_i, []),
     'kamd_profile_kernel_name': (ctypes.c_char_p, [_i]),
     'kamd_profile_read': (_i, [_i, _vp, _vp]),
+    'kamd_debug_transpose64': (_i, [_vp, _i, _vp, _vp, _i]),
 }
 for _t in ('f32', 'f64', 'f16', 'u8', 'i16', 'i32', 'i64'):
     SIGNATURES[f'kamd_sided_distance_forward_{_t}'] = (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp])

@@ -606,7 +606,21 @@ extern "C" int kamd_debug_phase_cycles(unsigned long long* out16, int reset) {
 }
 #endif
 
+namespace {
+__global__ __launch_bounds__(64) void debug_transpose64_kernel(const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out, int reference) {
+  const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  out[i] = reference ? kamd::wave_transpose64_reference(in[i]) : kamd::wave_transpose64(in[i]);
+}
+}  // namespace
+
 extern "C" {
+
+int kamd_debug_transpose64(void* stream, int n_matrices, const uint64_t* in, uint64_t* out, int reference) {
+  if (n_matrices <= 0) return 0;
+  hipLaunchKernelGGL(debug_transpose64_kernel, dim3((unsigned)n_matrices), dim3(64), 0, (hipStream_t)stream,
+                     (const unsigned long long*)in, (unsigned long long*)out, reference);
+  return (int)hipGetLastError();
+}
 
 size_t kamd_dibr_soft_mask_lean_capacity(int B, int H, int W, int K) {
   // records the segmented hit list must be able to hold: every 16x4-pixel sub-tile slot of every 32x32 tile owns 64*K

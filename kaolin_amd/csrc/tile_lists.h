@@ -118,9 +118,6 @@ __host__ __device__ inline PassGeom pass_geom(int H, int W, int tile) {
   return g;
 }
 
-#ifndef KAMD_BIN_ABL
-#define KAMD_BIN_ABL 0
-#endif
 constexpr int OVC = 32;               // pool chunk: header {next free, -, -, -} is unused; slots 1..31 hold entries
 constexpr int OVC_PAYLOAD = OVC - 1;
 constexpr unsigned int BRUTE_BIT = 0x80000000u;  // set in a tile's counter when an entry could not be stored
@@ -636,15 +633,15 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(
   if (live) {
     T v[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) v[i] = ((KAMD_BIN_ABL & 64) ? (T)(0.001f * (float)((f * 7 + i * 13) % 1000) - 0.5f) : in.img[f * 6 + i]) * in.mult;  // (64: timing experiments only)
+    for (int i = 0; i < 6; ++i) v[i] = in.img[f * 6 + i] * in.mult;
     // everything the record needs is requested up front, whether or not the face turns out to be kept: the kernel is bound
     // by its dependent round trips, and `valid` / `front` -> (kept?) -> z would be two more of them
     uint8_t valid_f = 1;
     T front_f = 0, z0 = 0, z1 = 0, z2 = 0;
     if (DO_R) {
       if (in.valid != nullptr) valid_f = in.valid[f];
-      if (in.front != nullptr && !(KAMD_BIN_ABL & 64)) front_f = in.front[f * in.lay.front_stride];
-      if (in.z != nullptr && !(KAMD_BIN_ABL & 64)) {
+      if (in.front != nullptr) front_f = in.front[f * in.lay.front_stride];
+      if (in.z != nullptr) {
         z0 = in.z[f * in.lay.z_face + 0 * in.lay.z_vertex];
         z1 = in.z[f * in.lay.z_face + 1 * in.lay.z_vertex];
         z2 = in.z[f * in.lay.z_face + 2 * in.lay.z_vertex];
@@ -667,12 +664,7 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(
         by1 = in.bbox_r[f * 4 + 3];
       }
       {
-#if KAMD_BIN_ABL & 8   // (timing experiments only: no record is written -- the stores sit behind a condition that never holds)
-        Rec4<T> dummy_r[5];
-        Rec4<T>* r = (v[0] == (T)123456.789) ? reinterpret_cast<Rec4<T>*>(in.rec_r + (size_t)f * REC_R) : dummy_r;
-#else
         Rec4<T>* r = reinterpret_cast<Rec4<T>*>(in.rec_r + (size_t)f * REC_R);
-#endif
         // (a face the rasterizer filters -- invalid / back facing, half of a closed mesh -- is on no list; the overflow
         // fallback walks every record of the mesh, so its box is stored empty: every strip rejects it, and the rest of
         // its record is never looked at nor written)
@@ -682,7 +674,7 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(
           r[2] = Rec4<T>{v[4], v[5], z0, z1};
           T e7[7] = {0, 0, 1, 0, 0, 1, 3};
           if constexpr (sizeof(T) == 4) {
-            if (!(KAMD_BIN_ABL & 16)) edge_coefficients(v, bx0, by0, bx1, by1, e7);  // (16: timing experiments only)
+            edge_coefficients(v, bx0, by0, bx1, by1, e7);
           }
           r[3] = Rec4<T>{e7[0], e7[3], e7[1], e7[4]};  // the two edges' A, then B: operand pairs of one packed fma
           r[4] = Rec4<T>{e7[2], e7[5], e7[6], z2};
@@ -715,17 +707,8 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(
       }
       {
         const size_t fs = (size_t)f;
-#if KAMD_BIN_ABL & 8
-        if (v[0] == (T)123456.789)
-#endif
-        {
         *reinterpret_cast<Rec4<T>*>(const_cast<T*>(soft_box<T>(in.rec_s, fs))) = Rec4<T>{bx0, by0, bx1, by1};
-        }
         T* body = const_cast<T*>(soft_body<T>(in.rec_s, (size_t)in.total_faces, fs));
-#if KAMD_BIN_ABL & 8
-        T dummy_s[16];
-        if (!(v[0] == (T)123456.789)) body = dummy_s;
-#endif
         Rec4<T>* r = reinterpret_cast<Rec4<T>*>(body);
         r[0] = Rec4<T>{v[0], v[1], v[2], v[3]};
         r[1] = Rec4<T>{v[4], v[5], 0, 0};
@@ -735,7 +718,7 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(
           const T x1 = v[k * 2], y1 = v[k * 2 + 1], x2 = v[((k + 1) % 3) * 2], y2 = v[((k + 1) % 3) * 2 + 1];
           const T A = y2 - y1, Bc = x1 - x2;
           const T down = A * A + Bc * Bc;
-          rc[k] = (KAMD_BIN_ABL & 32) ? (double)down : 1.0 / ((double)down + SOFT_EPS);  // (32: timing experiments only)
+          rc[k] = 1.0 / ((double)down + SOFT_EPS);
         }
       }
       PHASE_MARK(4);
@@ -751,18 +734,11 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(
   }
   PHASE_MARK(5);
   if (DO_R && LR.row_span != nullptr && blockIdx.x % SPAN_SAMPLE == 0) note_row_span(LR, act_r, b, ry0, ry1);
-#if KAMD_BIN_ABL   // (timing experiments only, wrong results: 1 = the rasterizer's faces on no list, 2 = the soft mask's, 4 = the last batches not appended)
-  if (KAMD_BIN_ABL & 1) act_r = false;
-  if (KAMD_BIN_ABL & 2) act_s = false;
-#endif
   if (DO_R && DO_S) {
     PendingEntry er, es;
     wave_bin<false>(act_r, big_r, b, first_b, f, rx0, rx1, ry0, ry1, 0, 0, 0, 0, LR, &er);
     PHASE_MARK(6);
     wave_bin<true>(act_s, big_s, b, first_b, f, sx0, sx1, sy0, sy1, pr_s.c_lo, pr_s.c_hi, pr_s.r_lo, pr_s.r_hi, LS, &es);
-#if KAMD_BIN_ABL & 4
-    er.on = es.on = false;
-#endif
     append_entry_pair(er, LR, es, LS);
   } else {
     if (DO_R) wave_bin<false>(act_r, big_r, b, first_b, f, rx0, rx1, ry0, ry1, 0, 0, 0, 0, LR);

@@ -529,6 +529,42 @@ def test_backward_without_the_forwards_signature_visits_every_tile():
     assert float(good.abs().max()) > 0
 
 
+def test_wave_transpose64_without_lds():
+    """The select kernel's 64 x 64 bit transpose (tile_bins.h: v_permlane32_swap / v_permlane16_swap, DPP moves, rotate + bit-field
+    insert -- no LDS crossbar since round 4) against numpy, on random matrices, the identity, single bits and full rows; the
+    __shfl_xor form it replaced gives the same."""
+    import ctypes
+    from kaolin_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    mats = [rng.integers(0, 2, size=(64, 64), dtype=np.uint8) for _ in range(40)]
+    mats.append(np.eye(64, dtype=np.uint8))
+    mats.append(np.zeros((64, 64), np.uint8))
+    mats.append(np.ones((64, 64), np.uint8))
+    for i, j in ((0, 63), (63, 0), (31, 32), (32, 31), (17, 5), (47, 16)):
+        m = np.zeros((64, 64), np.uint8)
+        m[i, j] = 1
+        mats.append(m)
+    for i in (0, 15, 16, 33, 63):
+        m = np.zeros((64, 64), np.uint8)
+        m[i, :] = 1
+        mats.append(m)
+    weights = (np.uint64(1) << np.arange(64, dtype=np.uint64))
+
+    def pack(m):      # row i -> uint64 with bit j = m[i, j]
+        return (m.astype(np.uint64) * weights[None, :]).sum(axis=1, dtype=np.uint64)
+    rows = np.stack([pack(m) for m in mats])                         # (n, 64)
+    want = np.stack([pack(m.T) for m in mats])
+    x = torch.from_numpy(rows.view(np.int64)).cuda()
+    for reference in (0, 1):
+        out = torch.zeros_like(x)
+        st = lib.kamd_debug_transpose64(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), len(mats), ctypes.c_void_p(x.data_ptr()),
+                                        ctypes.c_void_p(out.data_ptr()), reference)
+        assert st == 0
+        got = out.cpu().numpy().view(np.uint64)
+        assert np.array_equal(got, want), f'reference={reference}: {int((got != want).sum())} words differ'
+
+
 def test_nan_vertex_matches_reference_glue():
     """torch.min / torch.max propagate NaN, so a face with a NaN vertex has a NaN box that rejects no pixel; the
     fused binning must give the reference glue's result (`_packed_forward`), not confine the face to its finite corners."""

@@ -86,9 +86,7 @@ def test_forward_starts_where_the_object_is(shift):
     B, tiles_x, tiles_y = 3, (W + 15) // 16, (H + 15) // 16
     lib = kal._lib.load()
     assert work.numel() == lib.kamd_dibr_soft_mask_work_words(B, H, W)
-    n_groups = B * tiles_x * tiles_y
-    off = kal._C.render.mesh.WORK_HEADER + 8 * (4 * ((n_groups + 7) // 8)) * 4 + (n_groups + 3) // 4   # header, items, coverage bytes
-    span = work[off:off + 2 * B].view(B, 2).tolist()
+    span = kal._C.render.mesh.covered_row_spans(work, B, H, W).tolist()
     covered_rows = (face_idx >= 0).any(dim=2).cpu()                                  # (B, H)
     for b in range(B):
         rows = [r for r in range(tiles_y) if bool(covered_rows[b, r * 16:(r + 1) * 16].any())]
