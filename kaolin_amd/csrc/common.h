@@ -59,8 +59,23 @@ __device__ __forceinline__ float kamd_hround(float x) { return __half2float(__fl
 // a fixed number of workgroups per CU, found by sweeps (12-32: see the launch sites).  Sizing the grid to exactly one
 // resident set from the runtime's occupancy query was tried at the end of round 1 and measured at the start of round 2:
 // slower every time (soft_search 133 -> 146 us) -- items differ in cost, and more, smaller static shares balance better.
-// measurement knob: an integer from the environment (grid sweeps on the GPU box), `dflt` when unset or not positive
+// Measurement knobs (grids of the persistent kernels, thresholds, A/B switches of DESIGN.md's tables): an integer from the environment
+// -- in EXPERIMENT builds only (`make -C kaolin_amd/csrc variant NAME=... DEFS="-DKAMD_EXPERIMENT ..."`).  The product build
+// compiles every kamd_env_int(...) to its default: no getenv on a launch path, nothing a stray variable can change.
+#ifdef KAMD_EXPERIMENT
 static inline int kamd_env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  if (v == nullptr || *v == 0) return dflt;
+  const int x = atoi(v);
+  return x > 0 ? x : dflt;
+}
+#else
+static inline int kamd_env_int(const char*, int dflt) { return dflt; }
+#endif
+// The three switches the TESTS flip inside one process (they force a search path the sizes would not pick, so that both paths are
+// compared with the oracle and with each other): read per call in every build -- KAMD_SIDED_DISTANCE=brute, KAMD_TRIANGLE_DISTANCE=
+// brute|sweep (their call sites), KAMD_TS_THREADS (the sweep's workgroup size) through this.
+static inline int kamd_test_env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   if (v == nullptr || *v == 0) return dflt;
   const int x = atoi(v);

@@ -276,7 +276,6 @@ int soft2_search_launch(hipStream_t st, int B, int H, int W, int F, int K, float
   if (lean) sa.list = *lean;
   sa.idx_out = idx;
   sa.hit_count = hit_count;
-  sa.dbg = kamd_env_int("KAMD_SELECT_MODE", 0);
   Eval2Args<T> ea{};
   ea.B = B;
   ea.F = F;

@@ -30,10 +30,8 @@ using namespace kamd;
 // ---- K2 -------------------------------------------------------------------------------------------------
 // Per covered pixel the reference issues 3*D + 6*D float atomics on addresses shared by every pixel of the same
 // face (rasterization_cuda.cu:283,391-398): the run time is atomic contention (measured 2.4 ms for C4).  Here a
-// workgroup owns a 16x16-pixel block: every lane computes its pixel's 6 + 3*D contributions, finds / creates its
-// face's slot in an LDS hash table (one compare-and-swap) and adds them there with non-returning LDS atomics
-// (ds_add_f32: nothing to wait for); at the end one global atomic per touched (face, value) is issued.
-constexpr int RB_HT = 256;  // hash slots = pixels per block: every face finds a slot (linear probing terminates)
+// workgroup owns a 16x16-pixel block: every lane computes its pixel's 6 + 3*D contributions, runs of one face are merged
+// in registers (down the columns, then along the rows: DPP), and every run leaves as ONE atomic request.
 
 // numerators of d(w1)/d(.) and d(w2)/d(.) for the six vertex coordinates (ax, ay, bx, by, cx, cy), and k3
 // (rasterization_cuda.cu:287-371); the common 1/k3^2 is applied by the caller
@@ -70,25 +68,11 @@ __device__ __forceinline__ T barycentric_jacobian(const T* v, T aw, T bw, T cw, 
   return k3;
 }
 
-#ifndef KAMD_RBWD_DIRECT
-#define KAMD_RBWD_DIRECT 1  // 1 = no per-tile table: every wavefront stages its runs' totals in LDS rows of its own and sends one atomic request (a
-                            // face's values in consecutive lanes) per run; 0 = runs are first merged per face in a per-tile LDS hash table.
-                            // Measured at C4 (r03n / r03o / call 35-36): global float atomics cost ~60 ps per REQUEST (a line touched by an
-                            // instruction) chip-wide, whatever the lanes in it -- run-end lanes adding value by value: 219 us; staged, rows merged
-                            // only (20 requests per wavefront): 53 us; the table (14 per wavefront, but a CAS probe + 6 LDS float atomics per run:
-                            // 20 us of LDS pipe): 50; with the columns merged down the rows first (KAMD_RBWD_VERTICAL) the table 46 and the
-                            // staged form 42-43 -- the default.  Ablations of the table kernel (r03m): list walk + face_idx + barrier 11 us,
-                            // table clear + barriers + arithmetic + DPP merges 13, gathers 5, table inserts 20, flush 2.
-#endif
-#ifndef KAMD_RBWD_VERTICAL
-#define KAMD_RBWD_VERTICAL 1  // a column's sums of one face are merged down the wavefront's 4 rows before the rows' runs are merged (0: rows only)
-#endif
-#ifndef KAMD_RBWD_ABL
-#define KAMD_RBWD_ABL 0  // ablations for timing experiments (wrong results): 1 = no per-face gathers, 2 = no per-pixel loads besides face_idx
-#endif
-#ifndef KAMD_RBWD_FLUSH
-#define KAMD_RBWD_FLUSH 1  // 1 = the tile's per-face sums leave as global atomics; 0 / 2: no flush / plain stores (timing experiments, wrong results)
-#endif
+// How a tile's per-face sums reach memory (measured at C4, profiles/r03n / r03o): global float atomics cost ~60 ps per REQUEST (a line
+// touched by an instruction) chip-wide, whatever the lanes in it -- run-end lanes adding value by value: 219 us; runs merged per face
+// in a per-tile LDS hash table first (a CAS probe + six LDS float atomics per run: 20 us of LDS pipe): 50, 46 with the columns merged
+// down the rows first; every wavefront staging its runs' totals in LDS rows of its own and sending ONE atomic request per run (a face's
+// values in consecutive lanes), columns merged first: 41-43 -- the form below.
 #ifndef KAMD_RBWD_ORDER
 #define KAMD_RBWD_ORDER 1  // workgroup order of the backward: 1 = views interleaved, tile rows from the middle of the image outwards
 #endif                     // (as the forward's tile kernel; 0 = view-major, row-major: 49.4 vs 45.4 us at C4, 9 us of the step with feature gradients)
@@ -110,12 +94,7 @@ __device__ __forceinline__ void raster_backward_tile(
     const T* __restrict__ weights, const T* __restrict__ img, const T* __restrict__ feat, float eps,
     T* __restrict__ g_img, T* __restrict__ g_feat) {
   constexpr int NV = (DT > 0 && GF) ? 6 + 3 * DT : 6;
-  constexpr bool TABLE = DT > 0 && !KAMD_RBWD_DIRECT;  // per-tile LDS hash table of the faces' sums
-  __shared__ int s_key[TABLE ? RB_HT : 1];
-  __shared__ T s_acc[TABLE ? RB_HT * NV : 1];
-  __shared__ int s_used[TABLE ? 256 : 1];
-  __shared__ int s_nused;
-  constexpr bool STAGED = DT > 0 && !TABLE;                    // run totals go to global memory through per-wavefront staging rows
+  constexpr bool STAGED = DT > 0;                              // run totals go to global memory through per-wavefront staging rows
   __shared__ int s_runf[STAGED ? 4 : 1][STAGED ? 64 : 1];      // the runs' faces ...
   __shared__ T s_runv[STAGED ? 4 : 1][STAGED ? 64 * NV : 1];   // ... and their NV sums
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -124,43 +103,19 @@ __device__ __forceinline__ void raster_backward_tile(
   PHASE_DECL;
   const size_t tp = ((size_t)b * H + row) * W + col;
   const int f = in_image ? (int)face_idx[tp] : -1;
-  if (DT > 0 && !TABLE) {
+  if (DT > 0) {
     if (__ballot(f >= 0) == 0ull) return;  // nothing covered in this wavefront's 16 x 4 pixels (no workgroup-wide state: wavefronts are on their own)
-  }
-  if (TABLE) {
-    if (!__syncthreads_or(f >= 0)) return;  // nothing covered in this block
-    PHASE_MARK(0);
-#if KAMD_RBWD_ABL & 4   // (timing experiments only: the tile ends here)
-    if (f != -12345) return;
-#endif
-    for (int i = threadIdx.x; i < RB_HT; i += 256) s_key[i] = -1;
-    for (int i = threadIdx.x; i < RB_HT * NV; i += 256) s_acc[i] = 0;
-    if (threadIdx.x == 0) s_nused = 0;
-    __syncthreads();
-    PHASE_MARK(1);
   }
   T vals[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) vals[i] = 0;
   if (f >= 0) {
     const size_t tf = (size_t)b * F + (size_t)f;
-#if KAMD_RBWD_ABL & 2   // (timing experiments only: no per-pixel loads besides face_idx)
-    const T aw = (T)0.25 + (T)(f & 3) * (T)0.01, bw = (T)0.5, cw = (T)0.25 - (T)(f & 3) * (T)0.01;
-    const T gfake[4] = {(T)(f & 7), (T)1, (T)2, (T)3};
-    const T* g = gfake;
-#else
     const T aw = weights[tp * 3 + 0], bw = weights[tp * 3 + 1], cw = weights[tp * 3 + 2];
     const T* g = grad + tp * D;
-#endif
     T dw1[6], dw2[6];
-#if KAMD_RBWD_ABL & 1   // (timing experiments only: no per-face gathers)
-    const T fake[12] = {(T)(f & 15), (T)1, (T)3, (T)(f & 7), (T)5, (T)9, (T)1, (T)2, (T)(f & 3), (T)4, (T)5, (T)6};
-    const T k3 = barycentric_jacobian<T>(fake, aw, bw, cw, eps, dw1, dw2);
-    const T* ff = fake + 3;
-#else
     const T k3 = barycentric_jacobian<T>(img + tf * 6, aw, bw, cw, eps, dw1, dw2);
     const T* ff = feat + tf * 3 * D;
-#endif
     const int nd = DT > 0 ? DT : D;
     for (int d = 0; d < nd; ++d) {
       const T gd = g[d];
@@ -196,7 +151,6 @@ __device__ __forceinline__ void raster_backward_tile(
     // spent 42 % of its wave cycles waiting on LDS (SQ_WAIT_INST_LDS).
     const int rl = lane & 15;
     int fm = f;  // the face this lane's sums still belong to (-1 once they have been handed to the lane below)
-#if KAMD_RBWD_VERTICAL
     {
       // A face covers a few pixels in each of two or three rows: before the rows' runs are merged, every COLUMN of the
       // wavefront's 4 rows is merged downwards -- row r takes over the sums of row r - 1 where both hold the same face
@@ -216,7 +170,6 @@ __device__ __forceinline__ void raster_backward_tile(
       const int down_f = __shfl_down(f, 16, 64);
       if (wr < 3 && f >= 0 && down_f == f) fm = -1;
     }
-#endif
     const int prev_f = row_shr<1>(fm);
     const int next_f = row_shl<1>(fm);
     const bool run_start = rl == 0 || prev_f != fm;
@@ -243,72 +196,30 @@ __device__ __forceinline__ void raster_backward_tile(
 #undef KAMD_RB_STAGE
     PHASE_MARK(3);
     const bool run_end = rl == 15 || next_f != fm;
-    if constexpr (!TABLE) {
-      // The run totals leave through a per-wavefront LDS staging row so that ONE atomic instruction carries all the values of a
-      // face in consecutive lanes (24 contiguous bytes = one L2 atomic request per face; issued value by value from the
-      // run-end lanes, every instruction touches a different line per lane: 219 us, r03n).  No workgroup-wide state: no
-      // table to clear, no barrier, no LDS atomics (the round-2 table's cost 20 of the kernel's 49 us).
-      const unsigned long long ends = __ballot(fm >= 0 && run_end);
-      const int n_ends = __popcll(ends);
-      wave_lds_fence();  // (the previous tile's readers of this wavefront's rows are done)
-      if (fm >= 0 && run_end) {
-        const int q = __popcll(ends & ((1ull << lane) - 1ull));
-        s_runf[wave][q] = fm;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) s_runv[wave][q * NV + i] = vals[i];
-      }
-      wave_lds_fence();
-      for (int j = lane; j < n_ends * NV; j += 64) {
-        const int q = j / NV, c = j - q * NV;
-        const size_t tf = (size_t)b * F + (size_t)s_runf[wave][q];
-        const T v = s_runv[wave][j];
-        if (c < 6)
-          kamd_atomic_add(g_img + tf * 6 + c, v);
-        else if constexpr (GF)
-          kamd_atomic_add(g_feat + tf * 3 * D + (c - 6), v);
-      }
-    } else
-#if KAMD_RBWD_ABL & 8   // (timing experiments only: no hash insert / LDS adds)
-    if (f == -12345) {
-#else
+    // The run totals leave through a per-wavefront LDS staging row so that ONE atomic instruction carries all the values of a
+    // face in consecutive lanes (24 contiguous bytes = one L2 atomic request per face; issued value by value from the
+    // run-end lanes, every instruction touches a different line per lane: 219 us, r03n).  No workgroup-wide state: no
+    // table to clear, no barrier, no LDS atomics (the round-2 table's cost 20 of the kernel's 49 us).
+    const unsigned long long ends = __ballot(fm >= 0 && run_end);
+    const int n_ends = __popcll(ends);
+    wave_lds_fence();  // (the previous tile's readers of this wavefront's rows are done)
     if (fm >= 0 && run_end) {
-#endif
-      int slot = (int)(((unsigned)fm * 2654435761u) >> 24) & (RB_HT - 1);
-      for (;;) {  // at most 256 distinct faces for 256 slots: an empty slot always exists
-        const int k = atomicCAS(&s_key[slot], -1, fm);
-        if (k == -1) s_used[atomicAdd(&s_nused, 1)] = slot;
-        if (k == -1 || k == fm) break;
-        slot = (slot + 1) & (RB_HT - 1);
-      }
+      const int q = __popcll(ends & ((1ull << lane) - 1ull));
+      s_runf[wave][q] = fm;
 #pragma unroll
-      for (int i = 0; i < NV; ++i) atomicAdd(&s_acc[slot * NV + i], vals[i]);
+      for (int i = 0; i < NV; ++i) s_runv[wave][q * NV + i] = vals[i];
     }
-    }
-  }
-  if constexpr (TABLE) {
-    RBWD_DRAIN();
-    PHASE_MARK(4);
-    __syncthreads();
-    PHASE_MARK(5);
-    const int nused = s_nused;
-    for (int i = threadIdx.x; i < nused * NV; i += 256) {
-      const int slot = s_used[i / NV], v = i % NV;
-      const size_t tf = (size_t)b * F + (size_t)s_key[slot];
-      const T val = s_acc[slot * NV + v];
-#if KAMD_RBWD_FLUSH == 0      // (timing experiments only: wrong results)
-      if (val == (T)123456.0) g_img[tf * 6 + v] = val;
-#elif KAMD_RBWD_FLUSH == 2    // (timing experiments only: plain stores)
-      if (v < 6) g_img[tf * 6 + v] = val;
-#else
-      if (v < 6)
-        kamd_atomic_add(g_img + tf * 6 + v, val);
+    wave_lds_fence();
+    for (int j = lane; j < n_ends * NV; j += 64) {
+      const int q = j / NV, c = j - q * NV;
+      const size_t tf = (size_t)b * F + (size_t)s_runf[wave][q];
+      const T v = s_runv[wave][j];
+      if (c < 6)
+        kamd_atomic_add(g_img + tf * 6 + c, v);
       else if constexpr (GF)
-        kamd_atomic_add(g_feat + tf * 3 * D + (v - 6), val);
-#endif
+        kamd_atomic_add(g_feat + tf * 3 * D + (c - 6), v);
     }
-    PHASE_MARK(6);
-    RBWD_DRAIN();
-    PHASE_MARK(7);
+    }
   }
   PHASE_FLUSH(g_phase_rbwd);
 }
@@ -518,7 +429,7 @@ int raster2_draw(hipStream_t st, int B, int H, int W, int D, int F_dense, float 
   hipLaunchKernelGGL((raster_tile_kernel2<T, true>), raster2_grid(LR, B), dim3(256), 0, st, B, F_dense,
                      (const int64_t*)nullptr, H, W, D, pixel_scale(multiplier, H, W), eps,
                      raster2_wide_ok(W, interp, sel_idx, weights, co.soft_mask) | (weights_internal ? 2 : 0),
-                     kamd_env_int("KAMD_RASTER_MODE", 0), rec, LR, feat, interp, sel_idx, weights, co);
+                     rec, LR, feat, interp, sel_idx, weights, co);
   return (int)hipGetLastError();
 }
 template <typename T>

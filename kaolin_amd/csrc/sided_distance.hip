@@ -405,7 +405,7 @@ inline bool sd_force_brute() {
 extern "C" {
 
 size_t kamd_sided_distance_forward_workspace(int B, int N, int M, int elem_size) {
-  if ((elem_size != 4 && elem_size != 8) || B <= 0 || N <= 0 || M <= 0) return 0;
+  if ((elem_size != 2 && elem_size != 4 && elem_size != 8) || B <= 0 || N <= 0 || M <= 0) return 0;
   if (kamd::sdgrid_applicable(B, N, M) && !sd_force_brute()) return kamd::sdgrid_workspace_bytes(B, N, M, elem_size);
   if (elem_size != 4) return 0;
   SdPlan p = sd_plan(B, N, M);
@@ -498,7 +498,10 @@ int kamd_sided_distance_forward_f64(void* stream, int B, int N, int M, const dou
 
 int kamd_sided_distance_forward_f16(void* stream, int B, int N, int M, const uint16_t* p1, const uint16_t* p2,
                                     uint16_t* dist, int64_t* idx, void* workspace) {
-  (void)workspace;
+  if (B <= 0 || N <= 0 || M <= 0) return 0;
+  // large clouds: the exact grid search with c10::Half's arithmetic (the reference dispatches half on the same kernel as float)
+  if (workspace != nullptr && kamd::sdgrid_applicable(B, N, M) && !sd_force_brute())
+    return kamd::sdgrid_forward_f16((hipStream_t)stream, B, N, M, p1, p2, dist, idx, workspace);
   return sd_forward_generic_launch<__half>((hipStream_t)stream, B, N, M, (const __half*)p1, (const __half*)p2,
                                            (__half*)dist, idx);
 }

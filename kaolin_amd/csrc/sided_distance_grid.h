@@ -12,6 +12,8 @@ int sdgrid_forward_f32(hipStream_t st, int B, int N, int M, const float* p1, con
 int sdgrid_forward_f64(hipStream_t st, int B, int N, int M, const double* p1, const double* p2, double* dist, int64_t* idx,
                        void* workspace);
 // both directions of a chamfer distance, each cloud binned once (dist1/idx1: p1 -> p2, dist2/idx2: p2 -> p1)
+// at::Half clouds (raw 16-bit storage): the same exact search with c10::Half's arithmetic (sided_distance_cuda.cu:252)
+int sdgrid_forward_f16(hipStream_t st, int B, int N, int M, const void* p1, const void* p2, void* dist, int64_t* idx, void* workspace);
 bool sdgrid_pair_applicable(int B, int N, int M);
 size_t sdgrid_pair_workspace_bytes(int B, int N, int M, int elem_size = 4);
 int sdgrid_pair_forward_f32(hipStream_t st, int B, int N, int M, const float* p1, const float* p2, float* dist1,

@@ -378,6 +378,23 @@ __device__ __forceinline__ double sdg_dist(double tx, double ty, double tz, doub
   return __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));  // (the same pin as the all-pairs kernel and the oracle)
 }
 
+// at::Half clouds (the reference instantiates its kernel on c10::Half: every operator computes in float and rounds to half,
+// sided_distance_cuda.cu:252; restated in oracle_sided_distance_forward_f16): the coordinates travel as floats that hold half
+// values, the distance is the same expression with a rounding to half after every operation
+__device__ __forceinline__ float sdg_dist_half(float tx, float ty, float tz, float qx, float qy, float qz) {
+  const float dx = kamd_hround(tx - qx), dy = kamd_hround(ty - qy), dz = kamd_hround(tz - qz);
+  const float xx = kamd_hround(dx * dx), yy = kamd_hround(dy * dy), zz = kamd_hround(dz * dz);
+  return kamd_hround(kamd_hround(xx + yy) + zz);
+}
+template <bool HALF>
+__device__ __forceinline__ float sdg_dist_sel(float tx, float ty, float tz, float qx, float qy, float qz) {
+  return HALF ? sdg_dist_half(tx, ty, tz, qx, qy, qz) : sdg_dist(tx, ty, tz, qx, qy, qz);
+}
+template <bool HALF>
+__device__ __forceinline__ double sdg_dist_sel(double tx, double ty, double tz, double qx, double qy, double qz) {
+  return sdg_dist(tx, ty, tz, qx, qy, qz);
+}
+
 #ifndef KAMD_SDG_QUERY_WAVES
 #define KAMD_SDG_QUERY_WAVES 7  // waves per SIMD the search kernel is compiled for (72 VGPRs): the search is a chain of dependent loads, occupancy is what hides it
 #endif
@@ -398,14 +415,17 @@ constexpr int SDG_R0 = KAMD_SDG_R0;
 // the search for one query, shared by the one-direction and the two-direction kernels.  All SDG_GROUP lanes of a query
 // call it with the same (qx, qy, qz, c); on return every lane holds the query's (best, best_i).
 // TRACK: best_k = the winner's position in the sorted targets (-1 while the seed holds: the caller then looks target 0 up).
-template <bool TRACK, typename T>
+// HALF (T = float): the clouds hold half values and distances are computed as c10::Half would (sdg_dist_half).  A computed
+// distance then sits within 5 roundings of 2^-11 of the true one (plus the half subnormals' 6e-8 step), so the stopping rule
+// leaves that margin; the many exact ties of an 11-bit mantissa are broken by index like any other.
+template <bool TRACK, typename T, bool HALF = false>
 __device__ __forceinline__ void sdg_search(const Box& s_box, int G, T qx, T qy, T qz, int c,
                                            const T* __restrict__ T0, const int* __restrict__ start,
                                            const typename Vec4Of<T>::type* __restrict__ TS, int nt, int sub, T& best, int& best_i,
                                            int& best_k) {
   typedef typename Vec4Of<T>::type V4;
   // the reference's seed: target 0 unconditionally (a NaN distance sticks)
-  best = sdg_dist(T0[0], T0[1], T0[2], qx, qy, qz);
+  best = sdg_dist_sel<HALF>(T0[0], T0[1], T0[2], qx, qy, qz);
   best_i = 0;
   best_k = -1;
   if (sizeof(T) == 8 && !(fabs((double)qx) < 1e30 && fabs((double)qy) < 1e30 && fabs((double)qz) < 1e30)) {
@@ -413,7 +433,7 @@ __device__ __forceinline__ void sdg_search(const Box& s_box, int G, T qx, T qy, 
     if (best == best) {
       for (int k = sub; k < nt; k += SDG_GROUP) {
         const V4 t = TS[k];
-        const T d = sdg_dist(t.x, t.y, t.z, qx, qy, qz);
+        const T d = sdg_dist_sel<HALF>(t.x, t.y, t.z, qx, qy, qz);
         const int ti = sdg_unpack_idx(t.w);
         if (d < best || (d == best && ti < best_i)) {
           best = d;
@@ -495,7 +515,7 @@ __device__ __forceinline__ void sdg_search(const Box& s_box, int G, T qx, T qy, 
               const V4 ta = TS[k];
               const V4 tb = TS[two ? k + 1 : k];
               {
-                const T d = sdg_dist(ta.x, ta.y, ta.z, qx, qy, qz);
+                const T d = sdg_dist_sel<HALF>(ta.x, ta.y, ta.z, qx, qy, qz);
                 const int ti = sdg_unpack_idx(ta.w);
                 if (d < best || (d == best && ti < best_i)) {
                   best = d;
@@ -504,7 +524,7 @@ __device__ __forceinline__ void sdg_search(const Box& s_box, int G, T qx, T qy, 
                 }
               }
               if (two) {
-                const T d = sdg_dist(tb.x, tb.y, tb.z, qx, qy, qz);
+                const T d = sdg_dist_sel<HALF>(tb.x, tb.y, tb.z, qx, qy, qz);
                 const int ti = sdg_unpack_idx(tb.w);
                 if (d < best || (d == best && ti < best_i)) {
                   best = d;
@@ -543,7 +563,7 @@ __device__ __forceinline__ void sdg_search(const Box& s_box, int G, T qx, T qy, 
         for (int sgm = 0; sgm < nseg; ++sgm)
           for (int k = k0[sgm]; k < k1[sgm]; ++k) {
             const V4 t = TS[k];
-            const T d = sdg_dist(t.x, t.y, t.z, qx, qy, qz);
+            const T d = sdg_dist_sel<HALF>(t.x, t.y, t.z, qx, qy, qz);
             const int ti = sdg_unpack_idx(t.w);
             if (d < best || (d == best && ti < best_i)) {
               best = d;
@@ -581,7 +601,12 @@ __device__ __forceinline__ void sdg_search(const Box& s_box, int G, T qx, T qy, 
       if (whole_grid) break;
       // (squared in T: a float square overflows to +inf from bound ~1.8e19 on, and any finite fp64 `best` would then stop the
       // search after the first ring -- fp64 clouds reach the grid path with coordinates up to 1e30)
-      if (bound > 0.f && best < (T)bound * (T)bound * (T)0.99999f) break;
+      if (HALF) {
+        // every unvisited target's computed half distance is >= bound^2 (1 - 5 * 2^-11) - 1e-7 (an overflow to +inf included)
+        if (bound > 0.f && (float)best < bound * bound * 0.9975f - 2e-7f) break;
+      } else if (bound > 0.f && best < (T)bound * (T)bound * (T)0.99999f) {
+        break;
+      }
     }
   }
 }
@@ -595,10 +620,15 @@ __device__ __forceinline__ void sdg_search(const Box& s_box, int G, T qx, T qy, 
 // w1 * mean1 + w2 * mean2.  MODE == SDG_GRAD: every query also leaves d value / d (its own point) and adds
 // d value / d (its nearest point) with float atomics, both already scaled by w / n [/ (2 sqrt(dist))]: the atomics ride in
 // a kernel that waits on dependent loads anyway, and the backward pass is one multiply by the upstream gradient.
-template <int MODE, typename S>
-__global__ __launch_bounds__(256, (MODE == SDG_GRAD ? KAMD_SDG_QUERY_WAVES : 1)) void sdg_query(CloudT<S> A, CloudT<S> T, S* __restrict__ dist1, int64_t* __restrict__ idx1,
-                                                 S* __restrict__ dist2, int64_t* __restrict__ idx2, Fuse fz) {
-  static_assert(MODE == SDG_PLAIN || sizeof(S) == 4, "the chamfer modes are fp32");
+// O = the element type of the distance outputs (S, or __half for at::Half clouds whose coordinates arrive as floats: HALF)
+template <typename O, typename S>
+__device__ __forceinline__ O sdg_out(S v) { return (O)v; }
+template <>
+__device__ __forceinline__ __half sdg_out<__half, float>(float v) { return __float2half(v); }   // (exact: v holds a half value)
+template <int MODE, typename S, bool HALF = false, typename O = S>
+__global__ __launch_bounds__(256, (MODE == SDG_GRAD ? KAMD_SDG_QUERY_WAVES : 1)) void sdg_query(CloudT<S> A, CloudT<S> T, O* __restrict__ dist1, int64_t* __restrict__ idx1,
+                                                 O* __restrict__ dist2, int64_t* __restrict__ idx2, Fuse fz) {
+  static_assert(MODE == SDG_PLAIN || (sizeof(S) == 4 && !HALF), "the chamfer modes are fp32");
   typedef typename Vec4Of<S>::type V4;
   __shared__ Box s_box;
   __shared__ double s_sum[4];
@@ -628,7 +658,7 @@ __global__ __launch_bounds__(256, (MODE == SDG_GRAD ? KAMD_SDG_QUERY_WAVES : 1))
     const int cz = sdg_axis_cell((float)q.z, s_box.lo[2], s_box.inv[2], G);
     S best;
     int best_i, best_k;
-    sdg_search<MODE == SDG_GRAD, S>(s_box, G, q.x, q.y, q.z, (cz * G + cy) * G + cx, Tp, Tstart, Tsorted, nt, sub, best, best_i, best_k);
+    sdg_search<MODE == SDG_GRAD, S, HALF>(s_box, G, q.x, q.y, q.z, (cz * G + cy) * G + cx, Tp, Tstart, Tsorted, nt, sub, best, best_i, best_k);
     // Results leave from the first lanes of the query's group (every lane holds the merged result): lane 0 writes distance and
     // index and adds the term; in the chamfer gradient mode lanes 0..2 take one coordinate each -- the 12 bytes of the query's own
     // term are then consecutive lanes of ONE store instruction and the nearest target's three atomics ONE request (a global
@@ -638,9 +668,9 @@ __global__ __launch_bounds__(256, (MODE == SDG_GRAD ? KAMD_SDG_QUERY_WAVES : 1))
     if (live && sub < OUT_LANES) {
       if (sub == 0) {
         const size_t o = (size_t)b * nq + sdg_unpack_idx(q.w);
-        S* dist = fwd ? dist1 : dist2;
+        O* dist = fwd ? dist1 : dist2;
         int64_t* idx = fwd ? idx1 : idx2;
-        if (dist != nullptr) dist[o] = best;
+        if (dist != nullptr) dist[o] = sdg_out<O, S>(best);
         if (idx != nullptr) idx[o] = best_i;
       }
       if constexpr (MODE >= SDG_VALUE) {
@@ -811,13 +841,56 @@ int sdg_run(hipStream_t st, int B, int N, int M, const S* p1, const S* p2, S* di
   KAMD_RETURN_LAST_ERROR();
 }
 
+// at::Half clouds: converted to float once (exact), binned and searched by the float pipeline with half-rounded distances
+__global__ __launch_bounds__(256) void sdg_half_to_float(const __half* __restrict__ a, size_t na, const __half* __restrict__ b, size_t nb,
+                                                         float* __restrict__ out) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < na + nb; i += stride)
+    out[i] = __half2float(i < na ? a[i] : b[i - na]);
+}
+inline size_t sdg_half_copy_bytes(int B, int N, int M) { return al((size_t)B * ((size_t)N + M) * 3 * 4); }
+
 }  // namespace
+
+int sdgrid_forward_f16(hipStream_t st, int B, int N, int M, const void* p1, const void* p2, void* dist, int64_t* idx, void* workspace) {
+  float* f1 = (float*)workspace;
+  float* f2 = f1 + (size_t)B * N * 3;
+  void* rest = (char*)workspace + sdg_half_copy_bytes(B, N, M);
+  const size_t na = (size_t)B * N * 3, nb = (size_t)B * M * 3;
+  {
+    ProfScope p(K_SDG_BUILD, st);
+    size_t blocks = (na + nb + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sdg_half_to_float, dim3((unsigned)blocks), dim3(256), 0, st, (const __half*)p1, na, (const __half*)p2, nb, f1);
+  }
+  KAMD_CHECK(hipGetLastError());
+  SdgWs w = sdg_layout(rest, B, N, M, f1, f2, false, SDG_PLAIN, 4);
+  KAMD_CHECK(kamd_zero_async(rest, w.zero_bytes, st));
+  {
+    ProfScope p(K_SDG_BUILD, st);
+    int nwg = kamd_cdiv((long long)B * ((long long)N + M), SDG_BUILD_THREADS);
+    const int cus = sdg_num_cus();
+    if (nwg > cus) nwg = cus;
+    if (nwg > 128) nwg = 128;
+    hipLaunchKernelGGL(sdg_build<float>, dim3(nwg), dim3(SDG_BUILD_THREADS), 0, st, w.b, w.a, B, 0, w.scan_sums, w.scan_blocks, w.barrier, 4);
+  }
+  KAMD_CHECK(hipGetLastError());
+  {
+    ProfScope p(K_SDG_QUERY, st);
+    const dim3 grid(kamd_cdiv((long long)N * SDG_GROUP, 256), B, 1);
+    hipLaunchKernelGGL((sdg_query<SDG_PLAIN, float, true, __half>), grid, dim3(256), 0, st, w.a, w.b, (__half*)dist, idx, (__half*)nullptr,
+                       (int64_t*)nullptr, w.fuse);
+  }
+  KAMD_RETURN_LAST_ERROR();
+}
 
 bool sdgrid_applicable(int B, int N, int M) {
   // below this the brute-force kernels are as fast as the launches of the grid pipeline
   return B >= 1 && B <= 65535 && M >= 8192 && N >= 2048 && (long long)B * (long long)(M > N ? M : N) < (1ll << 30);
 }
 size_t sdgrid_workspace_bytes(int B, int N, int M, int elem_size) {
+  if (elem_size == 2)  // at::Half: float copies of both clouds in front of the float pipeline's workspace
+    return sdg_half_copy_bytes(B, N, M) + sdg_layout(nullptr, B, N, M, nullptr, nullptr, false, SDG_PLAIN, 4).total;
   return sdg_layout(nullptr, B, N, M, nullptr, nullptr, false, SDG_PLAIN, elem_size).total;
 }
 int sdgrid_forward_f64(hipStream_t st, int B, int N, int M, const double* p1, const double* p2, double* dist, int64_t* idx,

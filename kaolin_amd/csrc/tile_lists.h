@@ -103,6 +103,7 @@ constexpr double SOFT_EPS = 1e-7;     // the reference's literal EPS (dibr_soft_
 // time (measured on MI355X: ~33 ns each on one address, ~15 ns each on neighbouring words of a line), so counters that are hit
 // thousands of times per launch must not share lines.
 constexpr int COUNTER_STRIDE = 32;
+constexpr int MEDIUM_TILES = 16;      // a face whose tile rectangle holds more tiles than this is binned on its own (wave_bin), a lane per tile
 constexpr int SPAN_SAMPLE = 16;       // every SPAN_SAMPLE-th workgroup of the binning launch reports the tile rows its faces cover (note_row_span)
 constexpr int WORK_SHARDS = 8;        // worklist shards (one append counter each; workgroup id & 7 picks the shard)
 
@@ -427,6 +428,63 @@ __device__ __forceinline__ void append_entry_pair(const PendingEntry& pa, const 
     }
 }
 
+// NQ entries per lane for ONE list, each step taken for all of them before the next (as append_entry_pair does for two lists): the
+// NQ returning counter atomics are in flight together -- one round trip for NQ appends.  The no-cycle argument of append_entry
+// holds step by step (every allocation is published before any lane of the wavefront waits).
+template <int NQ>
+__device__ __forceinline__ void append_entries(const PendingEntry* pe, const Lists& L) {
+  unsigned int slot[NQ], c[NQ], i[NQ], v[NQ], p[NQ];
+  bool pooled[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    slot[q] = c[q] = i[q] = v[q] = p[q] = 0u;
+    pooled[q] = false;
+    if (pe[q].on) slot[q] = atomicAdd(L.count + pe[q].ti, 1u) & ~BRUTE_BIT;
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    if (pe[q].on) {
+      if (slot[q] < (unsigned int)L.C) {
+        L.inl[pe[q].ti * L.C + slot[q]] = pe[q].entry;
+      } else {
+        const unsigned int o = slot[q] - (unsigned int)L.C;
+        c[q] = o / OVC_PAYLOAD;
+        i[q] = o - c[q] * OVC_PAYLOAD;
+        if (c[q] >= (unsigned int)L.maxc)
+          atomicOr(L.count + pe[q].ti, BRUTE_BIT);
+        else
+          pooled[q] = true;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+    if (pooled[q] && i[q] == 0) p[q] = atomicAdd(L.pool_top, 1u);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+    if (pooled[q] && i[q] == 0) {
+      v[q] = p[q] < L.cap_chunks ? p[q] + 1u : 0xFFFFFFFFu;
+      __hip_atomic_store(L.tab + pe[q].ti * L.maxc + c[q], v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+    if (pooled[q] && i[q] != 0) {
+      unsigned int* link = L.tab + pe[q].ti * L.maxc + c[q];
+      do {
+        v[q] = __hip_atomic_load(link, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v[q] == 0u) __builtin_amdgcn_s_sleep(1);
+      } while (v[q] == 0u);
+    }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+    if (pooled[q]) {
+      if (v[q] == 0xFFFFFFFFu)
+        atomicOr(L.count + pe[q].ti, BRUTE_BIT);
+      else
+        L.pool[(size_t)(v[q] - 1u) * OVC + 1u + i[q]] = pe[q].entry;
+    }
+}
+
 // ---- one wavefront bins its 64 faces into one pass' lists ---------------------------------------------------------------
 // `active`: the lane's face takes part; (b, first_b): its mesh and the mesh's first packed face; tile rectangle
 // [tx0,tx1] x [ty0,ty1]; `big`: the rectangle exceeds 8 x 8 tiles (or the box is NaN).  `block` = packed face index >> 6
@@ -458,7 +516,53 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
       start = (unsigned int)__builtin_amdgcn_readlane((int)start, leader);
       if (mine && big) L.big_list[first_b + start + __popcll(bigm & ((1ull << lane) - 1ull))] = (unsigned int)f;
     }
-    const bool small = mine && !big;
+    // medium faces -- a rectangle of more than MEDIUM_TILES tiles (at most 8 x 8: beyond that a face is `big`): ONE step per face, a
+    // lane per tile of its rectangle, each appending a single-face entry.  In the loop below such a face would add a step per tile
+    // it alone touches: a wavefront of 64 consecutive faces ~100 pixels across (the floor under an object, the bowl of the knot
+    // scene) ran ~3 000 dependent steps while the rest of the launch waited -- 259 us instead of 41 at the C4 shape.
+    bool medium = mine && !big && (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > MEDIUM_TILES;
+    constexpr int MQ = 2;  // faces per step: their counter atomics share one round trip (one face per step: 144 us on the knot scene, whose
+                           // bowl is 170 such faces in three consecutive wavefronts per view -- each face a dependent returning atomic)
+    for (unsigned long long med = __ballot(medium); med != 0ull;) {
+      PendingEntry pe[MQ];
+#pragma unroll
+      for (int q = 0; q < MQ; ++q) {
+        pe[q].on = false;
+        pe[q].ti = 0;
+        pe[q].entry = make_uint4(0u, 0u, 0u, 0u);
+        if (med == 0ull) continue;  // (uniform)
+        const int l = __ffsll((long long)med) - 1;
+        med &= med - 1ull;
+        const int mx0 = __builtin_amdgcn_readlane(tx0, l), mx1 = __builtin_amdgcn_readlane(tx1, l);
+        const int my0 = __builtin_amdgcn_readlane(ty0, l), my1 = __builtin_amdgcn_readlane(ty1, l);
+        const int w = mx1 - mx0 + 1, n = w * (my1 - my0 + 1);   // (w, h in 1..8: n <= 64)
+        int ly = 0;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) ly += lane >= k * w ? 1 : 0;
+        const bool on = lane < n;
+        const int tx = mx0 + (lane - ly * w), ty = my0 + ly;
+        unsigned int sub = 0u;
+        if (SOFT) {
+          const int fc_lo = __builtin_amdgcn_readlane(c_lo, l), fc_hi = __builtin_amdgcn_readlane(c_hi, l);
+          const int fr_lo = __builtin_amdgcn_readlane(r_lo, l), fr_hi = __builtin_amdgcn_readlane(r_hi, l);
+          if (on) {  // the 16 x 4-pixel sub-tiles of tile (tx, ty) the face's pixel range reaches: bit = sy * 2 + sx
+            const int px0 = tx * S_TILE, py0 = ty * S_TILE;
+            const int sx0 = max(fc_lo - px0, 0) / SUB_W, sx1 = min(fc_hi - px0, S_TILE - 1) / SUB_W;
+            const int sy0 = max(fr_lo - py0, 0) / SUB_H, sy1 = min(fr_hi - py0, S_TILE - 1) / SUB_H;
+            const unsigned int colbits = (sx0 == 0 ? 1u : 0u) | (sx1 >= 1 ? 2u : 0u);
+            const unsigned int rowsel = ((1u << (2 * (sy1 + 1))) - 1u) & ~((1u << (2 * sy0)) - 1u) & 0x5555u;
+            sub = colbits * rowsel;
+          }
+        }
+        const unsigned long long one = 1ull << l;
+        pe[q].on = on;
+        pe[q].ti = (size_t)bL * L.ntiles + (on ? ty * L.tiles_x + tx : 0);
+        pe[q].entry = make_uint4(block, sub, (unsigned int)one, (unsigned int)(one >> 32));
+        if (SOFT && on && sub != 0u) atomicOr(L.sub_touched + pe[q].ti, sub);
+      }
+      append_entries<MQ>(pe, L);
+    }
+    const bool small = mine && !big && !medium;
     unsigned long long pending = 0ull;
     if (small) {
       const int w = tx1 - tx0 + 1, h = ty1 - ty0 + 1;  // 1..8 each

@@ -66,7 +66,8 @@ def test_workspace_queries_are_host_only_and_shape_driven():
     pair = lib.kamd_sided_distance_pair_forward_workspace
     assert sd(1, 100000, 100000, 4) > 0 and sd(2, 100000, 100000, 4) > sd(1, 100000, 100000, 4)
     assert sd(1, 100000, 100000, 8) > sd(1, 100000, 100000, 4)    # fp64: the same grid pipeline with double points in its sorted copy
-    assert sd(1, 1000, 1000, 8) == 0 and sd(1, 100000, 100000, 2) == 0   # small fp64 clouds / fp16: the generic kernel needs no scratch
+    assert sd(1, 1000, 1000, 8) == 0 and sd(1, 1000, 1000, 2) == 0   # small fp64 / fp16 clouds: the generic kernel needs no scratch
+    assert sd(1, 100000, 100000, 2) > sd(1, 100000, 100000, 4)      # at::Half takes the grid search too: float copies + the float pipeline
     assert sd(0, 10, 10, 4) == 0 and sd(1, 0, 10, 4) == 0
     # both directions from one binning pass: both clouds must be large enough for the grid search, fp32 / fp64
     assert pair(1, 100000, 100000, 4) > 0 and pair(1, 100000, 100000, 8) > pair(1, 100000, 100000, 4)
