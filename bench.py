@@ -401,6 +401,47 @@ def main():
                            'share_of_instrumented_step': round(ms / steps / inst_ms, 4), 'algorithmic_GBps': gbps}
         return table, inst_ms, face_idx, p_cov, over
 
+    def soft_work_units(sc, face_idx, boxlen=0.02, knum=30):
+        """What the soft-mask pass of a scene has to do, counted from the scene (per view, averages): `soft_pixels` = uncovered pixels
+        inside at least one face's enlarged box (the pixels the reference's kernel computes distances for), `soft_pairs` = (pixel,
+        face) pairs with the pixel inside the face's enlarged box (every one is a point-triangle distance in the reference: its
+        kernel's work unit), `soft_hits` = the pairs that make it into the knum-deep buffers.  Box counts per pixel through a 2-D
+        difference array.  (Pixel centres as dibr_soft_mask_cuda.cu:75-76: x = (2 px + 1 - W) / W, y = (H - 1 - 2 py) / H.)"""
+        with torch.no_grad():
+            _, fv_img, _ = kal.render.mesh.prepare_vertices(sc['verts'].detach().unsqueeze(0).expand(V, -1, -1), sc['faces'], proj,
+                                                           camera_rot=sc['rot'], camera_trans=sc['trans'])
+            x, y = fv_img[..., 0].double(), fv_img[..., 1].double()
+            x0, x1 = x.min(-1).values - boxlen, x.max(-1).values + boxlen
+            y0, y1 = y.min(-1).values - boxlen, y.max(-1).values + boxlen
+            c0 = torch.ceil((x0 * W + W - 1) / 2).clamp(0, W).long()
+            c1 = torch.floor((x1 * W + W - 1) / 2).clamp(-1, W - 1).long() + 1
+            r0 = torch.ceil((H - 1 - y1 * H) / 2).clamp(0, H).long()
+            r1 = torch.floor((H - 1 - y0 * H) / 2).clamp(-1, H - 1).long() + 1
+            ok = (c1 > c0) & (r1 > r0)
+            diff = torch.zeros((V, H + 1, W + 1), dtype=torch.int32, device=dev)
+            vi = torch.arange(V, device=dev).unsqueeze(1).expand_as(c0)[ok]
+            one = torch.ones_like(vi, dtype=torch.int32)
+            for rr, cc, sgn in ((r0, c0, 1), (r0, c1, -1), (r1, c0, -1), (r1, c1, 1)):
+                diff.index_put_((vi, rr[ok], cc[ok]), one * sgn, accumulate=True)
+            cnt = diff.cumsum(1).cumsum(2)[:, :H, :W]
+            unc = face_idx < 0
+            per_pixel = cnt[unc]
+            return {'soft_pixels': float((per_pixel > 0).sum()) / V, 'soft_pairs': float(per_pixel.sum()) / V,
+                    'soft_hits': float(per_pixel.clamp(max=knum).sum()) / V}
+
+    # the unit of work each kernel's duration scales with (scene_variants: a kernel's duration ratio between two scenes is judged
+    # against the ratio of these, not against 1)
+    KERNEL_WORK_UNIT = {'raster_tile_kernel': 'covered_tile_pixels', 'raster_backward_kernel': 'covered_tile_pixels',
+                        'soft_select_kernel': 'soft_pairs', 'soft_eval_kernel': 'soft_hits', 'soft_mask_backward_list_kernel': 'soft_hits',
+                        'bin_faces_kernel': 'faces', 'pv_forward_kernel': 'faces', 'pv_backward_kernel': 'faces',
+                        'weighted_sum2_kernels': 'pixels'}
+
+    def work_units(sc, face_idx, p_cov_):
+        u = {'faces': float(sc['F']), 'pixels': float(H * W), 'covered_pixels': float((face_idx >= 0).float().sum()) / V,
+             'covered_tile_pixels': float(p_cov_)}
+        u.update(soft_work_units(sc, face_idx))
+        return {k: round(v, 1) for k, v in u.items()}
+
     def front_faces(sc):
         """front-facing faces per view on average (what K1 / K2 read): counted from the scene, not assumed"""
         with torch.no_grad():
@@ -465,6 +506,7 @@ def main():
     # sphere), timed over fewer steps, with its own kernel table -- no kernel should be much slower than on the sphere
     # without an explanation in DESIGN.md
     scene_variants = None
+    headline_units = work_units(scene, face_idx, p_cov)
     if not args.quick and not args.no_scene_variants:
         scene_variants = {}
         for other in ('sphere', 'knot'):
@@ -480,8 +522,16 @@ def main():
                 table_o, inst_o, fi, p_cov_o, over_o = kernel_table(step_o, sc, n_o)
                 dt_o = timed(step_o, n_o, 2)
                 st_o = per_step_ms(step_o, max(n_o, 20))
+                wu_o = work_units(sc, fi, p_cov_o)
+                wr = {k: (round(wu_o[k] / headline_units[k], 3) if headline_units[k] > 0 else None) for k in wu_o}
                 scene_variants[other] = {
                     'faces': sc['F'], 'front_faces_per_view': round(sc['front_faces'], 1),
+                    'work_units_per_view': wu_o, 'vs_headline_scene_work_ratio': wr,
+                    # duration ratio / work ratio per kernel: ~1 = the kernel costs the same per unit of work on both scenes
+                    'kernel_ratio_over_work_ratio': {k: round(v['avg_us'] / kernels[k]['avg_us'] / wr[KERNEL_WORK_UNIT[k]], 2)
+                                                     for k, v in table_o.items()
+                                                     if k in kernels and kernels[k]['avg_us'] > 0 and wr.get(KERNEL_WORK_UNIT.get(k))},
+                    'kernel_work_unit': KERNEL_WORK_UNIT,
                     'covered_pixel_fraction': round(float((fi >= 0).float().mean()), 4),
                     'covered_tile_pixel_fraction': round(p_cov_o / (H * W), 4),
                     'ms_per_step': round(dt_o / n_o * 1e3, 4), 'per_step_ms': st_o,
@@ -827,7 +877,7 @@ def main():
                        'covered_pixel_fraction': round(covered, 4), 'covered_tile_pixel_fraction': round(p_cov / (H * W), 4),
                        'parallelism': f'views sharded {world}-way', 'look_at': list(args.look_at)},
             'per_step_ms': step_stats, 'feature_grad_variant': feature_grad, 'tutorial_loss_variant': tutorial, 'torch_loss_variant': torch_loss,
-            'scene_variants': scene_variants,
+            'work_units_per_view': headline_units, 'scene_variants': scene_variants,
             'roofline': roofline, 'step_roofline': step_roofline, 'step_traffic': step_traffic, 'kernels': kernels,
             'kernels_over_stream_copy_rate': over_peak,    # (algorithmic_GBps above what a streaming copy reaches = a byte model that is wrong)
             'kernels_note': f'per-kernel table: separate pass of {args.steps} steps with HIP events around every launch '

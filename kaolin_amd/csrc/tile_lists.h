@@ -103,7 +103,14 @@ constexpr double SOFT_EPS = 1e-7;     // the reference's literal EPS (dibr_soft_
 // time (measured on MI355X: ~33 ns each on one address, ~15 ns each on neighbouring words of a line), so counters that are hit
 // thousands of times per launch must not share lines.
 constexpr int COUNTER_STRIDE = 32;
-constexpr int MEDIUM_TILES = 16;      // a face whose tile rectangle holds more tiles than this is binned on its own (wave_bin), a lane per tile
+#ifndef KAMD_MEDIUM_TILES
+#define KAMD_MEDIUM_TILES 4
+#endif
+constexpr int MEDIUM_TILES = KAMD_MEDIUM_TILES;  // a face whose tile rectangle holds more tiles than this is binned on its own (wave_bin): single-face entries, no merging
+#ifndef KAMD_BIG_TILES_R
+#define KAMD_BIG_TILES_R 16
+#endif
+constexpr int BIG_TILES_R = KAMD_BIG_TILES_R;   // rasterizer pass: a face whose rectangle holds more tiles goes to its view's big list (as do rectangles beyond 8 x 8)
 constexpr int SPAN_SAMPLE = 16;       // every SPAN_SAMPLE-th workgroup of the binning launch reports the tile rows its faces cover (note_row_span)
 constexpr int WORK_SHARDS = 8;        // worklist shards (one append counter each; workgroup id & 7 picks the shard)
 
@@ -142,7 +149,11 @@ struct Lists {
 
 inline size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline unsigned int pool_chunks(long long total_faces, long long n_tiles_total) {
-  long long e = total_faces / 2 + 2 * n_tiles_total + 64;  // entries the pool can take beyond the inline slots
+  // entries the pool can take beyond the inline slots.  A face adds at most one entry per tile of its rectangle (fewer when its
+  // wavefront's faces share tiles), so this is 4 tiles' worth per face: past it the appends flag their tiles BRUTE, which is
+  // correct but slow -- a mesh whose face ORDER has no locality (49 210 faces shuffled: every entry holds one face) ran the
+  // rasterizer's tile kernel at 6.1 ms instead of 0.15 with the pool of rounds 2-3 (faces / 2).  16 bytes each, never cleared.
+  long long e = total_faces * 4 + 2 * n_tiles_total + 64;
   long long c = e / OVC_PAYLOAD + 64;
   if (c > 0x3fffffll) c = 0x3fffffll;
   return (unsigned int)c;
@@ -168,7 +179,7 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
   size_t off = 0;
   L.r.g = pass_geom(H, W, R_TILE);
   L.s.g = pass_geom(H, W, S_TILE);
-  L.r.C = 16; L.r.maxc = 8;     // 16 + 8 * 31 = 264 entries per 16 x 16 tile before the fallback
+  L.r.C = 16; L.r.maxc = 16;    // 16 + 16 * 31 = 512 entries per 16 x 16 tile before the fallback
   L.s.C = 64; L.s.maxc = 32;    // 64 + 32 * 31 = 1056 entries per 32 x 32 tile
   const size_t ntr = (size_t)B * L.r.g.ntiles, nts = (size_t)B * L.s.g.ntiles;
   if (with_r) {
@@ -379,12 +390,15 @@ __device__ __forceinline__ void append_entry_pair(const PendingEntry& pa, const 
   const Lists* Ls[2] = {&La, &Lb};
   unsigned int slot[2] = {0, 0}, c[2] = {0, 0}, i[2] = {0, 0}, v[2] = {0, 0};
   bool pooled[2] = {false, false};
+  // (the returned values are not touched before both atomics are issued: the first use of a result is what makes the wavefront
+  // wait for it -- masking the flag bit in the same statement serialised the two round trips)
 #pragma unroll
   for (int q = 0; q < 2; ++q)
-    if (pe[q]->on) slot[q] = atomicAdd(Ls[q]->count + pe[q]->ti, 1u) & ~BRUTE_BIT;
+    if (pe[q]->on) slot[q] = atomicAdd(Ls[q]->count + pe[q]->ti, 1u);
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const Lists& L = *Ls[q];
+    slot[q] &= ~BRUTE_BIT;
     if (pe[q]->on) {
       if (slot[q] < (unsigned int)L.C) {
         L.inl[pe[q]->ti * L.C + slot[q]] = pe[q]->entry;
@@ -428,61 +442,117 @@ __device__ __forceinline__ void append_entry_pair(const PendingEntry& pa, const 
     }
 }
 
-// NQ entries per lane for ONE list, each step taken for all of them before the next (as append_entry_pair does for two lists): the
-// NQ returning counter atomics are in flight together -- one round trip for NQ appends.  The no-cycle argument of append_entry
-// holds step by step (every allocation is published before any lane of the wavefront waits).
-template <int NQ>
-__device__ __forceinline__ void append_entries(const PendingEntry* pe, const Lists& L) {
-  unsigned int slot[NQ], c[NQ], i[NQ], v[NQ], p[NQ];
-  bool pooled[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    slot[q] = c[q] = i[q] = v[q] = p[q] = 0u;
-    pooled[q] = false;
-    if (pe[q].on) slot[q] = atomicAdd(L.count + pe[q].ti, 1u) & ~BRUTE_BIT;
+// The lane's own face (bit `own` of block `block`) appended as a single-face entry to the next NQ tiles of its rectangle, walked
+// row by row from (cx, cy) -- the medium faces of wave_bin.  A returning device-scope atomic is a ~2 us round trip here (it is
+// performed memory-side, beyond the XCD's L2) and nothing else in the kernel takes long, so the NQ counter atomics are issued
+// back to back -- a result's FIRST USE is what makes the wavefront wait, so none is touched before all are out -- and the entries
+// are written in a second walk over the same tiles (recomputing a tile index is cheaper than keeping it: NQ registers hold the
+// slots and nothing else; the fused binning kernel has to stay at 7 wavefronts per SIMD, the whole launch is resident at once).
+// The pool steps keep append_entry's order: every allocation of the wavefront is published before any of its lanes waits.
+struct RectWalk {
+  int x, y;
+  __device__ __forceinline__ void step(int tx0, int tx1) {
+    if (++x > tx1) {
+      x = tx0;
+      ++y;
+    }
   }
+};
+template <bool SOFT>
+__device__ __forceinline__ unsigned int sub_tiles_reached(int tx, int ty, int c_lo, int c_hi, int r_lo, int r_hi) {
+  if (!SOFT) return 0u;
+  // the 16 x 4-pixel sub-tiles of tile (tx, ty) the pixel range reaches: bit = sy * 2 + sx
+  const int px0 = tx * S_TILE, py0 = ty * S_TILE;
+  const int sx0 = max(c_lo - px0, 0) / SUB_W, sx1 = min(c_hi - px0, S_TILE - 1) / SUB_W;
+  const int sy0 = max(r_lo - py0, 0) / SUB_H, sy1 = min(r_hi - py0, S_TILE - 1) / SUB_H;
+  const unsigned int colbits = (sx0 == 0 ? 1u : 0u) | (sx1 >= 1 ? 2u : 0u);
+  const unsigned int rowsel = ((1u << (2 * (sy1 + 1))) - 1u) & ~((1u << (2 * sy0)) - 1u) & 0x5555u;
+  return colbits * rowsel;
+}
+constexpr int MEDIUM_BATCH_MAX = 16;
+__device__ __forceinline__ unsigned int* medium_slot_scratch() {
+  __shared__ unsigned int s[MEDIUM_BATCH_MAX * 256];  // (the binning kernels run 256 threads per workgroup)
+  return s;
+}
+template <bool SOFT, int NQ>
+__device__ __forceinline__ void append_own(int n_on, RectWalk& at, int tx0, int tx1, unsigned int tile_base, unsigned int block,
+                                           unsigned long long own, int c_lo, int c_hi, int r_lo, int r_hi, const Lists& L) {
+  static_assert(NQ <= MEDIUM_BATCH_MAX, "medium_slot_scratch");
+  unsigned int slot[NQ];
+  const RectWalk start = at;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    if (pe[q].on) {
+    slot[q] = 0u;
+    if (q < n_on) {
+      const unsigned int ti = tile_base + (unsigned int)(at.y * L.tiles_x + at.x);
+      const unsigned int sub = sub_tiles_reached<SOFT>(at.x, at.y, c_lo, c_hi, r_lo, r_hi);
+      if (SOFT && sub != 0u) atomicOr(L.sub_touched + ti, sub);
+      slot[q] = atomicAdd(L.count + ti, 1u);
+    }
+    at.step(tx0, tx1);
+  }
+  bool any_pooled = false;
+  RectWalk w = start;
+  // (the compiler must not see that this walk repeats the first one: it would keep all NQ tile indices and sub-tile masks alive
+  // instead of recomputing them -- 137 registers)
+  asm volatile("" : "+v"(w.x), "+v"(w.y) : "v"(slot[NQ - 1]));  // (... and not before the results are in: nothing of it is needed earlier)
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    slot[q] &= ~BRUTE_BIT;
+    if (q < n_on) {
+      const unsigned int ti = tile_base + (unsigned int)(w.y * L.tiles_x + w.x);
       if (slot[q] < (unsigned int)L.C) {
-        L.inl[pe[q].ti * L.C + slot[q]] = pe[q].entry;
+        const unsigned int sub = sub_tiles_reached<SOFT>(w.x, w.y, c_lo, c_hi, r_lo, r_hi);
+        L.inl[(size_t)ti * L.C + slot[q]] = make_uint4(block, sub, (unsigned int)own, (unsigned int)(own >> 32));
+      } else if ((slot[q] - (unsigned int)L.C) / OVC_PAYLOAD >= (unsigned int)L.maxc) {
+        atomicOr(L.count + ti, BRUTE_BIT);
       } else {
-        const unsigned int o = slot[q] - (unsigned int)L.C;
-        c[q] = o / OVC_PAYLOAD;
-        i[q] = o - c[q] * OVC_PAYLOAD;
-        if (c[q] >= (unsigned int)L.maxc)
-          atomicOr(L.count + pe[q].ti, BRUTE_BIT);
-        else
-          pooled[q] = true;
+        any_pooled = true;
       }
     }
+    w.step(tx0, tx1);
   }
+  if (__ballot(any_pooled) == 0ull) return;  // (uniform)
+  // Past a tile's inline slots (rare).  Rolled loops over slots parked in LDS: unrolled, their NQ x (slot, chunk, position)
+  // took the kernel from 68 to 137 registers.
+  unsigned int* parked = medium_slot_scratch() + threadIdx.x;
 #pragma unroll
-  for (int q = 0; q < NQ; ++q)
-    if (pooled[q] && i[q] == 0) p[q] = atomicAdd(L.pool_top, 1u);
-#pragma unroll
-  for (int q = 0; q < NQ; ++q)
-    if (pooled[q] && i[q] == 0) {
-      v[q] = p[q] < L.cap_chunks ? p[q] + 1u : 0xFFFFFFFFu;
-      __hip_atomic_store(L.tab + pe[q].ti * L.maxc + c[q], v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int q = 0; q < NQ; ++q) parked[q * 256] = q < n_on ? slot[q] : 0u;
+  const int n = min(n_on, NQ);
+  w = start;
+#pragma unroll 1
+  for (int q = 0; q < n; ++q) {  // step 1: allocate and publish (never waits)
+    const unsigned int sl = parked[q * 256];
+    const unsigned int o = sl - (unsigned int)L.C, c = o / OVC_PAYLOAD;
+    if (sl >= (unsigned int)L.C && c < (unsigned int)L.maxc && o - c * OVC_PAYLOAD == 0u) {
+      const unsigned int ti = tile_base + (unsigned int)(w.y * L.tiles_x + w.x);
+      const unsigned int p = atomicAdd(L.pool_top, 1u);
+      __hip_atomic_store(L.tab + (size_t)ti * L.maxc + c, p < L.cap_chunks ? p + 1u : 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-#pragma unroll
-  for (int q = 0; q < NQ; ++q)
-    if (pooled[q] && i[q] != 0) {
-      unsigned int* link = L.tab + pe[q].ti * L.maxc + c[q];
+    w.step(tx0, tx1);
+  }
+  w = start;
+#pragma unroll 1
+  for (int q = 0; q < n; ++q) {  // steps 2 and 3: the chunk (one's own publication is read back), then the entry
+    const unsigned int sl = parked[q * 256];
+    const unsigned int o = sl - (unsigned int)L.C, c = o / OVC_PAYLOAD;
+    if (sl >= (unsigned int)L.C && c < (unsigned int)L.maxc) {
+      const unsigned int ti = tile_base + (unsigned int)(w.y * L.tiles_x + w.x);
+      unsigned int* link = L.tab + (size_t)ti * L.maxc + c;
+      unsigned int v;
       do {
-        v[q] = __hip_atomic_load(link, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v[q] == 0u) __builtin_amdgcn_s_sleep(1);
-      } while (v[q] == 0u);
+        v = __hip_atomic_load(link, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v == 0u) __builtin_amdgcn_s_sleep(1);
+      } while (v == 0u);
+      if (v == 0xFFFFFFFFu) {
+        atomicOr(L.count + ti, BRUTE_BIT);
+      } else {
+        const unsigned int sub = sub_tiles_reached<SOFT>(w.x, w.y, c_lo, c_hi, r_lo, r_hi);
+        L.pool[(size_t)(v - 1u) * OVC + 1u + (o - c * OVC_PAYLOAD)] = make_uint4(block, sub, (unsigned int)own, (unsigned int)(own >> 32));
+      }
     }
-#pragma unroll
-  for (int q = 0; q < NQ; ++q)
-    if (pooled[q]) {
-      if (v[q] == 0xFFFFFFFFu)
-        atomicOr(L.count + pe[q].ti, BRUTE_BIT);
-      else
-        L.pool[(size_t)(v[q] - 1u) * OVC + 1u + i[q]] = pe[q].entry;
-    }
+    w.step(tx0, tx1);
+  }
 }
 
 // ---- one wavefront bins its 64 faces into one pass' lists ---------------------------------------------------------------
@@ -493,6 +563,10 @@ __device__ __forceinline__ void append_entries(const PendingEntry* pe, const Lis
 // own rectangle as a 64-bit mask over an 8 x 8 local grid; each step takes the first pending tile of the first pending
 // lane, ballots the lanes whose rectangle holds it and clears it everywhere.  Steps = distinct tiles.  The results are
 // parked one per lane and appended 64 tiles at a time (a returning atomic per step would serialise the loop on L2 latency).
+#ifdef KAMD_PHASE_PROF
+static __device__ unsigned long long g_phase_bin[16];  // [0..7] phases, [10] longest wavefront, [11] > 1000 ticks (10 us at 100 MHz), [12] > 2500;
+                                                       // wave_bin, both passes: [8] big-list appends, [9] medium faces, [15] the merging loop
+#endif
 template <bool SOFT>
 __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long first_b, long long f, int tx0, int tx1,
                                          int ty0, int ty1, int c_lo, int c_hi, int r_lo, int r_hi, const Lists& L,
@@ -508,6 +582,12 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
     const int bL = __builtin_amdgcn_readlane(b, leader);
     const bool mine = active && b == bL;
     remaining &= ~__ballot(mine);
+#ifdef KAMD_PHASE_PROF
+    unsigned long long wb_t = clock64();
+#define WB_MARK(i) { const unsigned long long wb_n = clock64(); if (lane == 0) atomicAdd(&g_phase_bin[i], wb_n - wb_t); wb_t = wb_n; }
+#else
+#define WB_MARK(i)
+#endif
     // big faces: appended to the mesh's big list
     const unsigned long long bigm = __ballot(mine && big);
     if (bigm != 0ull) {
@@ -516,52 +596,26 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
       start = (unsigned int)__builtin_amdgcn_readlane((int)start, leader);
       if (mine && big) L.big_list[first_b + start + __popcll(bigm & ((1ull << lane) - 1ull))] = (unsigned int)f;
     }
-    // medium faces -- a rectangle of more than MEDIUM_TILES tiles (at most 8 x 8: beyond that a face is `big`): ONE step per face, a
-    // lane per tile of its rectangle, each appending a single-face entry.  In the loop below such a face would add a step per tile
-    // it alone touches: a wavefront of 64 consecutive faces ~100 pixels across (the floor under an object, the bowl of the knot
-    // scene) ran ~3 000 dependent steps while the rest of the launch waited -- 259 us instead of 41 at the C4 shape.
-    bool medium = mine && !big && (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > MEDIUM_TILES;
-    constexpr int MQ = 2;  // faces per step: their counter atomics share one round trip (one face per step: 144 us on the knot scene, whose
-                           // bowl is 170 such faces in three consecutive wavefronts per view -- each face a dependent returning atomic)
-    for (unsigned long long med = __ballot(medium); med != 0ull;) {
-      PendingEntry pe[MQ];
-#pragma unroll
-      for (int q = 0; q < MQ; ++q) {
-        pe[q].on = false;
-        pe[q].ti = 0;
-        pe[q].entry = make_uint4(0u, 0u, 0u, 0u);
-        if (med == 0ull) continue;  // (uniform)
-        const int l = __ffsll((long long)med) - 1;
-        med &= med - 1ull;
-        const int mx0 = __builtin_amdgcn_readlane(tx0, l), mx1 = __builtin_amdgcn_readlane(tx1, l);
-        const int my0 = __builtin_amdgcn_readlane(ty0, l), my1 = __builtin_amdgcn_readlane(ty1, l);
-        const int w = mx1 - mx0 + 1, n = w * (my1 - my0 + 1);   // (w, h in 1..8: n <= 64)
-        int ly = 0;
-#pragma unroll
-        for (int k = 1; k < 8; ++k) ly += lane >= k * w ? 1 : 0;
-        const bool on = lane < n;
-        const int tx = mx0 + (lane - ly * w), ty = my0 + ly;
-        unsigned int sub = 0u;
-        if (SOFT) {
-          const int fc_lo = __builtin_amdgcn_readlane(c_lo, l), fc_hi = __builtin_amdgcn_readlane(c_hi, l);
-          const int fr_lo = __builtin_amdgcn_readlane(r_lo, l), fr_hi = __builtin_amdgcn_readlane(r_hi, l);
-          if (on) {  // the 16 x 4-pixel sub-tiles of tile (tx, ty) the face's pixel range reaches: bit = sy * 2 + sx
-            const int px0 = tx * S_TILE, py0 = ty * S_TILE;
-            const int sx0 = max(fc_lo - px0, 0) / SUB_W, sx1 = min(fc_hi - px0, S_TILE - 1) / SUB_W;
-            const int sy0 = max(fr_lo - py0, 0) / SUB_H, sy1 = min(fr_hi - py0, S_TILE - 1) / SUB_H;
-            const unsigned int colbits = (sx0 == 0 ? 1u : 0u) | (sx1 >= 1 ? 2u : 0u);
-            const unsigned int rowsel = ((1u << (2 * (sy1 + 1))) - 1u) & ~((1u << (2 * sy0)) - 1u) & 0x5555u;
-            sub = colbits * rowsel;
-          }
-        }
-        const unsigned long long one = 1ull << l;
-        pe[q].on = on;
-        pe[q].ti = (size_t)bL * L.ntiles + (on ? ty * L.tiles_x + tx : 0);
-        pe[q].entry = make_uint4(block, sub, (unsigned int)one, (unsigned int)(one >> 32));
-        if (SOFT && on && sub != 0u) atomicOr(L.sub_touched + pe[q].ti, sub);
-      }
-      append_entries<MQ>(pe, L);
+    WB_MARK(8);
+    // medium faces -- a rectangle of more than MEDIUM_TILES tiles (at most 8 x 8: beyond that a face is `big`): every lane walks the
+    // tiles of ITS OWN face and appends a single-face entry to each, MQ tiles per step with their counter atomics in flight
+    // together (append_own); steps = the largest rectangle of the wavefront / MQ, no cross-lane work at all.  The loop below merges the faces
+    // of a wavefront that share a tile into one entry, at one step of ~40 dependent instructions per DISTINCT tile of the
+    // wavefront: right for faces of a few pixels (64 of them share ~6 tiles), wrong for faces 30-200 pixels across (64 of them
+    // touch 500-3000 tiles, hardly any shared) -- the knot scene's bowl (170 faces per view) took the launch from 38 to 145 us,
+    // the same bowl cut into 2 720 faces of ~30 pixels to 133 us, with every other wavefront long gone.
+    const bool medium = mine && !big && (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > MEDIUM_TILES;
+    {
+#ifndef KAMD_MEDIUM_BATCH
+#define KAMD_MEDIUM_BATCH 8
+#endif
+      constexpr int MQ = KAMD_MEDIUM_BATCH;
+      const int n_own = medium ? (tx1 - tx0 + 1) * (ty1 - ty0 + 1) : 0;
+      RectWalk at{tx0, ty0};
+      for (int k0 = 0; __ballot(k0 < n_own) != 0ull; k0 += MQ)
+        append_own<SOFT, MQ>(n_own - k0, at, tx0, tx1, (unsigned int)bL * (unsigned int)L.ntiles, block, 1ull << lane, c_lo, c_hi, r_lo, r_hi, L);
     }
+    WB_MARK(9);
     const bool small = mine && !big && !medium;
     unsigned long long pending = 0ull;
     if (small) {
@@ -612,6 +666,7 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
       }
       if (++k == 64) flush();
     }
+    WB_MARK(15);
     if (deferred != nullptr && remaining == 0ull) {
       deferred->on = my_t >= 0;
       deferred->ti = (size_t)bL * L.ntiles + (my_t >= 0 ? my_t : 0);
@@ -699,9 +754,6 @@ __device__ __forceinline__ void note_row_span(const Lists& L, bool act, int b, i
   }
 }
 
-#ifdef KAMD_PHASE_PROF
-static __device__ unsigned long long g_phase_bin[16];  // [0..7] phases, [10] longest wavefront, [11] > 1000 ticks (10 us at 100 MHz), [12] > 2500
-#endif
 #ifndef KAMD_BIN_WAVES
 #define KAMD_BIN_WAVES 0  // waves per SIMD the binning kernel is compiled for (0: the compiler's choice, 70 VGPRs = 7; 8 spills: 48.6 vs 44.2 us)
 #endif
@@ -792,7 +844,10 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(
         rx1 = pr.c_hi / R_TILE;
         ry0 = pr.r_lo / R_TILE;
         ry1 = pr.r_hi / R_TILE;
-        big_r = pr.everywhere || rx1 - rx0 >= 8 || ry1 - ry0 >= 8;
+        // (the rasterizer's tile kernel tests every big face of the view against its tile -- a box compare per face -- so a face
+        // is cheaper there than as BIG_TILES_R single-face entries, each a memory-side atomic here: the knot scene's bowl, 170
+        // faces of 50-130 tiles per view, cost this launch 25 us as entries)
+        big_r = pr.everywhere || rx1 - rx0 >= 8 || ry1 - ry0 >= 8 || (rx1 - rx0 + 1) * (ry1 - ry0 + 1) > BIG_TILES_R;
       }
     }
     PHASE_MARK(3);

@@ -8,7 +8,12 @@ from kaolin_amd import _lib
 from kaolin_amd.utils import testing as T
 lib = _lib.load()
 V, H, W = 8, 1024, 1024
-fz, fimg, feats, nz = T.sphere_scene(level=50, num_views=V, device='cuda')
+scene = os.environ.get('KAMD_PROF_SCENE', 'sphere')   # sphere | knot | bowl (the knot scene's ~170 image-sized faces alone)
+if scene == 'bowl':
+    kv, kf = T.knot_mesh()
+    fz, fimg, feats, nz = T.mesh_scene(kv, kf[2 * 440 * 48 + 20 * 12 * 12 + 20 * 14 * 14:], V, 'cuda', torch.float, 0, 2.5)
+else:
+    fz, fimg, feats, nz = (T.knot_scene(num_views=V, device='cuda') if scene == 'knot' else T.sphere_scene(level=50, num_views=V, device='cuda'))
 feat = torch.cat(feats, -1).contiguous()
 for _ in range(2):
     kal.render.mesh.dibr_rasterization(H, W, fz, fimg, feat, nz)
@@ -26,6 +31,7 @@ raw.kamd_debug_phase_cycles(buf, 0)
 raw.kamd_debug_phase_cycles_raster(buf2, 0)
 raw.kamd_debug_phase_cycles_bin(buf3, 0)
 print('bin_faces: phases (index math | vertex loads | raster record incl. z loads | raster range | soft record | soft range | raster lists | soft lists) Mticks/step', [round(buf3[i] / n / 1e6, 1) for i in range(8)],
+      'of the lists: big-list appends', round(buf3[8] / n / 1e6, 1), 'medium faces', round(buf3[9] / n / 1e6, 1), 'merging loop', round(buf3[15] / n / 1e6, 1), ';',
       'longest wavefront', buf3[10], 'ticks (10 ns each); wavefronts > 1000 ticks', buf3[11] / n, '> 2500', buf3[12] / n, 'of', buf3[13] / n, '; mean wavefront', round(buf3[14] / max(buf3[13], 1) / 100.0, 2), 'us')
 for title, b, names in (
         ('soft_select', buf, ['setup', 'order entries', 'stream+cull', 'chunk masks', 'accept+transposes', 'pair write', 'tail']),
