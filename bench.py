@@ -403,7 +403,8 @@ def main():
 
     def soft_work_units(sc, face_idx, boxlen=0.02, knum=30):
         """What the soft-mask pass of a scene has to do, counted from the scene (per view, averages): `soft_pixels` = uncovered pixels
-        inside at least one face's enlarged box (the pixels the reference's kernel computes distances for), `soft_pairs` = (pixel,
+        inside at least one face's enlarged box (the pixels the reference's kernel computes distances for), `soft_items` = the
+        16 x 4 sub-tiles holding one, `soft_pairs` = (pixel,
         face) pairs with the pixel inside the face's enlarged box (every one is a point-triangle distance in the reference: its
         kernel's work unit), `soft_hits` = the pairs that make it into the knum-deep buffers.  Box counts per pixel through a 2-D
         difference array.  (Pixel centres as dibr_soft_mask_cuda.cu:75-76: x = (2 px + 1 - W) / W, y = (H - 1 - 2 py) / H.)"""
@@ -426,13 +427,20 @@ def main():
             cnt = diff.cumsum(1).cumsum(2)[:, :H, :W]
             unc = face_idx < 0
             per_pixel = cnt[unc]
-            return {'soft_pixels': float((per_pixel > 0).sum()) / V, 'soft_pairs': float(per_pixel.sum()) / V,
-                    'soft_hits': float(per_pixel.clamp(max=knum).sum()) / V}
+            out = {'soft_pixels': float((per_pixel > 0).sum()) / V, 'soft_pairs': float(per_pixel.sum()) / V,
+                   'soft_hits': float(per_pixel.clamp(max=knum).sum()) / V}
+            if H % 4 == 0 and W % 16 == 0:
+                # `soft_items`: the 16 x 4-pixel sub-tiles that hold such a pixel -- the search kernels' work items (a wavefront each)
+                reach = (cnt > 0) & unc
+                out['soft_items'] = float(reach.reshape(V, H // 4, 4, W // 16, 16).any(dim=4).any(dim=2).sum()) / V
+            return out
 
     # the unit of work each kernel's duration scales with (scene_variants: a kernel's duration ratio between two scenes is judged
     # against the ratio of these, not against 1)
     KERNEL_WORK_UNIT = {'raster_tile_kernel': 'covered_tile_pixels', 'raster_backward_kernel': 'covered_tile_pixels',
-                        'soft_select_kernel': 'soft_pairs', 'soft_eval_kernel': 'soft_hits', 'soft_mask_backward_list_kernel': 'soft_hits',
+                        # (select and eval run a wavefront per item, whatever the item holds: a scene of sparse items -- image-sized faces,
+                        # whose enlarged boxes put large uncovered areas within reach of one or two faces -- costs them per item)
+                        'soft_select_kernel': 'soft_items', 'soft_eval_kernel': 'soft_items', 'soft_mask_backward_list_kernel': 'soft_hits',
                         'bin_faces_kernel': 'faces', 'pv_forward_kernel': 'faces', 'pv_backward_kernel': 'faces',
                         'weighted_sum2_kernels': 'pixels'}
 
