@@ -105,3 +105,33 @@ def test_gpu_full_size_c5():
     ref = vox_oracle.trianglemeshes_to_voxelgrids(v, f, 256)
     assert out.shape == (1, 256, 256, 256) and torch.equal(out.cpu(), ref)
     assert 100000 < int(ref.sum()) < 400000
+
+
+@pytest.mark.gpu
+def test_gpu_1000_repetitions_on_dirty_memory():
+    """1 000 back-to-back calls over shapes with one and several meshes, the output landing on dirty memory every time (the
+    allocator hands the previous result back, overwritten with 0.5), every seventh call on a second stream: a voxel the clear
+    missed, a mark lost to the clear or an extent read before it was reduced would show up as a difference from the oracle."""
+    from kaolin_amd.utils.testing import geodesic_sphere
+    conv = _conv().trianglemeshes_to_voxelgrids
+    cases = []
+    for level, res, batch, dtype in ((50, 256, 1, torch.float), (6, 128, 3, torch.float), (2, 96, 2, torch.double), (10, 64, 5, torch.float)):
+        v, f = geodesic_sphere(level)
+        v = torch.stack([v.to(dtype) * torch.tensor([1.0, 0.6 + 0.1 * b, 1.2], dtype=dtype) for b in range(batch)])
+        cases.append((v.cuda(), f.cuda(), res, vox_oracle.trianglemeshes_to_voxelgrids(v, f, res).cuda()))
+    side = torch.cuda.Stream()
+    bad = 0
+    for rep in range(1000):
+        v, f, res, expected = cases[rep % len(cases)]
+        if rep % 7 == 3:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                out = conv(v, f, res)
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            out = conv(v, f, res)
+        out.record_stream(torch.cuda.current_stream())
+        bad += int(not torch.equal(out, expected))
+        out.fill_(0.5)       # the next result lands on dirty memory
+        del out
+    assert bad == 0
