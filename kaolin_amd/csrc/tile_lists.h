@@ -141,6 +141,10 @@ struct Lists {
   int C, maxc;
   unsigned int* big_count;    // [B]               zeroed; faces of mesh b in the big list
   unsigned int* big_list;     // [total_faces]     mesh b's segment starts at its first packed face
+  // raster pass only (0: none): big_rows_off 32-bit words behind big_count, zeroed: per view and tile row ceil(tiles_x / 64) 64-bit
+  // words, bit = some big face's tile rectangle holds the tile.  A view with ONE big face (a floor under the object) otherwise
+  // costs every tile of the view its background fast path: the big list is a candidate of all of them.
+  unsigned int big_rows_off;
   unsigned int* sub_touched;  // [B * ntiles]      zeroed; soft pass only: bit s = some enlarged box reaches sub-tile s
   int tiles_x, ntiles;
   // raster pass only (nullptr: none): the tile rows the mesh's boxes cover, per view -- where the tile kernels start
@@ -148,6 +152,7 @@ struct Lists {
 };
 
 inline size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
+__host__ __device__ inline int big_row_words(int tiles_x) { return (tiles_x + 63) >> 6; }
 inline unsigned int pool_chunks(long long total_faces, long long n_tiles_total) {
   // entries the pool can take beyond the inline slots.  A face adds at most one entry per tile of its rectangle (fewer when its
   // wavefront's faces share tiles), so this is 4 tiles' worth per face: past it the appends flag their tiles BRUTE, which is
@@ -162,7 +167,7 @@ inline unsigned int pool_chunks(long long total_faces, long long n_tiles_total) 
 // Host-side layout of one pass inside a workspace.  All zeroed arrays of both passes are placed in ONE contiguous region
 // at the start of the workspace so that a single fill kernel clears them.
 struct PassLayout {
-  size_t count, tab, pool_top, big_count, sub_touched, row_span;  // inside the zero region
+  size_t count, tab, pool_top, big_count, big_rows, sub_touched, row_span;  // inside the zero region
   size_t inl, pool, big_list, rec;                      // after it
   size_t pixcnt, prob_pm;                // soft pass: hits per (item, pixel) (u16); pixel-major probabilities (knum > 128 only)
   unsigned int cap_chunks;
@@ -187,6 +192,7 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
     L.r.tab = off; off += a256(ntr * L.r.maxc * 4);
     L.r.pool_top = off; off += 256;
     L.r.big_count = off; off += a256((size_t)B * 4);
+    L.r.big_rows = off; off += a256((size_t)B * L.r.g.tiles_y * big_row_words(L.r.g.tiles_x) * 8);
     L.r.row_span = off; off += a256((size_t)B * 2 * 4);
   }
   if (with_s) {
@@ -278,6 +284,7 @@ inline Lists lists_of(void* ws, const PassLayout& p, int B, bool soft) {
   l.maxc = p.maxc;
   l.big_count = (unsigned int*)(c + p.big_count);
   l.big_list = (unsigned int*)(c + p.big_list);
+  l.big_rows_off = (!soft && p.big_rows != 0) ? (unsigned int)((p.big_rows - p.big_count) / 4) : 0u;
   l.sub_touched = soft ? (unsigned int*)(c + p.sub_touched) : nullptr;
   l.tiles_x = p.g.tiles_x;
   l.ntiles = p.g.ntiles;
@@ -595,6 +602,22 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
       if (lane == leader) start = atomicAdd(L.big_count + bL, (unsigned int)__popcll(bigm));
       start = (unsigned int)__builtin_amdgcn_readlane((int)start, leader);
       if (mine && big) L.big_list[first_b + start + __popcll(bigm & ((1ull << lane) - 1ull))] = (unsigned int)f;
+      if (!SOFT && L.big_rows_off != 0u) {
+        // the tiles a big face's rectangle holds, a 64-bit word per 64 tiles of a row: one face at a time, a lane per row
+        const int wpr = big_row_words(L.tiles_x), tiles_y = L.ntiles / L.tiles_x;
+        unsigned long long* rows = reinterpret_cast<unsigned long long*>(L.big_count + L.big_rows_off) + (size_t)bL * tiles_y * wpr;
+        for (unsigned long long bm = bigm; bm != 0ull; bm &= bm - 1ull) {
+          const int l = __ffsll((long long)bm) - 1;
+          const int x0 = __builtin_amdgcn_readlane(tx0, l), x1 = __builtin_amdgcn_readlane(tx1, l);
+          const int y0 = __builtin_amdgcn_readlane(ty0, l), y1 = __builtin_amdgcn_readlane(ty1, l);
+          for (int row = y0 + lane; row <= y1; row += 64)
+            for (int w = x0 >> 6; w <= (x1 >> 6); ++w) {
+              const int lo = max(x0 - w * 64, 0), hi = min(x1 - w * 64, 63);  // bits lo..hi of word w
+              const unsigned long long m = (hi >= 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & ~((1ull << lo) - 1ull);
+              atomicOr(rows + (size_t)row * wpr + w, m);
+            }
+        }
+      }
     }
     WB_MARK(8);
     // medium faces -- a rectangle of more than MEDIUM_TILES tiles (at most 8 x 8: beyond that a face is `big`): every lane walks the

@@ -610,3 +610,37 @@ def test_zero_sized_image_gives_zero_gradients():
         assert out.shape == (2, H, W, 3) and soft.shape == (2, H, W) and idx.shape == (2, H, W)
         (out.sum() + soft.sum()).backward()
         assert a.grad is not None and float(a.grad.abs().max()) == 0.
+
+
+@pytest.mark.parametrize('H,W,views', [(512, 512, 3), (48, 2112, 2), (300, 200, 2)])
+def test_floor_under_the_object_vs_oracle(H, W, views):
+    """An object standing on a floor of two image-sized triangles: big faces go to their view's big list and mark the tiles of
+    their rectangles in per-row bit words (tile_lists.h, big_rows) -- tiles outside keep their own lists and the background
+    fast path.  2112 pixels across = 132 tile columns: three words per row.  (A face whose box is 'everywhere' -- a NaN vertex --
+    marks every tile: test_nan_vertex_matches_reference_glue.)"""
+    from kaolin_amd.utils import testing as T
+    v, f = T.geodesic_sphere(10)
+    v = v * 0.45
+    floor_v = torch.tensor([[-1.6, -0.5, -1.6], [1.6, -0.5, -1.6], [1.6, -0.5, 1.6], [-1.6, -0.5, 1.6]], dtype=v.dtype)
+    n = v.shape[0]
+    faces = torch.cat([f, torch.tensor([[n, n + 2, n + 1], [n, n + 3, n + 2]])])
+    fz, fimg, feats, nz = T.mesh_scene(torch.cat([v, floor_v]), faces, views, 'cpu', torch.float, 1, 2.5)
+    ref = oracle.dibr_rasterization(H, W, fz, fimg, torch.cat(feats, -1), nz, omp=True)
+    a = fimg.cuda().requires_grad_()
+    out, soft, face_idx = kal().render.mesh.dibr_rasterization(H, W, fz.cuda(), a, [x.cuda() for x in feats], nz.cuda())
+    assert torch.equal(face_idx.cpu(), ref['face_idx'])
+    assert torch.equal(torch.cat(out, -1).cpu(), ref['features'])
+    assert rel_close(soft.detach(), ref['soft_mask'])
+    floor_ids = torch.tensor([f.shape[0], f.shape[0] + 1])
+    assert bool(torch.isin(ref['face_idx'], floor_ids).any()), 'the floor is visible in the reference image'
+    # the standalone rasterizer takes the same lists
+    out2, idx2 = kal().render.mesh.rasterize(H, W, fz.cuda(), fimg.cuda(), [x.cuda() for x in feats], (nz >= 0).cuda())
+    assert torch.equal(idx2, face_idx) and torch.equal(torch.cat(out2, -1), torch.cat(out, -1))
+    torch.manual_seed(5)
+    g1 = torch.rand(ref['features'].shape)
+    g2 = torch.rand(ref['soft_mask'].shape)
+    ((torch.cat(out, -1) * g1.cuda()).sum() + (soft * g2.cuda()).sum()).backward()
+    gr_img, _ = oracle.rasterize_backward(g1, ref['face_idx'], ref['weights'], fimg, torch.cat(feats, -1), 1e-8)
+    gs_img = oracle.dibr_soft_mask_backward(g2, ref['soft_mask'], ref['face_idx'], ref['close_face_prob'], ref['close_face_idx'],
+                                            ref['close_face_dist_type'], ref['scaled_vertices'], 7000, 1000.)
+    assert rel_close(a.grad, gr_img + gs_img)
