@@ -31,11 +31,12 @@ def g_dibr():
     return np.load(os.path.join(GOLDEN_DIR, 'dibr_soft_mask.npz'))
 
 
-def rel_close(a, b, tol=1e-5):
+def rel_close(a, b, tol=1e-5, term_abs_sum=None):
     """ELEMENT-WISE: |a - b| <= tol |b| + tol median|b != 0| (kaolin_amd.utils.testing.elementwise_mismatch; through round 3
-    this scaled the tolerance by the largest element of `b`, which let small entries be off by orders of magnitude)."""
+    this scaled the tolerance by the largest element of `b`, which let small entries be off by orders of magnitude).
+    `term_abs_sum`: for sums of many float terms, + 64 eps * the sum of the terms' magnitudes (see there)."""
     from kaolin_amd.utils.testing import elementwise_mismatch
-    msg = elementwise_mismatch(a, b, tol)
+    msg = elementwise_mismatch(a, b, tol, term_abs_sum=term_abs_sum)
     assert msg is None, msg
     return True
 
@@ -640,7 +641,9 @@ def test_floor_under_the_object_vs_oracle(H, W, views):
     g1 = torch.rand(ref['features'].shape)
     g2 = torch.rand(ref['soft_mask'].shape)
     ((torch.cat(out, -1) * g1.cuda()).sum() + (soft * g2.cuda()).sum()).backward()
-    gr_img, _ = oracle.rasterize_backward(g1, ref['face_idx'], ref['weights'], fimg, torch.cat(feats, -1), 1e-8)
-    gs_img = oracle.dibr_soft_mask_backward(g2, ref['soft_mask'], ref['face_idx'], ref['close_face_prob'], ref['close_face_idx'],
-                                            ref['close_face_dist_type'], ref['scaled_vertices'], 7000, 1000.)
-    assert rel_close(a.grad, gr_img + gs_img)
+    gr_img, _, sr = oracle.rasterize_backward(g1, ref['face_idx'], ref['weights'], fimg, torch.cat(feats, -1), 1e-8, return_abs=True)
+    gs_img, ss = oracle.dibr_soft_mask_backward(g2, ref['soft_mask'], ref['face_idx'], ref['close_face_prob'], ref['close_face_idx'],
+                                                ref['close_face_dist_type'], ref['scaled_vertices'], 7000, 1000., return_abs=True)
+    # (the floor's vertices collect tens of thousands of float-atomic terms of both signs: the accumulation's own rounding scale
+    # joins the element-wise 1e-5, as for the knot scene's bowl in test_full_size_parity.py)
+    assert rel_close(a.grad, gr_img + gs_img, term_abs_sum=sr + ss)
