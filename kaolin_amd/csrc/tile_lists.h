@@ -476,7 +476,10 @@ __device__ __forceinline__ unsigned int sub_tiles_reached(int tx, int ty, int c_
   const unsigned int rowsel = ((1u << (2 * (sy1 + 1))) - 1u) & ~((1u << (2 * sy0)) - 1u) & 0x5555u;
   return colbits * rowsel;
 }
-constexpr int MEDIUM_BATCH_MAX = 16;
+#ifndef KAMD_MEDIUM_BATCH
+#define KAMD_MEDIUM_BATCH 8  // tiles a medium face appends per step (their counter atomics in flight together): 4 / 8 / 12 / 16 = 68 / 68 / 77 / 85 VGPRs, same time
+#endif
+constexpr int MEDIUM_BATCH_MAX = KAMD_MEDIUM_BATCH;
 __device__ __forceinline__ unsigned int* medium_slot_scratch() {
   __shared__ unsigned int s[MEDIUM_BATCH_MAX * 256];  // (the binning kernels run 256 threads per workgroup)
   return s;
@@ -629,9 +632,6 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
     // the same bowl cut into 2 720 faces of ~30 pixels to 133 us, with every other wavefront long gone.
     const bool medium = mine && !big && (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > MEDIUM_TILES;
     {
-#ifndef KAMD_MEDIUM_BATCH
-#define KAMD_MEDIUM_BATCH 8
-#endif
       constexpr int MQ = KAMD_MEDIUM_BATCH;
       const int n_own = medium ? (tx1 - tx0 + 1) * (ty1 - ty0 + 1) : 0;
       RectWalk at{tx0, ty0};

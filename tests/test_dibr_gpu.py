@@ -647,3 +647,31 @@ def test_floor_under_the_object_vs_oracle(H, W, views):
     # (the floor's vertices collect tens of thousands of float-atomic terms of both signs: the accumulation's own rounding scale
     # joins the element-wise 1e-5, as for the knot scene's bowl in test_full_size_parity.py)
     assert rel_close(a.grad, gr_img + gs_img, term_abs_sum=sr + ss)
+
+
+@pytest.mark.parametrize('n,size', [(400, 0.7), (3500, 0.6), (150, 1.6)])
+def test_stacked_medium_faces_vs_oracle(n, size):
+    """Hundreds of faces of 5-16 tiles (up to 64 in the soft pass) piled on the same tiles: each appends single-face entries (tile_lists.h,
+    append_own), far past a tile's inline slots -- pool chunks, the slots parked in LDS, and with 3 500 of them past the 512 entries a
+    rasterizer tile's table holds (the tile is flagged and scans its mesh).  face_idx / features bit-exact, soft mask and gradient
+    at 1e-5 against the oracle."""
+    H = W = 256
+    g = torch.Generator().manual_seed(n)
+    centre = (torch.rand((n, 1, 2), generator=g) - 0.5) * 0.5
+    img = (centre + (torch.rand((n, 3, 2), generator=g) - 0.5) * size).unsqueeze(0).float()
+    z = -(torch.rand((1, n, 3), generator=g) + 1).float()
+    feat = torch.rand((1, n, 3, 2), generator=g).float()
+    nz = torch.ones((1, n))
+    ref = oracle.dibr_rasterization(H, W, z, img, feat, nz, omp=True)
+    a = img.cuda().requires_grad_()
+    out, soft, face_idx = kal().render.mesh.dibr_rasterization(H, W, z.cuda(), a, feat.cuda(), nz.cuda())
+    assert torch.equal(face_idx.cpu(), ref['face_idx'])
+    assert torch.equal(out.cpu(), ref['features'])
+    assert rel_close(soft.detach(), ref['soft_mask'])
+    torch.manual_seed(6)
+    g1, g2 = torch.rand(ref['features'].shape), torch.rand(ref['soft_mask'].shape)
+    ((out * g1.cuda()).sum() + (soft * g2.cuda()).sum()).backward()
+    gr_img, _, sr = oracle.rasterize_backward(g1, ref['face_idx'], ref['weights'], img, feat, 1e-8, return_abs=True)
+    gs_img, ss = oracle.dibr_soft_mask_backward(g2, ref['soft_mask'], ref['face_idx'], ref['close_face_prob'], ref['close_face_idx'],
+                                                ref['close_face_dist_type'], ref['scaled_vertices'], 7000, 1000., return_abs=True)
+    assert rel_close(a.grad, gr_img + gs_img, term_abs_sum=sr + ss)
