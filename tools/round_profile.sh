@@ -10,7 +10,7 @@ timeout 500 python -m pytest tests -m gpu -q --durations=15 --timeout 280 > $out
 timeout 320 python bench.py 2> $out/bench.err | tail -1 > $out/bench.json
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 cd /tmp && export TMPDIR=/tmp
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python $repo/bench.py --no-cpu-baseline --no-contract-ops 2> $out/prof.err | tail -1 > $out/bench_under_rocprof.json
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python $repo/bench.py --no-cpu-baseline --no-contract-ops --no-scene-variants 2> $out/prof.err | tail -1 > $out/bench_under_rocprof.json
 find $out/prof -name '*kernel_stats.csv' -exec cp {} $out/kernel_stats.csv \;
 if [ -n "$pmc" ]; then
   timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_f -- python $repo/tools/pmc_traffic.py > /dev/null 2>&1
