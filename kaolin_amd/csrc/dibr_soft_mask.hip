@@ -305,7 +305,10 @@ int soft2_search_launch(hipStream_t st, int B, int H, int W, int F, int K, float
   ea.magic = tl::work_magic(B, H, W);
   // one wavefront (select) / workgroup (eval) per work item; the number of items is known on the device only, so the
   // grids cover the worklist round-robin
-  static const int sel_per_cu = kamd_env_int("KAMD_SOFT_SELECT_PER_CU", 32);
+  // (select: 128 workgroups per CU -- with 32, a scene of many light items (the knot: 37 600) ran five places per workgroup one
+  // after the other in a fixed deal: 237 us; 64: 213; 128: 203, most workgroups take one place and the dispatcher balances them;
+  // C4's 5 300 items do not care: profiles/r04j_select_grid_ab.txt)
+  static const int sel_per_cu = kamd_env_int("KAMD_SOFT_SELECT_PER_CU", 128);
   static const int eval_per_cu = kamd_env_int("KAMD_SOFT_EVAL_PER_CU", 32);
   const long long sel_want = (long long)KAMD_NUM_CU * sel_per_cu, eval_want = (long long)KAMD_NUM_CU * eval_per_cu;
   const dim3 sel_grid((unsigned)(n_sub < sel_want ? (n_sub > 0 ? n_sub : 1) : sel_want));
