@@ -248,7 +248,10 @@ int kamd_dibr_soft_mask_backward_f64(void* stream, int B, int H, int W, int F, i
 /* per (mesh, 16x16-pixel tile): does the tile hold a covered pixel; a copy of    */
 /* the covered tile rows per view (2 words each); and the list of the tiles that  */
 /* hold a covered pixel (32 shards of ceil(B/8)*ceil(tiles/4) words), which the   */
-/* rasterizer's backward walks.  Requires B*H*W < 2^31.                            */
+/* rasterizer's backward walks.  Word 1 of the header receives a signature of the  */
+/* layout (a hash of B, H, W) from the forward's last launch: the fused backward  */
+/* walks the covered-tile list only when it finds it there and visits every tile  */
+/* otherwise.  Requires B*H*W < 2^31.                                              */
 /* Records each of the three hit arrays must hold (64*K per sub-tile slot).       */
 size_t kamd_dibr_soft_mask_lean_capacity(int B, int H, int W, int K);
 size_t kamd_dibr_soft_mask_work_words(int B, int H, int W);
