@@ -93,6 +93,18 @@ __global__ __launch_bounds__(256) void td_prep_kernel(int F, const T* __restrict
   const T rad = td_sqrt(r2) * (T)1.0001;
   st3(r + 36, c);
   r[39] = rad + (T)1e-5 * (max3abs(c) + rad);
+  // Every bound the searches cull with (face sphere, face plane, tile sphere, tile slab) is a bound on the TRUE distance to the
+  // triangle.  The reference's value is the computed one, and for a face without area it can be far below the true distance: the
+  // cross product of two (nearly) parallel edges is the rounding error of its products, project_plane() then measures the distance
+  // to a plane of arbitrary orientation through v1 (dist_type 0) -- a face with two equal vertices seen from afar may "win" with a
+  // distance of 1e-4.  The reference's sequential loop takes such a face; so must we: a face whose normal is not resolved
+  // (|n| <= 4e4 eps |a| |b|: relative direction error above ~1e-4, the head-room of the bounds; also zero, NaN and underflowed
+  // normals) gets an infinite radius -- the face tests never cull it, and neither do its tile's (non-finite tile radius).
+  {
+    const V3<T> a = v1 - v2;
+    const T k = (T)4e4 * (sizeof(T) == 4 ? (T)1.1920929e-7 : (T)2.220446049250313e-16);
+    if (!(dot(normal, normal) > k * k * dot(a, a) * dot(e31, e31))) r[39] = (T)INFINITY;
+  }
   if (centres != nullptr) {  // float copies for the Morton sort / tile spheres (radius rounded up)
     centres[(size_t)f * 3 + 0] = (float)c.x;
     centres[(size_t)f * 3 + 1] = (float)c.y;
