@@ -319,6 +319,11 @@ __device__ __forceinline__ bool pixel_range(T xmin, T ymin, T xmax, T ymax, int 
   out->c_hi = (int)fminf(ch, (float)(W - 1));
   out->r_lo = (int)fmaxf(rl, 0.0f);
   out->r_hi = (int)fminf(rh, (float)(H - 1));
+  // an INVERTED box (min > max: the contract operators take the caller's boxes as they come, and a negative boxlen inverts the
+  // enlarged ones) holds no pixel centre -- x >= xmin and x < xmax cannot both hold -- and with more than the two pixels of slack
+  // its range comes out empty: it must not reach the tile arithmetic, whose rectangles assume lo <= hi (a rectangle of negative
+  // width made the binning kernel's tile loop spin for ever: found by tools/round4/fuzz_rasterize_ops.py)
+  if (out->c_lo > out->c_hi || out->r_lo > out->r_hi) return false;
   return true;
 }
 

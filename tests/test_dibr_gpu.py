@@ -685,3 +685,38 @@ def test_stacked_medium_faces_vs_oracle(n, size):
     gr_img, _, sr = oracle.rasterize_backward(g1, ref['face_idx'], ref['weights'], img, feat, 1e-8, return_abs=True)
     gs_img, ss = _soft_backward_on_the_gpu_forwards_outputs(g2, img, face_idx, ref)
     assert rel_close(a.grad, gr_img + gs_img, term_abs_sum=sr + ss)
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize('dtype', [torch.float, torch.double])
+def test_inverted_boxes_and_meshes_without_faces_in_the_packed_operator(dtype):
+    """The contract operator takes the caller's boxes as they come: a box with min > max holds no pixel (the reference tests
+    x >= xmin and x < xmax) -- it must give the oracle's image, and it must not reach the binning kernel's tile arithmetic (a
+    rectangle of negative width made its loop spin for ever).  And a packed batch in which NO mesh has a face (null workspace)
+    is an image of background.  Both found by tools/round4/fuzz_rasterize_ops.py."""
+    M = kal()._C.render.mesh
+    g = torch.Generator().manual_seed(3)
+    H, W, mult = 41, 1340, 37.5
+    counts = [40, 0, 126]
+    first = torch.tensor([0, 40, 40, 166])
+    F = 166
+    size = 10.0 ** (torch.rand(F, generator=g) * 2.5 - 2.2)
+    img = (((torch.rand(F, 1, 2, generator=g) - 0.5) * 2.2 + (torch.rand(F, 3, 2, generator=g) - 0.5) * size.view(-1, 1, 1)) * mult).to(dtype)
+    z = -(torch.rand(F, 3, generator=g) * 2 + 0.2).to(dtype)
+    feat = torch.rand(F, 3, 2, generator=g).to(dtype)
+    lo, hi = img.min(dim=1)[0], img.max(dim=1)[0]
+    bbox = torch.cat([lo + 0.02 * mult, hi - 0.02 * mult], dim=-1).contiguous()      # too small; inverted for the small faces
+    assert bool((bbox[:, 0] > bbox[:, 2]).any())
+    want = oracle.packed_rasterize_forward(H, W, z, img, bbox, feat, first, mult, 1e-8, omp=True)
+    got = M.packed_rasterize_forward_cuda(H, W, z.cuda(), img.cuda(), bbox.cuda(), feat.cuda(), first.cuda(), mult, 1e-8)
+    assert torch.equal(got[1].cpu(), want[1]) and torch.equal(got[0].cpu(), want[0]) and torch.equal(got[2].cpu(), want[2])
+    # no face in any mesh
+    e = lambda *s: torch.zeros(*s, dtype=dtype, device='cuda')   # noqa: E731
+    out = M.packed_rasterize_forward_cuda(4, 304, e(0, 3), e(0, 3, 2), e(0, 4), e(0, 3, 3), torch.zeros(3, dtype=torch.long, device='cuda'), 1000., 1e-8)
+    assert out[1].shape == (2, 4, 304) and bool((out[1] == -1).all()) and float(out[0].abs().sum()) == 0 and float(out[2].abs().sum()) == 0
+    # a negative boxlen inverts the soft mask's enlarged boxes
+    fz, fimg, feats, nz = _scene(6, 1, dtype)
+    _, face_idx = kal().render.mesh.rasterize(64, 64, fz.cuda(), fimg.cuda(), [x.cuda() for x in feats], (nz >= 0).cuda())
+    soft = kal().render.mesh.dibr_soft_mask(fimg.cuda(), face_idx, 7000., -0.05, 30, 1000.)
+    ref = oracle.dibr_soft_mask(fimg, face_idx.cpu(), 7000., -0.05, 30, 1000., omp=True)[0]
+    assert rel_close(soft, ref)
