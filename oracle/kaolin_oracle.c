@@ -238,7 +238,7 @@ DEFINE_SIDED_BWD(oracle_sided_distance_backward_f64, double)
 #define FN(n) n##_f32
 #define SQRTFN sqrtf
 #define FMAFN fmaf
-#define REF_TILE 1024
+#define REF_TILE 512  /* the FORWARD launcher instantiates BLOCK_SIZE = 512 for float AND double (unbatched_triangle_distance_cuda.cu:424-433); the 1024 / 512 of :37-38 is the backward's thread count */
 #include "tridist_oracle.inc"
 #undef T
 #undef FN
@@ -265,7 +265,7 @@ DEFINE_SIDED_BWD(oracle_sided_distance_backward_f64, double)
 #define FN(n) n##_f32_unfused
 #define SQRTFN sqrtf
 #define FMAFN ORACLE_UNFUSED_FMA
-#define REF_TILE 1024
+#define REF_TILE 512  /* the FORWARD launcher instantiates BLOCK_SIZE = 512 for float AND double (unbatched_triangle_distance_cuda.cu:424-433); the 1024 / 512 of :37-38 is the backward's thread count */
 #include "tridist_oracle.inc"
 #undef T
 #undef FN

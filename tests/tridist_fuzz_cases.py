@@ -37,7 +37,7 @@ def check_case(case):
         fv[::3, 2] = fv[::3, 1]                     # two equal vertices
         fv[1::5] = fv[1::5, :1]                     # a point
         fv[2::7, 2] = (fv[2::7, 0] + fv[2::7, 1]) / 2   # collinear
-        # (not at faces 512, 1024, ...: the reference re-seeds its running best at every block of 1024 (float) / 512 (double) faces, so
+        # (not at faces 512, 1024, ...: the reference re-seeds its running best at every block of 512 faces, so
         # a block whose FIRST face yields NaN is ignored as a whole -- the documented deviation of DESIGN section 2, which this sweep is
         # not about; it showed up here as faces 1536+ found by the GPU and ignored by the oracle)
         fv[512::512] = keep
