@@ -42,7 +42,9 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--gpus', type=int, default=None,
+                    help='ranks (one per GPU).  Under torch.distributed.run it must equal WORLD_SIZE; as a plain `python bench.py '
+                         '--gpus N` with N > 1 the script launches its own N ranks (see relaunch_as_ranks)')
     ap.add_argument('--steps', type=int, default=100)   # (0.045 s of timed region: a single host hiccup is 0.3 % of it, not 2 %)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--views-per-gpu', type=int, default=8)
@@ -263,6 +265,26 @@ def time_contract_operators(verts, faces, proj, rot, trans, feats3, G1, G2, H, W
                     'around them is outside the events; ms = median of the event-bracketed calls after 3 warm-up calls'}
 
 
+def relaunch_as_ranks(n):
+    """`python bench.py --gpus N` (N > 1) without a launcher: run the same command line as N ranks under
+    torch.distributed.run on this node (rendezvous on 127.0.0.1, a free port) and exit with its status; rank 0 of that job prints
+    the JSON line.  With fewer visible GPUs than ranks the ranks share devices round robin -- RCCL refuses two ranks on one device,
+    so gloo carries the (300 KB per step) collectives then, and the line says so (`distributed.ranks_per_gpu`)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if torch.cuda.device_count() < n:
+        env.setdefault('KAMD_DIST_BACKEND', 'gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
     if args.quick:
@@ -270,8 +292,14 @@ def main():
     if args.cpu_extras_only:
         print(json.dumps(cpu_reference_extras(args.chamfer_points, sphere_frequency=args.sphere_frequency)))
         return
+    launched = 'WORLD_SIZE' in os.environ or 'RANK' in os.environ     # a launcher (torch.distributed.run) made this process a rank
+    if args.gpus is not None and args.gpus > 1 and not launched:
+        relaunch_as_ranks(args.gpus)
     D.init_from_env()
     rank, world = D.rank(), D.world_size()
+    if args.gpus is not None and args.gpus != world:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the job has {world} rank(s) (WORLD_SIZE={os.environ.get("WORLD_SIZE")}): '
+                         'launch one rank per GPU, or run plain `python bench.py --gpus N`')
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP operators have no CPU fallback)'
     dev = torch.device('cuda', torch.cuda.current_device())
     lib = _lib.load()
@@ -896,7 +924,9 @@ def main():
             'graph_replay': graph_replay, 'contract_operators': contract_ops,
             'distributed': {'initialized': D.is_distributed(),
                             'backend': torch.distributed.get_backend() if D.is_distributed() else None,
-                            'collectives_posted_per_step': round(reducer_posted_per_step, 3)},
+                            'collectives_posted_per_step': round(reducer_posted_per_step, 3),
+                            'visible_gpus': torch.cuda.device_count(),
+                            'ranks_per_gpu': max(1, -(-world // max(torch.cuda.device_count(), 1)))},
             'cpu_baseline': cpu, 'chamfer': chamfer, 'c5': c5,
         }
         print(json.dumps(out))

@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include "profile.h"
 #include "sided_distance_grid.h"
+#include "reseed.h"
 #include <type_traits>
 #include "../../include/kaolin_amd.h"
 
@@ -140,11 +141,22 @@ __global__ __launch_bounds__(SDG_THREADS) void sd_forward_generic(
     for (int k = threadIdx.x; k < cnt * 3; k += SDG_THREADS) tile[k] = A::load(P2 + (size_t)t0 * 3 + k);
     __syncthreads();
     if (active) {
-      for (int k = 0; k < cnt; ++k) {
-        acc_t d = A::dist(tile[k * 3 + 0], tile[k * 3 + 1], tile[k * 3 + 2], qx, qy, qz);
-        if ((t0 + k) == 0 || d < best) {
-          best = d;
-          best_i = t0 + k;
+      // the reference's loop exactly: tiles of 512 targets, each seeded by its first target whatever it yields (`k == 0 ||`,
+      // sided_distance_cuda.cu:88) and merged with `k2 == 0 || result > best` (:193) -- a NaN at a tile's start hides the tile
+      for (int kb = 0; kb < cnt; kb += kamd::SD_REF_TILE) {
+        const int ke = min(cnt, kb + kamd::SD_REF_TILE);
+        acc_t tb = A::dist(tile[kb * 3 + 0], tile[kb * 3 + 1], tile[kb * 3 + 2], qx, qy, qz);
+        int tbi = t0 + kb;
+        for (int k = kb + 1; k < ke; ++k) {
+          acc_t d = A::dist(tile[k * 3 + 0], tile[k * 3 + 1], tile[k * 3 + 2], qx, qy, qz);
+          if (d < tb) {
+            tb = d;
+            tbi = t0 + k;
+          }
+        }
+        if ((t0 + kb) == 0 || best > tb) {
+          best = tb;
+          best_i = tbi;
         }
       }
     }
@@ -245,8 +257,9 @@ __global__ __launch_bounds__(256) void sd_final_f32(
     const float* __restrict__ part_d, const int* __restrict__ part_c,
     float* __restrict__ dist, int64_t* __restrict__ idx) {
   const size_t total = (size_t)B * N;
-  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= total) return;
+  const size_t gid_ = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = gid_ < total;
+  const size_t gid = live ? gid_ : total - 1;
   const int b = (int)(gid / N);
   float best = part_d[gid];
   int c = part_c[gid];
@@ -276,8 +289,18 @@ __global__ __launch_bounds__(256) void sd_final_f32(
       }
     }
   }
-  dist[gid] = best;
-  idx[gid] = found;
+  // the reference re-seeds at every tile of 512 targets: a winner inside a tile whose first target yields NaN is not its answer
+  // (reseed.h; the test is one more gather per query whose winner is past the first tile)
+  {
+    auto dist_f = [](float tx, float ty, float tz, float x, float y, float z) { return SdArith<float>::dist(tx, ty, tz, x, y, z); };
+    auto load_f = [](const float* p) { return *p; };
+    const bool need = live && kamd::sd_winner_in_dead_tile<float>(T, found, qx, qy, qz, dist_f, load_f);
+    if (__any(need)) kamd::sd_reseed_fix<float>(need, qx, qy, qz, T, M, best, found, dist_f, load_f);
+  }
+  if (live) {
+    dist[gid] = best;
+    idx[gid] = found;
+  }
 }
 
 // split plan shared by the workspace query and the launcher

@@ -35,6 +35,7 @@
 #include "profile.h"
 #include "sided_distance_grid.h"
 #include "grid_common.h"
+#include "reseed.h"
 
 namespace kamd {
 namespace {
@@ -241,16 +242,20 @@ __global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(CloudT<T> X, Clou
       const int n = first ? X.n : Y.n;
       const T* Pt = (first ? X.pts : Y.pts) + (size_t)b * n * 3;
       float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      bool odd_first = false;  // a non-finite coordinate at a point index 512 k: as a TARGET it can hide its tile (reseed.h)
       for (int i = part * SDG_BUILD_THREADS + tid; i < n; i += P * SDG_BUILD_THREADS) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-          const float v = (float)Pt[(size_t)i * 3 + a];  // (the grid lives in float, whatever the points' type)
+          const T vt = Pt[(size_t)i * 3 + a];
+          const float v = (float)vt;  // (the grid lives in float, whatever the points' type)
           if (isfinite(v)) {
             lo[a] = fminf(lo[a], v);
             hi[a] = fmaxf(hi[a], v);
           }
+          odd_first = odd_first || (i >= SD_REF_TILE && (i & (SD_REF_TILE - 1)) == 0 && !(fabs((double)vt) < (double)INFINITY));
         }
       }
+      if (odd_first) atomicMax((first ? X.box : Y.box) + (size_t)b * 8 + 6, 1u);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
 #pragma unroll
@@ -612,6 +617,30 @@ __device__ __forceinline__ void sdg_search(const Box& s_box, int G, T qx, T qy, 
 }
 
 
+// The reference re-seeds at every tile of 512 targets (reseed.h): a winner inside a tile whose first target yields NaN is redone
+// over the live tiles by the whole wavefront.  Only clouds with a non-finite point at an index 512 k get here (the build leaves a
+// flag in the box record); out of line, so that the search kernels' registers are the search's.
+template <typename S>
+struct Reseeded {
+  S best;
+  int best_i, redone;
+};
+template <typename S, bool HALF>
+__device__ __attribute__((noinline)) Reseeded<S> sdg_reseed(bool live, int sub, S qx, S qy, S qz, const S* Tp, int nt, S best, int best_i) {
+  auto dist_f = [](S tx, S ty, S tz, S x, S y, S z) { return sdg_dist_sel<HALF>(tx, ty, tz, x, y, z); };
+  auto load_f = [](const S* p) { return *p; };
+  const bool need = live && sd_winner_in_dead_tile<S>(Tp, best_i, qx, qy, qz, dist_f, load_f);  // (uniform within a query's group)
+  Reseeded<S> r{best, best_i, 0};
+  if (!__any(need)) return r;
+  sd_reseed_fix<S>(need && sub == 0, qx, qy, qz, Tp, nt, best, best_i, dist_f, load_f);
+  // the group's other lanes take lane 0's result
+  const int g0 = (threadIdx.x & 63) - sub;
+  const S fb = reseed_shfl(best, g0);
+  const int fi = reseed_shfl(best_i, g0);
+  if (need) r = Reseeded<S>{fb, fi, 1};
+  return r;
+}
+
 // blockIdx.z = direction: 0 answers the queries A against the targets T (dist1 / idx1), 1 the reverse (dist2 / idx2).
 // The search runs on the TARGETS' grid; the queries only have to arrive in a spatially coherent order, which their own
 // sorted copy provides whichever grid it was sorted on.
@@ -632,6 +661,7 @@ __global__ __launch_bounds__(256, (MODE == SDG_GRAD ? KAMD_SDG_QUERY_WAVES : 1))
   typedef typename Vec4Of<S>::type V4;
   __shared__ Box s_box;
   __shared__ double s_sum[4];
+  __shared__ unsigned int s_odd_first;
   const int b = blockIdx.y;
   const bool fwd = blockIdx.z == 0;
   const int nq = fwd ? A.n : T.n, nt = fwd ? T.n : A.n, G = fwd ? T.G : A.G;
@@ -639,8 +669,12 @@ __global__ __launch_bounds__(256, (MODE == SDG_GRAD ? KAMD_SDG_QUERY_WAVES : 1))
   const S* Tp = (fwd ? T.pts : A.pts) + (size_t)b * nt * 3;
   const int* Tstart = (fwd ? T.start : A.start) + (size_t)b * (NC + 1);
   const V4* Tsorted = (fwd ? T.sorted : A.sorted) + (size_t)b * nt;
-  if (threadIdx.x == 0) s_box = sdg_box_decode((fwd ? T.box : A.box) + (size_t)b * 8, G);
+  if (threadIdx.x == 0) {
+    s_box = sdg_box_decode((fwd ? T.box : A.box) + (size_t)b * 8, G);
+    s_odd_first = ((fwd ? T.box : A.box) + (size_t)b * 8)[6];  // the build found a non-finite target at an index 512 k
+  }
   __syncthreads();
+  const bool odd_first = s_odd_first != 0u;  // (workgroup-uniform)
   // 100k queries are only ~1.5 wavefronts per SIMD and every query is a chain of dependent loads (cell range ->
   // targets): SDG_GROUP lanes share a query so that as many more loads are in flight; the lanes' (dist, idx) are merged
   // with a butterfly after every ring
@@ -659,6 +693,12 @@ __global__ __launch_bounds__(256, (MODE == SDG_GRAD ? KAMD_SDG_QUERY_WAVES : 1))
     S best;
     int best_i, best_k;
     sdg_search<MODE == SDG_GRAD, S, HALF>(s_box, G, q.x, q.y, q.z, (cz * G + cy) * G + cx, Tp, Tstart, Tsorted, nt, sub, best, best_i, best_k);
+    if (__builtin_expect(odd_first, 0)) {
+      const Reseeded<S> r = sdg_reseed<S, HALF>(live, sub, q.x, q.y, q.z, Tp, nt, best, best_i);
+      best = r.best;
+      best_i = r.best_i;
+      if (r.redone) best_k = -1;  // (looked up below, like the seed's)
+    }
     // Results leave from the first lanes of the query's group (every lane holds the merged result): lane 0 writes distance and
     // index and adds the term; in the chamfer gradient mode lanes 0..2 take one coordinate each -- the 12 bytes of the query's own
     // term are then consecutive lanes of ONE store instruction and the nearest target's three atomics ONE request (a global
@@ -682,8 +722,8 @@ __global__ __launch_bounds__(256, (MODE == SDG_GRAD ? KAMD_SDG_QUERY_WAVES : 1))
           // coalesced store at its slot, and the atomics of neighbouring queries land on neighbouring targets
           float k = fwd ? fz.c1 : fz.c2;
           if (!fz.squared) k = k / (2.f * root);
-          if (best_k < 0) {  // the seed (target 0) is the nearest: its place in the sorted targets
-            const int2 cr = (fwd ? T.cellrank : A.cellrank)[(size_t)b * nt];
+          if (best_k < 0) {  // the seed (target 0) is the nearest, or the winner was redone: its place in the sorted targets
+            const int2 cr = (fwd ? T.cellrank : A.cellrank)[(size_t)b * nt + best_i];
             best_k = Tstart[cr.x] + cr.y;
           }
           const V4 t = Tsorted[best_k];

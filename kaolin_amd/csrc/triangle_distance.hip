@@ -12,8 +12,10 @@
 // -fmad=true makes of the reference's expressions (same pin in oracle/tridist_oracle.inc; the unfused evaluation of rounds
 // 1-2 failed the reference's own tolerance test six times as often: profiles/r03a_k7_contraction_ab.txt); point_at's
 // parameter is a float (:172).  The reference's rsqrt() (:144) is evaluated as 1 / sqrt() (IEEE), the same pin as the oracle.
-// Deviation (documented in DESIGN.md): the reference re-seeds its running best at every 1024-face (512 for
-// double) tile, which only matters when a tile's first face yields a NaN distance; here only face 0 seeds.
+// The reference re-seeds its running best at every block of 512 faces (the forward launcher's BLOCK_SIZE for float and double,
+// :424-433; :303,:310): a block whose FIRST face yields a NaN distance for a query is ignored as a whole for it.  The searches
+// here take the minimum over all faces (NaN never wins, face 0 seeds); td_reseed_check_kernel / td_reseed_slow_kernel then redo
+// the queries whose winner sits in such a block over the live blocks only -- the reference's answer on every input.
 //
 // MI355X design.  This is an all-pairs search (N x F closest-point evaluations, ~90 VALU each with three IEEE
 // divides): VALU-bound by orders of magnitude, so the work is cut rather than the bytes:
@@ -29,7 +31,6 @@
 //     and only the tiles that come closer than a query's best bound are staged and walked (identical results).
 #include <string.h>
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_radix_sort.hpp>
 #include "common.h"
 #include <stdlib.h>
 #include "profile.h"
@@ -62,10 +63,14 @@ template <typename T> __device__ __forceinline__ T td_abs(T x) { return x < 0 ? 
 template <typename T> __device__ __forceinline__ T max3abs(V3<T> v) { return fmax(td_abs(v.x), fmax(td_abs(v.y), td_abs(v.z))); }
 
 // ---- per-face invariants ----------------------------------------------------------------------------
+// blk_flag[b] != 0: face 512 b (the first of the reference's block b) may yield a NaN distance for an ordinary query;
+// queue_count: the re-seed pass' append counter, zeroed here.
 template <typename T>
 __global__ __launch_bounds__(256) void td_prep_kernel(int F, const T* __restrict__ faces, T* __restrict__ rec,
-                                                      float* __restrict__ centres, float* __restrict__ radius) {
+                                                      float* __restrict__ centres, float* __restrict__ radius,
+                                                      int* __restrict__ blk_flag, int* __restrict__ queue_count) {
   const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f == 0) *queue_count = 0;
   if (f >= F) return;
   const T* fv = faces + (size_t)f * 9;
   const V3<T> v1 = ld3(fv), v2 = ld3(fv + 3), v3 = ld3(fv + 6);
@@ -97,20 +102,70 @@ __global__ __launch_bounds__(256) void td_prep_kernel(int F, const T* __restrict
   // triangle.  The reference's value is the computed one, and for a face without area it can be far below the true distance: the
   // cross product of two (nearly) parallel edges is the rounding error of its products, project_plane() then measures the distance
   // to a plane of arbitrary orientation through v1 (dist_type 0) -- a face with two equal vertices seen from afar may "win" with a
-  // distance of 1e-4.  The reference's sequential loop takes such a face; so must we: a face whose normal is not resolved
-  // (|n| <= 4e4 eps |a| |b|: relative direction error above ~1e-4, the head-room of the bounds; also zero, NaN and underflowed
-  // normals) gets an infinite radius -- the face tests never cull it, and neither do its tile's (non-finite tile radius).
+  // distance of 1e-4.  The reference's sequential loop takes such a face; so must we.  Three kinds of face whose normal is not
+  // resolved (|n| <= 4e4 eps |a| |b|: relative direction error above ~1e-4, the head-room of the bounds):
+  //  * the normal is EXACTLY zero (v1 == v2, v1 == v3, exactly cancelling products -- most duplicate-vertex faces of real
+  //    meshes): the unit normal is 0 * inf = NaN, the plane case yields a NaN distance, which never wins; every other case
+  //    measures the distance to a point ON the face, so the sphere bound stands: the face keeps its finite radius;
+  //  * the normal is rounding noise with a finite unit vector g: whatever case is taken, the computed distance is at least
+  //    |g . (p - c)| - radius (the plane case measures the distance to the plane through v1 with normal g, the others to points
+  //    of the face): the record carries -radius, td_face_far() tests that slab instead of the sphere, and the sweep moves such
+  //    faces behind the Hilbert order so that they do not blow up the tiles of their neighbours;
+  //  * anything else (non-finite vertices, an underflowed normal): an infinite radius -- no test culls the face.
+  const T nn = dot(normal, normal);
+  bool finite_v = true;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) finite_v = finite_v && td_abs(fv[k]) < (T)INFINITY;
   {
     const V3<T> a = v1 - v2;
     const T k = (T)4e4 * (sizeof(T) == 4 ? (T)1.1920929e-7 : (T)2.220446049250313e-16);
-    if (!(dot(normal, normal) > k * k * dot(a, a) * dot(e31, e31))) r[39] = (T)INFINITY;
+    const bool resolved = nn > k * k * dot(a, a) * dot(e31, e31);  // false for NaN
+    if (!finite_v || !(r[39] < (T)INFINITY)) {
+      r[39] = (T)INFINITY;
+    } else if (!resolved) {
+      const bool zero_normal = normal.x == 0 && normal.y == 0 && normal.z == 0;
+      const T uu = dot(ld3(r + 33), ld3(r + 33));
+      if (zero_normal) {
+        // (finite radius kept)
+      } else if (uu > (T)0.98 && uu < (T)1.02) {
+        r[39] = -r[39];
+      } else {
+        r[39] = (T)INFINITY;
+      }
+    }
+  }
+  // The reference's block-first faces (512 b): can this one yield a NaN distance for a query of ordinary size?  Not if its
+  // vertices are finite and of moderate size, its three edges have a non-zero squared length and its unit normal is finite (then
+  // every quotient is finite or +-inf, never 0/0 or inf/inf, and no sum mixes infinities) -- td_reseed_check_kernel evaluates
+  // the flagged ones, and every block-first face for a query that is itself huge or not finite.
+  if ((f & 511) == 0) {
+    const T big = sizeof(T) == 4 ? (T)1e9 : (T)1e75;
+    bool clean = finite_v && r[21] > 0 && r[22] > 0 && r[23] > 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) clean = clean && td_abs(fv[k]) <= big;
+#pragma unroll
+    for (int k = 33; k < 36; ++k) clean = clean && td_abs(r[k]) < (T)INFINITY;
+    blk_flag[f >> 9] = clean ? 0 : 1;
   }
   if (centres != nullptr) {  // float copies for the Morton sort / tile spheres (radius rounded up)
     centres[(size_t)f * 3 + 0] = (float)c.x;
     centres[(size_t)f * 3 + 1] = (float)c.y;
     centres[(size_t)f * 3 + 2] = (float)c.z;
-    radius[f] = (float)r[39] * 1.000001f + 1e-30f;
+    // (a face tested by its own slab says nothing about its tile: infinite, like the faces nothing culls)
+    radius[f] = r[39] < 0 ? INFINITY : (float)r[39] * 1.000001f + 1e-30f;
   }
+}
+
+// can face record r be skipped for a query with pc = p - centre, d2c = |pc|^2 and reach = sqrt(best) with head-room?  (false for
+// NaN / inf: then the face is evaluated).  PLANE: also test the distance to the face's plane (the sweep; the all-pairs kernel keeps
+// its 11-instruction sphere test).  A negative radius marks a face whose normal is rounding noise (td_prep_kernel).
+template <typename T, bool PLANE>
+__device__ __forceinline__ bool td_face_far(const T* __restrict__ r, V3<T> pc, T d2c, T reach, int mode = 0) {
+  const T rad = r[39];
+  if (rad < 0) return td_abs(pc.x * r[33] + pc.y * r[34] + pc.z * r[35]) + rad > reach;
+  const T rr = reach + rad;
+  if (d2c > rr * rr) return true;
+  return PLANE && !(mode & 2) && rad < (T)INFINITY && td_abs(pc.x * r[33] + pc.y * r[34] + pc.z * r[35]) > reach;
 }
 
 // closest-point evaluation of one (point, face record) pair; returns the float-rounded squared distance
@@ -183,8 +238,7 @@ __global__ __launch_bounds__(TD_THREADS) void td_main_kernel(
       const T* r = tile + k * TD_REC;
       const V3<T> pc = p - ld3(r + 36);
       const T d2c = dot(pc, pc);
-      const T reach = bound + r[39];
-      const bool skip = d2c > reach * reach;  // false for NaN / inf: then the face is evaluated
+      const bool skip = td_face_far<T, false>(r, pc, d2c, bound);  // false for NaN / inf: then the face is evaluated
       if (!__any(active && !skip)) continue;
       if (!active || skip) continue;
       int type;
@@ -344,6 +398,139 @@ __global__ __launch_bounds__(256) void td_backward_kernel(
   }
 }
 
+
+// ---- the reference's block re-seed ---------------------------------------------------------------------------------------
+// unbatched_triangle_distance_cuda.cu:247-313: faces are walked in blocks of 512; inside a block the running best is seeded
+// UNCONDITIONALLY by the block's first face (`sub_face_idx == 0 ||`, :303) and improved by `best_dist > dist`; blocks are merged
+// with `start_face_idx == 0 || out_dist > best_dist` (:310).  A block whose first face yields NaN for a query is therefore
+// ignored as a whole for it (block 0: the NaN sticks).  The searches above return the minimum over ALL faces with face 0's seed
+// rule, which is the reference's answer unless the winner sits in such a dead block: td_reseed_check_kernel evaluates the first
+// face of the winner's block (only where td_prep_kernel flagged it, or for a query that is itself huge / not finite: everything
+// else cannot yield NaN) and queues the query; td_reseed_slow_kernel redoes a queued query over the live blocks, a workgroup each.
+constexpr int TD_REF_BLOCK = 512;
+
+struct TdReseed {
+  int* blk_flag;     // ceil(F / 512)
+  int* queue_count;  // 1 (zeroed by td_prep_kernel)
+  int* queue;        // N
+};
+inline size_t td_reseed_bytes(int N, int F) {
+  return (((size_t)kamd_cdiv(F, TD_REF_BLOCK) * 4 + 255) & ~(size_t)255) + 256 + (((size_t)N * 4 + 255) & ~(size_t)255);
+}
+inline TdReseed td_reseed_layout(char* base, int N, int F) {
+  TdReseed r;
+  r.blk_flag = (int*)base;
+  base += ((size_t)kamd_cdiv(F, TD_REF_BLOCK) * 4 + 255) & ~(size_t)255;
+  r.queue_count = (int*)base;
+  r.queue = (int*)(base + 256);
+  (void)N;
+  return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void td_reseed_check_kernel(int N, const T* __restrict__ points, const T* __restrict__ rec,
+                                                              const int* __restrict__ blk_flag, const int64_t* __restrict__ face_idx,
+                                                              int* __restrict__ queue_count, int* __restrict__ queue) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool dead = false;
+  if (i < N) {
+    const int bf = (int)face_idx[i];
+    if (bf >= TD_REF_BLOCK) {
+      const int blk = bf / TD_REF_BLOCK;
+      const V3<T> p = ld3(points + (size_t)i * 3);
+      const T big = sizeof(T) == 4 ? (T)1e9 : (T)1e75;
+      if (blk_flag[blk] != 0 || !(max3abs(p) <= big)) {
+        int type;
+        const float d = td_eval<T>(rec + (size_t)blk * TD_REF_BLOCK * TD_REC, p, &type);
+        dead = d != d;
+      }
+    }
+  }
+  const unsigned long long m = __ballot(dead);
+  if (m == 0ull) return;
+  const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(queue_count, __popcll(m));
+  base = __shfl(base, leader, 64);
+  if (dead) queue[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void td_reseed_slow_kernel(int F, const T* __restrict__ points, const T* __restrict__ rec,
+                                                             const int* __restrict__ queue_count, const int* __restrict__ queue,
+                                                             T* __restrict__ out_dist, int64_t* __restrict__ out_idx,
+                                                             int32_t* __restrict__ out_type) {
+  __shared__ float s_d[4];
+  __shared__ int s_f[4], s_t[4];
+  const int n = *queue_count;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int q = blockIdx.x; q < n; q += gridDim.x) {
+    const int i = queue[q];
+    const V3<T> p = ld3(points + (size_t)i * 3);
+    // block 0 is live (a NaN at face 0 sticks and such a query is never queued): every thread starts from face 0
+    int type;
+    float best = td_eval<T>(rec, p, &type);
+    int best_f = 0;
+    for (int b0 = 0; b0 < F; b0 += TD_REF_BLOCK) {
+      if (b0 != 0) {
+        int t0;
+        const float d0 = td_eval<T>(rec + (size_t)b0 * TD_REC, p, &t0);  // (uniform over the workgroup)
+        if (d0 != d0) continue;
+      }
+      const int b1 = min(F, b0 + TD_REF_BLOCK);
+      for (int f = b0 + (int)threadIdx.x; f < b1; f += 256) {
+        int t;
+        const float d = td_eval<T>(rec + (size_t)f * TD_REC, p, &t);
+        if (d < best) {  // ascending f per thread: the lowest index of a thread's ties stays; NaN never wins
+          best = d;
+          best_f = f;
+          type = t;
+        }
+      }
+    }
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+      const float od = __shfl_xor(best, sh, 64);
+      const int of = __shfl_xor(best_f, sh, 64), ot = __shfl_xor(type, sh, 64);
+      if (od < best || (od == best && of < best_f)) {
+        best = od;
+        best_f = of;
+        type = ot;
+      }
+    }
+    __syncthreads();  // the previous query's reader is done
+    if (lane == 0) {
+      s_d[wave] = best;
+      s_f[wave] = best_f;
+      s_t[wave] = type;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (s_d[w] < best || (s_d[w] == best && s_f[w] < best_f)) {
+          best = s_d[w];
+          best_f = s_f[w];
+          type = s_t[w];
+        }
+      out_dist[i] = (T)best;
+      out_idx[i] = best_f;
+      out_type[i] = type;
+    }
+  }
+}
+
+template <typename T>
+int td_reseed_launch(hipStream_t st, int N, int F, const T* points, const T* rec, const TdReseed& rs, T* dist, int64_t* face_idx,
+                     int32_t* dist_type) {
+  if (F <= TD_REF_BLOCK) return 0;  // a single block: nothing to re-seed
+  kamd::ProfScope prof_(kamd::K_TD_FINAL, st);
+  hipLaunchKernelGGL(td_reseed_check_kernel<T>, dim3(kamd_cdiv(N, 256)), dim3(256), 0, st, N, points, rec, (const int*)rs.blk_flag,
+                     (const int64_t*)face_idx, rs.queue_count, rs.queue);
+  hipLaunchKernelGGL(td_reseed_slow_kernel<T>, dim3(KAMD_NUM_CU * 4), dim3(256), 0, st, F, points, rec, (const int*)rs.queue_count,
+                     (const int*)rs.queue, dist, face_idx, dist_type);
+  return (int)hipGetLastError();
+}
+
 inline size_t td_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 #include "triangle_sweep.inc"
@@ -380,6 +567,8 @@ int td_forward_launch(hipStream_t st, int N, int F, const T* points, const T* fa
   const TdPlan p = td_plan(N, F);
   T* rec = (T*)workspace;
   char* w = (char*)workspace + td_align((size_t)F * TD_REC * sizeof(T));
+  const TdReseed rs = td_reseed_layout(w, N, F);
+  w += td_reseed_bytes(N, F);
   T* part_d = (T*)w;
   w += td_align((size_t)p.S * N * sizeof(T));
   int* part_i = (int*)w;
@@ -388,7 +577,7 @@ int td_forward_launch(hipStream_t st, int N, int F, const T* points, const T* fa
   {
     kamd::ProfScope prof_(kamd::K_TD_PREP, st);
     hipLaunchKernelGGL(td_prep_kernel<T>, dim3(kamd_cdiv(F, 256)), dim3(256), 0, st, F, faces, rec, (float*)nullptr,
-                       (float*)nullptr);
+                       (float*)nullptr, rs.blk_flag, rs.queue_count);
   }
   KAMD_CHECK(hipGetLastError());
   {
@@ -402,7 +591,8 @@ int td_forward_launch(hipStream_t st, int N, int F, const T* points, const T* fa
     hipLaunchKernelGGL(td_final_kernel<T>, dim3(kamd_cdiv(N, 256)), dim3(256), 0, st, N, p.S, part_d, part_i, part_t,
                      dist, face_idx, dist_type);
   }
-  KAMD_RETURN_LAST_ERROR();
+  KAMD_CHECK(hipGetLastError());
+  return td_reseed_launch<T>(st, N, F, points, (const T*)rec, rs, dist, face_idx, dist_type);
 }
 
 template <typename T>
@@ -424,9 +614,9 @@ extern "C" {
 size_t kamd_triangle_distance_forward_workspace(int N, int F, int elem_size) {
   if (N <= 0 || F <= 0) return 0;
   const TdPlan p = td_plan(N, F);
-  const size_t brute = td_align((size_t)F * TD_REC * elem_size) + td_align((size_t)p.S * N * elem_size) +
+  const size_t brute = td_align((size_t)F * TD_REC * elem_size) + td_reseed_bytes(N, F) + td_align((size_t)p.S * N * elem_size) +
                        2 * td_align((size_t)p.S * N * sizeof(int));
-  const size_t sweep = td_align((size_t)F * TD_REC * elem_size) + ts_layout(nullptr, N, F, elem_size).total;
+  const size_t sweep = td_align((size_t)F * TD_REC * elem_size) + td_reseed_bytes(N, F) + ts_layout(nullptr, N, F, elem_size).total;
   return brute > sweep ? brute : sweep;  // either path may be taken (KAMD_TRIANGLE_DISTANCE)
 }
 int kamd_triangle_distance_forward_f32(void* stream, int N, int F, const float* points, const float* faces, float* dist,

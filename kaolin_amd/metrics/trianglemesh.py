@@ -20,8 +20,11 @@ class _UnbatchedTriangleDistanceCuda(torch.autograd.Function):
     def forward(ctx, points, face_vertices):
         pts, tris = points.contiguous(), face_vertices.contiguous()
         n, dev = pts.shape[0], pts.device
-        out = (torch.zeros(n, device=dev, dtype=pts.dtype), torch.zeros(n, device=dev, dtype=torch.long),
-               torch.zeros(n, device=dev, dtype=torch.int32))
+        # the operator writes every element of its three outputs when there is a face; with none they keep the zeros the
+        # reference allocates (unbatched_triangle_distance_cuda.cu:247: the loop never runs)
+        alloc = torch.empty if tris.shape[0] > 0 else torch.zeros
+        out = (alloc(n, device=dev, dtype=pts.dtype), alloc(n, device=dev, dtype=torch.long),
+               alloc(n, device=dev, dtype=torch.int32))
         _C.metrics.unbatched_triangle_distance_forward_cuda(pts, tris, *out)
         ctx.mark_non_differentiable(out[1], out[2])
         ctx.set_materialize_grads(False)
@@ -54,6 +57,8 @@ def point_to_mesh_distance(pointclouds, face_vertices):
     # GPU tensors take the HIP operator, CPU tensors the torch formulation below (the reference's split, :88-93)
     fn = _UnbatchedTriangleDistanceCuda.apply if pointclouds.is_cuda else _unbatched_naive_point_to_mesh_distance
     per_item = [fn(pointclouds[b], face_vertices[b]) for b in range(pointclouds.shape[0])]
+    if len(per_item) == 1:  # (B = 1: the item's outputs with a leading axis, no copy -- torch.stack would move 16 B per point)
+        return tuple(column.unsqueeze(0) for column in per_item[0])
     return tuple(torch.stack(column, dim=0) for column in zip(*per_item))
 
 

@@ -357,3 +357,56 @@ def test_bench_two_processes_sharing_gpu0(tmp_path):
     a, b = torch.load(g2).double(), torch.load(g1).double()
     assert a.shape == b.shape and float(b.abs().max()) > 0
     assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
+@pytest.mark.gpu
+def test_bench_gpus_flag_launches_its_own_ranks(tmp_path):
+    """plain `python bench.py --gpus 2 --quick` (no launcher) must run TWO ranks by itself -- it re-executes
+    under torch.distributed.run -- and print one line with n_gpus 2; a launcher-made job whose world disagrees with --gpus is an
+    error, not a silent one-rank run."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['KAMD_DIST_BACKEND'] = 'gloo'
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--quick', '--steps', '3', '--warmup', '1', '--res', '256',
+           '--sphere-frequency', '16']
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=380)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['config']['global_views'] == 16 and line['distributed']['initialized']
+    assert line['distributed']['collectives_posted_per_step'] == 1 and line['distributed']['ranks_per_gpu'] == 2
+    bad = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+                          '127.0.0.1', '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--quick'],
+                         env=env, capture_output=True, text=True, timeout=280)
+    assert bad.returncode != 0 and '--gpus 2' in (bad.stdout + bad.stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_eight_rank_dress_rehearsal_of_c4(tmp_path):
+    """The 8-GPU run of config C4 as far as a one-GPU box can rehearse it: `python bench.py --gpus 8` launches eight ranks that
+    share GPU 0 (gloo carries the collective), 8 views of the 50 000-face sphere at 1024^2 each = the 64 global views of
+    BASELINE.json's configs[3]; the line must say so, post ONE collective per step, and rank 0's all-reduced vertex gradient must
+    equal a single process rendering the same 64 views."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['KAMD_DIST_BACKEND'] = 'gloo'
+    g8, g1 = str(tmp_path / 'grad8.pt'), str(tmp_path / 'grad1.pt')
+    common = ['--quick', '--steps', '2', '--warmup', '1', '--no-scene-variants']
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--dump-vertex-grad', g8] + common, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 8 and line['config']['global_views'] == 64 and line['config']['views_per_gpu'] == 8
+    assert line['config']['height'] == 1024 and line['config']['faces'] == 50000
+    assert line['distributed']['collectives_posted_per_step'] == 1 and line['scaling'] == 'weak'
+    assert abs(line['value'] - 64 * 1024 * 1024 / (line['ms_per_step'] * 1e-3) / 1e6) <= 1e-3 * line['value']
+    one = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--views-per-gpu', '64', '--dump-vertex-grad', g1]
+                         + common, env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-4000:]
+    a, b = torch.load(g8).double(), torch.load(g1).double()
+    assert a.shape == b.shape and float(b.abs().max()) > 0
+    assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())

@@ -613,3 +613,81 @@ def test_fused_chamfer_on_concurrent_streams():
             torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         assert all(torch.equal(o, r) for o, r in zip(outs, ref))
+
+
+def _nan_safe_equal(a, b):
+    return torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a.double()), torch.nan_to_num(b.double()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float, torch.double, torch.half])
+@pytest.mark.parametrize('shape', [(2, 3000, 9000), (1, 700, 2100), (2, 5000, 40000)])
+def test_reference_reseed_at_every_512_targets(dtype, shape):
+    """The reference seeds its running minimum again at every tile of 512 targets (`k == 0 ||`, sided_distance_cuda.cu:88,138,187,
+    merged with `result > best`, :193): a NaN distance at a tile's FIRST target hides the whole tile for that query.
+    Non-finite targets sit at indices 512 k here -- NaN (hides the tile for every query), +inf (hides it for a query with +inf in
+    the same coordinate) -- and elsewhere (never win); grid path, all-pairs fast path, the generic kernel, every float dtype:
+    distances and indices must equal the oracle's, which walks the reference's tiles."""
+    pc = _pc()
+    B, N, M = shape
+    g = torch.Generator().manual_seed(M + N)
+    p1, p2 = torch.rand(B, N, 3, generator=g), torch.rand(B, M, 3, generator=g)
+    p2[0, 512, 1] = float('nan')
+    p2[0, 1536, 0] = float('inf')
+    p2[0, 1537, 0] = float('nan')           # not a tile start: never wins, hides nothing
+    p2[B - 1, 2048, 2] = float('nan')
+    if M > 20000:
+        p2[0, 512 * 37, 0] = float('nan')
+        p2[B - 1, 512 * 64, 1] = float('-inf')
+    p1[0, 11, 0] = float('inf')             # d = NaN against the +inf target at 1536: that tile is dead for this query only
+    p1[B - 1, 12, 1] = float('-inf')
+    # queries right at points of the hidden tiles: their true nearest neighbour is ignored by the reference
+    p1[0, 100:400] = p2[0, 513:813] + 1e-3
+    p1[B - 1, 500:550] = p2[B - 1, 2049:2099]
+    p1, p2 = p1.to(dtype), p2.to(dtype)
+    d_ref, i_ref = oracle.sided_distance_forward(p1, p2, omp=True)
+    assert int((i_ref[0, 100:400] // 512 == 1).sum()) == 0          # (the case is what it claims to be)
+    for force in (None, 'brute'):
+        if force:
+            os.environ['KAMD_SIDED_DISTANCE'] = force
+        try:
+            d, i = pc.sided_distance(p1.cuda(), p2.cuda())
+        finally:
+            os.environ.pop('KAMD_SIDED_DISTANCE', None)
+        assert torch.equal(i.cpu(), i_ref), f'{force}: {int((i.cpu() != i_ref).sum())} indices differ'
+        assert _nan_safe_equal(d.cpu(), d_ref), force
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('squared', [True, False])
+def test_chamfer_with_nan_targets_at_tile_starts(squared):
+    """The fused chamfer operator (grid search in both directions, gradient pieces left by the search launch) with NaN points at
+    indices 512 k of either cloud: value and both gradients must equal the composition of sided_distance calls, whose indices the
+    previous test pins to the oracle."""
+    pc = _pc()
+    B, N, M = 2, 9000, 10000
+    g = torch.Generator().manual_seed(77)
+    p1, p2 = torch.rand(B, N, 3, generator=g), torch.rand(B, M, 3, generator=g)
+    p2[0, 1024, 0] = float('nan')
+    p1[1, 4096, 2] = float('nan')
+    p1[0, 200:300] = p2[0, 1100:1200] + 1e-3
+    a, b = p1.cuda().requires_grad_(True), p2.cuda().requires_grad_(True)
+    out = pc.chamfer_distance(a, b, 1., 1., squared=squared)
+    assert type(out.grad_fn).__name__.startswith('_ChamferDistanceFunction')
+    out.sum().backward()
+    a2, b2 = p1.cuda().requires_grad_(True), p2.cuda().requires_grad_(True)
+    (d1, i1), (d2, i2) = pc.sided_distance(a2, b2), pc.sided_distance(b2, a2)
+    i1_ref = oracle.sided_distance_forward(p1, p2, omp=True)[1]
+    i2_ref = oracle.sided_distance_forward(p2, p1, omp=True)[1]
+    assert torch.equal(i1.cpu(), i1_ref) and torch.equal(i2.cpu(), i2_ref)
+    if not squared:
+        d1, d2 = d1.sqrt(), d2.sqrt()
+    ref = d1.mean(-1) + d2.mean(-1)
+    ref.sum().backward()
+    # (a NaN point makes its own distance NaN, hence the item's mean and every gradient of the item through the mean's scale: the
+    # comparison is on the NaN pattern and on the finite entries)
+    assert _nan_safe_equal(torch.nan_to_num(out.detach().cpu(), nan=-1.).float(), torch.nan_to_num(ref.detach().cpu(), nan=-1.).float()) or \
+        torch.allclose(torch.nan_to_num(out.detach(), nan=-1.), torch.nan_to_num(ref.detach(), nan=-1.), rtol=2e-6, atol=0)
+    for got, want in ((a.grad, a2.grad), (b.grad, b2.grad)):
+        assert torch.equal(torch.isnan(got), torch.isnan(want))
+        assert _scale_close(torch.nan_to_num(got), torch.nan_to_num(want))

@@ -328,3 +328,77 @@ def test_gpu_sweep_ties_duplicates_and_non_finite(dtype):
     same = lambda a, b: torch.equal(torch.nan_to_num(a.double(), nan=-7.), torch.nan_to_num(b.double(), nan=-7.))  # noqa: E731
     assert torch.equal(i_s, i_b) and torch.equal(t_s, t_b) and same(d_s, d_b)
     assert torch.equal(i_s.cpu(), i_ref) and torch.equal(t_s.cpu(), t_ref) and same(d_s.cpu(), d_ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float, torch.double])
+@pytest.mark.parametrize('N,F', [(70000, 5000), (4000, 3000)])
+def test_gpu_reference_block_reseed(dtype, N, F):
+    """The reference seeds its running best again at every block of 512 faces (`sub_face_idx == 0 ||`,
+    unbatched_triangle_distance_cuda.cu:303, merged with `out_dist > best_dist`, :310): a block whose FIRST face yields a NaN
+    distance for a query is ignored as a whole for it.  Faces 512 k are degenerate here in the ways that yield NaN -- v1 == v2 (NaN
+    for the queries beyond v1: query dependent), a NaN vertex (every query), a vertex at +inf -- next to queries that sit ON faces
+    of the hidden blocks, a huge and an infinite query; the sweep (default from 65536 queries) and the all-pairs kernels must both
+    equal the oracle, which walks the reference's blocks."""
+    g = torch.Generator().manual_seed(F + N)
+    c = torch.rand(F, 1, 3, generator=g)
+    fv = c + (torch.rand(F, 3, 3, generator=g) - 0.5) * 0.06
+    fv[512, 1] = fv[512, 0]
+    fv[1024, 2, 1] = float('nan')
+    fv[1536, 2] = fv[1536, 1]            # v2 == v3: the normal is rounding noise, not zero -- finite distances, nothing hidden
+    fv[2048, 0] = fv[2048, 2]
+    if F > 4608:
+        fv[4608, 0, 0] = float('inf')
+    pts = torch.rand(N, 3, generator=g)
+    pts[:300] = fv[513:813].mean(1)      # on faces of block 1
+    pts[300:600] = fv[1030:1330, 0]      # on vertices of block 2 (hidden for every query)
+    pts[600:700] = fv[2049:2149].mean(1)
+    pts[700] = torch.tensor([3e9, 0., 0.]) if dtype == torch.float else torch.tensor([1e80, 0., 0.])
+    pts[701] = torch.tensor([float('inf'), 0.5, 0.5])
+    pts[702] = torch.tensor([0.5, float('nan'), 0.5])
+    fv, pts = fv.to(dtype), pts.to(dtype)
+    d_ref, i_ref, t_ref = oracle.triangle_distance_forward(pts, fv, omp=True)
+    assert int((i_ref[300:600] // 512 == 2).sum()) == 0      # (block 2 is hidden from every query)
+    same = lambda a, b: torch.equal(torch.nan_to_num(a.double(), nan=-7.), torch.nan_to_num(b.double(), nan=-7.))  # noqa: E731
+    for force in (None, 'brute', 'sweep'):
+        if force:
+            os.environ['KAMD_TRIANGLE_DISTANCE'] = force
+        try:
+            d, i, t = _gpu_fwd(pts, fv)
+        finally:
+            os.environ.pop('KAMD_TRIANGLE_DISTANCE', None)
+        assert torch.equal(i.cpu(), i_ref), f'{force}: {int((i.cpu() != i_ref).sum())} face indices differ'
+        assert torch.equal(t.cpu().to(t_ref.dtype), t_ref) and same(d.cpu(), d_ref), force
+
+
+@pytest.mark.gpu
+def test_gpu_sweep_with_one_percent_degenerate_faces():
+    """faces without area used to give their whole 64-face tile an infinite bound (1-2 % of such faces: most tiles
+    walked by every query).  Faces whose normal is exactly zero keep their sphere, the others are moved behind the curve order and
+    tested by their own slab: results equal the oracle's, and the sweep stays within 3x of the same mesh without them."""
+    import time
+    from kaolin_amd.utils.testing import geodesic_sphere
+    v, f = geodesic_sphere(50)                      # 50 000 faces
+    fv = v[f].float()
+    g = torch.Generator().manual_seed(1)
+    bad = torch.randperm(fv.shape[0], generator=g)[:500]
+    fvd = fv.clone()
+    fvd[bad[:250], 1] = fvd[bad[:250], 0]           # v1 == v2: zero normal
+    fvd[bad[250:], 2] = fvd[bad[250:], 1]           # v2 == v3: rounding-noise normal
+    pts = torch.rand(200000, 3, generator=g) * 1.2 - 0.6
+    d_ref, i_ref, t_ref = oracle.triangle_distance_forward(pts[:20000], fvd, omp=True)
+
+    def run(mesh):
+        out = _gpu_fwd(pts, mesh)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            out = _gpu_fwd(pts, mesh)
+        torch.cuda.synchronize()
+        return out, (time.perf_counter() - t0) / 3
+    (d, i, t), t_bad = run(fvd)
+    _, t_clean = run(fv)
+    assert torch.equal(i.cpu()[:20000], i_ref) and torch.equal(t.cpu()[:20000].to(t_ref.dtype), t_ref)
+    assert torch.equal(torch.nan_to_num(d.cpu()[:20000]), torch.nan_to_num(d_ref))
+    print(f'sweep 200k x 50k: clean {t_clean * 1e3:.2f} ms, 1 % degenerate {t_bad * 1e3:.2f} ms')
+    assert t_bad < 3 * t_clean + 1e-3

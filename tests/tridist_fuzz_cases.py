@@ -33,14 +33,14 @@ def check_case(case):
     elif kind == 'mixed_sizes':
         fv = c + (r(F, 3, 3) - 0.5) * (10.0 ** (r(F, 1, 1) * 4 - 3))
     elif kind == 'degenerate':
-        keep = fv[512::512].clone()
         fv[::3, 2] = fv[::3, 1]                     # two equal vertices
         fv[1::5] = fv[1::5, :1]                     # a point
         fv[2::7, 2] = (fv[2::7, 0] + fv[2::7, 1]) / 2   # collinear
-        # (not at faces 512, 1024, ...: the reference re-seeds its running best at every block of 512 faces, so
-        # a block whose FIRST face yields NaN is ignored as a whole -- the documented deviation of DESIGN section 2, which this sweep is
-        # not about; it showed up here as faces 1536+ found by the GPU and ignored by the oracle)
-        fv[512::512] = keep
+        # Faces 512, 1024, ... take part: the reference re-seeds its running best at every block of 512 faces, so a block whose
+        # FIRST face yields NaN for a query is ignored as a whole for it (unbatched_triangle_distance_cuda.cu:303,310) -- the GPU
+        # follows since round 5 (td_reseed_*), and half of the cases put a face with v1 == v2 (NaN for the queries beyond v1) there
+        if (case // 2) % 2 == 1:
+            fv[512::512, 1] = fv[512::512, 0]
     elif kind == 'duplicates':
         fv = fv[torch.randint(0, max(F // 6, 1), (F,), generator=g)]
     elif kind == 'flat':
