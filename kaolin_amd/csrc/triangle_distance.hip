@@ -162,10 +162,21 @@ __global__ __launch_bounds__(256) void td_prep_kernel(int F, const T* __restrict
 template <typename T, bool PLANE>
 __device__ __forceinline__ bool td_face_far(const T* __restrict__ r, V3<T> pc, T d2c, T reach, int mode = 0) {
   const T rad = r[39];
+#ifdef KAMD_TD_FAR_BRANCHY
   if (rad < 0) return td_abs(pc.x * r[33] + pc.y * r[34] + pc.z * r[35]) + rad > reach;
   const T rr = reach + rad;
   if (d2c > rr * rr) return true;
   return PLANE && !(mode & 2) && rad < (T)INFINITY && td_abs(pc.x * r[33] + pc.y * r[34] + pc.z * r[35]) > reach;
+#else
+  // (straight-line: this test runs ~1e8 times per call at C5, a branch on the face's kind costs more than the four selects)
+  const bool slab_only = rad < 0;
+  const T rr = reach + rad;
+  const bool sphere_far = d2c > rr * rr && !slab_only;
+  if (!PLANE) return sphere_far || (slab_only && td_abs(pc.x * r[33] + pc.y * r[34] + pc.z * r[35]) + rad > reach);
+  const T h = td_abs(pc.x * r[33] + pc.y * r[34] + pc.z * r[35]);
+  const bool plane_far = (slab_only || !(mode & 2)) && rad < (T)INFINITY && h > (slab_only ? reach - rad : reach);
+  return sphere_far || plane_far;
+#endif
 }
 
 // closest-point evaluation of one (point, face record) pair; returns the float-rounded squared distance
