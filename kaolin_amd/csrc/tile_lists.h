@@ -152,6 +152,18 @@ struct Lists {
 };
 
 inline size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
+// The rasterizer's plan (raster3.inc): which tiles hold work -- entries of their own, a big face over them, or a shape the
+// streaming fill does not take (a partial tile at the image's edge) -- as one 64-bit word per (view, tile row, 64 tiles) and as
+// PLAN_GROUPS compact lists {view, ty << 16 | tx}: list g holds the tiles of the views b % 8 == g (workgroup w runs on XCD w % 8: a
+// view's records and features stay in one XCD's L2), rows from the middle of the covered rows outwards.
+constexpr int PLAN_GROUPS = 8;
+constexpr int PLAN_MAX_UNITS = 2048;  // (tile rows) x (64-tile segments per row) of one view that the plan kernel holds in LDS
+struct RasterPlan {
+  unsigned int* count;            // [PLAN_GROUPS]
+  uint2* list;                    // [PLAN_GROUPS * cap]
+  unsigned long long* work_rows;  // [B * tiles_y * segs]
+  unsigned int cap;
+};
 __host__ __device__ inline int big_row_words(int tiles_x) { return (tiles_x + 63) >> 6; }
 inline unsigned int pool_chunks(long long total_faces, long long n_tiles_total) {
   // entries the pool can take beyond the inline slots.  A face adds at most one entry per tile of its rectangle (fewer when its
@@ -169,6 +181,8 @@ inline unsigned int pool_chunks(long long total_faces, long long n_tiles_total) 
 struct PassLayout {
   size_t count, tab, pool_top, big_count, big_rows, sub_touched, row_span;  // inside the zero region
   size_t inl, pool, big_list, rec;                      // after it
+  size_t plan_count, plan_list, plan_rows;               // raster pass: the plan of the tiles that hold work (RasterPlan)
+  unsigned int plan_cap;
   size_t pixcnt, prob_pm;                // soft pass: hits per (item, pixel) (u16); pixel-major probabilities (knum > 128 only)
   unsigned int cap_chunks;
   int C, maxc;
@@ -209,6 +223,10 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
     L.r.pool = off; off += a256((size_t)L.r.cap_chunks * OVC * 16);
     L.r.big_list = off; off += a256((size_t)total_faces * 4);
     L.r.rec = off; off += a256((size_t)total_faces * REC_R * esz);
+    L.r.plan_cap = (unsigned int)(((size_t)B + PLAN_GROUPS - 1) / PLAN_GROUPS * L.r.g.ntiles);
+    L.r.plan_count = off; off += 256;
+    L.r.plan_list = off; off += a256((size_t)PLAN_GROUPS * L.r.plan_cap * 8);
+    L.r.plan_rows = off; off += a256((size_t)B * L.r.g.tiles_y * big_row_words(L.r.g.tiles_x) * 8);
   }
   if (with_s) {
     L.s.cap_chunks = pool_chunks(total_faces, (long long)nts);
@@ -271,6 +289,10 @@ inline size_t work_words(int B, int H, int W) {
   return work_covlist_offset_words(B, H, W) + (size_t)COV_SHARDS * cov_shard_cap((size_t)B, (size_t)pass_geom(H, W, R_TILE).ntiles);
 }
 
+inline RasterPlan plan_of(void* ws, const PassLayout& p) {
+  char* c = (char*)ws;
+  return RasterPlan{(unsigned int*)(c + p.plan_count), (uint2*)(c + p.plan_list), (unsigned long long*)(c + p.plan_rows), p.plan_cap};
+}
 inline Lists lists_of(void* ws, const PassLayout& p, int B, bool soft) {
   char* c = (char*)ws;
   Lists l;
