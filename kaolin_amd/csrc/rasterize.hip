@@ -428,6 +428,13 @@ int raster2_draw(hipStream_t st, int B, int H, int W, int D, int F_dense, float 
   if (!raster2_grid_fits(H, W)) return (int)hipErrorInvalidValue;
   kamd::ProfScope prof_(kamd::K_RASTER_TILE, st);
   const int wide_ok = raster2_wide_ok(W, interp, sel_idx, weights, co.soft_mask) | (weights_internal ? 2 : 0);
+  if constexpr (sizeof(T) == 4) {
+    if (raster4_applicable()) {
+      hipLaunchKernelGGL((raster_wave_kernel<true>), raster4_grid(LR, B), dim3(256), 0, st, B, F_dense, (const int64_t*)nullptr, H, W, D,
+                         pixel_scale(multiplier, H, W), eps, wide_ok, rec, LR, feat, interp, sel_idx, weights, co, LR.ntiles / LR.tiles_x);
+      return (int)hipGetLastError();
+    }
+  }
   if (plan != nullptr && raster3_applicable(H, W, LR)) {
     const int tiles_y = LR.ntiles / LR.tiles_x;
     hipLaunchKernelGGL(raster_plan_kernel, dim3(tl::PLAN_GROUPS), dim3(256), 0, st, LR, *plan, B, H, W, tiles_y,

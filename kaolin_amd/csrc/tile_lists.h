@@ -1118,6 +1118,39 @@ __device__ __forceinline__ void queue_items_reached(unsigned long long unc, unsi
     }
   }
 }
+// queue_items_reached for a tile owned by ONE wavefront (raster4.inc): `unc[w]` = the uncovered pixels of the tile's 16 x 4 strip w,
+// `covered` = the tile holds a covered pixel.  Called by the whole wavefront (uniform arguments); lane 0 appends.
+__device__ __forceinline__ void queue_items_wave(const unsigned long long* unc, unsigned int reach, bool covered, int B, int b, int tx, int ty,
+                                                 int tiles_x_s, int lane, unsigned int tile_order, uint4* __restrict__ work_items,
+                                                 unsigned int* __restrict__ work_counts, unsigned int shard_cap,
+                                                 unsigned char* __restrict__ tile_cov, size_t cov_index, size_t ntiles_r) {
+  if (lane != 0) return;
+  const unsigned int shard = (tile_order * (unsigned int)B + (unsigned int)b) & (WORK_SHARDS - 1);
+  if (tile_cov != nullptr) {
+    tile_cov[cov_index] = covered ? 1 : 0;
+    if (covered) {  // the covered-tile list lives behind the coverage bytes and the span copy (work_covlist_offset_words)
+      const unsigned int cs = cov_shard_of(B, b, tile_order);
+      const unsigned int pos = atomicAdd(work_counts + WORK_COV_WORD + cs * COUNTER_STRIDE, 1u);
+      unsigned int* list = reinterpret_cast<unsigned int*>(tile_cov) + cov_list_words_after_cov((size_t)B, (size_t)B * ntiles_r);
+      const unsigned int cap = cov_shard_cap((size_t)B, ntiles_r);
+      if (pos < cap) list[(size_t)cs * cap + pos] = (unsigned int)cov_index;
+    }
+  }
+  int n = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) n += (unc[w] != 0ull && reached(reach, w)) ? 1 : 0;
+  if (n > 0) {
+    unsigned int pos = atomicAdd(work_counts + shard * COUNTER_STRIDE, (unsigned int)n);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const unsigned long long u = unc[w];
+      if (u == 0ull || !reached(reach, w)) continue;
+      if (pos < shard_cap)
+        work_items[(size_t)shard * shard_cap + pos] = make_uint4(item_id_of(B, b, tx, ty, tiles_x_s, w), (unsigned int)u, (unsigned int)(u >> 32), 0u);
+      ++pos;
+    }
+  }
+}
 // A background tile that lies fully inside the image: every pixel of every sub-tile is uncovered, so ONE lane can queue
 // the tile's items without hearing from the other wavefronts (no LDS, no barrier).  Called by one lane.
 __device__ __forceinline__ void queue_items_background(unsigned int reach, int B, int b, int tx, int ty, int tiles_x_s, unsigned int tile_order,
