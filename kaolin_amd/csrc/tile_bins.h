@@ -163,6 +163,17 @@ __device__ __forceinline__ double row_shr(double v) {
   return __hiloint2double(row_shr<N>(__double2hiint(v)), row_shr<N>(__double2loint(v)));
 }
 
+// ---- inclusive scan over a wavefront without the LDS crossbar: DPP row shifts inside the four rows of 16 lanes (a lane without a
+// source reads 0), then the row totals broadcast with v_readlane
+__device__ __forceinline__ int wave_inclusive_scan_dpp(int v) {
+  const int lane = threadIdx.x & 63;
+  v += row_shr<1>(v);
+  v += row_shr<2>(v);
+  v += row_shr<4>(v);
+  v += row_shr<8>(v);
+  const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+  return v + (lane >= 16 ? t0 : 0) + (lane >= 32 ? t1 : 0) + (lane >= 48 ? t2 : 0);
+}
 // ---- inclusive scan over a wavefront ----------------------------------------------------------------
 __device__ __forceinline__ int wave_inclusive_scan(int v) {
   const int lane = threadIdx.x & 63;

@@ -1092,21 +1092,23 @@ __device__ __forceinline__ void queue_items_reached(unsigned long long unc, unsi
   if (lane == 0) s_item_unc[wave] = item ? unc : 0ull;
   const int any_covered = __syncthreads_or(covered ? 1 : 0);
   if (threadIdx.x == 0) {
-    if (tile_cov != nullptr) {
-      tile_cov[cov_index] = any_covered ? 1 : 0;
-      if (any_covered) {  // the covered-tile list lives behind the coverage bytes and the span copy (work_covlist_offset_words)
-        const unsigned int cs = cov_shard_of(B, b, tile_order);
-        const unsigned int pos = atomicAdd(work_counts + WORK_COV_WORD + cs * COUNTER_STRIDE, 1u);
-        unsigned int* list = reinterpret_cast<unsigned int*>(tile_cov) + cov_list_words_after_cov((size_t)B, (size_t)B * ntiles_r);
-        const unsigned int cap = cov_shard_cap((size_t)B, ntiles_r);
-        if (pos < cap) list[(size_t)cs * cap + pos] = (unsigned int)cov_index;  // (always: cov_shard_of sends no shard more; the consumer clamps too)
-      }
-    }
     int n = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) n += s_item_unc[w] != 0ull ? 1 : 0;
+    // the two appends' counter atomics are issued together (a returning atomic is a ~2 us round trip performed memory-side, and the
+    // workgroup cannot retire before it: the first USE of a result is what makes the wavefront wait -- the lesson of the binning kernel)
+    const bool list_cov = tile_cov != nullptr && any_covered;
+    const unsigned int cs = cov_shard_of(B, b, tile_order);
+    unsigned int pos_c = 0u, pos = 0u;
+    if (list_cov) pos_c = atomicAdd(work_counts + WORK_COV_WORD + cs * COUNTER_STRIDE, 1u);
+    if (n > 0) pos = atomicAdd(work_counts + shard * COUNTER_STRIDE, (unsigned int)n);
+    if (tile_cov != nullptr) tile_cov[cov_index] = any_covered ? 1 : 0;
+    if (list_cov) {  // the covered-tile list lives behind the coverage bytes and the span copy (work_covlist_offset_words)
+      unsigned int* list = reinterpret_cast<unsigned int*>(tile_cov) + cov_list_words_after_cov((size_t)B, (size_t)B * ntiles_r);
+      const unsigned int cap = cov_shard_cap((size_t)B, ntiles_r);
+      if (pos_c < cap) list[(size_t)cs * cap + pos_c] = (unsigned int)cov_index;  // (always: cov_shard_of sends no shard more; the consumer clamps too)
+    }
     if (n > 0) {
-      unsigned int pos = atomicAdd(work_counts + shard * COUNTER_STRIDE, (unsigned int)n);
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
         const unsigned long long u = s_item_unc[w];
