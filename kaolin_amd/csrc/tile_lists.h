@@ -1120,6 +1120,54 @@ __device__ __forceinline__ void queue_items_reached(unsigned long long unc, unsi
     }
   }
 }
+// The same in two steps, for a caller that has its own barrier (the rasterizer's tile kernel joins the barrier that frees its staging
+// arrays with this one, and lets the counters' round trips run beside its output stores): every wavefront's lane 0 has written
+// s_item_unc[wave] (queue_item_word) BEFORE the caller's __syncthreads_or(covered); then ONE thread calls queue_begin (issues the
+// returning atomics, uses nothing) and, later, queue_finish (the stores that need the positions).
+__device__ __forceinline__ unsigned long long queue_item_word(unsigned long long unc, unsigned int reach, int wave) {
+  return (unc != 0ull && reached(reach, wave)) ? unc : 0ull;
+}
+struct QueueTicket {
+  unsigned int pos_c, pos, cs, shard;
+  int n;
+  bool list_cov;
+};
+__device__ __forceinline__ QueueTicket queue_begin(bool any_covered, int B, int b, unsigned int tile_order, unsigned int* __restrict__ work_counts,
+                                                   const unsigned long long* s_item_unc, unsigned char* __restrict__ tile_cov) {
+  QueueTicket t;
+  t.shard = (tile_order * (unsigned int)B + (unsigned int)b) & (WORK_SHARDS - 1);
+  t.n = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) t.n += s_item_unc[w] != 0ull ? 1 : 0;
+  t.list_cov = tile_cov != nullptr && any_covered;
+  t.cs = cov_shard_of(B, b, tile_order);
+  t.pos_c = 0u;
+  t.pos = 0u;
+  if (t.list_cov) t.pos_c = atomicAdd(work_counts + WORK_COV_WORD + t.cs * COUNTER_STRIDE, 1u);
+  if (t.n > 0) t.pos = atomicAdd(work_counts + t.shard * COUNTER_STRIDE, (unsigned int)t.n);
+  return t;
+}
+__device__ __forceinline__ void queue_finish(const QueueTicket& t, bool any_covered, int B, int b, int tx, int ty, int tiles_x_s,
+                                             uint4* __restrict__ work_items, unsigned int shard_cap, const unsigned long long* s_item_unc,
+                                             unsigned char* __restrict__ tile_cov, size_t cov_index, size_t ntiles_r) {
+  if (tile_cov != nullptr) tile_cov[cov_index] = any_covered ? 1 : 0;
+  if (t.list_cov) {
+    unsigned int* list = reinterpret_cast<unsigned int*>(tile_cov) + cov_list_words_after_cov((size_t)B, (size_t)B * ntiles_r);
+    const unsigned int cap = cov_shard_cap((size_t)B, ntiles_r);
+    if (t.pos_c < cap) list[(size_t)t.cs * cap + t.pos_c] = (unsigned int)cov_index;
+  }
+  if (t.n > 0) {
+    unsigned int pos = t.pos;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const unsigned long long u = s_item_unc[w];
+      if (u == 0ull) continue;
+      if (pos < shard_cap)
+        work_items[(size_t)t.shard * shard_cap + pos] = make_uint4(item_id_of(B, b, tx, ty, tiles_x_s, w), (unsigned int)u, (unsigned int)(u >> 32), 0u);
+      ++pos;
+    }
+  }
+}
 // queue_items_reached for a tile owned by ONE wavefront (raster4.inc): `unc[w]` = the uncovered pixels of the tile's 16 x 4 strip w,
 // `covered` = the tile holds a covered pixel.  Called by the whole wavefront (uniform arguments); lane 0 appends.
 __device__ __forceinline__ void queue_items_wave(const unsigned long long* unc, unsigned int reach, bool covered, int B, int b, int tx, int ty,
