@@ -105,8 +105,9 @@ def algorithmic_bytes(kernel, B, P, F, Fv, D, K, esz=4, P_cov=None):
 STREAM_COPY_GBS = 6300.0   # what a streaming copy reaches on MI355X (HBM_PEAK_GBS note): no kernel moves its bytes faster
 
 
-# kernels of the fused DIB-R operator that share the GPU with a concurrent launch in the timed region (backward: the
-# soft-mask list kernel runs on a side stream beside raster_backward)
+# kernels of the fused DIB-R operator that MAY share the GPU with a concurrent launch in the timed region: the backward's pair.  Since
+# round 2 they run one after the other on the caller's stream in the product build (the side stream is an experiment-build knob,
+# KAMD_BWD_SIDE_STREAM=1); ties between near-equal shares are still resolved away from them
 OVERLAPPED = {'raster_backward_kernel', 'soft_mask_backward_list_kernel'}
 
 
@@ -635,6 +636,7 @@ def main():
                             'kernels_without_counters': sorted(k for k in kernels if k not in per_kernel),
                             'source': tj.get('_source', 'profiles/traffic.json')}
     roofline = None
+    notes = {}   # the long strings of the line, printed LAST (a reader that truncates the line's tail loses prose, not numbers)
     if dom and dom_n:
         dom_us = dom_ms / dom_n * 1e3                        # measured inside the timed region
         dom_bytes = int(round(algorithmic_bytes(dom, V, H * W, F, Fv, 3, 30, P_cov=p_cov)))
@@ -642,7 +644,10 @@ def main():
         roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': round(dom_gbps, 1), 'peak': HBM_PEAK_GBS,
                     'unit': 'GB/s', 'frac': round(dom_gbps / HBM_PEAK_GBS, 4),
                     'traffic': traffic if args.scene == 'sphere' else None, 'avg_launch_us': round(dom_us, 2),
-                    'algorithmic_bytes_per_launch': dom_bytes}
+                    'algorithmic_bytes_per_launch': dom_bytes,
+                    # `traffic` is NOT measured in this run: it is read from the tracked file below, which a PMC pass of an earlier
+                    # call wrote (its `_source` says which command, on which commit of the library)
+                    'traffic_source': (f'profiles/traffic.json: {tj.get("_source", "?")}' if traffic and args.scene == 'sphere' else None)}
         if traffic and args.scene == 'sphere':
             # the same duration against the bytes the PMC counters saw the kernel move (FETCH_SIZE + WRITE_SIZE)
             roofline['frac_on_counter_bytes'] = round(traffic / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
@@ -653,7 +658,7 @@ def main():
             launch_bytes = int(round(V * (H * W * (8 + 4 * 3 + 4) + p_cov * 12 + Fv * 88)))
             roofline['launch_bytes'] = launch_bytes
             roofline['frac_on_launch_bytes'] = round(launch_bytes / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
-            roofline['bytes_note'] = ('algorithmic bytes (achieved / frac) = SURVEY 8(d) K1: 32 B/pixel (face_idx i64 + 3 weights + 3 features) + 88 B '
+            notes['roofline.bytes_note'] = ('algorithmic bytes (achieved / frac) = SURVEY 8(d) K1: 32 B/pixel (face_idx i64 + 3 weights + 3 features) + 88 B '
                                       'per front face; the fused launch also writes 4 B/pixel of soft mask and leaves the 12 B/pixel of '
                                       'weights unwritten in tiles without a covered pixel (internal to the autograd node): launch_bytes / '
                                       'frac_on_launch_bytes count exactly what it writes and reads; frac_on_counter_bytes = the PMC bytes')
@@ -872,8 +877,10 @@ def main():
             for _ in range(more):
                 cdt += cpu_pass(sres)
             reps += more
+        # `cores` = the threads a reading actually used, everywhere in this object (the OpenMP port: every host core; the torch oracles
+        # of other_paths: at most 16, their dense temporaries scale badly beyond); `host_cores` = what the box has
         cpu = {'value': round(reps * sres * sres / cdt / 1e6, 4), 'unit': 'Mpixels/s', 'cores': oracle.num_threads(True),
-               'kind': 'port',
+               'kind': 'port', 'host_cores': os.cpu_count(),
                'sample': f'{reps} pass(es) over 1 view of the same {F}-triangle mesh at {sres}x{sres} (the brute-force reference algorithm costs '
                          f'O(faces) per pixel at any resolution), oracle forward (OpenMP over pixels) + both backward passes '
                          f'(single thread), {cdt:.1f} s'}
@@ -903,6 +910,12 @@ def main():
             'value_at_median_ms_per_step': round(world * V * H * W / (step_stats['median'] * 1e-3) / 1e6, 2),
             'torch_loss_value': torch_loss['value'] if torch_loss else None,
             'torch_loss_median_ms_per_step': torch_loss['per_step_ms']['median'] if torch_loss else None,
+            'feature_grad_value': feature_grad['value'] if feature_grad else None,
+            'tutorial_loss_value': tutorial['value'] if tutorial else None,
+            'host_enqueue_ms_per_step': round(dibr_enqueue_ms, 4),
+            'graph_replay_ms_per_step': (graph_replay or {}).get('ms_per_step'),
+            'roofline': roofline,
+            'cpu_baseline': None if cpu is None else {k: v for k, v in cpu.items() if k not in ('other_paths', 'sample')} | {'sample': cpu['sample']},
             'config': {'workload': f'{"C4" if args.scene == "sphere" else "C4 shape, scene " + args.scene}: dibr_rasterization fwd+bwd, {V} views/GPU at {H}x{W} of a {F}-triangle '
                                    f'{"geodesic sphere" if args.scene == "sphere" else "non-convex knot scene (kaolin_amd.utils.testing.knot_mesh)"} '
                                    f'(shared vertices), D=3 static face features (uv + mask channel; gradient w.r.t. the vertices only), '
@@ -912,22 +925,23 @@ def main():
                        'scene': args.scene, 'front_faces_per_view': round(Fv, 1),
                        'covered_pixel_fraction': round(covered, 4), 'covered_tile_pixel_fraction': round(p_cov / (H * W), 4),
                        'parallelism': f'views sharded {world}-way', 'look_at': list(args.look_at)},
-            'per_step_ms': step_stats, 'feature_grad_variant': feature_grad, 'tutorial_loss_variant': tutorial, 'torch_loss_variant': torch_loss,
-            'work_units_per_view': headline_units, 'scene_variants': scene_variants,
-            'roofline': roofline, 'step_roofline': step_roofline, 'step_traffic': step_traffic, 'kernels': kernels,
-            'kernels_over_stream_copy_rate': over_peak,    # (algorithmic_GBps above what a streaming copy reaches = a byte model that is wrong)
-            'kernels_note': f'per-kernel table: separate pass of {args.steps} steps with HIP events around every launch '
-                            f'({inst_ms_per_step:.4f} ms/step: the events and the single-stream order they need cost the '
-                            f'difference); the timed region brackets the roofline kernel only',
-            'instrumented_ms_per_step': round(inst_ms_per_step, 4),
-            'host_enqueue_ms_per_step': round(dibr_enqueue_ms, 4),
-            'graph_replay': graph_replay, 'contract_operators': contract_ops,
+            'per_step_ms': step_stats, 'kernels': kernels, 'step_roofline': step_roofline,
             'distributed': {'initialized': D.is_distributed(),
                             'backend': torch.distributed.get_backend() if D.is_distributed() else None,
                             'collectives_posted_per_step': round(reducer_posted_per_step, 3),
                             'visible_gpus': torch.cuda.device_count(),
                             'ranks_per_gpu': max(1, -(-world // max(torch.cuda.device_count(), 1)))},
-            'cpu_baseline': cpu, 'chamfer': chamfer, 'c5': c5,
+            'chamfer': chamfer, 'c5': c5,
+            'feature_grad_variant': feature_grad, 'tutorial_loss_variant': tutorial, 'torch_loss_variant': torch_loss,
+            'work_units_per_view': headline_units, 'scene_variants': scene_variants,
+            'step_traffic': step_traffic,
+            'kernels_over_stream_copy_rate': over_peak,    # (algorithmic_GBps above what a streaming copy reaches = a byte model that is wrong)
+            'instrumented_ms_per_step': round(inst_ms_per_step, 4),
+            'graph_replay': graph_replay, 'contract_operators': contract_ops,
+            'cpu_baseline_other_paths': (cpu or {}).get('other_paths'),
+            'notes': dict(notes, kernels_note=f'per-kernel table: separate pass of {args.steps} steps with HIP events around every launch '
+                                              f'({inst_ms_per_step:.4f} ms/step: the events and the single-stream order they need cost the '
+                                              f'difference); the timed region brackets the roofline kernel only'),
         }
         print(json.dumps(out))
     if D.is_distributed():

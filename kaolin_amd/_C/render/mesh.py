@@ -524,7 +524,10 @@ class _TopologyCache:
         if hit is not None and hit[0] is faces and hit[1] == faces._version and hit[2] == num_vertices:
             return hit[3]
         hit = self.by_key.get(_storage_key(faces))
-        if hit is not None and hit[2] == num_vertices:
+        # (the key holds the CALLER's version counter; the entry is only good while the tensor it pins is unchanged since it was
+        # cached -- `q = p.data` after an in-place edit of `p` has a fresh counter at 0, the cached `p`'s address, shape and stride,
+        # and stale contents behind the entry: ADVICE r04)
+        if hit is not None and hit[2] == num_vertices and hit[0]._version == hit[1]:
             return hit[3]
         return None
 

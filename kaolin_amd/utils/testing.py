@@ -52,7 +52,12 @@ def elementwise_mismatch(a, b, tol=1e-5, term_abs_sum=None, sum_ulps=64.0):
     floor = float(nz.median()) if nz.numel() else 0.0
     bound = tol * b.abs() + tol * floor
     if term_abs_sum is not None:
+        plain = bound
         bound = bound + sum_ulps * eps * term_abs_sum.detach().double().cpu()
+        # how many elements pass only thanks to the accumulation slack (it must not grow silently): kept in
+        # `last_slack_use` and printed by the full-size tests (pytest -s / the captured stdout of a failure)
+        needed = ((a - b).abs() > plain) & ((a - b).abs() <= bound)
+        elementwise_mismatch.last_slack_use = (int(needed.sum()), int(a.numel()))
     bad = ~((a - b).abs() <= bound)                      # (NaN anywhere fails)
     both_nan = torch.isnan(a) & torch.isnan(b)
     bad &= ~both_nan
@@ -64,6 +69,9 @@ def elementwise_mismatch(a, b, tol=1e-5, term_abs_sum=None, sum_ulps=64.0):
     return (f'{int(bad.sum())} of {a.numel()} elements outside |a-b| <= {tol:g}|b| + {tol:g}*{floor:.3e}'
             f'{"" if term_abs_sum is None else f" + {sum_ulps:g} eps sum|terms|"}; worst at flat index {i}: '
             f'{float(a.reshape(-1)[i])!r} vs {float(b.reshape(-1)[i])!r} ({float(excess.reshape(-1)[i]):.2f}x the bound{extra})')
+
+
+elementwise_mismatch.last_slack_use = (0, 0)
 
 
 def elementwise_close(a, b, tol=1e-5):

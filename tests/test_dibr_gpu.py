@@ -37,6 +37,9 @@ def rel_close(a, b, tol=1e-5, term_abs_sum=None):
     `term_abs_sum`: for sums of many float terms, + 64 eps * the sum of the terms' magnitudes (see there)."""
     from kaolin_amd.utils.testing import elementwise_mismatch
     msg = elementwise_mismatch(a, b, tol, term_abs_sum=term_abs_sum)
+    if term_abs_sum is not None:
+        used, of = elementwise_mismatch.last_slack_use
+        print(f'[term_abs_sum slack] {used} of {of} elements pass only with the 64 eps sum|terms| accumulation slack')
     assert msg is None, msg
     return True
 

@@ -108,7 +108,7 @@ def test_forward_lists_exactly_the_tiles_with_covered_pixels(H, W, views):
     """The fused forward leaves, next to its worklist, the list of the 16 x 16 tiles that hold a covered pixel (sharded, in
     dispatch order); the rasterizer's backward pass walks that list instead of launching a workgroup per tile.  The list
     must be the set of tiles face_idx says are covered -- each once -- and the backward over it must equal the backward that
-    visits every tile (KAMD_BWD_COV_LIST=2 is read once per process, so the comparison is against the plain operators)."""
+    visits every tile (KAMD_BWD_COV_LIST=2 exists in experiment builds only -- the product build reads no environment knob -- so the comparison is against the plain operators)."""
     import kaolin_amd as kal
     from kaolin_amd.utils import testing as T
     fz, fimg, feats, nz = T.sphere_scene(level=16, num_views=views, device='cuda')

@@ -1,12 +1,13 @@
 #!/bin/bash
 # One call on the GPU box that regenerates everything kept under profiles/ for a round:
-#   bash tools/round_profile.sh <tag> [pmc]
+#   bash tools/round_profile.sh <tag> [pmc] [commit]   (commit: `git rev-parse --short HEAD` of the library, recorded in traffic.json's _source --
+#   the GPU box has no .git)
 # writes gpurun_out/<tag>/{pytest_gpu.log, bench.json, bench_under_rocprof.json, kernel_stats.csv,
 # pmc_fetch.csv, pmc_write.csv}.  PMC passes run on their own (never combined with a trace domain).
 set -u
-tag=${1:-r01x}; pmc=${2:-}
+tag=${1:-r01x}; pmc=${2:-}; commit=${3:-unknown}
 repo=$(pwd); out=$repo/gpurun_out/$tag; mkdir -p $out
-timeout 500 python -m pytest tests -m gpu -q --durations=15 --timeout 280 > $out/pytest_gpu.log 2>&1; tail -2 $out/pytest_gpu.log
+timeout 700 python -m pytest tests -m gpu -q -rP --durations=15 --timeout 600 > $out/pytest_gpu.log 2>&1; tail -2 $out/pytest_gpu.log
 timeout 320 python bench.py 2> $out/bench.err | tail -1 > $out/bench.json
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 cd /tmp && export TMPDIR=/tmp
@@ -26,7 +27,7 @@ if [ -n "$pmc" ]; then
   rm -rf $out/pmc1 $out/pmc2
   # the tables kept under profiles/ (traffic.json: calibrated HBM bytes per launch of every kernel, the DIB-R step, the chamfer step /
   # operator and config C5; raw per-kernel tables of the four passes)
-  python $repo/tools/parse_traffic.py $out/pmc_fetch.csv $out/pmc_write.csv $out/traffic.json "tools/round_profile.sh $tag pmc (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/pmc_traffic.py)" > /dev/null 2> $out/parse_traffic.err
+  python $repo/tools/parse_traffic.py $out/pmc_fetch.csv $out/pmc_write.csv $out/traffic.json "tools/round_profile.sh $tag pmc (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/pmc_traffic.py), library built from commit $commit" > /dev/null 2> $out/parse_traffic.err
   python $repo/tools/pmc_table.py $out/pmc_fetch.csv $out/pmc_FETCH_SIZE.txt "rocprofv3 --pmc FETCH_SIZE --output-format csv -- python tools/pmc_traffic.py" > /dev/null 2>&1
   python $repo/tools/pmc_table.py $out/pmc_write.csv $out/pmc_WRITE_SIZE.txt "rocprofv3 --pmc WRITE_SIZE --output-format csv -- python tools/pmc_traffic.py" > /dev/null 2>&1
   python $repo/tools/pmc_table.py $out/pmc_sq1.csv $out/pmc_SQ_waves_insts.txt "rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -- python tools/pmc_traffic.py" > /dev/null 2>&1
