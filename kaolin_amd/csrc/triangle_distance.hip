@@ -35,6 +35,7 @@
 #include <stdlib.h>
 #include "profile.h"
 #include "grid_common.h"
+#include "phase_prof.h"
 #include "../../include/kaolin_amd.h"
 
 namespace {
@@ -619,6 +620,17 @@ int td_backward_launch(hipStream_t st, int N, int F, const T* grad, const T* poi
 }
 
 }  // namespace
+
+#ifdef KAMD_PHASE_PROF
+extern "C" int kamd_debug_phase_cycles_ts(unsigned long long* out16, int reset) {
+  int rc = (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_ts), 16 * sizeof(unsigned long long));
+  if (reset) {
+    unsigned long long z[16] = {0};
+    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ts), z, sizeof(z));
+  }
+  return rc;
+}
+#endif
 
 extern "C" {
 
