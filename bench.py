@@ -399,6 +399,20 @@ def main():
             dt = float(t.item())
         return dt
 
+    def host_enqueue_idle_ms(fn, steps=20):
+        """Host time to enqueue ONE step with the GPU idle (a synchronize between steps, outside the clock): what the Python / torch /
+        HIP-runtime side of a step costs by itself.  `host_enqueue_ms_per_step` -- the enqueue time of the timed region's K steps
+        back to back -- also contains the waits of a host that runs ahead of a slower GPU until the runtime's queue is full: on a
+        GPU-bound step it converges to the GPU's time per step and says nothing about the host."""
+        torch.cuda.synchronize()
+        tot = 0.0
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            fn()
+            tot += time.perf_counter() - t0
+            torch.cuda.synchronize()
+        return tot / steps * 1e3
+
     def covered_tile_pixels(face_idx):
         """pixels of the 16 x 16 tiles that hold a covered pixel, per view on average (what the fused backward's tile walk reads)"""
         c = (face_idx >= 0)
@@ -505,6 +519,7 @@ def main():
     dt = timed(dibr_step, args.steps, 2)      # (two untimed steps in this mode: its event pool is created on first use)
     reducer_posted_per_step = (reducer.posted - posted0) / (args.steps + 2)
     dibr_enqueue_ms = timed.enqueue_ms
+    dibr_enqueue_idle_ms = host_enqueue_idle_ms(dibr_step)
     lib.kamd_profile_enable(0)
     lib.kamd_profile_select(-1)
     dom_ms, dom_n = _lib.kernel_profile(reset=True).get(dom, (0.0, 0)) if dom else (0.0, 0)
@@ -690,6 +705,7 @@ def main():
 
         cdt = timed(chamfer_step, args.steps, args.warmup)
         chamfer_enqueue_ms = timed.enqueue_ms
+        chamfer_enqueue_idle_ms = host_enqueue_idle_ms(chamfer_step)
         lib.kamd_profile_reset()
         lib.kamd_profile_enable(1)                 # per-kernel durations: a separate, instrumented pass
         timed(chamfer_step, args.steps, 0)
@@ -700,6 +716,7 @@ def main():
                              'evaluates far fewer and returns the brute-force-identical result)',
                    'value': round(pairs / cdt / 1e6, 1), 'ms_per_step': round(cdt / args.steps * 1e3, 4), 'points': n,
                    'host_enqueue_ms_per_step': round(chamfer_enqueue_ms, 4),
+                   'host_enqueue_gpu_idle_ms_per_step': round(chamfer_enqueue_idle_ms, 4),
                    'kernels_avg_us': {k: round(v[0] / v[1] * 1e3, 2) for k, v in cprof.items()},
                    'hbm_frac_of_8TBps': round(192.0 * n / (cdt / args.steps) / 1e9 / HBM_PEAK_GBS, 6)}
         # roofline of the search launch (the largest kernel of the chamfer step): SURVEY 8(d)'s forward bytes -- 36 B per point and
@@ -913,6 +930,7 @@ def main():
             'feature_grad_value': feature_grad['value'] if feature_grad else None,
             'tutorial_loss_value': tutorial['value'] if tutorial else None,
             'host_enqueue_ms_per_step': round(dibr_enqueue_ms, 4),
+            'host_enqueue_gpu_idle_ms_per_step': round(dibr_enqueue_idle_ms, 4),   # (the host's own cost: see host_enqueue_idle_ms)
             'graph_replay_ms_per_step': (graph_replay or {}).get('ms_per_step'),
             'roofline': roofline,
             'cpu_baseline': None if cpu is None else {k: v for k, v in cpu.items() if k not in ('other_paths', 'sample')} | {'sample': cpu['sample']},
