@@ -106,7 +106,7 @@ def chamfer_distance_forward(p1, p2, w1, w2, squared, with_grad):
         out = torch.empty((batch_size,), dtype=torch.float32, device=device)
         ws = torch.empty(((nbytes + 7) // 8,), dtype=torch.int64, device=device)
         st = lib.kamd_chamfer_distance_forward_f32(
-            torch.cuda.current_stream().cuda_stream, batch_size, num_p1, num_p2, p1.data_ptr(), p2.data_ptr(), float(w1),
+            _lib.stream_ptr(device), batch_size, num_p1, num_p2, p1.data_ptr(), p2.data_ptr(), float(w1),
             float(w2), 1 if squared else 0, 1 if with_grad else 0, out.data_ptr(), None, None, None, None, ws.data_ptr())
     if st != 0:
         _lib.check(st, 'chamfer_distance_forward')
@@ -124,7 +124,7 @@ def chamfer_distance_backward_fused(grad_output, state, batch_size, num_p1, num_
         g1 = torch.empty((batch_size, num_p1, 3), dtype=torch.float32, device=device)
         g2 = torch.empty((batch_size, num_p2, 3), dtype=torch.float32, device=device)
         st = lib.kamd_chamfer_distance_backward_fused_f32(
-            torch.cuda.current_stream().cuda_stream, batch_size, num_p1, num_p2, grad_output.data_ptr(), state.data_ptr(),
+            _lib.stream_ptr(device), batch_size, num_p1, num_p2, grad_output.data_ptr(), state.data_ptr(),
             g1.data_ptr(), g2.data_ptr())
     if st != 0:
         _lib.check(st, fn)

@@ -41,9 +41,24 @@ for case in range(seed0, seed0 + n_cases):
     elif kind == 'plane':
         p2[..., 1] = 0.125
         p1[..., 1] = 0.125
+    # round 5: non-finite points, at the reference's tile starts (target indices 512 k: a NaN distance there hides the tile) and elsewhere,
+    # in half of the cases; a third of the cases on the all-pairs kernels
+    if case % 2 == 1:
+        nbad = ri(1, 12)
+        where = torch.randint(0, M // 512, (nbad,), generator=g) * 512
+        where[nbad // 2:] += torch.randint(0, 512, (nbad - nbad // 2,), generator=g)
+        vals = torch.tensor([float('nan'), float('inf'), float('-inf')])[torch.randint(0, 3, (nbad,), generator=g)]
+        p2[torch.randint(0, B, (nbad,), generator=g), where.clamp(max=M - 1), torch.randint(0, 3, (nbad,), generator=g)] = vals
+        p1[0, ri(0, N - 1), ri(0, 2)] = float('inf')
+        p1[B - 1, ri(0, N - 1), ri(0, 2)] = float('nan')
     p1, p2 = p1.to(dtype), p2.to(dtype)
     d_ref, i_ref = oracle.sided_distance_forward(p1, p2, omp=True)
-    d, i = kal.metrics.pointcloud.sided_distance(p1.cuda(), p2.cuda())
+    if case % 3 == 2:
+        os.environ['KAMD_SIDED_DISTANCE'] = 'brute'
+    try:
+        d, i = kal.metrics.pointcloud.sided_distance(p1.cuda(), p2.cuda())
+    finally:
+        os.environ.pop('KAMD_SIDED_DISTANCE', None)
     ok_i = torch.equal(i.cpu(), i_ref)
     ok_d = torch.equal(d.cpu(), d_ref) or bool(((d.cpu() == d_ref) | (torch.isnan(d.cpu()) & torch.isnan(d_ref))).all())
     if not (ok_i and ok_d):
