@@ -334,8 +334,23 @@ __device__ __forceinline__ bool pixel_range(T xmin, T ymin, T xmax, T ymax, int 
   out->everywhere = !(multiplier > 0.f) || !(fxmin == fxmin) || !(fxmax == fxmax) || !(fymin == fymin) || !(fymax == fymax);
   if (out->everywhere) return true;
   const float sx = (float)W / multiplier, sy = (float)H / multiplier;
+#ifdef KAMD_PIXEL_RANGE_SLACK_ONLY
+  // (rounds 2-4, A/B builds: a whole pixel of slack on either side)
   const float cl = floorf((fxmin * sx + (float)(W - 1)) * 0.5f) - 1.0f, ch = ceilf((fxmax * sx + (float)(W - 1)) * 0.5f) + 1.0f;
   const float rl = floorf(((float)(H - 1) - fymax * sy) * 0.5f) - 1.0f, rh = ceilf(((float)(H - 1) - fymin * sy) * 0.5f) + 1.0f;
+#else
+  // Round 5: tight.  A pixel centre passes the kernels' test `x >= xmin && x < xmax` exactly when its column lies in
+  // [u(xmin), u(xmax)) with u(x) = (x W / multiplier + W - 1) / 2 the column as a real number: the columns are ceil(u(xmin)) ...
+  // ceil(u(xmax)) - 1.  The float evaluation of u and of the kernels' centres (pixel_x: fl(multiplier / W) times an exact integer)
+  // is off by ~1e-4 of a pixel at 1024 columns, so the two ends move OUTWARDS by d = 1e-3 + 1e-6 W (rows likewise): at most one
+  // column too many, once in a few hundred boxes.  The whole pixel of slack on either side that rounds 2-4 used here binned a face
+  // six pixels across as if it were nine: 437 k (tile, face) pairs at C4 where the boxes hold pixel centres in 301 k, and every
+  // sub-tile bit -- hence every work item of the soft mask -- as generous.  (Shrinking the generous range with the kernels' own
+  // test, four short loops per face, is exact but cost the binning launch 4 us: profiles/r05u_*.)
+  const float dx = 1e-3f + 1e-6f * (float)W, dy = 1e-3f + 1e-6f * (float)H;
+  const float cl = ceilf((fxmin * sx + (float)(W - 1)) * 0.5f - dx), ch = ceilf((fxmax * sx + (float)(W - 1)) * 0.5f + dx) - 1.0f;
+  const float rl = ceilf(((float)(H - 1) - fymax * sy) * 0.5f - dy) , rh = ceilf(((float)(H - 1) - fymin * sy) * 0.5f + dy) - 1.0f;
+#endif
   if (ch < 0.0f || cl > (float)(W - 1) || rh < 0.0f || rl > (float)(H - 1)) return false;
   out->c_lo = (int)fmaxf(cl, 0.0f);
   out->c_hi = (int)fminf(ch, (float)(W - 1));
