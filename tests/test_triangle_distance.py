@@ -390,12 +390,14 @@ def test_gpu_sweep_with_one_percent_degenerate_faces():
 
     def run(mesh):
         out = _gpu_fwd(pts, mesh)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
+        best = float('inf')
+        for _ in range(6):                           # (the fastest of six single calls: a shared box's hiccups are not the subject)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
             out = _gpu_fwd(pts, mesh)
-        torch.cuda.synchronize()
-        return out, (time.perf_counter() - t0) / 3
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return out, best
     (d, i, t), t_bad = run(fvd)
     _, t_clean = run(fv)
     assert torch.equal(i.cpu()[:20000], i_ref) and torch.equal(t.cpu()[:20000].to(t_ref.dtype), t_ref)
