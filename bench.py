@@ -16,8 +16,10 @@ resident in HBM when the timed region starts.  The same run also times chamfer_d
 100k x 100k (config C3, one batch item per GPU) and reports it under "chamfer".
 
 Rank 0 prints ONE JSON line.  "roofline" describes the kernel with the largest share of the DIB-R step, timed
-live with HIP events on the launch stream inside the timed region (libkaolin_amd's kamd_profile_* hooks; the table
-of every kernel comes from a separate, fully instrumented pass of the same step before it); "cpu_baseline" is the CPU
+live with HIP events on the launch stream inside the timed region (libkaolin_amd's kamd_profile_* hooks: the DIB-R kernels
+are launched through hipExtLaunchKernelGGL, whose two events take the dispatch's own begin and end timestamps -- the interval
+rocprofv3's kernel trace reports; the table of every kernel comes from a separate, fully instrumented pass of the same step
+before it); "cpu_baseline" is the CPU
 oracle (OpenMP) timed on a bounded sample on this box's host cores (rank 0, N = 1 only).
 """
 import argparse
@@ -422,7 +424,8 @@ def main():
         return float(tiles.float().sum()) * 256.0 / V
 
     def kernel_table(step, sc, steps):
-        """One fully instrumented pass (HIP events around every launch of the library): per-kernel average durations."""
+        """One fully instrumented pass (every launch of the library timed with HIP events: the DIB-R kernels by their own begin / end
+        timestamps, multi-launch operators by two records around them): per-kernel average durations."""
         lib.kamd_profile_reset()
         lib.kamd_profile_select(-1)
         lib.kamd_profile_enable(1)
@@ -500,7 +503,7 @@ def main():
                                                             camera_rot=sc['rot'], camera_trans=sc['trans'])
         return float((normals[..., 2] >= 0).float().sum()) / V
 
-    # ---------------- DIB-R.  Two event records around a launch cost a few microseconds of stream time, and timing every
+    # ---------------- DIB-R.  Timing a launch costs stream time (a profiled dispatch, or two event records), and timing every
     # kernel also keeps the operator's two concurrent launches (side stream) on one stream.  So: (1) an instrumented
     # pass outside the timed region gives the per-kernel table and names the dominant kernel; (2) the timed region runs
     # the step as users run it, with HIP events around the dominant kernel only (the roofline line's duration).
@@ -957,9 +960,10 @@ def main():
             'instrumented_ms_per_step': round(inst_ms_per_step, 4),
             'graph_replay': graph_replay, 'contract_operators': contract_ops,
             'cpu_baseline_other_paths': (cpu or {}).get('other_paths'),
-            'notes': dict(notes, kernels_note=f'per-kernel table: separate pass of {args.steps} steps with HIP events around every launch '
-                                              f'({inst_ms_per_step:.4f} ms/step: the events and the single-stream order they need cost the '
-                                              f'difference); the timed region brackets the roofline kernel only'),
+            'notes': dict(notes, kernels_note=f'per-kernel table: separate pass of {args.steps} steps with every launch timed by HIP events '
+                                              f'(hipExtLaunchKernelGGL start / stop events = the dispatch\'s own timestamps for the DIB-R kernels, two '
+                                              f'records around multi-launch operators; {inst_ms_per_step:.4f} ms/step: the events and the single-stream '
+                                              f'order they need cost the difference); the timed region times the roofline kernel only'),
         }
         print(json.dumps(out))
     if D.is_distributed():

@@ -313,28 +313,24 @@ int soft2_search_launch(hipStream_t st, int B, int H, int W, int F, int K, float
   const long long sel_want = (long long)KAMD_NUM_CU * sel_per_cu, eval_want = (long long)KAMD_NUM_CU * eval_per_cu;
   const dim3 sel_grid((unsigned)(n_sub < sel_want ? (n_sub > 0 ? n_sub : 1) : sel_want));
   const dim3 eval_grid((unsigned)(n_sub < eval_want ? (n_sub > 0 ? n_sub : 1) : eval_want));
-  {
-    kamd::ProfScope prof_(kamd::K_SOFT_SELECT, st);
-    if (lean)
-      hipLaunchKernelGGL((soft_select_kernel<T, true>), sel_grid, dim3(64), 0, st, sa);
-    else
-      hipLaunchKernelGGL((soft_select_kernel<T, false>), sel_grid, dim3(64), 0, st, sa);
-  }
+  if (lean)
+    KAMD_LAUNCH_TIMED(kamd::K_SOFT_SELECT, (soft_select_kernel<T, true>), sel_grid, dim3(64), 0, st, sa);
+  else
+    KAMD_LAUNCH_TIMED(kamd::K_SOFT_SELECT, (soft_select_kernel<T, false>), sel_grid, dim3(64), 0, st, sa);
   KAMD_CHECK(hipGetLastError());
   const bool lds_fold = K <= S2_LDS_KMAX;
   const size_t shmem = lds_fold ? (size_t)64 * (K > 0 ? K : 1) * sizeof(T) : 0;
   {
-    kamd::ProfScope prof_(kamd::K_SOFT_TILE, st);
     if (lean) {
       if (lds_fold)
-        hipLaunchKernelGGL((soft_eval_kernel<T, true, true>), eval_grid, dim3(S2_EVAL_THREADS), shmem, st, ea);
+        KAMD_LAUNCH_TIMED(kamd::K_SOFT_TILE, (soft_eval_kernel<T, true, true>), eval_grid, dim3(S2_EVAL_THREADS), shmem, st, ea);
       else
-        hipLaunchKernelGGL((soft_eval_kernel<T, true, false>), eval_grid, dim3(S2_EVAL_THREADS), 0, st, ea);
+        KAMD_LAUNCH_TIMED(kamd::K_SOFT_TILE, (soft_eval_kernel<T, true, false>), eval_grid, dim3(S2_EVAL_THREADS), 0, st, ea);
     } else {
       if (lds_fold)
-        hipLaunchKernelGGL((soft_eval_kernel<T, false, true>), eval_grid, dim3(S2_EVAL_THREADS), shmem, st, ea);
+        KAMD_LAUNCH_TIMED(kamd::K_SOFT_TILE, (soft_eval_kernel<T, false, true>), eval_grid, dim3(S2_EVAL_THREADS), shmem, st, ea);
       else
-        hipLaunchKernelGGL((soft_eval_kernel<T, false, false>), eval_grid, dim3(S2_EVAL_THREADS), 0, st, ea);
+        KAMD_LAUNCH_TIMED(kamd::K_SOFT_TILE, (soft_eval_kernel<T, false, false>), eval_grid, dim3(S2_EVAL_THREADS), 0, st, ea);
     }
   }
   KAMD_CHECK(hipGetLastError());
@@ -393,8 +389,7 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
     in.H = H;
     in.W = W;
     in.rec_s = rec;
-    kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
-    hipLaunchKernelGGL((tl::bin_faces_kernel2<T, false, true>), dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, in, none, LS);
+    KAMD_LAUNCH_TIMED(kamd::K_BIN_FACES, (tl::bin_faces_kernel2<T, false, true>), dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, in, none, LS);
   }
   KAMD_CHECK(hipGetLastError());
   {
@@ -417,11 +412,10 @@ int soft_mask_backward_list_launch(hipStream_t st, int B, int H, int W, int F, i
                                    float sigmainv, float multiplier, T* g_img) {
   if ((long long)B * H * W <= 0 || F <= 0) return 0;
   {
-    kamd::ProfScope prof_(kamd::K_SOFT_BACKWARD_LIST, st);
     // persistent workgroups over the rounds of 256 hits (their number is known on the device only)
     static const int per_cu = kamd_env_int("KAMD_SOFT_BWD_PER_CU", 16);
-    hipLaunchKernelGGL(soft_mask_backward_flat_kernel<T>, dim3(KAMD_NUM_CU * per_cu), dim3(256), 0, st, H, W, F, flat_view_magic(F),
-                       grad, soft_mask, list, img, (T)img_scale, sigmainv, multiplier, 1.0 / (double)multiplier, g_img);
+    KAMD_LAUNCH_TIMED(kamd::K_SOFT_BACKWARD_LIST, soft_mask_backward_flat_kernel<T>, dim3(KAMD_NUM_CU * per_cu), dim3(256), 0, st, H, W, F,
+                      flat_view_magic(F), grad, soft_mask, list, img, (T)img_scale, sigmainv, multiplier, 1.0 / (double)multiplier, g_img);
   }
   KAMD_RETURN_LAST_ERROR();
 }
@@ -492,8 +486,7 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
     in.W = W;
     in.rec_r = rec_r;
     in.rec_s = rec_s;
-    kamd::ProfScope prof_(kamd::K_BIN_FACES, st);
-    hipLaunchKernelGGL((tl::bin_faces_kernel2<T, true, true>), dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, in, LR, LS);
+    KAMD_LAUNCH_TIMED(kamd::K_BIN_FACES, (tl::bin_faces_kernel2<T, true, true>), dim3(kamd_cdiv(total_faces, 256)), dim3(256), 0, st, in, LR, LS);
   }
   KAMD_CHECK(hipGetLastError());
   tl::ClassifyOut co{};

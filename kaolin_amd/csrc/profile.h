@@ -1,10 +1,15 @@
-// Optional per-kernel timing with HIP events recorded on the launch stream (off by default, zero cost then).
+// Optional per-kernel timing with HIP events on the launch stream (off by default, zero cost then).
 // bench.py switches it on to obtain each kernel's average launch duration; the same figures come out of
-// `rocprofv3 --kernel-trace --stats` (profiles/).  Two event records per launch cost a few microseconds of stream time
-// each, so the timed region of bench.py brackets only the kernel of its roofline line (kamd_profile_select) and the
-// full per-kernel table comes from a separate pass.
+// `rocprofv3 --kernel-trace --stats` (profiles/).  Two forms:
+//   * ProfScope: two event records around whatever is enqueued inside the scope (several launches, a library call).  The
+//     interval holds the command processor's gaps on both sides of a kernel (~2-5 us per launch at C4), and the records cost
+//     stream time, so the timed region of bench.py times only the kernel of its roofline line (kamd_profile_select) and the
+//     full per-kernel table comes from a separate pass;
+//   * KAMD_LAUNCH_TIMED (round 5): a single launch through hipExtLaunchKernelGGL, whose two events take the dispatch's OWN
+//     begin and end timestamps -- the interval rocprofv3's kernel trace reports.  The DIB-R kernels use it.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 namespace kamd {
 
@@ -36,4 +41,31 @@ struct ProfScope {
   }
 };
 
+// the events of one launch (both null when the kernel is not being timed)
+void prof_kernel_events(hipEvent_t* start, hipEvent_t* stop);
+void prof_kernel_done(int id, hipEvent_t start, hipEvent_t stop);
+struct ProfKernel {
+  int id;
+  hipEvent_t start = nullptr, stop = nullptr;
+  bool on;
+  explicit ProfKernel(int id_) : id(id_), on(prof_enabled(id_)) {
+    if (on) prof_kernel_events(&start, &stop);
+    on = on && start != nullptr && stop != nullptr;
+  }
+  void done() {
+    if (on) prof_kernel_done(id, start, stop);
+  }
+};
+
 }  // namespace kamd
+
+// one kernel launch, timed by its own begin / end timestamps when kernel ID is being profiled
+#define KAMD_LAUNCH_TIMED(ID, KERNEL, GRID, BLOCK, SHMEM, ST, ...)                                                \
+  do {                                                                                                            \
+    kamd::ProfKernel pk_(ID);                                                                                     \
+    if (pk_.on)                                                                                                   \
+      hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, SHMEM, ST, pk_.start, pk_.stop, 0, __VA_ARGS__);                 \
+    else                                                                                                          \
+      hipLaunchKernelGGL(KERNEL, GRID, BLOCK, SHMEM, ST, __VA_ARGS__);                                            \
+    pk_.done();                                                                                                   \
+  } while (0)

@@ -73,6 +73,15 @@ void prof_end(int id, hipStream_t st) {
   (void)hipEventRecord(e, st);
   g_pending.push_back(Pending{id, s, e});
 }
+void prof_kernel_events(hipEvent_t* start, hipEvent_t* stop) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  *start = get_event();
+  *stop = get_event();
+}
+void prof_kernel_done(int id, hipEvent_t start, hipEvent_t stop) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_pending.push_back(Pending{id, start, stop});
+}
 }  // namespace kamd
 
 extern "C" {

@@ -355,14 +355,13 @@ int rasterize_backward_launch(hipStream_t st, int B, int H, int W, int F, int D,
   const long long total = (long long)B * H * W;
   if (total <= 0 || F <= 0) return 0;
   const dim3 grid((unsigned)(B * ((W + 15) / 16) * ((H + 15) / 16)));
-  kamd::ProfScope prof_(kamd::K_RASTER_BACKWARD, st);
 #define KAMD_RB(DT)                                                                                                   \
   if (g_feat != nullptr)                                                                                              \
-    hipLaunchKernelGGL((raster_backward_kernel<T, DT, true>), grid, dim3(256), 0, st, B, H, W, F, D, grad, face_idx,  \
-                       weights, img, feat, eps, g_img, g_feat, tile_cov, row_span);                                   \
+    KAMD_LAUNCH_TIMED(kamd::K_RASTER_BACKWARD, (raster_backward_kernel<T, DT, true>), grid, dim3(256), 0, st, B, H, W, F, D, grad, face_idx,  \
+                      weights, img, feat, eps, g_img, g_feat, tile_cov, row_span);                                    \
   else                                                                                                                \
-    hipLaunchKernelGGL((raster_backward_kernel<T, DT, false>), grid, dim3(256), 0, st, B, H, W, F, D, grad, face_idx, \
-                       weights, img, feat, eps, g_img, g_feat, tile_cov, row_span)
+    KAMD_LAUNCH_TIMED(kamd::K_RASTER_BACKWARD, (raster_backward_kernel<T, DT, false>), grid, dim3(256), 0, st, B, H, W, F, D, grad, face_idx, \
+                      weights, img, feat, eps, g_img, g_feat, tile_cov, row_span)
   switch (D) {
     case 1: KAMD_RB(1); break;
     case 2: KAMD_RB(2); break;
@@ -386,14 +385,13 @@ int rasterize_backward_list_launch(hipStream_t st, int B, int H, int W, int F, i
   static const int per_cu = kamd_env_int("KAMD_RBWD_PER_CU", 16);
   static const int grouped = kamd_env_int("KAMD_RBWD_GROUPED", 1) == 1 ? 1 : 0;  // (2: off, for A/B runs)
   const dim3 grid((unsigned)(((std::min<long long>(n_groups, (long long)KAMD_NUM_CU * per_cu) + 7) / 8) * 8));  // (a multiple of 8: every group served)
-  kamd::ProfScope prof_(kamd::K_RASTER_BACKWARD, st);
 #define KAMD_RBL(DT)                                                                                                       \
   if (g_feat != nullptr)                                                                                                   \
-    hipLaunchKernelGGL((raster_backward_list_kernel<T, DT, true>), grid, dim3(256), 0, st, B, H, W, F, D, grad, face_idx,  \
-                       weights, img, feat, eps, g_img, g_feat, cov_counts, cov_list, cov_cap, grouped, magic_word, magic);  \
+    KAMD_LAUNCH_TIMED(kamd::K_RASTER_BACKWARD, (raster_backward_list_kernel<T, DT, true>), grid, dim3(256), 0, st, B, H, W, F, D, grad, face_idx,  \
+                      weights, img, feat, eps, g_img, g_feat, cov_counts, cov_list, cov_cap, grouped, magic_word, magic);  \
   else                                                                                                                     \
-    hipLaunchKernelGGL((raster_backward_list_kernel<T, DT, false>), grid, dim3(256), 0, st, B, H, W, F, D, grad, face_idx, \
-                       weights, img, feat, eps, g_img, g_feat, cov_counts, cov_list, cov_cap, grouped, magic_word, magic)
+    KAMD_LAUNCH_TIMED(kamd::K_RASTER_BACKWARD, (raster_backward_list_kernel<T, DT, false>), grid, dim3(256), 0, st, B, H, W, F, D, grad, face_idx, \
+                      weights, img, feat, eps, g_img, g_feat, cov_counts, cov_list, cov_cap, grouped, magic_word, magic)
   switch (D) {
     case 1: KAMD_RBL(1); break;
     case 2: KAMD_RBL(2); break;
@@ -426,16 +424,17 @@ int raster2_draw(hipStream_t st, int B, int H, int W, int D, int F_dense, float 
                  const tl::Lists& LR, const T* feat, T* interp, int64_t* sel_idx, T* weights, const tl::ClassifyOut& co,
                  bool weights_internal, const tl::RasterPlan* plan) {
   if (!raster2_grid_fits(H, W)) return (int)hipErrorInvalidValue;
-  kamd::ProfScope prof_(kamd::K_RASTER_TILE, st);
   const int wide_ok = raster2_wide_ok(W, interp, sel_idx, weights, co.soft_mask) | (weights_internal ? 2 : 0);
   if constexpr (sizeof(T) == 4) {
     if (raster4_applicable()) {
+      kamd::ProfScope prof_(kamd::K_RASTER_TILE, st);
       hipLaunchKernelGGL((raster_wave_kernel<true>), raster4_grid(LR, B), dim3(256), 0, st, B, F_dense, (const int64_t*)nullptr, H, W, D,
                          pixel_scale(multiplier, H, W), eps, wide_ok, rec, LR, feat, interp, sel_idx, weights, co, LR.ntiles / LR.tiles_x);
       return (int)hipGetLastError();
     }
   }
   if (plan != nullptr && raster3_applicable(H, W, LR)) {
+    kamd::ProfScope prof_(kamd::K_RASTER_TILE, st);
     const int tiles_y = LR.ntiles / LR.tiles_x;
     hipLaunchKernelGGL(raster_plan_kernel, dim3(tl::PLAN_GROUPS), dim3(256), 0, st, LR, *plan, B, H, W, tiles_y,
                        raster3_fill_ok<T>(W, D, interp, sel_idx, weights, co.soft_mask));
@@ -452,9 +451,9 @@ int raster2_draw(hipStream_t st, int B, int H, int W, int D, int F_dense, float 
     }
     return (int)hipGetLastError();
   }
-  hipLaunchKernelGGL((raster_tile_kernel2<T, true>), raster2_grid(LR, B), dim3(256), 0, st, B, F_dense,
-                     (const int64_t*)nullptr, H, W, D, pixel_scale(multiplier, H, W), eps, wide_ok,
-                     rec, LR, feat, interp, sel_idx, weights, co);
+  KAMD_LAUNCH_TIMED(kamd::K_RASTER_TILE, (raster_tile_kernel2<T, true>), raster2_grid(LR, B), dim3(256), 0, st, B, F_dense,
+                    (const int64_t*)nullptr, H, W, D, pixel_scale(multiplier, H, W), eps, wide_ok,
+                    rec, LR, feat, interp, sel_idx, weights, co);
   return (int)hipGetLastError();
 }
 template <typename T>
