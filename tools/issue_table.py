@@ -2,14 +2,16 @@
 What bounds each kernel, from the raw counter tables of one tools/round_profile.sh pass (tools/pmc_table.py wrote them):
 
   cycles      SQ_BUSY_CYCLES / 32    the launch's length in shader clocks (the counter is summed over the chip's 32 shader engines)
-  valu busy   SQ_ACTIVE_INST_VALU * 4 / 1024 / cycles   a wave64 vector instruction holds its SIMD's 16 lanes for 4 clocks (the
-              counter is in those quad-clocks); MI355X has 256 CUs x 4 SIMDs.  1.0 = every vector pipe issues without a gap.
+  valu        SQ_ACTIVE_INST_VALU * 4 / 1024 / cycles   the counter is in quad-clocks (one per wave64 vector instruction: a SIMD's issue
+              cadence); MI355X has 256 CUs x 4 SIMDs.  An UPPER BOUND of the vector pipes' utilisation: a CDNA4 SIMD is 32 lanes wide
+              and executes the instruction in 2 clocks.  Measured (profiles/r05z_soft_backward_diet_ab.txt): the soft mask's backward
+              reads 1.08 here and takes the same time with 15 % fewer vector instructions.
   salu busy   SQ_INSTS_SALU / 256 / cycles              one scalar unit per CU, one instruction per clock
   lds busy    SQ_ACTIVE_INST_LDS * 4 / 256 / cycles      one LDS pipe per CU (quad-clocks as above) -- an upper bound
   occupancy   SQ_WAVE_CYCLES * 4 / (8192 * cycles)       resident wavefronts / the chip's 8192 slots
   waiting     SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES          share of a resident wavefront's time spent waiting for an instruction's operands
   hbm         calibrated FETCH + WRITE bytes per launch (traffic.json) / (cycles / 2.4 GHz) / 8 TB/s
-The largest of the columns names the bound; when none is near 1 the launch is a chain of dependent round trips (latency)."""
+No column near 1 = the launch is a chain of dependent round trips (latency), which is what every DIB-R kernel is."""
 import json, re, sys
 
 
@@ -35,7 +37,7 @@ t1, t2 = table(sys.argv[1]), table(sys.argv[2])
 traffic = json.load(open(sys.argv[3]))
 out = open(sys.argv[4], 'w') if len(sys.argv) > 4 else sys.stdout
 # the profile tables' kernel names -> the names of bench.py's kernel table / traffic.json
-short = [('bin_faces_kernel2<float, true, true>', 'bin_faces_kernel'), ('raster_tile_kernel2<float, true>', 'raster_tile_kernel'),
+short = [('tl::bin_faces_kernel2<float, true, true>', 'bin_faces_kernel'), ('raster_tile_kernel2<float, true>', 'raster_tile_kernel'),
          ('soft_select_kernel<float, true>', 'soft_select_kernel'), ('soft_eval_kernel<float, true, true>', 'soft_eval_kernel'),
          ('soft_mask_backward_flat_kernel<float>', 'soft_mask_backward_list_kernel'), ('raster_backward_list_kernel<float', 'raster_backward_kernel'),
          ('pv_forward_kernel<float>', 'pv_forward_kernel'), ('pv_backward_kernel<float>', 'pv_backward_kernel'),

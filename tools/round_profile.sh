@@ -32,6 +32,7 @@ if [ -n "$pmc" ]; then
   python $repo/tools/pmc_table.py $out/pmc_write.csv $out/pmc_WRITE_SIZE.txt "rocprofv3 --pmc WRITE_SIZE --output-format csv -- python tools/pmc_traffic.py" > /dev/null 2>&1
   python $repo/tools/pmc_table.py $out/pmc_sq1.csv $out/pmc_SQ_waves_insts.txt "rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -- python tools/pmc_traffic.py" > /dev/null 2>&1
   python $repo/tools/pmc_table.py $out/pmc_sq2.csv $out/pmc_SQ_lds_vmem.txt "rocprofv3 --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM --output-format csv -- python tools/pmc_traffic.py" > /dev/null 2>&1
+  python $repo/tools/issue_table.py $out/pmc_SQ_waves_insts.txt $out/pmc_SQ_lds_vmem.txt $out/traffic.json $out/issue_table.txt > /dev/null 2>&1
   rm -f $out/pmc_fetch.csv $out/pmc_write.csv $out/pmc_sq1.csv $out/pmc_sq2.csv   # (tens of MB; the tables above are what is kept)
 fi
 rm -rf $out/prof
