@@ -65,7 +65,7 @@ def parse():
     ap.add_argument('--quick', action='store_true',
                     help='development probe: the headline step and its kernel table only (no variants, graph replay, contract '
                          'operators, chamfer, C5, CPU baseline)')
-    ap.add_argument('--scene', choices=['sphere', 'knot'], default='sphere',
+    ap.add_argument('--scene', choices=['sphere', 'knot', 'knot_shuffled'], default='sphere',
                     help='the mesh of the headline step: sphere = config C4 (BASELINE.json; the default and the only one `value` may be '
                          'quoted on), knot = the non-convex ~49k-triangle scene of kaolin_amd.utils.testing.knot_mesh (depth complexity up '
                          'to 8-11, image-sized triangles, geometry leaving the image); the default run also times the knot scene and reports '
@@ -564,7 +564,7 @@ def main():
     headline_units = work_units(scene, face_idx, p_cov)
     if not args.quick and not args.no_scene_variants:
         scene_variants = {}
-        for other in ('sphere', 'knot'):
+        for other in ('sphere', 'knot', 'knot_shuffled'):
             if other == args.scene:
                 continue
             try:
@@ -577,6 +577,14 @@ def main():
                 table_o, inst_o, fi, p_cov_o, over_o = kernel_table(step_o, sc, n_o)
                 dt_o = timed(step_o, n_o, 2)
                 st_o = per_step_ms(step_o, max(n_o, 20))
+                if other == 'knot_shuffled':   # the knot with its faces in a random order: the same work, only the list order differs
+                    scene_variants[other] = {
+                        'faces': sc['F'], 'ms_per_step': round(dt_o / n_o * 1e3, 4), 'per_step_ms': st_o,
+                        'kernels_avg_us': {k: v['avg_us'] for k, v in table_o.items()},
+                        'vs_ordered_knot_step': (round(dt_o / n_o * 1e3 / scene_variants['knot']['ms_per_step'], 3)
+                                                 if 'ms_per_step' in scene_variants.get('knot', {}) else None)}
+                    del sc, step_o
+                    continue
                 wu_o = work_units(sc, fi, p_cov_o)
                 wr = {k: (round(wu_o[k] / headline_units[k], 3) if headline_units[k] > 0 else None) for k in wu_o}
                 scene_variants[other] = {
@@ -938,7 +946,7 @@ def main():
             'roofline': roofline,
             'cpu_baseline': None if cpu is None else {k: v for k, v in cpu.items() if k not in ('other_paths', 'sample')} | {'sample': cpu['sample']},
             'config': {'workload': f'{"C4" if args.scene == "sphere" else "C4 shape, scene " + args.scene}: dibr_rasterization fwd+bwd, {V} views/GPU at {H}x{W} of a {F}-triangle '
-                                   f'{"geodesic sphere" if args.scene == "sphere" else "non-convex knot scene (kaolin_amd.utils.testing.knot_mesh)"} '
+                                   f'{"geodesic sphere" if args.scene == "sphere" else "non-convex knot scene (kaolin_amd.utils.testing.knot_mesh)" + (", faces in random order" if args.scene == "knot_shuffled" else "")} '
                                    f'(shared vertices), D=3 static face features (uv + mask channel; gradient w.r.t. the vertices only), '
                                    f'knum=30, sigmainv=7000, boxlen=0.02, loss = sum(features*G1) + sum(soft_mask*G2) (fused weighted_sum), '
                                    f'prepare_vertices + vertex-gradient all-reduce (posted from the autograd hook) inside the step',

@@ -20,7 +20,7 @@ enum KernelId {
   K_TD_PREP, K_TD_MAIN, K_TD_FINAL, K_TD_BACKWARD,
   K_VOX_VERTICES, K_VOX_FACES, K_MEMSET, K_PV_FORWARD, K_PV_BACKWARD, K_MESH_INTERSECTION,
   K_DEFTET_FORWARD, K_DEFTET_SORT, K_DEFTET_BACKWARD, K_SPC_STAGE, K_SPC_BUILD, K_MASK_IOU, K_TEXTURE_MAPPING,
-  K_WEIGHTED_SUM,
+  K_WEIGHTED_SUM, K_SOFT_SELECT_ROUNDS,
   K_NUM
 };
 

@@ -15,7 +15,7 @@ const char* const kNames[K_NUM] = {
     "vox_clear_extent_kernel", "vox_mark_kernel", "zero_fill", "pv_forward_kernel", "pv_backward_kernel", "mesh_intersection_kernel",
     "deftet_forward(pixel sort + search)", "deftet_sort_interp_kernel", "deftet_backward_kernel",
     "mesh_to_spc_stage(count|emit)", "mesh_to_spc_build(sort + unique + octree + results)", "mask_iou_kernels",
-    "texture_mapping_kernel", "weighted_sum2_kernels"};
+    "texture_mapping_kernel", "weighted_sum2_kernels", "soft_select_rounds_kernel"};
 struct Pending {
   int id;
   hipEvent_t start, stop;

@@ -184,6 +184,7 @@ struct PassLayout {
   size_t plan_count, plan_list, plan_rows;               // raster pass: the plan of the tiles that hold work (RasterPlan)
   unsigned int plan_cap;
   size_t pixcnt, prob_pm;                // soft pass: hits per (item, pixel) (u16); pixel-major probabilities (knum > 128 only)
+  size_t over_count, over_list;          // soft pass: the work places soft_select hands to its rounds launch (count zeroed; soft2.inc)
   unsigned int cap_chunks;
   int C, maxc;
   PassGeom g;
@@ -193,6 +194,7 @@ struct Layout {
   PassLayout r, s;        // raster / soft (either may be absent: offsets 0)
   size_t total;
 };
+inline unsigned int work_shard_cap(int B, int H, int W);  // (the worklist's capacity per shard, below)
 inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, bool with_r, bool with_s, int K = 0) {
   Layout L{};
   size_t off = 0;
@@ -215,6 +217,7 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
     L.s.pool_top = off; off += 256;
     L.s.big_count = off; off += a256((size_t)B * 4);
     L.s.sub_touched = off; off += a256(nts * 4);
+    L.s.over_count = off; off += 256;
   }
   L.zero_bytes = off;
   if (with_r) {
@@ -236,6 +239,7 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
     L.s.rec = off; off += a256((size_t)total_faces * rec_s_scalars(esz) * esz);
     const size_t item_pixels = nts * S_SUBS * 64;
     L.s.pixcnt = off; off += a256(item_pixels * 2);
+    L.s.over_list = off; off += a256((size_t)WORK_SHARDS * work_shard_cap(B, H, W) * 4);
     L.s.prob_pm = off; off += K > 128 ? a256(item_pixels * (size_t)K * esz) : 0;
   }
   L.total = off + 256;

@@ -201,13 +201,17 @@ def knot_scene(num_views=8, device='cpu', dtype=torch.float, seed=0, distance=2.
 
 
 def scene_mesh(name, frequency=50):
-    """The meshes bench.py and the full-size parity tests render: 'sphere' (config C4: geodesic sphere, 20 f^2 triangles) or
-    'knot' (:func:`knot_mesh`).  -> (vertices float64, faces int64)"""
+    """The meshes bench.py and the full-size parity tests render: 'sphere' (config C4: geodesic sphere, 20 f^2 triangles),
+    'knot' (:func:`knot_mesh`) or 'knot_shuffled' (the knot's faces in a random order: neighbours in the list are not neighbours
+    on the screen -- the reference's loops over all faces do not care, tile lists do).  -> (vertices float64, faces int64)"""
     if name == 'sphere':
         return geodesic_sphere(frequency)
     if name == 'knot':
         return knot_mesh()
-    raise ValueError(f'unknown scene {name!r} (sphere | knot)')
+    if name == 'knot_shuffled':
+        v, f = knot_mesh()
+        return v, f[torch.randperm(f.shape[0], generator=torch.Generator().manual_seed(1))].contiguous()
+    raise ValueError(f'unknown scene {name!r} (sphere | knot | knot_shuffled)')
 
 
 def fibonacci_cameras(num_views, distance=2.5, dtype=torch.float):

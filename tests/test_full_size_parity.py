@@ -151,6 +151,21 @@ def test_knot_scene_8_views_1024_vs_oracle():
     assert band > 200000
 
 
+def test_knot_scene_with_shuffled_faces_1024_vs_oracle():
+    """The reference's loops over all faces do not care about the ORDER of the face list (dibr_soft_mask_cuda.cu:80,
+    rasterization_cuda.cu:88); tile lists of {64-face block, mask} entries do: with the knot's faces in a random order every entry
+    holds one face and a 32 x 32 tile of the soft pass ~3 000 of them -- the select kernel's path for tiles with more entries than
+    ordered slots (rounds of consecutive block ranks, soft2.inc), the rasterizer's chunked lists.  Three views at 1024^2 against the
+    oracle, as the ordered scene above (VERDICT r04 missing #3 / next #6 ii)."""
+    from kaolin_amd.utils import testing as T
+    v, f = T.scene_mesh('knot_shuffled')
+    fz, fimg, feats, nz = T.mesh_scene(v, f, num_views=8, device='cpu')
+    vs = [0, 3, 6]
+    band = _check_views_vs_oracle(1024, 1024, fz[vs].contiguous(), fimg[vs].contiguous(), torch.cat([x[vs] for x in feats], -1).contiguous(),
+                                  nz[vs].contiguous(), expect_cover=(0.05, 0.8))
+    assert band > 60000
+
+
 def test_knot_scene_rasterize_with_valid_faces_1024_vs_oracle():
     """`rasterize` with a caller-supplied `valid_faces` mask at full size (the reference's fixture passes one:
     test_rasterization.py:62-71,146-158): a random third of the knot scene's faces switched off, two views, face_idx and
