@@ -258,7 +258,10 @@ int soft2_search_launch(hipStream_t st, int B, int H, int W, int F, int K, float
                         uint8_t* hit_count, const HitList2<T>* lean, unsigned short* pixcnt, T* prob_pm,
                         void* zero_p = nullptr, size_t zero_bytes = 0,  // (a 16-byte aligned range the eval launch clears)
                         const unsigned int* span_src = nullptr, unsigned int* span_dst = nullptr, int span_n = 0,
-                        unsigned int* magic_dst = nullptr, unsigned int* over_count = nullptr, unsigned int* over_list = nullptr) {
+                        unsigned int* magic_dst = nullptr, unsigned int* over_count = nullptr, unsigned int* over_list = nullptr,
+                        unsigned int* ord_count = nullptr, uint4* ord_list = nullptr) {
+  if (over_count == nullptr || over_list == nullptr || ord_count == nullptr || ord_list == nullptr)
+    return (int)hipErrorInvalidValue;  // (the workspace's hand-over and dealing lists)
   const unsigned int shard_cap = tl::work_shard_cap(B, H, W);
   const long long n_sub = (long long)B * LS.ntiles * tl::S_SUBS;
   Select2Args<T> sa{};
@@ -277,7 +280,10 @@ int soft2_search_launch(hipStream_t st, int B, int H, int W, int F, int K, float
   sa.idx_out = idx;
   sa.hit_count = hit_count;
   sa.over_count = over_count;
-  sa.over_list = over_count != nullptr ? over_list : nullptr;
+  sa.over_list = over_list;
+  sa.ord_count = ord_count;
+  sa.ord_list = ord_list;
+  sa.ord_cap = (unsigned int)tl::WORK_SHARDS * shard_cap;
   Eval2Args<T> ea{};
   ea.B = B;
   ea.F = F;
@@ -305,6 +311,9 @@ int soft2_search_launch(hipStream_t st, int B, int H, int W, int F, int K, float
   ea.span_n = span_n;
   ea.magic_dst = magic_dst;
   ea.magic = tl::work_magic(B, H, W);
+  ea.ord_count = sa.ord_count;
+  ea.ord_list = sa.ord_list;
+  ea.ord_cap = sa.ord_cap;
   // one wavefront (select) / workgroup (eval) per work item; the number of items is known on the device only, so the
   // grids cover the worklist round-robin
   // (select: 128 workgroups per CU -- with 32, a scene of many light items (the knot: 37 600) ran five places per workgroup one
@@ -320,7 +329,7 @@ int soft2_search_launch(hipStream_t st, int B, int H, int W, int F, int K, float
   else
     KAMD_LAUNCH_TIMED(kamd::K_SOFT_SELECT, (soft_select_kernel<T, false>), sel_grid, dim3(64), 0, st, sa);
   KAMD_CHECK(hipGetLastError());
-  if (sa.over_list != nullptr) {  // the items of tiles with more entries than ordered slots (usually none: the grid reads a counter and leaves)
+  {  // the items of tiles with more entries than ordered slots (usually none), and the deal of all items for the eval launch
     const dim3 rounds_grid((unsigned)(n_sub < S2_ROUNDS_GRID ? (n_sub > 0 ? n_sub : 1) : S2_ROUNDS_GRID));
     if (lean)
       KAMD_LAUNCH_TIMED(kamd::K_SOFT_SELECT_ROUNDS, (soft_select_rounds_kernel<T, true>), rounds_grid, dim3(64), 0, st, sa);
@@ -413,7 +422,8 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
     KAMD_CHECK(soft2_search_launch<T>(st, B, H, W, F, K, sigmainv, multiplier, rec, LS, work, soft_mask, prob, idx, type,
                                       hit_count, lean, (unsigned short*)((char*)workspace + lay.s.pixcnt),
                                       (T*)((char*)workspace + lay.s.prob_pm), nullptr, 0, nullptr, nullptr, 0, nullptr,
-                                      (unsigned int*)((char*)workspace + lay.s.over_count), (unsigned int*)((char*)workspace + lay.s.over_list)));
+                                      (unsigned int*)((char*)workspace + lay.s.over_count), (unsigned int*)((char*)workspace + lay.s.over_list),
+                                      (unsigned int*)((char*)workspace + lay.s.ord_count), (uint4*)((char*)workspace + lay.s.ord_list)));
   KAMD_RETURN_LAST_ERROR();
 }
 
@@ -520,7 +530,8 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
                                       (T*)((char*)workspace + lay.s.prob_pm), zero_in_eval ? (void*)g_img_zero : nullptr,
                                       zero_in_eval ? g_bytes : 0, LR.row_span, work + tl::work_span_offset_words(B, H, W), 2 * B,
                                       work + tl::WORK_MAGIC_WORD, (unsigned int*)((char*)workspace + lay.s.over_count),
-                                      (unsigned int*)((char*)workspace + lay.s.over_list)));
+                                      (unsigned int*)((char*)workspace + lay.s.over_list), (unsigned int*)((char*)workspace + lay.s.ord_count),
+                                      (uint4*)((char*)workspace + lay.s.ord_list)));
   KAMD_RETURN_LAST_ERROR();
 }
 

@@ -185,6 +185,7 @@ struct PassLayout {
   unsigned int plan_cap;
   size_t pixcnt, prob_pm;                // soft pass: hits per (item, pixel) (u16); pixel-major probabilities (knum > 128 only)
   size_t over_count, over_list;          // soft pass: the work places soft_select hands to its rounds launch (count zeroed; soft2.inc)
+  size_t ord_count, ord_list;            // soft pass: the items dealt by pair count for soft_eval (counts zeroed, a line each)
   unsigned int cap_chunks;
   int C, maxc;
   PassGeom g;
@@ -218,6 +219,7 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
     L.s.big_count = off; off += a256((size_t)B * 4);
     L.s.sub_touched = off; off += a256(nts * 4);
     L.s.over_count = off; off += 256;
+    L.s.ord_count = off; off += 4 * COUNTER_STRIDE * 4;  // (S2_CLASSES counters, a 128-byte line each)
   }
   L.zero_bytes = off;
   if (with_r) {
@@ -240,6 +242,7 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
     const size_t item_pixels = nts * S_SUBS * 64;
     L.s.pixcnt = off; off += a256(item_pixels * 2);
     L.s.over_list = off; off += a256((size_t)WORK_SHARDS * work_shard_cap(B, H, W) * 4);
+    L.s.ord_list = off; off += a256((size_t)4 * WORK_SHARDS * work_shard_cap(B, H, W) * 16);  // (S2_CLASSES lists of work records)
     L.s.prob_pm = off; off += K > 128 ? a256(item_pixels * (size_t)K * esz) : 0;
   }
   L.total = off + 256;
