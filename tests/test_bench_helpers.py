@@ -60,3 +60,17 @@ def test_cpu_reference_extras_small_sample():
     assert r['chamfer_torch_oracle']['max_rel_diff_vs_restated_kernel'] < 1e-5
     assert r['rasterize_torch_oracle']['face_idx_equals_restated_kernel'] is True
     assert all(v['kind'] == 'port' and v['cores'] >= 1 for v in r.values())
+
+
+def test_knot_shuffled_scene_is_a_permutation_of_the_knot():
+    """bench.py --scene knot_shuffled / scene_variants.knot_shuffled and the full-size parity test render the knot's faces in a
+    fixed random order: the same triangles (as a multiset of vertex-index triples), the same vertices, another list order."""
+    import torch
+    from kaolin_amd.utils import testing as T
+    v0, f0 = T.scene_mesh('knot')
+    v1, f1 = T.scene_mesh('knot_shuffled')
+    assert torch.equal(v0, v1) and f0.shape == f1.shape and not torch.equal(f0, f1)
+    key = lambda f: torch.sort((f[:, 0] * v0.shape[0] + f[:, 1]) * v0.shape[0] + f[:, 2]).values
+    assert torch.equal(key(f0), key(f1))
+    _, f2 = T.scene_mesh('knot_shuffled')
+    assert torch.equal(f1, f2)  # (a fixed seed: every run renders the same order)
