@@ -7,8 +7,7 @@ namespace kamd {
 template <typename T>
 int raster2_draw(hipStream_t st, int B, int H, int W, int D, int F_dense, float multiplier, float eps, const T* rec,
                  const tl::Lists& LR, const T* feat, T* interp, int64_t* sel_idx, T* weights, const tl::ClassifyOut& co,
-                 bool weights_internal,   // background tiles leave `weights` unwritten (read only where face_idx >= 0)
-                 const tl::RasterPlan* plan);  // the workspace's plan region (tl::plan_of): plan + fill / tile workgroups (raster3.inc); nullptr: a workgroup per tile
+                 bool weights_internal);  // background tiles leave `weights` unwritten (read only where face_idx >= 0)
 // rasterize.hip: the rasterizer's backward kernel; tile_cov (one byte per (mesh, 16 x 16 tile), tl::work_cov_offset_words)
 // lets workgroups of tiles without a covered pixel leave at once (nullptr: found out from face_idx); row_span: the forward's
 // covered-row spans (tl::work_span_offset_words; nullptr: start from the middle of the image)

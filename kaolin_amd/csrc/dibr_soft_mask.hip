@@ -520,9 +520,8 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
   co.work_counts = work;
   co.shard_cap = tl::work_shard_cap(B, H, W);
   co.tile_cov = reinterpret_cast<unsigned char*>(work + tl::work_cov_offset_words(B, H, W));
-  const tl::RasterPlan plan = tl::plan_of(workspace, lay.r);
   KAMD_CHECK(kamd::raster2_draw<T>(st, B, H, W, D, F, (float)multiplier, eps, rec_r, LR, feat, interp, face_idx, weights, co,
-                                   kamd_env_int("KAMD_DIBR_BG_WEIGHTS", 2) != 1, total_faces > 0 ? &plan : nullptr));
+                                   kamd_env_int("KAMD_DIBR_BG_WEIGHTS", 2) != 1));
   if (total_faces > 0)
     KAMD_CHECK(soft2_search_launch<T>(st, B, H, W, F, K, sigmainv, (float)multiplier, rec_s, LS, work, soft_mask, (T*)nullptr,
                                       (int64_t*)nullptr, (uint8_t*)nullptr, (uint8_t*)nullptr, &list,

@@ -26,7 +26,6 @@ namespace {
 using namespace kamd;
 
 #include "raster2.inc"
-#include "raster3.inc"
 
 // ---- K2 -------------------------------------------------------------------------------------------------
 // Per covered pixel the reference issues 3*D + 6*D float atomics on addresses shared by every pixel of the same
@@ -422,35 +421,9 @@ template int raster_backward_draw_list<double>(hipStream_t, int, int, int, int, 
 template <typename T>
 int raster2_draw(hipStream_t st, int B, int H, int W, int D, int F_dense, float multiplier, float eps, const T* rec,
                  const tl::Lists& LR, const T* feat, T* interp, int64_t* sel_idx, T* weights, const tl::ClassifyOut& co,
-                 bool weights_internal, const tl::RasterPlan* plan) {
+                 bool weights_internal) {
   if (!raster2_grid_fits(H, W)) return (int)hipErrorInvalidValue;
   const int wide_ok = raster2_wide_ok(W, interp, sel_idx, weights, co.soft_mask) | (weights_internal ? 2 : 0);
-  if constexpr (sizeof(T) == 4) {
-    if (raster4_applicable()) {
-      kamd::ProfScope prof_(kamd::K_RASTER_TILE, st);
-      hipLaunchKernelGGL((raster_wave_kernel<true>), raster4_grid(LR, B), dim3(256), 0, st, B, F_dense, (const int64_t*)nullptr, H, W, D,
-                         pixel_scale(multiplier, H, W), eps, wide_ok, rec, LR, feat, interp, sel_idx, weights, co, LR.ntiles / LR.tiles_x);
-      return (int)hipGetLastError();
-    }
-  }
-  if (plan != nullptr && raster3_applicable(H, W, LR)) {
-    kamd::ProfScope prof_(kamd::K_RASTER_TILE, st);
-    const int tiles_y = LR.ntiles / LR.tiles_x;
-    hipLaunchKernelGGL(raster_plan_kernel, dim3(tl::PLAN_GROUPS), dim3(256), 0, st, LR, *plan, B, H, W, tiles_y,
-                       raster3_fill_ok<T>(W, D, interp, sel_idx, weights, co.soft_mask));
-    // (KAMD_RASTER_FILL_POS, experiment builds: 1 = the fill before the tiles, 2 = after)
-    const bool fill_first = kamd_env_int("KAMD_RASTER_FILL_POS", 1) == 1;
-    for (int step = 0; step < 2; ++step) {
-      if ((step == 0) == fill_first)
-        hipLaunchKernelGGL((raster_fill_kernel<T>), dim3(raster3_fill_wgs(B, tiles_y)), dim3(256), 0, st, B, H, W, D, wide_ok, LR.tiles_x, LR.ntiles,
-                           tiles_y, *plan, interp, sel_idx, weights, co);
-      else
-        hipLaunchKernelGGL((raster_tile_kernel3<T>), dim3(tl::PLAN_GROUPS * plan->cap), dim3(256), 0, st, B, F_dense, H, W, D,
-                           pixel_scale(multiplier, H, W), eps, wide_ok, rec, LR, feat, interp, sel_idx, weights, co,
-                           (const unsigned int*)plan->count, (const uint2*)plan->list, plan->cap, tiles_y);
-    }
-    return (int)hipGetLastError();
-  }
   KAMD_LAUNCH_TIMED(kamd::K_RASTER_TILE, (raster_tile_kernel2<T, true>), raster2_grid(LR, B), dim3(256), 0, st, B, F_dense,
                     (const int64_t*)nullptr, H, W, D, pixel_scale(multiplier, H, W), eps, wide_ok,
                     rec, LR, feat, interp, sel_idx, weights, co);
@@ -467,9 +440,9 @@ template int raster_backward_draw<float>(hipStream_t, int, int, int, int, int, c
 template int raster_backward_draw<double>(hipStream_t, int, int, int, int, int, const double*, const int64_t*, const double*,
                                           const double*, const double*, float, double*, double*, const unsigned char*, const unsigned int*);
 template int raster2_draw<float>(hipStream_t, int, int, int, int, int, float, float, const float*, const tl::Lists&, const float*,
-                                 float*, int64_t*, float*, const tl::ClassifyOut&, bool, const tl::RasterPlan*);
+                                 float*, int64_t*, float*, const tl::ClassifyOut&, bool);
 template int raster2_draw<double>(hipStream_t, int, int, int, int, int, float, float, const double*, const tl::Lists&,
-                                  const double*, double*, int64_t*, double*, const tl::ClassifyOut&, bool, const tl::RasterPlan*);
+                                  const double*, double*, int64_t*, double*, const tl::ClassifyOut&, bool);
 }  // namespace kamd
 
 #ifdef KAMD_PHASE_PROF

@@ -152,18 +152,6 @@ struct Lists {
 };
 
 inline size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
-// The rasterizer's plan (raster3.inc): which tiles hold work -- entries of their own, a big face over them, or a shape the
-// streaming fill does not take (a partial tile at the image's edge) -- as one 64-bit word per (view, tile row, 64 tiles) and as
-// PLAN_GROUPS compact lists {view, ty << 16 | tx}: list g holds the tiles of the views b % 8 == g (workgroup w runs on XCD w % 8: a
-// view's records and features stay in one XCD's L2), rows from the middle of the covered rows outwards.
-constexpr int PLAN_GROUPS = 8;
-constexpr int PLAN_MAX_UNITS = 2048;  // (tile rows) x (64-tile segments per row) of one view that the plan kernel holds in LDS
-struct RasterPlan {
-  unsigned int* count;            // [PLAN_GROUPS]
-  uint2* list;                    // [PLAN_GROUPS * cap]
-  unsigned long long* work_rows;  // [B * tiles_y * segs]
-  unsigned int cap;
-};
 __host__ __device__ inline int big_row_words(int tiles_x) { return (tiles_x + 63) >> 6; }
 inline unsigned int pool_chunks(long long total_faces, long long n_tiles_total) {
   // entries the pool can take beyond the inline slots.  A face adds at most one entry per tile of its rectangle (fewer when its
@@ -181,8 +169,6 @@ inline unsigned int pool_chunks(long long total_faces, long long n_tiles_total) 
 struct PassLayout {
   size_t count, tab, pool_top, big_count, big_rows, sub_touched, row_span;  // inside the zero region
   size_t inl, pool, big_list, rec;                      // after it
-  size_t plan_count, plan_list, plan_rows;               // raster pass: the plan of the tiles that hold work (RasterPlan)
-  unsigned int plan_cap;
   size_t pixcnt, prob_pm;                // soft pass: hits per (item, pixel) (u16); pixel-major probabilities (knum > 128 only)
   size_t over_count, over_list;          // soft pass: the work places soft_select hands to its rounds launch (count zeroed; soft2.inc)
   size_t ord_count, ord_list;            // soft pass: the items dealt by pair count for soft_eval (counts zeroed, a line each)
@@ -228,10 +214,6 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
     L.r.pool = off; off += a256((size_t)L.r.cap_chunks * OVC * 16);
     L.r.big_list = off; off += a256((size_t)total_faces * 4);
     L.r.rec = off; off += a256((size_t)total_faces * REC_R * esz);
-    L.r.plan_cap = (unsigned int)(((size_t)B + PLAN_GROUPS - 1) / PLAN_GROUPS * L.r.g.ntiles);
-    L.r.plan_count = off; off += 256;
-    L.r.plan_list = off; off += a256((size_t)PLAN_GROUPS * L.r.plan_cap * 8);
-    L.r.plan_rows = off; off += a256((size_t)B * L.r.g.tiles_y * big_row_words(L.r.g.tiles_x) * 8);
   }
   if (with_s) {
     L.s.cap_chunks = pool_chunks(total_faces, (long long)nts);
@@ -296,10 +278,6 @@ inline size_t work_words(int B, int H, int W) {
   return work_covlist_offset_words(B, H, W) + (size_t)COV_SHARDS * cov_shard_cap((size_t)B, (size_t)pass_geom(H, W, R_TILE).ntiles);
 }
 
-inline RasterPlan plan_of(void* ws, const PassLayout& p) {
-  char* c = (char*)ws;
-  return RasterPlan{(unsigned int*)(c + p.plan_count), (uint2*)(c + p.plan_list), (unsigned long long*)(c + p.plan_rows), p.plan_cap};
-}
 inline Lists lists_of(void* ws, const PassLayout& p, int B, bool soft) {
   char* c = (char*)ws;
   Lists l;
@@ -1186,39 +1164,6 @@ __device__ __forceinline__ void queue_finish(const QueueTicket& t, bool any_cove
       if (u == 0ull) continue;
       if (pos < shard_cap)
         work_items[(size_t)t.shard * shard_cap + pos] = make_uint4(item_id_of(B, b, tx, ty, tiles_x_s, w), (unsigned int)u, (unsigned int)(u >> 32), 0u);
-      ++pos;
-    }
-  }
-}
-// queue_items_reached for a tile owned by ONE wavefront (raster4.inc): `unc[w]` = the uncovered pixels of the tile's 16 x 4 strip w,
-// `covered` = the tile holds a covered pixel.  Called by the whole wavefront (uniform arguments); lane 0 appends.
-__device__ __forceinline__ void queue_items_wave(const unsigned long long* unc, unsigned int reach, bool covered, int B, int b, int tx, int ty,
-                                                 int tiles_x_s, int lane, unsigned int tile_order, uint4* __restrict__ work_items,
-                                                 unsigned int* __restrict__ work_counts, unsigned int shard_cap,
-                                                 unsigned char* __restrict__ tile_cov, size_t cov_index, size_t ntiles_r) {
-  if (lane != 0) return;
-  const unsigned int shard = (tile_order * (unsigned int)B + (unsigned int)b) & (WORK_SHARDS - 1);
-  if (tile_cov != nullptr) {
-    tile_cov[cov_index] = covered ? 1 : 0;
-    if (covered) {  // the covered-tile list lives behind the coverage bytes and the span copy (work_covlist_offset_words)
-      const unsigned int cs = cov_shard_of(B, b, tile_order);
-      const unsigned int pos = atomicAdd(work_counts + WORK_COV_WORD + cs * COUNTER_STRIDE, 1u);
-      unsigned int* list = reinterpret_cast<unsigned int*>(tile_cov) + cov_list_words_after_cov((size_t)B, (size_t)B * ntiles_r);
-      const unsigned int cap = cov_shard_cap((size_t)B, ntiles_r);
-      if (pos < cap) list[(size_t)cs * cap + pos] = (unsigned int)cov_index;
-    }
-  }
-  int n = 0;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) n += (unc[w] != 0ull && reached(reach, w)) ? 1 : 0;
-  if (n > 0) {
-    unsigned int pos = atomicAdd(work_counts + shard * COUNTER_STRIDE, (unsigned int)n);
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const unsigned long long u = unc[w];
-      if (u == 0ull || !reached(reach, w)) continue;
-      if (pos < shard_cap)
-        work_items[(size_t)shard * shard_cap + pos] = make_uint4(item_id_of(B, b, tx, ty, tiles_x_s, w), (unsigned int)u, (unsigned int)(u >> 32), 0u);
       ++pos;
     }
   }
