@@ -607,19 +607,22 @@ int dibr_backward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K
 
 #ifdef KAMD_PHASE_PROF
 extern "C" int kamd_debug_phase_cycles_bin(unsigned long long* out16, int reset) {
-  int rc = (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(tl::g_phase_bin), 16 * sizeof(unsigned long long));
+  // (rows summed, except [10]: the longest wavefront = the rows' maximum)
+  static unsigned long long host[PHASE_ROWS * 16];
+  int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(tl::g_phase_bin), sizeof(host));
+  for (int i = 0; i < 16; ++i) {
+    out16[i] = 0;
+    for (int r = 0; r < PHASE_ROWS; ++r) out16[i] = i == 10 ? (host[r * 16 + i] > out16[i] ? host[r * 16 + i] : out16[i]) : out16[i] + host[r * 16 + i];
+  }
   if (reset) {
-    unsigned long long z[16] = {0};
-    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(tl::g_phase_bin), z, sizeof(z));
+    for (size_t i = 0; i < sizeof(host) / 8; ++i) host[i] = 0;
+    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(tl::g_phase_bin), host, sizeof(host));
   }
   return rc;
 }
 extern "C" int kamd_debug_phase_cycles(unsigned long long* out16, int reset) {
-  int rc = (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_select), 16 * sizeof(unsigned long long));
-  if (reset) {
-    unsigned long long z[16] = {0};
-    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_select), z, sizeof(z));
-  }
+  int rc = 0;
+  PHASE_READ(g_phase_select, out16, reset, rc);
   return rc;
 }
 #endif

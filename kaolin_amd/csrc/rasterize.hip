@@ -424,7 +424,7 @@ int raster2_draw(hipStream_t st, int B, int H, int W, int D, int F_dense, float 
                  bool weights_internal) {
   if (!raster2_grid_fits(H, W)) return (int)hipErrorInvalidValue;
   const int wide_ok = raster2_wide_ok(W, interp, sel_idx, weights, co.soft_mask) | (weights_internal ? 2 : 0);
-  KAMD_LAUNCH_TIMED(kamd::K_RASTER_TILE, (raster_tile_kernel2<T, true>), raster2_grid(LR, B), dim3(256), 0, st, B, F_dense,
+  KAMD_LAUNCH_TIMED(kamd::K_RASTER_TILE, (raster_tile_kernel2<T, true, false>), raster2_grid(LR, B), dim3(256), 0, st, KAMD_TILE_HEAD_ARGS(LR, co, F_dense), B,
                     (const int64_t*)nullptr, H, W, D, pixel_scale(multiplier, H, W), eps, wide_ok,
                     rec, LR, feat, interp, sel_idx, weights, co);
   return (int)hipGetLastError();
@@ -447,19 +447,13 @@ template int raster2_draw<double>(hipStream_t, int, int, int, int, int, float, f
 
 #ifdef KAMD_PHASE_PROF
 extern "C" int kamd_debug_phase_cycles_rbwd(unsigned long long* out16, int reset) {
-  int rc = (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_rbwd), 16 * sizeof(unsigned long long));
-  if (reset) {
-    unsigned long long z[16] = {0};
-    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_rbwd), z, sizeof(z));
-  }
+  int rc = 0;
+  PHASE_READ(g_phase_rbwd, out16, reset, rc);
   return rc;
 }
 extern "C" int kamd_debug_phase_cycles_raster(unsigned long long* out16, int reset) {
-  int rc = (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_raster), 16 * sizeof(unsigned long long));
-  if (reset) {
-    unsigned long long z[16] = {0};
-    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_raster), z, sizeof(z));
-  }
+  int rc = 0;
+  PHASE_READ(g_phase_raster, out16, reset, rc);
   return rc;
 }
 #endif

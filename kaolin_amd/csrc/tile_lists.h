@@ -601,7 +601,7 @@ __device__ __forceinline__ void append_own(int n_on, RectWalk& at, int tx0, int 
 // lane, ballots the lanes whose rectangle holds it and clears it everywhere.  Steps = distinct tiles.  The results are
 // parked one per lane and appended 64 tiles at a time (a returning atomic per step would serialise the loop on L2 latency).
 #ifdef KAMD_PHASE_PROF
-static __device__ unsigned long long g_phase_bin[16];  // [0..7] phases, [10] longest wavefront, [11] > 1000 ticks (10 us at 100 MHz), [12] > 2500;
+static __device__ unsigned long long g_phase_bin[PHASE_ROWS * 16];  // [0..7] phases, [10] longest wavefront, [11] > 1000 ticks (10 us at 100 MHz), [12] > 2500;
                                                        // wave_bin, both passes: [8] big-list appends, [9] medium faces, [15] the merging loop
 #endif
 template <bool SOFT>
@@ -621,7 +621,7 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
     remaining &= ~__ballot(mine);
 #ifdef KAMD_PHASE_PROF
     unsigned long long wb_t = clock64();
-#define WB_MARK(i) { const unsigned long long wb_n = clock64(); if (lane == 0) atomicAdd(&g_phase_bin[i], wb_n - wb_t); wb_t = wb_n; }
+#define WB_MARK(i) { const unsigned long long wb_n = clock64(); if (lane == 0) atomicAdd(&PHASE_ROW(g_phase_bin)[i], wb_n - wb_t); wb_t = wb_n; }
 #else
 #define WB_MARK(i)
 #endif
@@ -959,11 +959,11 @@ __global__ __launch_bounds__(256) void bin_faces_kernel2(
 #ifdef KAMD_PHASE_PROF
   if ((threadIdx.x & 63) == 0) {
     const unsigned long long tot = wall_clock64() - wall0;
-    atomicAdd(&g_phase_bin[14], tot);
-    atomicMax(&g_phase_bin[10], tot);
-    if (tot > 1000ull) atomicAdd(&g_phase_bin[11], 1ull);
-    if (tot > 2500ull) atomicAdd(&g_phase_bin[12], 1ull);
-    atomicAdd(&g_phase_bin[13], 1ull);
+    atomicAdd(&PHASE_ROW(g_phase_bin)[14], tot);
+    atomicMax(&PHASE_ROW(g_phase_bin)[10], tot);
+    if (tot > 1000ull) atomicAdd(&PHASE_ROW(g_phase_bin)[11], 1ull);
+    if (tot > 2500ull) atomicAdd(&PHASE_ROW(g_phase_bin)[12], 1ull);
+    atomicAdd(&PHASE_ROW(g_phase_bin)[13], 1ull);
   }
 #endif
 }

@@ -623,11 +623,8 @@ int td_backward_launch(hipStream_t st, int N, int F, const T* grad, const T* poi
 
 #ifdef KAMD_PHASE_PROF
 extern "C" int kamd_debug_phase_cycles_ts(unsigned long long* out16, int reset) {
-  int rc = (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_ts), 16 * sizeof(unsigned long long));
-  if (reset) {
-    unsigned long long z[16] = {0};
-    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ts), z, sizeof(z));
-  }
+  int rc = 0;
+  PHASE_READ(g_phase_ts, out16, reset, rc);
   return rc;
 }
 #endif

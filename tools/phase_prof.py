@@ -24,9 +24,12 @@ raw.kamd_debug_phase_cycles(buf, 1)
 raw.kamd_debug_phase_cycles_raster(buf2, 1)
 raw.kamd_debug_phase_cycles_bin(buf3, 1)
 n = 5
+lib.kamd_profile_reset(); lib.kamd_profile_enable(1)
 for _ in range(n):
     kal.render.mesh.dibr_rasterization(H, W, fz, fimg, feat, nz)
 torch.cuda.synchronize()
+lib.kamd_profile_enable(0)
+print('kernel us in this (instrumented) build:', {k: round(v[0] / v[1] * 1e3, 1) for k, v in _lib.kernel_profile(reset=True).items()})
 raw.kamd_debug_phase_cycles(buf, 0)
 raw.kamd_debug_phase_cycles_raster(buf2, 0)
 raw.kamd_debug_phase_cycles_bin(buf3, 0)
@@ -35,9 +38,11 @@ print('bin_faces: phases (index math | vertex loads | raster record incl. z load
       'longest wavefront', buf3[10], 'ticks (10 ns each); wavefronts > 1000 ticks', buf3[11] / n, '> 2500', buf3[12] / n, 'of', buf3[13] / n, '; mean wavefront', round(buf3[14] / max(buf3[13], 1) / 100.0, 2), 'us')
 for title, b, names in (
         ('soft_select', buf, ['setup', 'order entries', 'stream+cull', 'chunk masks', 'accept+transposes', 'pair write', 'tail']),
-        ('raster_tile', buf2, ['setup (touched)', 'entries load', 'scan+ids', 'stage+cull+readlane', 'mask (readlane)',
-                               'walk 1 (signs)', 'walk 2 (divisions)', 'tail of loops', 'output+classify', 'background tile'])):
+        ('raster_tile', buf2, ['setup (count known)', 'entries, ids, records -> LDS', 'cull + uniform edge loop', 'exact walks', 'loop tail (barriers)',
+                               'feature gather + idx store', 'output barrier', 'LDS staging + row stores', 'worklist tickets + drain', 'background tile'])):
     tot = sum(b[:10]) or 1
     print(title)
     for i, nm in enumerate(names):
-        print(f'  {nm:22s} {b[i] / n / 1e6:10.2f} Mticks/step  {100.0 * b[i] / tot:5.1f} %')
+        print(f'  {nm:28s} {b[i] / n / 1e6:10.2f} Mticks/step  {100.0 * b[i] / tot:5.1f} %')
+    if title == 'raster_tile' and b[10]:
+        print(f'  wavefronts of tiles with candidates {b[10] / n:.0f}: {sum(b[:9]) / b[10]:.0f} ticks each; of background tiles {b[11] / n:.0f}: {b[9] / max(b[11], 1):.0f} ticks each')
