@@ -627,6 +627,18 @@ int kamd_trianglemeshes_to_voxelgrids_f64(void* stream, int B, int V, int F, int
                                           const double* origin, const double* scale, double* norm,
                                           double* grid);
 
+/* The same marks as one BIT per voxel (the sparse result of trianglemeshes_to_voxelgrids(return_sparse=True): the reference builds  */
+/* its COO tensor from the unique voxel indices and never allocates R^3 scalars, kaolin/ops/conversions/pointcloud.py:66-73).       */
+/* bits: B * kamd_trianglemeshes_to_voxelbits_words(R) uint32 words, cleared by the call; voxel ((x R + y) R + z) of mesh b = bit     */
+/* (lin & 31) of word b * words + (lin >> 5).  norm: as kamd_trianglemeshes_to_voxelgrids_*.                                          */
+size_t kamd_trianglemeshes_to_voxelbits_words(int R);
+int kamd_trianglemeshes_to_voxelbits_f32(void* stream, int B, int V, int F, int R, const float* vertices,
+                                         const int64_t* faces, const float* origin, const float* scale, float* norm,
+                                         uint32_t* bits);
+int kamd_trianglemeshes_to_voxelbits_f64(void* stream, int B, int V, int F, int R, const double* vertices,
+                                         const int64_t* faces, const double* origin, const double* scale, double* norm,
+                                         uint32_t* bits);
+
 /* ------------------------------------------------------------------------- */
 /* Optional per-kernel timing (HIP events recorded on the launch stream).      */
 /* Not part of the reference's interface: used by bench.py for its roofline    */
@@ -639,6 +651,13 @@ int kamd_profile_reset(void);
 int kamd_profile_num_kernels(void);
 const char* kamd_profile_kernel_name(int id);
 int kamd_profile_read(int id, double* total_ms, int64_t* launches);
+
+/* Work counters of the exact triangle-distance search (no reference counterpart; bench.py's VALU figure for C5).  While `on`,      */
+/* every kamd_triangle_distance_forward_* call that takes the sweep counts its work and SYNCHRONISES to read the counts back;        */
+/* out8 (optional) receives the last call's: tiles staged, tile walks (per wavefront), (query, tile) sphere tests, face steps (per   */
+/* wavefront of 64 lanes), closest-point evaluations (unbatched_triangle_distance_cuda.cu:237-317, one per lane), sum of tiles       */
+/* needed per query, queries needing > 48 tiles, hard queries.  Off by default: the product path counts nothing.                     */
+int kamd_triangle_distance_work_counters(int on, unsigned long long* out8);
 
 /* ---- self-test hook (no reference counterpart) ------------------------------------------------------------------ */
 /* The 64 x 64 bit transpose of the soft mask's select kernel (csrc/tile_bins.h wave_transpose64: gfx950 lane-swap and DPP      */

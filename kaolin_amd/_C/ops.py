@@ -6,10 +6,12 @@ from .. import _lib
 from .._checks import torch_check
 
 
-def trianglemeshes_to_voxelgrids_cuda(vertices, faces, resolution, origin=None, scale=None):
+def trianglemeshes_to_voxelgrids_cuda(vertices, faces, resolution, origin=None, scale=None, return_sparse=False):
     """vertices (B, V, 3) raw; faces (F, 3) int64 shared by the batch; origin (B, 3) / scale (B) of the normalisation
     ``(vertices - origin) / scale`` or None (per-mesh minimum / largest extent, computed on the device)
-    -> dense (B, R, R, R) grid of 0/1 in the vertices' dtype."""
+    -> dense (B, R, R, R) grid of 0/1 in the vertices' dtype; ``return_sparse``: the same as a coalesced sparse COO tensor built
+    from a BIT grid (R^3 / 8 bytes per mesh) -- R^3 scalars are never allocated (reference: the COO of the unique voxel indices,
+    kaolin/ops/conversions/pointcloud.py:66-73)."""
     fn = 'trianglemeshes_to_voxelgrids_cuda'
     torch_check(vertices.is_cuda and faces.is_cuda, f'{fn}: vertices and faces must be CUDA tensors')
     torch_check(vertices.dim() == 3 and vertices.size(2) == 3, 'vertices must of size {batch_size, num_vertices, 3}')
@@ -30,6 +32,25 @@ def trianglemeshes_to_voxelgrids_cuda(vertices, faces, resolution, origin=None, 
         # the kernels gather vertices unchecked; the reference's indexing raises (a device assert) on such a mesh
         raise IndexError(f'{fn}: faces hold an index outside [0, num_vertices)')
     lib = _lib.load()
+    if return_sparse:
+        with _lib.on_device(v.device):
+            words = int(lib.kamd_trianglemeshes_to_voxelbits_words(R))
+            bits = torch.empty((B, words), dtype=torch.int32, device=v.device)
+            norm = _lib.workspace(lib.kamd_trianglemeshes_to_voxelgrids_workspace(B, V, v.element_size()), v.device)
+            st = getattr(lib, f'kamd_trianglemeshes_to_voxelbits_{sfx}')(
+                _lib.stream_ptr(v.device), B, V, F, R, _lib.ptr(v), _lib.ptr(f), _lib.ptr(origin), _lib.ptr(scale), _lib.ptr(norm),
+                _lib.ptr(bits))
+        _lib.check(st, fn)
+        # compaction, sized by the occupied words: (mesh, word) of every non-zero word, its 32 bits, the set ones -> linear
+        # voxel indices in ascending order per mesh (= the order of a coalesced COO tensor)
+        nzw = torch.nonzero(bits)                                           # (n_words, 2), lexicographic
+        w = bits[nzw[:, 0], nzw[:, 1]]
+        on = ((w.unsqueeze(1) >> torch.arange(32, device=v.device, dtype=torch.int32)) & 1).bool()   # (n_words, 32)
+        sel = torch.nonzero(on)                                             # (nnz, 2): (word slot, bit), lexicographic
+        lin = nzw[sel[:, 0], 1] * 32 + sel[:, 1]
+        idx = torch.stack([nzw[sel[:, 0], 0], lin // (R * R), (lin // R) % R, lin % R])
+        return torch.sparse_coo_tensor(idx, torch.ones(idx.shape[1], dtype=v.dtype, device=v.device), (B, R, R, R),
+                                       is_coalesced=True)
     with _lib.on_device(v.device):
         grid = torch.empty((B, R, R, R), dtype=v.dtype, device=v.device)
         norm = _lib.workspace(lib.kamd_trianglemeshes_to_voxelgrids_workspace(B, V, v.element_size()), v.device)

@@ -41,6 +41,7 @@ SIGNATURES = {
     'kamd_dibr_soft_mask_work_words': (_sz, [_i, _i, _i]),
     'kamd_dibr_rasterization_workspace': (_sz, [_i, _i, _i, _i, _i, _i]),
     'kamd_trianglemeshes_to_voxelgrids_workspace': (_sz, [_i, _i, _i]),
+    'kamd_trianglemeshes_to_voxelbits_words': (_sz, [_i]),
     'kamd_mask_iou_workspace': (_sz, [_i]),
     'kamd_weighted_sum2_workspace': (_sz, []),
     'kamd_deftet_forward_workspace': (_sz, [_i, _i, _i, _i]),
@@ -57,6 +58,7 @@ SIGNATURES = {
     'kamd_profile_num_kernels': (_i, []),
     'kamd_profile_kernel_name': (ctypes.c_char_p, [_i]),
     'kamd_profile_read': (_i, [_i, _vp, _vp]),
+    'kamd_triangle_distance_work_counters': (_i, [_i, _vp]),
     'kamd_debug_transpose64': (_i, [_vp, _i, _vp, _vp, _i]),
 }
 for _t in ('f32', 'f64', 'f16', 'u8', 'i16', 'i32', 'i64'):
@@ -105,6 +107,7 @@ for _t in ('f32', 'f64'):
     SIGNATURES[f'kamd_triangle_distance_forward_{_t}'] = (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_triangle_distance_backward_{_t}'] = (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
     SIGNATURES[f'kamd_trianglemeshes_to_voxelgrids_{_t}'] = (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp])
+    SIGNATURES[f'kamd_trianglemeshes_to_voxelbits_{_t}'] = (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp])
 
 _lock = threading.Lock()
 _lib = None

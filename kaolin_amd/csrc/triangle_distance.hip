@@ -639,6 +639,12 @@ size_t kamd_triangle_distance_forward_workspace(int N, int F, int elem_size) {
   const size_t sweep = td_align((size_t)F * TD_REC * elem_size) + td_reseed_bytes(N, F) + ts_layout(nullptr, N, F, elem_size).total;
   return brute > sweep ? brute : sweep;  // either path may be taken (KAMD_TRIANGLE_DISTANCE)
 }
+int kamd_triangle_distance_work_counters(int on, unsigned long long* out8) {
+  if (out8 != nullptr)
+    for (int i = 0; i < 8; ++i) out8[i] = g_ts_stats_last[i];
+  g_ts_stats_on = on != 0 ? 1 : 0;
+  return 0;
+}
 int kamd_triangle_distance_forward_f32(void* stream, int N, int F, const float* points, const float* faces, float* dist,
                                        int64_t* face_idx, int32_t* dist_type, void* workspace) {
   return td_forward_launch<float>((hipStream_t)stream, N, F, points, faces, dist, face_idx, dist_type, workspace);

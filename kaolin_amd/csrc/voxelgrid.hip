@@ -34,16 +34,25 @@ namespace {
 constexpr int VOX_MAXD = 20;
 constexpr int VOX_MAXL0 = 10;
 
+__host__ __device__ inline size_t vox_bit_words(int R) { return ((size_t)R * R * R + 31) / 32; }
 template <typename T> __device__ __forceinline__ T vox_rint(T x);
 template <> __device__ __forceinline__ float vox_rint<float>(float x) { return rintf(x); }
 template <> __device__ __forceinline__ double vox_rint<double>(double x) { return rint(x); }
 
-template <typename T>
+// BITS: `grid` is the mesh's BIT grid (one bit per voxel, 32 per word, voxel ((x R + y) R + z) = bit of that linear index) -- the
+// sparse result (return_sparse=True) is compacted from it and never sees R^3 scalars (the reference builds its COO from the unique
+// voxel indices, kaolin/ops/conversions/pointcloud.py:66-73; at R = 1024 a dense float grid is 4 GB, the bit grid 128 MB)
+template <typename T, bool BITS>
 __device__ __forceinline__ void vox_mark(T* __restrict__ grid, int R, T x, T y, T z) {
   const T s = (T)(R - 1);
   const T rx = vox_rint<T>(x * s), ry = vox_rint<T>(y * s), rz = vox_rint<T>(z * s);
-  if (rx >= 0 && rx <= s && ry >= 0 && ry <= s && rz >= 0 && rz <= s)
-    grid[((size_t)(int)rx * R + (int)ry) * R + (int)rz] = (T)1;
+  if (rx >= 0 && rx <= s && ry >= 0 && ry <= s && rz >= 0 && rz <= s) {
+    const size_t lin = ((size_t)(int)rx * R + (int)ry) * R + (int)rz;
+    if (BITS)
+      atomicOr(reinterpret_cast<unsigned int*>(grid) + (lin >> 5), 1u << (unsigned int)(lin & 31));
+    else
+      grid[lin] = (T)1;
+  }
 }
 
 template <typename T>
@@ -187,7 +196,7 @@ __device__ __forceinline__ void vox_norm_cache(const T* __restrict__ part, const
   __syncthreads();
 }
 
-template <typename T>
+template <typename T, bool BITS>
 __global__ __launch_bounds__(256) void vox_mark_kernel(long long nvert, long long total, int B, int V, int F, int R, int L0,
                                                        double thr_d, const T* __restrict__ vertices,
                                                        const int64_t* __restrict__ faces, const T* __restrict__ origin_in,
@@ -212,7 +221,9 @@ __global__ __launch_bounds__(256) void vox_mark_kernel(long long nvert, long lon
   } else {
     vox_norm_of<T>(part, origin_in, scale_in, b, o, &sc);
   }
-  T* grid = grid_all + (size_t)b * R * R * R;
+  // (BITS: the meshes' bit grids are vox_bit_words(R) words apart)
+  T* grid = BITS ? reinterpret_cast<T*>(reinterpret_cast<unsigned int*>(grid_all) + (size_t)b * vox_bit_words(R))
+                 : grid_all + (size_t)b * R * R * R;
   const T* vb = vertices + (size_t)b * V * 3;
   if (is_vertex) {
     // one thread per vertex: (v - origin) / scale, two roundings as the reference's torch ops
@@ -223,7 +234,7 @@ __global__ __launch_bounds__(256) void vox_mark_kernel(long long nvert, long lon
       norm[b * 4 + 2] = o[2];
       norm[b * 4 + 3] = sc;
     }
-    vox_mark<T>(grid, R, (vb[(size_t)i * 3] - o[0]) / sc, (vb[(size_t)i * 3 + 1] - o[1]) / sc, (vb[(size_t)i * 3 + 2] - o[2]) / sc);
+    vox_mark<T, BITS>(grid, R, (vb[(size_t)i * 3] - o[0]) / sc, (vb[(size_t)i * 3 + 1] - o[1]) / sc, (vb[(size_t)i * 3 + 2] - o[2]) / sc);
     return;
   }
   const unsigned int path = (unsigned int)((gid - nvert) % npath);
@@ -244,9 +255,9 @@ __global__ __launch_bounds__(256) void vox_mark_kernel(long long nvert, long lon
     vox_mids<T>(cur, mid);
     const int shift = 2 * (L0 - 1 - l);
     if ((path & ((1u << (shift + 2)) - 1u)) == 0u) {
-      vox_mark<T>(grid, R, mid[0], mid[1], mid[2]);
-      vox_mark<T>(grid, R, mid[3], mid[4], mid[5]);
-      vox_mark<T>(grid, R, mid[6], mid[7], mid[8]);
+      vox_mark<T, BITS>(grid, R, mid[0], mid[1], mid[2]);
+      vox_mark<T, BITS>(grid, R, mid[3], mid[4], mid[5]);
+      vox_mark<T, BITS>(grid, R, mid[6], mid[7], mid[8]);
     }
     T child[9];
     vox_child<T>(cur, mid, (int)((path >> shift) & 3u), child);
@@ -270,9 +281,9 @@ __global__ __launch_bounds__(256) void vox_mark_kernel(long long nvert, long lon
     }
     if (d < VOX_MAXD && vox_keep<T>(t, thr)) {
       vox_mids<T>(t, mid);
-      vox_mark<T>(grid, R, mid[0], mid[1], mid[2]);
-      vox_mark<T>(grid, R, mid[3], mid[4], mid[5]);
-      vox_mark<T>(grid, R, mid[6], mid[7], mid[8]);
+      vox_mark<T, BITS>(grid, R, mid[0], mid[1], mid[2]);
+      vox_mark<T, BITS>(grid, R, mid[3], mid[4], mid[5]);
+      vox_mark<T, BITS>(grid, R, mid[6], mid[7], mid[8]);
       digits &= ~(3ull << (2 * d));  // first child
       ++d;
       continue;
@@ -284,13 +295,13 @@ __global__ __launch_bounds__(256) void vox_mark_kernel(long long nvert, long lon
   }
 }
 
-template <typename T>
+template <typename T, bool BITS>
 int vox_launch(hipStream_t st, int B, int V, int F, int R, const T* vertices, const int64_t* faces, const T* origin,
                const T* scale, T* scratch, T* grid) {
   if (B <= 0 || R <= 1) return 0;
   T* norm = scratch;
   T* part = scratch + (size_t)B * 4;
-  const size_t bytes = (size_t)B * R * R * R * sizeof(T);
+  const size_t bytes = BITS ? (size_t)B * vox_bit_words(R) * 4 : (size_t)B * R * R * R * sizeof(T);
   // torch's allocations are 512-byte aligned and bytes is a multiple of 16 for every R >= 2 with T = double; float grids of
   // odd R leave a tail of < 16 bytes to the generic fill
   const size_t n16 = ((uintptr_t)grid & 15) == 0 ? bytes / 16 : 0;
@@ -318,7 +329,7 @@ int vox_launch(hipStream_t st, int B, int V, int F, int R, const T* vertices, co
     const double thr = ((double)(R - 1) / ((double)R * (double)R)) * ((double)(R - 1) / ((double)R * (double)R));
     {
       kamd::ProfScope prof_(kamd::K_VOX_FACES, st);
-      hipLaunchKernelGGL(vox_mark_kernel<T>, dim3(kamd_cdiv(total, 256)), dim3(256), 0, st, nvert, total, B, V, F > 0 ? F : 1,
+      hipLaunchKernelGGL((vox_mark_kernel<T, BITS>), dim3(kamd_cdiv(total, 256)), dim3(256), 0, st, nvert, total, B, V, F > 0 ? F : 1,
                          R, L0, thr, vertices, faces, origin, scale, (const T*)part, norm, grid);
     }
     KAMD_CHECK(hipGetLastError());
@@ -337,11 +348,21 @@ size_t kamd_trianglemeshes_to_voxelgrids_workspace(int B, int V, int elem_size) 
 int kamd_trianglemeshes_to_voxelgrids_f32(void* stream, int B, int V, int F, int R, const float* vertices,
                                           const int64_t* faces, const float* origin, const float* scale, float* norm,
                                           float* grid) {
-  return vox_launch<float>((hipStream_t)stream, B, V, F, R, vertices, faces, origin, scale, norm, grid);
+  return vox_launch<float, false>((hipStream_t)stream, B, V, F, R, vertices, faces, origin, scale, norm, grid);
 }
 int kamd_trianglemeshes_to_voxelgrids_f64(void* stream, int B, int V, int F, int R, const double* vertices,
                                           const int64_t* faces, const double* origin, const double* scale, double* norm,
                                           double* grid) {
-  return vox_launch<double>((hipStream_t)stream, B, V, F, R, vertices, faces, origin, scale, norm, grid);
+  return vox_launch<double, false>((hipStream_t)stream, B, V, F, R, vertices, faces, origin, scale, norm, grid);
+}
+// the same marks as ONE BIT per voxel: bits[b * words + (lin >> 5)] bit (lin & 31), words = kamd_trianglemeshes_to_voxelbits_words(R)
+size_t kamd_trianglemeshes_to_voxelbits_words(int R) { return R > 1 ? vox_bit_words(R) : 0; }
+int kamd_trianglemeshes_to_voxelbits_f32(void* stream, int B, int V, int F, int R, const float* vertices, const int64_t* faces,
+                                         const float* origin, const float* scale, float* norm, uint32_t* bits) {
+  return vox_launch<float, true>((hipStream_t)stream, B, V, F, R, vertices, faces, origin, scale, norm, reinterpret_cast<float*>(bits));
+}
+int kamd_trianglemeshes_to_voxelbits_f64(void* stream, int B, int V, int F, int R, const double* vertices, const int64_t* faces,
+                                         const double* origin, const double* scale, double* norm, uint32_t* bits) {
+  return vox_launch<double, true>((hipStream_t)stream, B, V, F, R, vertices, faces, origin, scale, norm, reinterpret_cast<double*>(bits));
 }
 }  // extern "C"

@@ -108,10 +108,18 @@ class SharedGradientReducer:
     :meth:`remove`.
     """
 
-    def __init__(self, params, average=False):
+    def __init__(self, params, average=False, single_bucket=False):
+        """``single_bucket``: ONE collective per ``backward()`` whatever the number of shared parameters ("one
+        all_reduce(SUM) of the shared-parameter gradient ... + texture grad if trained") -- the gradients are packed into one flat
+        bucket and its all-reduce is posted from the hook of the LAST parameter whose gradient arrives (a parameter that receives
+        no gradient in a pass is sent as zeros by :meth:`wait`).  Default: one collective per parameter, each posted the moment
+        its gradient is ready."""
         self.params = [p for p in params if p.requires_grad]
         self.average = average
+        self.single_bucket = bool(single_bucket) and len(self.params) > 1
         self._pending = []
+        self._arrived = set()
+        self._bucket = None
         self.posted = 0
         self._sync = True
         self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
@@ -133,11 +141,42 @@ class SharedGradientReducer:
     def _hook(self, p):
         if not self._sync or not is_distributed() or p.grad is None:
             return
+        if self.single_bucket:
+            self._arrived.add(id(p))
+            if len(self._arrived) == len(self.params):
+                self._post_bucket()
+            return
         g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
         self._pending.append((p, g, _all_reduce_tensor(g, async_op=True)))
         self.posted += 1
 
+    def _post_bucket(self):
+        dtype = self.params[0].dtype
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(dtype) for p in self.params])
+        self._bucket = (flat, _all_reduce_tensor(flat, async_op=True))
+        self._arrived = set()
+        self.posted += 1
+
     def wait(self):
+        if self.single_bucket and self._sync and is_distributed():
+            if self._bucket is None and self._arrived:
+                self._post_bucket()     # (some parameter received no gradient in this pass: every rank still posts the same size)
+            if self._bucket is not None:
+                flat, work = self._bucket
+                if work is not None:
+                    work.wait()
+                if self.average:
+                    flat /= world_size()
+                off = 0
+                for p in self.params:
+                    n = p.numel()
+                    g = flat[off:off + n].view_as(p).to(p.dtype)
+                    if p.grad is None:
+                        p.grad = g.clone()
+                    else:
+                        p.grad.copy_(g)
+                    off += n
+                self._bucket = None
         for p, g, work in self._pending:
             if work is not None:
                 work.wait()

@@ -60,6 +60,9 @@ def trianglemeshes_to_voxelgrids(vertices, faces, resolution, origin=None, scale
     assert resolution > 1
     if vertices.is_cuda and vertices.dtype in (torch.float32, torch.float64) and vertices.shape[1] > 0:
         # the normalisation (and its default origin / scale) is part of the device pass: no torch glue kernels
+        if return_sparse:
+            # the COO tensor straight from the marked voxels (a bit grid, compacted): no R^3 scalars on the way
+            return _C.ops.trianglemeshes_to_voxelgrids_cuda(vertices, faces, resolution, origin, scale, return_sparse=True)
         dense = _C.ops.trianglemeshes_to_voxelgrids_cuda(vertices, faces, resolution, origin, scale)
     else:
         if origin is None:

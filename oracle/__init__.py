@@ -103,7 +103,15 @@ def packed_rasterize_forward(height, width, face_vertices_z, face_vertices_image
     return interp, sel, wts
 
 
-def rasterize_backward(grad, face_idx, weights, face_vertices_image, face_features, eps, return_abs=False):
+def set_num_threads(n):
+    """OpenMP build only: the number of threads its parallel loops use (bench.py: every hardware thread of the host)."""
+    f = lib(True).oracle_set_num_threads
+    f.argtypes = [ctypes.c_int]
+    f.restype = None
+    f(int(n))
+
+
+def rasterize_backward(grad, face_idx, weights, face_vertices_image, face_features, eps, return_abs=False, omp=False):
     """rasterization.cpp:106-168 (interpolated_features is accepted by the reference but never read).  ``return_abs``: also
     the per-element sum of the terms' MAGNITUDES (float64) -- the scale any float32 accumulation's rounding error lives on."""
     grad, face_idx, weights = _cpu(grad), _cpu(face_idx, torch.long), _cpu(weights)
@@ -111,7 +119,8 @@ def rasterize_backward(grad, face_idx, weights, face_vertices_image, face_featur
     B, H, W, D = grad.shape
     F = img.shape[1]
     g_img, g_feat = torch.zeros_like(img), torch.zeros_like(feat)
-    f = getattr(lib(False), f'oracle_rasterize_backward_{_SFX[grad.dtype]}')
+    # (omp: pixels in parallel, atomic double adds in unspecified order -- the CPU baseline's timing; the parity tests use the serial build)
+    f = getattr(lib(omp), f'oracle_rasterize_backward_{_SFX[grad.dtype]}')
     abs_img = torch.zeros(img.shape, dtype=torch.double) if return_abs else None
     f(_ci(B), _ci(H), _ci(W), _ci(F), _ci(D), _p(grad), _p(face_idx), _p(weights), _p(img), _p(feat), _cf(eps),
       _p(g_img), _p(g_feat), _p(abs_img) if return_abs else ctypes.c_void_p(0))
@@ -135,7 +144,7 @@ def dibr_soft_mask_forward(face_vertices_image, face_large_bboxes, selected_face
 
 
 def dibr_soft_mask_backward(grad_soft_mask, soft_mask, selected_face_idx, close_face_prob, close_face_idx,
-                            close_face_dist_type, face_vertices_image, sigmainv, multiplier, return_abs=False):
+                            close_face_dist_type, face_vertices_image, sigmainv, multiplier, return_abs=False, omp=False):
     """dibr_soft_mask.cpp:110-183; face_vertices_image already scaled.  ``return_abs``: as in :func:`rasterize_backward`."""
     g, soft, sel = _cpu(grad_soft_mask), _cpu(soft_mask), _cpu(selected_face_idx, torch.long)
     prob, idx, typ = _cpu(close_face_prob), _cpu(close_face_idx, torch.long), _cpu(close_face_dist_type, torch.uint8)
@@ -143,7 +152,7 @@ def dibr_soft_mask_backward(grad_soft_mask, soft_mask, selected_face_idx, close_
     B, F = img.shape[0], img.shape[1]
     H, W, K = sel.shape[1], sel.shape[2], prob.shape[-1]
     g_img = torch.zeros_like(img)
-    f = getattr(lib(False), f'oracle_dibr_soft_mask_backward_{_SFX[img.dtype]}')
+    f = getattr(lib(omp), f'oracle_dibr_soft_mask_backward_{_SFX[img.dtype]}')
     abs_img = torch.zeros(img.shape, dtype=torch.double) if return_abs else None
     f(_ci(B), _ci(H), _ci(W), _ci(F), _ci(K), _p(g), _p(soft), _p(sel), _p(prob), _p(idx), _p(typ), _p(img),
       _cf(sigmainv), _cf(multiplier), _p(g_img), _p(abs_img) if return_abs else ctypes.c_void_p(0))

@@ -37,6 +37,15 @@
 
 #define ORACLE_API __attribute__((visibility("default")))
 
+/* (bench.py's cpu_baseline: every hardware thread of the host, whatever the OpenMP runtime's default) */
+ORACLE_API void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 ORACLE_API int oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

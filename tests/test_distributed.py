@@ -125,6 +125,22 @@ def _views_worker(rank, world, port, out):
     assert reducer.posted == 2          # one collective per shared parameter, posted from inside backward()
     reducer.wait()
     reducer.remove()
+    per_param = {'verts': verts.grad.clone(), 'tex': tex.grad.clone()}
+    # the same with ONE collective for both parameters ("a single all-reduce", also with a trained texture)
+    verts.grad = tex.grad = None
+    bucket = D.SharedGradientReducer([verts, tex], single_bucket=True)
+    (_view_loss(verts, my_cams) + ((tex - my_targets) ** 2).sum()).backward()
+    assert bucket.posted == 1           # posted from the hook of the last gradient to arrive
+    bucket.wait()
+    assert torch.equal(verts.grad, per_param['verts']) and torch.equal(tex.grad, per_param['tex'])
+    # ... and when one of them receives no gradient in a pass: wait() posts the bucket with zeros in its place
+    verts.grad = tex.grad = None
+    _view_loss(verts, my_cams).backward()
+    assert bucket.posted == 1
+    bucket.wait()
+    assert bucket.posted == 2 and torch.equal(verts.grad, per_param['verts']) and float(tex.grad.abs().sum()) == 0.0
+    bucket.remove()
+    verts.grad, tex.grad = per_param['verts'], per_param['tex']
     if rank == 0:
         torch.save({'verts': verts.grad, 'tex': tex.grad}, out)
     D.barrier()

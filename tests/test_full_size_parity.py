@@ -249,3 +249,43 @@ def test_c3_chamfer_100k_x_100k_vs_oracle():
     g1a, g2a = oracle.sided_distance_backward(w, p1, p2, i12.cpu())
     g2b, g1b = oracle.sided_distance_backward(w, p2, p1, i21.cpu())
     assert rel_close(a.grad, g1a + g1b, 1e-5) and rel_close(b.grad, g2a + g2b, 1e-5)
+
+
+def test_c3_batch8_equals_sharded_items():
+    """"Single-GPU reference run: the same 8 items as one B=8 call; sharded result must match it (idx bit-exact,
+    grads 1e-5)" -- item r = what rank r of the 8-GPU run holds (torch.manual_seed(r), two rand(1, n, 3) draws, a shared offset)."""
+    pc = kal().metrics.pointcloud
+    n = 100000
+    items = []
+    for r in range(8):
+        g = torch.Generator().manual_seed(r)
+        items.append((torch.rand((1, n, 3), generator=g), torch.rand((1, n, 3), generator=g)))
+    base8 = torch.cat([it[0] for it in items], 0).cuda()
+    p28 = torch.cat([it[1] for it in items], 0).cuda().requires_grad_()
+    off8 = torch.zeros(3, device='cuda', requires_grad=True)
+    p18 = base8 + off8
+    d12, i12 = pc.sided_distance(p18, p28)
+    d21, i21 = pc.sided_distance(p28, p18)
+    loss8 = pc.chamfer_distance(p18, p28)
+    assert loss8.shape == (8,)
+    loss8.sum().backward()
+    off_sum = torch.zeros(3, dtype=torch.float64)
+    off_abs = torch.zeros(3, dtype=torch.float64)       # the sum of the magnitudes of the terms the offset's gradient adds up
+    for r in range(8):                                  # the sharded run: one B = 1 call per item
+        base = items[r][0].cuda()
+        p2 = items[r][1].cuda().requires_grad_()
+        off = torch.zeros(3, device='cuda', requires_grad=True)
+        p1 = base + off
+        p1.retain_grad()
+        e12, j12 = pc.sided_distance(p1, p2)
+        e21, j21 = pc.sided_distance(p2, p1)
+        assert torch.equal(j12[0], i12[r]) and torch.equal(j21[0], i21[r]), r
+        assert torch.equal(e12[0].detach(), d12[r].detach()) and torch.equal(e21[0].detach(), d21[r].detach()), r
+        loss = pc.chamfer_distance(p1, p2)
+        assert abs(float(loss) - float(loss8[r])) <= 1e-6 * float(loss8[r])
+        loss.sum().backward()
+        assert rel_close(p2.grad[0], p28.grad[r], 1e-5)
+        off_sum += off.grad.double().cpu()              # what the all-reduce of the sharded run sums
+        off_abs += p1.grad.double().abs().sum((0, 1)).cpu()
+    # (3 floats, each the sum of 8 x 100 000 float terms of both signs, added in two different orders)
+    assert rel_close(off8.grad.cpu(), off_sum.float(), 1e-5, term_abs_sum=off_abs.float())

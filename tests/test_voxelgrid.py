@@ -68,6 +68,31 @@ def test_gpu_vs_reference_golden(gold, name, return_sparse):
 
 
 @pytest.mark.gpu
+def test_gpu_sparse_result_never_allocates_the_dense_grid():
+    """return_sparse=True builds the COO tensor from the marked voxels (a bit grid, compacted) -- the reference builds it from the
+    unique voxel indices and never holds R^3 scalars (kaolin/ops/conversions/pointcloud.py:66-73); round 5 returned
+    dense.to_sparse(): 4 GB at R = 1024.  Same indices, same order, and the call's peak memory stays far below one dense grid."""
+    from kaolin_amd.utils.testing import geodesic_sphere
+    v, f = geodesic_sphere(16)
+    v = (v[None] * torch.tensor([1.0, 0.8, 1.2])).repeat(2, 1, 1)
+    v[1] *= 0.5
+    res = 384
+    vc, fc = v.cuda(), f.cuda()
+    dense = _conv().trianglemeshes_to_voxelgrids(vc, fc, res)
+    want = dense.to_sparse()
+    del dense
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    got = _conv().trianglemeshes_to_voxelgrids(vc, fc, res, return_sparse=True)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    assert got.is_sparse and got.is_coalesced() and got.shape == want.shape and got.dtype == want.dtype
+    assert torch.equal(got.indices(), want.indices()) and torch.equal(got.values(), want.values())
+    assert peak < 0.25 * 2 * res ** 3 * 4, peak        # (two dense grids would be 453 MB; the bit grids are 14 MB)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('dtype', [torch.float, torch.double])
 @pytest.mark.parametrize('level,res', [(8, 128), (2, 200), (16, 96)])
 def test_gpu_vs_oracle_spheres(dtype, level, res):
