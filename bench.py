@@ -944,9 +944,11 @@ def main():
         fz, fimg, nz = fv_cam[..., 2].cpu(), fv_img.cpu(), normals[..., 2].cpu()
         feat = feats3[:1].cpu()
 
-        # every hardware thread of the host, in the forward AND in the two backward passes (round 6: the backward passes of the OpenMP
+        # every hardware thread available to the process, in the forward AND in the two backward passes (round 6: the backward passes of the OpenMP
         # build run pixels in parallel too; VERDICT r05: a line that says N cores must not contain a serial leg)
-        oracle.set_num_threads(os.cpu_count())
+        # (every hardware thread this process may run on: on the round-6 box os.cpu_count() said 256, the affinity mask 128, and 256
+        # OpenMP threads on 128 allowed CPUs ran the forward thirty times slower)
+        oracle.set_num_threads(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count())
         cpu_legs = {'forward_s': 0.0, 'backward_s': 0.0}
 
         def cpu_pass(res):
