@@ -451,6 +451,9 @@ extern "C" int kamd_debug_phase_cycles_rbwd(unsigned long long* out16, int reset
   PHASE_READ(g_phase_rbwd, out16, reset, rc);
   return rc;
 }
+extern "C" int kamd_debug_tile_times(unsigned long long* out, int n_tiles) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_times), (size_t)(n_tiles < 65536 ? n_tiles : 65536) * 32);
+}
 extern "C" int kamd_debug_phase_cycles_raster(unsigned long long* out16, int reset) {
   int rc = 0;
   PHASE_READ(g_phase_raster, out16, reset, rc);
