@@ -7,7 +7,7 @@
 set -u
 tag=${1:-r01x}; pmc=${2:-}; commit=${3:-unknown}
 repo=$(pwd); out=$repo/gpurun_out/$tag; mkdir -p $out
-timeout 700 python -m pytest tests -m gpu -q -rP --durations=15 --timeout 600 > $out/pytest_gpu.log 2>&1; tail -2 $out/pytest_gpu.log
+timeout 1500 python -m pytest tests -m gpu -q -rP --durations=15 --timeout 1500 > $out/pytest_gpu.log 2>&1; tail -2 $out/pytest_gpu.log
 timeout 320 python bench.py 2> $out/bench.err | tail -1 > $out/bench.json
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 cd /tmp && export TMPDIR=/tmp
