@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void td_prep_kernel(int F, const T* __restrict
       const T uu = dot(ld3(r + 33), ld3(r + 33));
       if (zero_normal) {
         // (finite radius kept)
-      } else if (uu > (T)0.98 && uu < (T)1.02) {
+      } else if (uu > (T)0.9999 && uu < (T)1.0001) {  // (|g| = 1 within the slab test's 0.1 % head-room -- ADVICE r05: 0.98..1.02 left a 1 % error in |g|)
         r[39] = -r[39];
       } else {
         r[39] = (T)INFINITY;

@@ -723,3 +723,43 @@ def test_inverted_boxes_and_meshes_without_faces_in_the_packed_operator(dtype):
     soft = kal().render.mesh.dibr_soft_mask(fimg.cuda(), face_idx, 7000., -0.05, 30, 1000.)
     ref = oracle.dibr_soft_mask(fimg, face_idx.cpu(), 7000., -0.05, 30, 1000., omp=True)[0]
     assert rel_close(soft, ref)
+
+
+# ------------------------------------------------------------------ box edges within a hair of pixel centres
+@pytest.mark.parametrize('dtype', [torch.float, torch.double])
+@pytest.mark.parametrize('H,W,big_x', [(16, 4096, False), (64, 1024, False), (24, 2048, True)])
+def test_box_edges_within_two_thousandths_of_a_pixel_centre(dtype, H, W, big_x):
+    """The binning launch turns a face's box into pixel ranges with the CLOSED FORM of the kernels' test (tl::pixel_range: columns
+    ceil(u(xmin)) .. ceil(u(xmax)) - 1, the ends moved outwards by 1e-3 + 1e-6 W pixels for the float roundings of u and of the
+    kernels' pixel centres).  A face it missed would silently lose a covered or a soft pixel.  Here every face has box edges within
+    +-2e-3 pixel of pixel centres -- on them, a float ulp beside them, 5e-4 and 2e-3 pixel away on either side -- at widths up to
+    4096 and, `big_x`, with the mesh pushed to the image's right edge where |x| is largest: face_idx, the K-buffer indices and the
+    soft mask must equal the oracle's, which tests every pixel against every face."""
+    g = torch.Generator().manual_seed(1234 + H + W)
+    F = 600
+    cols = torch.randint(2, W - 8, (F,), generator=g).double() if not big_x else torch.randint(W - 200, W - 8, (F,), generator=g).double()
+    rows = torch.randint(1, H - 4, (F,), generator=g).double()
+    wpx = torch.randint(1, 6, (F,), generator=g).double()
+    hpx = torch.randint(1, 4, (F,), generator=g).double()
+    offs = torch.tensor([0.0, 1e-7, -1e-7, 5e-4, -5e-4, 2e-3, -2e-3, 1e-3, -1e-3])
+    pick = lambda: offs[torch.randint(0, len(offs), (F,), generator=g)].double()
+    # pixel centre of column c in NDC: (2 c + 1 - W) / W; of row r: (H - 2 r - 1) / H
+    x0 = (2 * (cols + pick()) + 1 - W) / W
+    x1 = (2 * (cols + wpx + pick()) + 1 - W) / W
+    y_top = (H - 2 * (rows + pick()) - 1) / H
+    y_bot = (H - 2 * (rows + hpx + pick()) - 1) / H
+    xm = (2 * (cols + wpx * torch.rand(F, generator=g).double() + pick()) + 1 - W) / W
+    y_third = torch.where(torch.rand(F, generator=g) < 0.5, y_top, y_bot)   # (the box stays [min, max] of the hair-offset coordinates)
+    fimg = torch.stack([torch.stack([x0, y_top], -1), torch.stack([x1, y_bot], -1), torch.stack([xm, y_third], -1)], 1)
+    fimg = fimg.to(dtype)[None].contiguous()
+    fz = (-1.0 - torch.rand((1, F, 3), generator=g).double()).to(dtype)
+    feat = torch.rand((1, F, 3, 2), generator=g).double().to(dtype)
+    nz = torch.ones((1, F), dtype=dtype)
+    ref = oracle.dibr_rasterization(H, W, fz, fimg, feat, nz, boxlen=0.002, knum=8, omp=True)
+    out, soft, face_idx = kal().render.mesh.dibr_rasterization(H, W, fz.cuda(), fimg.cuda(), feat.cuda(), nz.cuda(), boxlen=0.002, knum=8)
+    assert torch.equal(face_idx.cpu(), ref['face_idx'])
+    assert int((ref['face_idx'] >= 0).sum()) > 500
+    assert torch.equal(out.cpu(), ref['features'])
+    assert rel_close(soft, ref['soft_mask'])
+    s2, prob, idx, typ = _c_forward(fimg.cuda(), face_idx, 7000, 0.002, 8, 1000.)
+    assert torch.equal(idx.cpu(), ref['close_face_idx']) and torch.equal(typ.cpu(), ref['close_face_dist_type'])

@@ -8,11 +8,7 @@ set -u
 tag=${1:-r01x}; pmc=${2:-}; commit=${3:-unknown}
 repo=$(pwd); out=$repo/gpurun_out/$tag; mkdir -p $out
 timeout 1500 python -m pytest tests -m gpu -q -rP --durations=15 --timeout 1500 > $out/pytest_gpu.log 2>&1; tail -2 $out/pytest_gpu.log
-timeout 320 python bench.py 2> $out/bench.err | tail -1 > $out/bench.json
-timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 cd /tmp && export TMPDIR=/tmp
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python $repo/bench.py --no-cpu-baseline --no-contract-ops --no-scene-variants 2> $out/prof.err | tail -1 > $out/bench_under_rocprof.json
-find $out/prof -name '*kernel_stats.csv' -exec cp {} $out/kernel_stats.csv \;
 if [ -n "$pmc" ]; then
   timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_f -- python $repo/tools/pmc_traffic.py > /dev/null 2>&1
   timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_w -- python $repo/tools/pmc_traffic.py > /dev/null 2>&1
@@ -35,5 +31,14 @@ if [ -n "$pmc" ]; then
   python $repo/tools/issue_table.py $out/pmc_SQ_waves_insts.txt $out/pmc_SQ_lds_vmem.txt $out/traffic.json $out/issue_table.txt > /dev/null 2>&1
   rm -f $out/pmc_fetch.csv $out/pmc_write.csv $out/pmc_sq1.csv $out/pmc_sq2.csv   # (tens of MB; the tables above are what is kept)
 fi
+# the bench line and the kernel trace come AFTER the counters: bench.py's roofline.traffic reads profiles/traffic.json, which must be
+# THIS library's (the committed line cited the table of an earlier commit)
+if [ -s $out/traffic.json ]; then cp $out/traffic.json $repo/profiles/traffic.json; fi
+cd $repo
+timeout 600 python bench.py 2> $out/bench.err | tail -1 > $out/bench.json
+timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+cd /tmp && export TMPDIR=/tmp
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python $repo/bench.py --no-cpu-baseline --no-contract-ops --no-scene-variants 2> $out/prof.err | tail -1 > $out/bench_under_rocprof.json
+find $out/prof -name '*kernel_stats.csv' -exec cp {} $out/kernel_stats.csv \;
 rm -rf $out/prof
 cd $repo; ls -la $out; cat $out/bench.json | cut -c1-400
