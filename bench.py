@@ -979,7 +979,7 @@ def main():
         cpu_legs['forward_s'] = cpu_legs['backward_s'] = 0.0
         cdt = cpu_pass(sres)
         reps = 1
-        if sres == 1024 and cdt < 10.0:                        # many host cores: repeat the view until ~12 s are spent
+        if cdt < 10.0:                                         # many host cores: repeat the view until ~12 s are spent
             more = min(int(math.ceil(12.0 / cdt)) - 1, 15)
             for _ in range(more):
                 cdt += cpu_pass(sres)
