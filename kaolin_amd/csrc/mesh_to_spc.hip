@@ -12,8 +12,8 @@
 //     are tested at once, the survivors of each depth kept as bits of one word), so proposals are materialised every
 //     third level only; each stage is a count
 //     pass, a scan and an emit pass (the host reads one number per stage: output sizes are data-dependent);
-//   * pairs leave a stage ordered by (triangle, Morton code); a stable radix sort on the 3*level key bits (rocPRIM, as
-//     the reference uses cub) then makes "first of every run" the smallest triangle of every voxel;
+//   * pairs leave a stage ordered by (triangle, Morton code); a stable radix sort on the 3*level key bits (the kernels
+//     below, 8 bits a pass; the reference calls thrust) then makes "first of every run" the smallest triangle of every voxel;
 //   * run heads, compaction, ALL octree levels and their sizes are produced on the device into one workspace; the host
 //     reads the level sizes once, allocates the three results and a last kernel gathers them.
 // Voxel tests use the reference's expressions in its operand order (float differences, double projections, comparison
@@ -21,7 +21,6 @@
 // oracle/mesh_to_spc_oracle.inc.
 #include <string.h>
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_radix_sort.hpp>
 #include "common.h"
 #include "profile.h"
 #include "../../include/kaolin_amd.h"
@@ -269,6 +268,77 @@ int ms_scan(hipStream_t st, int64_t n_bound, const int64_t* n_ptr, const int* in
   return (int)hipGetLastError();
 }
 
+// ---- stable LSD radix sort of (Morton code, triangle) pairs by code, 8 bits a pass ---------------------------------------
+// The reference sorts with thrust (mesh_to_spc_cuda.cu:388-392); here: per pass a digit histogram per block of 2 048 pairs, ONE
+// exclusive scan over the (digit, block) counts (ms_scan) and a scatter that ranks the pairs of a block in their original order
+// (wavefront by wavefront: the lanes sharing a digit are found with eight ballots, lower lanes first; wavefronts and rounds of 256
+// in order through LDS counters), so equal codes keep their order -- triangles ascending inside a voxel, which is what picks a
+// voxel's face.  No library, nothing but launches on the stream.
+constexpr int MS_SORT_ITEMS = 8, MS_SORT_BLOCK = 256 * MS_SORT_ITEMS;
+__global__ __launch_bounds__(256) void ms_sort_hist_kernel(int64_t n, const uint64_t* __restrict__ keys, int shift, int nblk,
+                                                           int* __restrict__ hist) {
+  __shared__ int s_h[256];
+  s_h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * MS_SORT_BLOCK;
+#pragma unroll
+  for (int r = 0; r < MS_SORT_ITEMS; ++r) {
+    const int64_t e = base + r * 256 + threadIdx.x;
+    if (e < n) atomicAdd(&s_h[(int)((keys[e] >> shift) & 255u)], 1);
+  }
+  __syncthreads();
+  hist[(size_t)threadIdx.x * nblk + blockIdx.x] = s_h[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void ms_sort_scatter_kernel(int64_t n, const uint64_t* __restrict__ keys,
+                                                              const int64_t* __restrict__ vals, int shift, int nblk,
+                                                              const int64_t* __restrict__ offs, uint64_t* __restrict__ keys_out,
+                                                              int64_t* __restrict__ vals_out) {
+  __shared__ long long s_run[256];
+  __shared__ int s_wc[4][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  s_run[tid] = offs[(size_t)tid * nblk + blockIdx.x];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) s_wc[w][tid] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * MS_SORT_BLOCK;
+  for (int r = 0; r < MS_SORT_ITEMS; ++r) {
+    const int64_t e = base + r * 256 + tid;
+    const bool on = e < n;
+    const uint64_t key = on ? keys[e] : 0ull;
+    const int64_t val = on ? vals[e] : 0;
+    const int digit = (int)((key >> shift) & 255u);
+    // the lanes of this wavefront that hold the same digit (and a pair at all)
+    unsigned long long peers = __ballot(on);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const unsigned long long m = __ballot((digit >> bit) & 1);
+      peers &= ((digit >> bit) & 1) ? m : ~m;
+    }
+    const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+    if (on && rank == 0) s_wc[wave][digit] = __popcll(peers);
+    __syncthreads();
+    if (on) {
+      long long pos = s_run[digit] + rank;
+      for (int w = 0; w < wave; ++w) pos += s_wc[w][digit];
+      keys_out[pos] = key;
+      vals_out[pos] = val;
+    }
+    __syncthreads();
+    s_run[tid] += (s_wc[0][tid] + s_wc[1][tid]) + (s_wc[2][tid] + s_wc[3][tid]);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s_wc[w][tid] = 0;
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void ms_copy_words_kernel(int64_t n, const int64_t* __restrict__ a, int64_t* __restrict__ a_out,
+                                                            const int64_t* __restrict__ b, int64_t* __restrict__ b_out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    a_out[i] = a[i];
+    if (b != nullptr) b_out[i] = b[i];
+  }
+}
+inline int ms_sort_blocks(int64_t n) { return (int)((n > 0 ? n : 1) + MS_SORT_BLOCK - 1) / MS_SORT_BLOCK; }
+
 // ---- after the sort: one voxel per run of equal Morton codes, then the octree bottom-up --------------------------------
 // sizes[0] = voxels, sizes[1 + l] = nodes of octree level l (root = level 0)
 __global__ __launch_bounds__(256) void ms_heads_kernel(int64_t n_host, const int64_t* __restrict__ n_ptr,
@@ -379,20 +449,16 @@ __global__ __launch_bounds__(256) void ms_gather_octree_kernel(int level, int64_
 
 // workspace of kamd_mesh_to_spc_build for n pairs at `level` (8-byte words unless noted):
 //   sizes (16) | sorted morton (n) | sorted tri (n) | unique morton A (n) | unique tri (n) | morton B (n) | pos (n + 1)
-//   | scan sums (n / 1024 + 2) | flag (n ints) | level bytes (level * n) | rocPRIM temp
+//   | scan sums (n / 1024 + 2) | flag (n ints) | level bytes (level * n)
+//   | the sort's (digit, block) counts (256 * blocks ints), their offsets (256 * blocks + 1) and scan sums
 struct MsWs {
   int64_t *sizes, *sm, *st, *um, *ut, *mb, *pos, *sums;
   int* flag;
   unsigned char* level_bytes;
-  void* sort_tmp;
-  size_t sort_tmp_bytes, total_bytes;
+  int* sort_hist;
+  int64_t *sort_offs, *sort_sums;
+  size_t total_bytes;
 };
-size_t ms_sort_tmp_bytes(int64_t n, int level) {
-  size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs((void*)nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int64_t*)nullptr,
-                            (int64_t*)nullptr, (size_t)n, 0u, (unsigned)(3 * level > 0 ? 3 * level : 1), (hipStream_t)0);
-  return bytes;
-}
 MsWs ms_ws(void* base, int64_t n, int level) {
   MsWs w;
   char* p = (char*)base;
@@ -412,8 +478,10 @@ MsWs ms_ws(void* base, int64_t n, int level) {
   w.sums = (int64_t*)take(((size_t)n / 1024 + 2) * 8);
   w.flag = (int*)take((size_t)(n > 0 ? n : 1) * 4);
   w.level_bytes = (unsigned char*)take((size_t)(level > 0 ? level : 1) * (size_t)(n > 0 ? n : 1));
-  w.sort_tmp_bytes = ms_sort_tmp_bytes(n, level);
-  w.sort_tmp = (void*)take(w.sort_tmp_bytes ? w.sort_tmp_bytes : 1);
+  const size_t hn = (size_t)256 * (size_t)ms_sort_blocks(n);
+  w.sort_hist = (int*)take(hn * 4);
+  w.sort_offs = (int64_t*)take((hn + 1) * 8);
+  w.sort_sums = (int64_t*)take((hn / 1024 + 2) * 8);
   w.total_bytes = (size_t)(p - (char*)base);
   return w;
 }
@@ -460,13 +528,29 @@ int kamd_mesh_to_spc_build(void* stream, int64_t n, int level, const int64_t* mo
   const MsWs w = ms_ws(workspace, n, level);
   if (workspace == nullptr || workspace_bytes < w.total_bytes) return (int)hipErrorInvalidValue;
   kamd::ProfScope prof_(kamd::K_SPC_BUILD, st);
-  size_t tmp = w.sort_tmp_bytes;
-  if (level > 0) {
-    KAMD_CHECK(rocprim::radix_sort_pairs(w.sort_tmp, tmp, (const uint64_t*)morton, (uint64_t*)w.sm, triangle_id, w.st, (size_t)n,
-                                         0u, (unsigned)(3 * level), st));
-  } else {  // a single voxel: every key is 0, the order is already by triangle
-    KAMD_CHECK(hipMemcpyAsync(w.sm, morton, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
-    KAMD_CHECK(hipMemcpyAsync(w.st, triangle_id, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+  {
+    // (level 0: a single voxel, every key is 0 and the order is already by triangle -- one pass over no bits would do; a copy)
+    const int passes = (3 * level + 7) / 8;
+    const int nblk = ms_sort_blocks(n);
+    const uint64_t* src_k = (const uint64_t*)morton;
+    const int64_t* src_v = triangle_id;
+    if (passes == 0) {
+      unsigned cg = (unsigned)kamd_cdiv(n, 256);
+      if (cg > (unsigned)KAMD_NUM_CU * 8u) cg = (unsigned)KAMD_NUM_CU * 8u;
+      hipLaunchKernelGGL(ms_copy_words_kernel, dim3(cg), dim3(256), 0, st, n, morton, w.sm, triangle_id, w.st);
+    }
+    for (int k = 0; k < passes; ++k) {  // the last pass lands in (sm, st); (um, ut) is the other side
+      const bool to_sorted = ((passes - 1 - k) & 1) == 0;
+      uint64_t* dst_k = (uint64_t*)(to_sorted ? w.sm : w.um);
+      int64_t* dst_v = to_sorted ? w.st : w.ut;
+      hipLaunchKernelGGL(ms_sort_hist_kernel, dim3(nblk), dim3(256), 0, st, n, src_k, 8 * k, nblk, w.sort_hist);
+      KAMD_CHECK(ms_scan(st, (int64_t)256 * nblk, nullptr, w.sort_hist, w.sort_offs, w.sort_sums));
+      hipLaunchKernelGGL(ms_sort_scatter_kernel, dim3(nblk), dim3(256), 0, st, n, src_k, src_v, 8 * k, nblk,
+                         (const int64_t*)w.sort_offs, dst_k, dst_v);
+      src_k = dst_k;
+      src_v = dst_v;
+    }
+    KAMD_CHECK(hipGetLastError());
   }
   const unsigned g = (unsigned)kamd_cdiv(n, 256);
   hipLaunchKernelGGL(ms_heads_kernel, dim3(g), dim3(256), 0, st, n, (const int64_t*)nullptr, (const int64_t*)w.sm, 0, w.flag);
@@ -487,7 +571,8 @@ int kamd_mesh_to_spc_build(void* stream, int64_t n, int level, const int64_t* mo
     cur = nxt;
     nxt = (t == w.um) ? w.sm : t;
   }
-  KAMD_CHECK(hipMemcpyAsync(sizes, w.sizes, (size_t)(1 + level) * 8, hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(ms_copy_words_kernel, dim3(1), dim3(256), 0, st, (int64_t)(1 + level), (const int64_t*)w.sizes, sizes,
+                     (const int64_t*)nullptr, (int64_t*)nullptr);
   KAMD_RETURN_LAST_ERROR();
 }
 

@@ -13,7 +13,7 @@ dev = 'cuda'
 v, f = T.scene_mesh(scene, 50) if hasattr(T, 'scene_mesh') else T.geodesic_sphere(50)
 verts = v.float().to(dev).requires_grad_()
 faces = f.to(dev)
-cams = T.fibonacci_cameras(64, 2.5)[:V].to(dev)
+cams = T.fibonacci_cameras(V, 2.5).to(dev)   # (bench.py build_scene at N = 1)
 rot, trans = kal.render.camera.generate_rotate_translate_matrices(cams, torch.zeros_like(cams), torch.tensor([[0., 1., 0.]], device=dev).expand(V, -1))
 proj = kal.render.camera.generate_perspective_projection(math.pi / 4).to(dev)
 g = torch.Generator().manual_seed(0)
