@@ -64,7 +64,7 @@ struct CloudT {
   typedef typename Vec4Of<T>::type V4;
   int n, G;             // points per batch item; cells per axis of the grid it is binned on
   const T* pts;         // (B, n, 3)
-  unsigned int* box;    // (B, 8) encoded {lo[3], hi[3]} of the grid's box (floats), 0 = no finite point yet
+  unsigned int* box;    // (B, 8 words, SDG_BOX_STRIDE words apart) encoded {lo[3], hi[3]} of the grid's box (floats), 0 = no finite point yet, [6] = flag
   int* count;           // (B, G^3) zero before the build
   int* start;           // (B, G^3 + 1)
   int2* cellrank;       // (B, n) {cell, rank inside the cell}
@@ -111,6 +111,14 @@ struct SdgWs {
 #define KAMD_SDG_BUILD_THREADS 512  // build knob for experiments
 #endif
 constexpr int SDG_BUILD_THREADS = KAMD_SDG_BUILD_THREADS;  // workgroup of the build kernel = cells per scan block
+#ifndef KAMD_SDG_BUILD_UNROLL
+#define KAMD_SDG_BUILD_UNROLL 1  // points a build thread bins / scatters at a time (4 / 8: their round trips in flight together -- no faster, profiles/r06r_*)
+#endif
+constexpr int SDG_BUILD_UNROLL = KAMD_SDG_BUILD_UNROLL;
+constexpr int SDG_BAR_GROUPS = 8;   // groups of the grid barrier's arrivals (sdg_grid_barrier)
+constexpr int SDG_BOX_STRIDE = 32;  // words between the words of a box record: every word on a 128-byte line of its own (phase 1 merges the
+                                    // workgroups' extents with atomicMax, and atomics on one line are performed one at a time: 64 workgroups x 6
+                                    // words on ONE line were ~15 us of the build)
 // query workgroups of a chamfer launch at most (each leaves one partial sum)
 inline size_t sdg_partials(int B) { return (size_t)2 * B > 8192 ? (size_t)2 * B : 8192; }
 
@@ -133,9 +141,9 @@ inline SdgWs sdg_layout(void* base, int B, int N, int M, const void* p1, const v
   const size_t nca = (size_t)w.a.G * w.a.G * w.a.G, ncb = (size_t)w.b.G * w.b.G * w.b.G;
   w.b.count = (int*)take((size_t)B * ncb * 4);
   w.a.count = (int*)take((size_t)B * nca * 4);
-  w.b.box = (unsigned int*)take((size_t)B * 8 * 4);
-  w.a.box = pair ? (unsigned int*)take((size_t)B * 8 * 4) : w.b.box;
-  w.barrier = (unsigned int*)take(64);
+  w.b.box = (unsigned int*)take((size_t)B * 8 * SDG_BOX_STRIDE * 4);
+  w.a.box = pair ? (unsigned int*)take((size_t)B * 8 * SDG_BOX_STRIDE * 4) : w.b.box;
+  w.barrier = (unsigned int*)take((size_t)(1 + SDG_BAR_GROUPS) * 128);
   w.fuse = Fuse{};
   if (mode >= SDG_GRAD) {
     w.fuse.scat_a = (float*)take((size_t)B * N * 12);
@@ -186,14 +194,22 @@ __device__ __forceinline__ V sdg_ld(const V* p) { return __hip_atomic_load(p, __
 template <typename V>
 __device__ __forceinline__ void sdg_st(V* p, V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__device__ __forceinline__ void sdg_grid_barrier(unsigned int* counter, unsigned int target, int naps) {
+// Arrivals are counted in two levels: atomics on ONE line are performed one at a time (~40 ns each, memory-side), so 128 workgroups
+// arriving on one counter spent ~5 us per barrier doing just that.  A workgroup arrives on the counter of its group (id % 8, a
+// 128-byte line each); the group's last arrival -- the one whose returned count completes the group for this phase -- arrives on
+// the top counter, which everybody polls.
+__device__ __forceinline__ void sdg_grid_barrier(unsigned int* bar, unsigned int phase /* 1, 2, ... */, int nwg, int naps) {
   __builtin_amdgcn_s_waitcnt(0);  // this wave's stores and atomics have been performed
   __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int g = blockIdx.x % SDG_BAR_GROUPS;
+    const unsigned int members = (unsigned int)((nwg - g + SDG_BAR_GROUPS - 1) / SDG_BAR_GROUPS);
+    const unsigned int groups = (unsigned int)(nwg < SDG_BAR_GROUPS ? nwg : SDG_BAR_GROUPS);
+    const unsigned int before = __hip_atomic_fetch_add(bar + 32 * (1 + g), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (before + 1u == members * phase) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // every poll is a coherent load of ONE address: hundreds of workgroups polling back to back queue up on its memory
     // channel, in front of the arrivals they are waiting for -- nap between polls
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < groups * phase)
       for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(8);
   }
   __syncthreads();
@@ -205,7 +221,8 @@ __device__ __forceinline__ Box sdg_box_decode(const unsigned int* w, int G) {
   Box bx;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    const unsigned int ulo = COHERENT ? sdg_ld(w + a) : w[a], uhi = COHERENT ? sdg_ld(w + 3 + a) : w[3 + a];
+    const unsigned int ulo = COHERENT ? sdg_ld(w + a * SDG_BOX_STRIDE) : w[a * SDG_BOX_STRIDE];
+    const unsigned int uhi = COHERENT ? sdg_ld(w + (3 + a) * SDG_BOX_STRIDE) : w[(3 + a) * SDG_BOX_STRIDE];
     float lo = 0.f, hi = 0.f;  // no finite point on this axis
     if (ulo != 0u && uhi != 0u) {
       lo = sdg_unord(~ulo);
@@ -222,6 +239,17 @@ __device__ __forceinline__ Box sdg_box_decode(const unsigned int* w, int G) {
 
 // X = the targets' cloud, Y = the other one; own_box_y: Y is binned on its own box (chamfer), else on X's (sided_distance)
 template <typename T>
+#ifdef KAMD_SDG_PHASE_TIMES  // development: workgroup 0 prints how long each phase of the build and each wait at a barrier took (100 MHz clock)
+#define KAMD_SDG_T(i) const unsigned long long sdg_t##i = wall_clock64();
+#define KAMD_SDG_T_PRINT()                                                                                                     \
+  if (blockIdx.x == 0 && threadIdx.x == 0)                                                                                     \
+    printf("sdg_build wg 0 (us): bbox %.2f wait %.2f | rank %.2f wait %.2f | scan a %.2f wait %.2f | scan b %.2f wait %.2f | scatter %.2f\n", \
+           (sdg_t1 - sdg_t0) * 0.01, (sdg_t2 - sdg_t1) * 0.01, (sdg_t3 - sdg_t2) * 0.01, (sdg_t4 - sdg_t3) * 0.01, (sdg_t5 - sdg_t4) * 0.01, \
+           (sdg_t6 - sdg_t5) * 0.01, (sdg_t7 - sdg_t6) * 0.01, (sdg_t8 - sdg_t7) * 0.01, (sdg_t9 - sdg_t8) * 0.01);
+#else
+#define KAMD_SDG_T(i)
+#define KAMD_SDG_T_PRINT()
+#endif
 __global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(CloudT<T> X, CloudT<T> Y, int B, int own_box_y, int* sums, int scan_blocks,
                                                                unsigned int* barrier, int naps) {
   __shared__ float s_red[6][SDG_BUILD_THREADS / 64];
@@ -229,7 +257,8 @@ __global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(CloudT<T> X, Clou
   __shared__ int s_off;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nwg = gridDim.x, wg = blockIdx.x;
-  unsigned int arrivals = 0;
+  unsigned int phase = 0;
+  KAMD_SDG_T(0)
 
   // ---- phase 1: bounding boxes.  Units = (cloud, batch item); a unit is shared by P workgroups
   {
@@ -255,7 +284,7 @@ __global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(CloudT<T> X, Clou
           odd_first = odd_first || (i >= SD_REF_TILE && (i & (SD_REF_TILE - 1)) == 0 && !(fabs((double)vt) < (double)INFINITY));
         }
       }
-      if (odd_first) atomicMax((first ? X.box : Y.box) + (size_t)b * 8 + 6, 1u);
+      if (odd_first) atomicMax((first ? X.box : Y.box) + ((size_t)b * 8 + 6) * SDG_BOX_STRIDE, 1u);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
 #pragma unroll
@@ -279,36 +308,72 @@ __global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(CloudT<T> X, Clou
           l = fminf(l, s_red[tid][w]);
           h = fmaxf(h, s_red[3 + tid][w]);
         }
-        unsigned int* box = (first ? X.box : Y.box) + (size_t)b * 8;
+        unsigned int* box = (first ? X.box : Y.box) + (size_t)b * 8 * SDG_BOX_STRIDE;
         if (l <= h) {  // this workgroup saw a finite value on the axis
-          atomicMax(box + tid, ~sdg_ord(l));
-          atomicMax(box + 3 + tid, sdg_ord(h));
+          atomicMax(box + tid * SDG_BOX_STRIDE, ~sdg_ord(l));
+          atomicMax(box + (3 + tid) * SDG_BOX_STRIDE, sdg_ord(h));
         }
       }
     }
   }
-  arrivals += nwg;
-  sdg_grid_barrier(barrier, arrivals, naps);
+  KAMD_SDG_T(1)
+  sdg_grid_barrier(barrier, ++phase, nwg, naps);
+  KAMD_SDG_T(2)
 
-  // ---- phase 2: cell id + rank inside the cell (the value the counting atomicAdd returns)
+  // ---- phase 2: cell id + rank inside the cell (the value the counting atomicAdd returns).  A thread takes SDG_BUILD_UNROLL
+  // points at a time: their coordinates are requested together, then their counting atomics -- a point is a chain of two
+  // memory-side round trips (~1 + 2 us) and 65 536 threads hold ~3 points each: one after the other that was three chains.
+  // The grid's box (six coherent words) is decoded once per (cloud, batch item) a thread meets, not per point.
   const long long per_b = (long long)X.n + Y.n, total = per_b * B;
-  for (long long t = (long long)wg * SDG_BUILD_THREADS + tid; t < total; t += (long long)nwg * SDG_BUILD_THREADS) {
-    const int b = (int)(t / per_b);
-    int i = (int)(t - (long long)b * per_b);
-    const bool first = i < X.n;
-    if (!first) i -= X.n;
-    const int n = first ? X.n : Y.n, G = first ? X.G : Y.G;
-    const Box bx = sdg_box_decode<true>((first ? X.box : Y.box) + (size_t)b * 8, G);
-    const T* Pt = (first ? X.pts : Y.pts) + ((size_t)b * n + i) * 3;
-    const int cx = sdg_axis_cell((float)Pt[0], bx.lo[0], bx.inv[0], G);
-    const int cy = sdg_axis_cell((float)Pt[1], bx.lo[1], bx.inv[1], G);
-    const int cz = sdg_axis_cell((float)Pt[2], bx.lo[2], bx.inv[2], G);
-    const int c = (cz * G + cy) * G + cx;
-    const int rank = atomicAdd((first ? X.count : Y.count) + (size_t)b * ((size_t)G * G * G) + c, 1);
-    (first ? X.cellrank : Y.cellrank)[(size_t)b * n + i] = make_int2(c, rank);
+  const long long stride = (long long)nwg * SDG_BUILD_THREADS;
+  {
+    int box_u = -1;
+    Box bx{};
+    for (long long t0 = (long long)wg * SDG_BUILD_THREADS + tid; t0 < total; t0 += stride * SDG_BUILD_UNROLL) {
+      float p[SDG_BUILD_UNROLL][3];
+      int iu[SDG_BUILD_UNROLL], bu[SDG_BUILD_UNROLL], cu[SDG_BUILD_UNROLL], rk[SDG_BUILD_UNROLL];
+      bool fu[SDG_BUILD_UNROLL], on[SDG_BUILD_UNROLL];
+#pragma unroll
+      for (int u = 0; u < SDG_BUILD_UNROLL; ++u) {
+        const long long t = t0 + (long long)u * stride;
+        on[u] = t < total;
+        const long long tt = on[u] ? t : t0;
+        bu[u] = (int)(tt / per_b);
+        int i = (int)(tt - (long long)bu[u] * per_b);
+        fu[u] = i < X.n;
+        if (!fu[u]) i -= X.n;
+        iu[u] = i;
+        const T* Pt = (fu[u] ? X.pts : Y.pts) + ((size_t)bu[u] * (fu[u] ? X.n : Y.n) + i) * 3;
+        p[u][0] = (float)Pt[0];
+        p[u][1] = (float)Pt[1];
+        p[u][2] = (float)Pt[2];
+      }
+#pragma unroll
+      for (int u = 0; u < SDG_BUILD_UNROLL; ++u) {
+        const int G = fu[u] ? X.G : Y.G;
+        const int uu = fu[u] ? bu[u] : B + bu[u];
+        if (uu != box_u) {
+          bx = sdg_box_decode<true>((fu[u] ? X.box : Y.box) + (size_t)bu[u] * 8 * SDG_BOX_STRIDE, G);
+          box_u = uu;
+        }
+        const int cx = sdg_axis_cell(p[u][0], bx.lo[0], bx.inv[0], G);
+        const int cy = sdg_axis_cell(p[u][1], bx.lo[1], bx.inv[1], G);
+        const int cz = sdg_axis_cell(p[u][2], bx.lo[2], bx.inv[2], G);
+        cu[u] = (cz * G + cy) * G + cx;
+      }
+#pragma unroll
+      for (int u = 0; u < SDG_BUILD_UNROLL; ++u) {
+        const int G = fu[u] ? X.G : Y.G;
+        rk[u] = on[u] ? atomicAdd((fu[u] ? X.count : Y.count) + (size_t)bu[u] * ((size_t)G * G * G) + cu[u], 1) : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < SDG_BUILD_UNROLL; ++u)
+        if (on[u]) (fu[u] ? X.cellrank : Y.cellrank)[(size_t)bu[u] * (fu[u] ? X.n : Y.n) + iu[u]] = make_int2(cu[u], rk[u]);
+    }
   }
-  arrivals += nwg;
-  sdg_grid_barrier(barrier, arrivals, naps);
+  KAMD_SDG_T(3)
+  sdg_grid_barrier(barrier, ++phase, nwg, naps);
+  KAMD_SDG_T(4)
 
   // ---- phase 3: exclusive scan of the counts: start[c] = points in cells < c, start[NC] = n.  A unit = (cloud, batch item,
   // block of SDG_BUILD_THREADS cells).  3a leaves every block's total, 3b adds up the totals before its block and scans it:
@@ -327,8 +392,9 @@ __global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(CloudT<T> X, Clou
     const int tot = sdg_block_inclusive(i < NC ? sdg_ld(cnt + i) : 0, s_wave);
     if (tid == SDG_BUILD_THREADS - 1) sdg_st(sums + ((size_t)z * B + b) * scan_blocks + blk, tot);
   }
-  arrivals += nwg;
-  sdg_grid_barrier(barrier, arrivals, naps);
+  KAMD_SDG_T(5)
+  sdg_grid_barrier(barrier, ++phase, nwg, naps);
+  KAMD_SDG_T(6)
   for (int u = wg; u < units3; u += nwg) {
     const int z = u / (B * scan_blocks), b = (u / scan_blocks) % B, blk = u % scan_blocks;
     const bool first = z == 0;
@@ -351,26 +417,52 @@ __global__ __launch_bounds__(SDG_BUILD_THREADS) void sdg_build(CloudT<T> X, Clou
     if (i < NC) sdg_st(start + i, off + inc - v);
     if (i == NC - 1) sdg_st(start + NC, off + inc);
   }
-  arrivals += nwg;
-  sdg_grid_barrier(barrier, arrivals, naps);
+  KAMD_SDG_T(7)
+  sdg_grid_barrier(barrier, ++phase, nwg, naps);
+  KAMD_SDG_T(8)
 
-  // ---- phase 4: counting-sort scatter without further atomics: point -> start[cell] + rank, as float4 {xyz, index}
-  for (long long t = (long long)wg * SDG_BUILD_THREADS + tid; t < total; t += (long long)nwg * SDG_BUILD_THREADS) {
-    const int b = (int)(t / per_b);
-    int i = (int)(t - (long long)b * per_b);
-    const bool first = i < X.n;
-    if (!first) i -= X.n;
-    const int n = first ? X.n : Y.n, G = first ? X.G : Y.G;
-    const int2 cr = (first ? X.cellrank : Y.cellrank)[(size_t)b * n + i];
-    const int pos = sdg_ld((first ? X.start : Y.start) + (size_t)b * ((size_t)G * G * G + 1) + cr.x) + cr.y;
-    const T* Pt = (first ? X.pts : Y.pts) + ((size_t)b * n + i) * 3;
-    typename CloudT<T>::V4 rec;
-    rec.x = Pt[0];
-    rec.y = Pt[1];
-    rec.z = Pt[2];
-    rec.w = sdg_pack_idx(i, (T)0);
-    (first ? X.sorted : Y.sorted)[(size_t)b * n + pos] = rec;
+  // ---- phase 4: counting-sort scatter without further atomics: point -> start[cell] + rank, as float4 {xyz, index};
+  // SDG_BUILD_UNROLL points of a thread at a time, as in phase 2 (record -> start of its cell -> store: two round trips)
+  for (long long t0 = (long long)wg * SDG_BUILD_THREADS + tid; t0 < total; t0 += stride * SDG_BUILD_UNROLL) {
+    int iu[SDG_BUILD_UNROLL], bu[SDG_BUILD_UNROLL], st[SDG_BUILD_UNROLL];
+    int2 cr[SDG_BUILD_UNROLL];
+    bool fu[SDG_BUILD_UNROLL], on[SDG_BUILD_UNROLL];
+    T p[SDG_BUILD_UNROLL][3];
+#pragma unroll
+    for (int u = 0; u < SDG_BUILD_UNROLL; ++u) {
+      const long long t = t0 + (long long)u * stride;
+      on[u] = t < total;
+      const long long tt = on[u] ? t : t0;
+      bu[u] = (int)(tt / per_b);
+      int i = (int)(tt - (long long)bu[u] * per_b);
+      fu[u] = i < X.n;
+      if (!fu[u]) i -= X.n;
+      iu[u] = i;
+      const int n = fu[u] ? X.n : Y.n;
+      cr[u] = (fu[u] ? X.cellrank : Y.cellrank)[(size_t)bu[u] * n + i];
+      const T* Pt = (fu[u] ? X.pts : Y.pts) + ((size_t)bu[u] * n + i) * 3;
+      p[u][0] = Pt[0];
+      p[u][1] = Pt[1];
+      p[u][2] = Pt[2];
+    }
+#pragma unroll
+    for (int u = 0; u < SDG_BUILD_UNROLL; ++u) {
+      const int G = fu[u] ? X.G : Y.G;
+      st[u] = sdg_ld((fu[u] ? X.start : Y.start) + (size_t)bu[u] * ((size_t)G * G * G + 1) + cr[u].x);
+    }
+#pragma unroll
+    for (int u = 0; u < SDG_BUILD_UNROLL; ++u) {
+      if (!on[u]) continue;
+      typename CloudT<T>::V4 rec;
+      rec.x = p[u][0];
+      rec.y = p[u][1];
+      rec.z = p[u][2];
+      rec.w = sdg_pack_idx(iu[u], (T)0);
+      (fu[u] ? X.sorted : Y.sorted)[(size_t)bu[u] * (fu[u] ? X.n : Y.n) + st[u] + cr[u].y] = rec;
+    }
   }
+  KAMD_SDG_T(9)
+  KAMD_SDG_T_PRINT()
 }
 
 // ---- 5. query ----------------------------------------------------------------------------------------------------------
@@ -401,7 +493,7 @@ __device__ __forceinline__ double sdg_dist_sel(double tx, double ty, double tz, 
 }
 
 #ifndef KAMD_SDG_QUERY_WAVES
-#define KAMD_SDG_QUERY_WAVES 7  // waves per SIMD the search kernel is compiled for (72 VGPRs): the search is a chain of dependent loads, occupancy is what hides it
+#define KAMD_SDG_QUERY_WAVES 7  // waves per SIMD the search kernel is compiled for (72 VGPRs): occupancy is what hides the search's dependent loads
 #endif
 #ifndef KAMD_SDG_GROUP
 #define KAMD_SDG_GROUP 4  // build knob; 100k x 100k (profiles/r02y_sdg.txt): 2 lanes 60 us, 4: 56, 8: 61, 16: 85 for both directions
@@ -414,6 +506,9 @@ constexpr int SDG_GROUP = KAMD_SDG_GROUP;
 #define KAMD_SDG_BATCH 1  // rows of a ring a lane takes at a time (> 1: their cell ranges are loaded together; measured at 100k x 100k: 62.9 us either way
                           // on a uniform cloud, 131 (1) vs 139 us (3) on a sphere surface: more registers, lower occupancy)
 #endif
+#ifndef KAMD_SDG_XCD_CHUNKS
+#define KAMD_SDG_XCD_CHUNKS 1  // the search's chunks of queries dealt to the XCDs in contiguous eighths (0: by blockIdx)
+#endif
 constexpr int SDG_R0 = KAMD_SDG_R0;
 [[maybe_unused]] constexpr int SDG_BATCH = KAMD_SDG_BATCH;
 
@@ -424,7 +519,7 @@ constexpr int SDG_R0 = KAMD_SDG_R0;
 // distance then sits within 5 roundings of 2^-11 of the true one (plus the half subnormals' 6e-8 step), so the stopping rule
 // leaves that margin; the many exact ties of an 11-bit mantissa are broken by index like any other.
 template <bool TRACK, typename T, bool HALF = false>
-__device__ __forceinline__ void sdg_search(const Box& s_box, int G, T qx, T qy, T qz, int c,
+__device__ __forceinline__ void sdg_search(const Box& s_box, int G, T qx, T qy, T qz, int cx, int cy, int cz,
                                            const T* __restrict__ T0, const int* __restrict__ start,
                                            const typename Vec4Of<T>::type* __restrict__ TS, int nt, int sub, T& best, int& best_i,
                                            int& best_k) {
@@ -461,7 +556,6 @@ __device__ __forceinline__ void sdg_search(const Box& s_box, int G, T qx, T qy, 
     return;
   }
   if (best == best) {  // uniform within the group (same query)
-    const int cx = c % G, cy = (c / G) % G, cz = c / (G * G);
     // rounding head-room of the geometric bound: cell membership is decided by a rounded (v - lo) * inv
     const float q[3] = {(float)qx, (float)qy, (float)qz};
     float slack[3];
@@ -541,7 +635,60 @@ __device__ __forceinline__ void sdg_search(const Box& s_box, int G, T qx, T qy, 
           }
       }
 #else
-      for (int j = sub; j < nrows; j += SDG_GROUP) {
+      // The first ring (at most 3 x 3 rows; fp32) by the query's four lanes TOGETHER: every lane requests the cell ranges of its
+      // rows (sub, sub + 4, sub + 8) at once, the ranges travel inside the quad (DPP quad_perm: register moves), and the four
+      // lanes walk every row side by side -- lane s takes the targets k0 + s, k0 + s + 4, ... -- so that a quad's loads fall on
+      // ONE 64-byte line.  The search is bound by the lines a gather instruction touches (the CU's texture path takes one line
+      // per clock: with a lane per row every target load of a wavefront touched 64 different lines, ~25 M line accesses per
+      // call at 100k x 100k = the launch's duration; measured profiles/r06q_*: neither fewer iterations nor more loads in flight
+      // changed it, on the contrary).  (d, idx) compare as one 64-bit key: a distance is a sum of squares, never negative, so
+      // its bit pattern orders as the value does, and the index in the low word breaks ties towards the lower one.
+      bool ring_done = false;
+      if constexpr (sizeof(T) == 4 && SDG_GROUP == 4) {
+        if (r == r_first && nrows <= 3 * SDG_GROUP) {
+          int ks[3], ke[3];
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const int j = sub + u * SDG_GROUP;
+            ks[u] = 0;
+            ke[u] = 0;
+            if (j < nrows) {
+              const int zq = (j >= ny ? 1 : 0) + (j >= 2 * ny ? 1 : 0);  // (j / ny: at most three rows of rows)
+              const int row = ((z0 + zq) * G + (y0 + j - zq * ny)) * G;
+              ks[u] = start[row + x0];
+              ke[u] = start[row + x1 + 1];
+            }
+          }
+          unsigned long long kbest = ((unsigned long long)__float_as_uint((float)best) << 32) | (unsigned int)best_i;
+          int kk = best_k;
+          // a row's range from the lane that holds it (quad_perm: lane SRC of the quad for everybody), then its targets, four at a time.
+          // (Measured and not kept, profiles/r06s_*: the next target of ALL nine rows requested together, 2 or 3 such passes -- 72 -> 128
+          // registers, 7 -> 4 wavefronts per SIMD: 75.9 vs 53.5 us; occupancy is what hides this search's dependent loads.)
+#define KAMD_SDG_ROW(U, SRC)                                                                                              \
+          {                                                                                                               \
+            const int ka = __builtin_amdgcn_update_dpp(0, ks[U], (SRC) * 0x55, 0xF, 0xF, false);                            \
+            const int kz = __builtin_amdgcn_update_dpp(0, ke[U], (SRC) * 0x55, 0xF, 0xF, false);                            \
+            for (int k = ka + sub; k < kz; k += SDG_GROUP) {                                                              \
+              const V4 t = TS[k];                                                                                         \
+              const float d = (float)sdg_dist_sel<HALF>(t.x, t.y, t.z, qx, qy, qz);                                      \
+              const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)sdg_unpack_idx(t.w); \
+              if (key < kbest) {                                                                                          \
+                kbest = key;                                                                                              \
+                kk = k;                                                                                                   \
+              }                                                                                                           \
+            }                                                                                                             \
+          }
+          KAMD_SDG_ROW(0, 0) KAMD_SDG_ROW(0, 1) KAMD_SDG_ROW(0, 2) KAMD_SDG_ROW(0, 3)
+          KAMD_SDG_ROW(1, 0) KAMD_SDG_ROW(1, 1) KAMD_SDG_ROW(1, 2) KAMD_SDG_ROW(1, 3)
+          KAMD_SDG_ROW(2, 0)
+#undef KAMD_SDG_ROW
+          best = (T)__uint_as_float((unsigned int)(kbest >> 32));
+          best_i = (int)(unsigned int)kbest;
+          if (TRACK) best_k = kk;
+          ring_done = true;
+        }
+      }
+      for (int j = sub; !ring_done && j < nrows; j += SDG_GROUP) {
         const int z = z0 + j / ny, y = y0 + j % ny;
         const int row = (z * G + y) * G;
         const bool shell_row = r == r_first || (abs(z - cz) == r) || (abs(y - cy) == r);
@@ -670,8 +817,8 @@ __global__ __launch_bounds__(256, (MODE == SDG_GRAD ? KAMD_SDG_QUERY_WAVES : 1))
   const int* Tstart = (fwd ? T.start : A.start) + (size_t)b * (NC + 1);
   const V4* Tsorted = (fwd ? T.sorted : A.sorted) + (size_t)b * nt;
   if (threadIdx.x == 0) {
-    s_box = sdg_box_decode((fwd ? T.box : A.box) + (size_t)b * 8, G);
-    s_odd_first = ((fwd ? T.box : A.box) + (size_t)b * 8)[6];  // the build found a non-finite target at an index 512 k
+    s_box = sdg_box_decode((fwd ? T.box : A.box) + (size_t)b * 8 * SDG_BOX_STRIDE, G);
+    s_odd_first = ((fwd ? T.box : A.box) + (size_t)b * 8 * SDG_BOX_STRIDE)[6 * SDG_BOX_STRIDE];  // the build found a non-finite target at an index 512 k
   }
   __syncthreads();
   const bool odd_first = s_odd_first != 0u;  // (workgroup-uniform)
@@ -683,7 +830,24 @@ __global__ __launch_bounds__(256, (MODE == SDG_GRAD ? KAMD_SDG_QUERY_WAVES : 1))
   // a workgroup takes the chunks of 256 / SDG_GROUP queries blockIdx.x, blockIdx.x + gridDim.x, ...: one chunk each unless the chamfer
   // modes' partial-sum buffer holds fewer workgroups than there are chunks
   const int nchunks = (int)(((long long)nq * SDG_GROUP + 255) / 256);
-  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+  // Which chunk a workgroup starts with: workgroups are dealt to the eight XCDs round-robin by their flat id, and every XCD has an
+  // L2 of its own.  Queries arrive in cell order, so CONSECUTIVE chunks read neighbouring targets: the workgroups of one XCD take
+  // one contiguous eighth of the chunks and its L2 fetches an eighth of the targets (plus a rim) instead of all of them -- with the
+  // plain blockIdx order every XCD missed on every line (TCC_MISS 414 k of 846 k requests per call, profiles/r06s_*).
+  int chunk0 = blockIdx.x;
+  if (KAMD_SDG_XCD_CHUNKS) {
+    const unsigned int gx = gridDim.x, base = (gx * (blockIdx.y + gridDim.y * blockIdx.z)) & 7u;
+    const unsigned int xcd = (base + blockIdx.x) & 7u;
+    unsigned int before = 0u;  // workgroups of this slice on the XCDs dealt before this one (in the order of their first workgroup)
+    for (unsigned int r = 0; r < 8u; ++r) {
+      const unsigned int first = (r + 8u - base) & 7u;         // first blockIdx.x of the slice on XCD r
+      const unsigned int cnt = first < gx ? (gx - first + 7u) / 8u : 0u;
+      if (r < xcd) before += cnt;
+    }
+    const unsigned int first_mine = (xcd + 8u - base) & 7u;
+    chunk0 = (int)(before + (blockIdx.x - first_mine) / 8u);
+  }
+  for (int chunk = chunk0; chunk < nchunks; chunk += gridDim.x) {
     const int slot = (chunk * 256 + threadIdx.x) / SDG_GROUP;
     const bool live = slot < nq;
     const V4 q = (fwd ? A.sorted : T.sorted)[(size_t)b * nq + (live ? slot : 0)];
@@ -692,7 +856,7 @@ __global__ __launch_bounds__(256, (MODE == SDG_GRAD ? KAMD_SDG_QUERY_WAVES : 1))
     const int cz = sdg_axis_cell((float)q.z, s_box.lo[2], s_box.inv[2], G);
     S best;
     int best_i, best_k;
-    sdg_search<MODE == SDG_GRAD, S, HALF>(s_box, G, q.x, q.y, q.z, (cz * G + cy) * G + cx, Tp, Tstart, Tsorted, nt, sub, best, best_i, best_k);
+    sdg_search<MODE == SDG_GRAD, S, HALF>(s_box, G, q.x, q.y, q.z, cx, cy, cz, Tp, Tstart, Tsorted, nt, sub, best, best_i, best_k);
     if (__builtin_expect(odd_first, 0)) {
       const Reseeded<S> r = sdg_reseed<S, HALF>(live, sub, q.x, q.y, q.z, Tp, nt, best, best_i);
       best = r.best;
