@@ -284,6 +284,8 @@ int soft2_search_launch(hipStream_t st, int B, int H, int W, int F, int K, float
   sa.ord_count = ord_count;
   sa.ord_list = ord_list;
   sa.ord_cap = (unsigned int)tl::WORK_SHARDS * shard_cap;
+  sa.bitwords = s2_bitwords_of(F);
+  const size_t sel_shmem = (size_t)2 * sa.bitwords * 4;
   Eval2Args<T> ea{};
   ea.B = B;
   ea.F = F;
@@ -325,16 +327,16 @@ int soft2_search_launch(hipStream_t st, int B, int H, int W, int F, int K, float
   const dim3 sel_grid((unsigned)(n_sub < sel_want ? (n_sub > 0 ? n_sub : 1) : sel_want));
   const dim3 eval_grid((unsigned)(n_sub < eval_want ? (n_sub > 0 ? n_sub : 1) : eval_want));
   if (lean)
-    KAMD_LAUNCH_TIMED(kamd::K_SOFT_SELECT, (soft_select_kernel<T, true>), sel_grid, dim3(64), 0, st, sa);
+    KAMD_LAUNCH_TIMED(kamd::K_SOFT_SELECT, (soft_select_kernel<T, true>), sel_grid, dim3(64), sel_shmem, st, sa);
   else
-    KAMD_LAUNCH_TIMED(kamd::K_SOFT_SELECT, (soft_select_kernel<T, false>), sel_grid, dim3(64), 0, st, sa);
+    KAMD_LAUNCH_TIMED(kamd::K_SOFT_SELECT, (soft_select_kernel<T, false>), sel_grid, dim3(64), sel_shmem, st, sa);
   KAMD_CHECK(hipGetLastError());
   {  // the items of tiles with more entries than ordered slots (usually none), and the deal of all items for the eval launch
     const dim3 rounds_grid((unsigned)(n_sub < S2_ROUNDS_GRID ? (n_sub > 0 ? n_sub : 1) : S2_ROUNDS_GRID));
     if (lean)
-      KAMD_LAUNCH_TIMED(kamd::K_SOFT_SELECT_ROUNDS, (soft_select_rounds_kernel<T, true>), rounds_grid, dim3(64), 0, st, sa);
+      KAMD_LAUNCH_TIMED(kamd::K_SOFT_SELECT_ROUNDS, (soft_select_rounds_kernel<T, true>), rounds_grid, dim3(64), sel_shmem, st, sa);
     else
-      KAMD_LAUNCH_TIMED(kamd::K_SOFT_SELECT_ROUNDS, (soft_select_rounds_kernel<T, false>), rounds_grid, dim3(64), 0, st, sa);
+      KAMD_LAUNCH_TIMED(kamd::K_SOFT_SELECT_ROUNDS, (soft_select_rounds_kernel<T, false>), rounds_grid, dim3(64), sel_shmem, st, sa);
     KAMD_CHECK(hipGetLastError());
   }
   const bool lds_fold = K <= S2_LDS_KMAX;
