@@ -1005,9 +1005,12 @@ int sdg_run(hipStream_t st, int B, int N, int M, const S* p1, const S* p2, S* di
     int nwg = kamd_cdiv((long long)B * ((long long)N + M), SDG_BUILD_THREADS);
     const int cus = sdg_num_cus();
     if (nwg > cus) nwg = cus;
-    // measured at 100k + 100k points (profiles/r02j): 128 workgroups and ~0.5 us between polls are the fastest (46 us; 256
-    // workgroups polling back to back: 53 us; 64 workgroups: 51 us)
-    const int cap = kamd_env_int("KAMD_SDG_WGS", 128);
+    // One workgroup per CU.  Measured (profiles/r06zz_sdg_build_workgroups.txt) since the barrier is two-level and the box words
+    // sit on lines of their own: 100k + 100k points 37.3 us with 128 workgroups, 32.8 with 256, 33.7 with 512; the 8 items of C3
+    // as one call 155 / 124 / 118 us.  Not two per CU: the kernel spins on a grid barrier, every workgroup must become resident,
+    // and up to four queues of a process run kernels side by side -- four concurrent builds of 256 workgroups of 8 wavefronts are
+    // exactly the chip's 8 192 wavefront slots, four of 512 could wait for each other for ever.
+    const int cap = kamd_env_int("KAMD_SDG_WGS", cus);
     if (nwg > cap) nwg = cap;
     const int naps = kamd_env_int("KAMD_SDG_NAPS", 4);
     hipLaunchKernelGGL(sdg_build<S>, dim3(nwg), dim3(SDG_BUILD_THREADS), 0, st, cb, ca, B, pair ? 1 : 0, w.scan_sums,
