@@ -392,6 +392,9 @@ int kamd_texture_mapping_backward_f64(void* stream, int B, int64_t N, int C, int
 /* not needed: not computed).  workspace: kamd_dibr_rasterization_workspace.   */
 /* `weights` is meaningful only where face_idx >= 0 (background tiles do not write */
 /* it: the backward reads it only there).                                         */
+/* `work` of ..._backward is the forward's, unchanged in between; the backward   */
+/* uses a part of it as scratch (per-XCD partial sums of the gradients of faces  */
+/* whose enlarged box spans more than 8 x 8 soft tiles; left cleared).           */
 /* grad_img_to_zero (optional, (B,F,3,2)): cleared by the forward's one fill      */
 /* launch so that the caller can hand it to ..._backward as g_img without a fill */
 /* launch of its own.                                                            */
@@ -421,7 +424,7 @@ int kamd_dibr_rasterization_backward_f32(void* stream, int B, int H, int W, int 
                                          const float* soft_mask, const int32_t* hit_pair,
                                          const float* hit_prob,
                                          const int32_t* hit_rec, const int32_t* item_count,
-                                         const uint32_t* work, const float* img, const float* feat,
+                                         uint32_t* work, const float* img, const float* feat,
                                          double multiplier, float eps, float sigmainv,
                                          float* g_img, float* g_feat);
 int kamd_dibr_rasterization_backward_f64(void* stream, int B, int H, int W, int F, int D, int K,
@@ -430,7 +433,7 @@ int kamd_dibr_rasterization_backward_f64(void* stream, int B, int H, int W, int 
                                          const double* soft_mask, const int32_t* hit_pair,
                                          const double* hit_prob,
                                          const int32_t* hit_rec, const int32_t* item_count,
-                                         const uint32_t* work, const double* img, const double* feat,
+                                         uint32_t* work, const double* img, const double* feat,
                                          double multiplier, float eps, float sigmainv,
                                          double* g_img, double* g_feat);
 

@@ -254,7 +254,8 @@ WORK_FLAT_WORD = 8 * COUNTER_STRIDE              # the flat hit list's shard cou
 FLAT_SHARDS = 64                                 # soft2.inc
 COV_SHARDS = 32                                  # the covered-tile list's shard counters follow the flat list's
 WORK_COV_WORD = WORK_FLAT_WORD + FLAT_SHARDS * COUNTER_STRIDE
-WORK_HEADER = WORK_COV_WORD + COV_SHARDS * COUNTER_STRIDE
+WORK_BIGHASH_WORD = WORK_COV_WORD + COV_SHARDS * COUNTER_STRIDE   # the hot faces of the soft backward: count, 4096 bits, 4096 tags, 8 x 4096 x 8 partial sums
+WORK_HEADER = WORK_BIGHASH_WORD + 32 + 4096 // 32 + 4096 + 8 * 4096 * 8
 
 
 def covered_tiles(work, batch_size, height, width):

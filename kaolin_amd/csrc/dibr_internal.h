@@ -20,5 +20,6 @@ int raster_backward_draw(hipStream_t st, int B, int H, int W, int F, int D, cons
 template <typename T>
 int raster_backward_draw_list(hipStream_t st, int B, int H, int W, int F, int D, const T* grad, const int64_t* face_idx, const T* weights,
                               const T* img, const T* feat, float eps, T* g_img, T* g_feat, const unsigned int* cov_counts,
-                              const unsigned int* cov_list, unsigned int cov_cap, const unsigned int* magic_word);
+                              const unsigned int* cov_list, unsigned int cov_cap, const unsigned int* magic_word,
+                              unsigned int* bigwork /* work + tl::WORK_BIGHASH_WORD: the hot faces' partial sums are folded in and cleared; or nullptr */);
 }  // namespace kamd

@@ -432,13 +432,13 @@ int soft_mask_forward_launch(hipStream_t st, int B, int H, int W, int F, int K, 
 template <typename T>
 int soft_mask_backward_list_launch(hipStream_t st, int B, int H, int W, int F, int K, const T* grad, const T* soft_mask,
                                    const HitList2<T>& list, const unsigned int* work, const T* img, double img_scale,
-                                   float sigmainv, float multiplier, T* g_img) {
+                                   float sigmainv, float multiplier, T* g_img, unsigned int* bigwork = nullptr) {
   if ((long long)B * H * W <= 0 || F <= 0) return 0;
   {
     // persistent workgroups over the rounds of 256 hits (their number is known on the device only)
     static const int per_cu = kamd_env_int("KAMD_SOFT_BWD_PER_CU", 16);
     KAMD_LAUNCH_TIMED(kamd::K_SOFT_BACKWARD_LIST, soft_mask_backward_flat_kernel<T>, dim3(KAMD_NUM_CU * per_cu), dim3(256), 0, st, H, W, F,
-                      flat_view_magic(F), grad, soft_mask, list, img, (T)img_scale, sigmainv, multiplier, 1.0 / (double)multiplier, g_img);
+                      flat_view_magic(F), grad, soft_mask, list, img, (T)img_scale, sigmainv, multiplier, 1.0 / (double)multiplier, g_img, bigwork);
   }
   KAMD_RETURN_LAST_ERROR();
 }
@@ -479,6 +479,7 @@ int dibr_forward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K,
   const tl::Layout lay = tl::make_layout(B, H, W, total_faces, (int)sizeof(T), true, true, K);
   tl::Lists LR = tl::lists_of(workspace, lay.r, B, false);
   tl::Lists LS = tl::lists_of(workspace, lay.s, B, true);
+  if (sizeof(T) == 4) LS.big_hash = work + tl::WORK_BIGHASH_WORD;  // (the soft pass' big faces are entered for the backward pass: tile_lists.h)
   // (KAMD_ROW_ORDER=2: the tile kernels start from the middle of the image instead of the middle of the covered rows: A/B runs)
   const bool row_span = kamd_env_int("KAMD_ROW_ORDER", 1) == 1;
   if (!row_span) LR.row_span = nullptr;
@@ -563,7 +564,7 @@ int side_stream(SideStream** out) {
 template <typename T>
 int dibr_backward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K, const T* grad_feat, const T* grad_soft,
                         const int64_t* face_idx, const T* weights, const T* soft_mask, const HitList2<T>& list,
-                        const unsigned int* work, const T* img, const T* feat, double multiplier, float eps, float sigmainv,
+                        unsigned int* work, const T* img, const T* feat, double multiplier, float eps, float sigmainv,
                         T* g_img, T* g_feat) {
   // The two backward kernels are independent and used to overlap on a side stream (61 || 73 us: ~110 together).  Since the
   // rasterizer's backward leaves empty tiles at once (48 us) the fork / join events and the contention cost more than the
@@ -577,13 +578,17 @@ int dibr_backward_fused(hipStream_t st, int B, int H, int W, int F, int D, int K
   // the rasterizer's backward walks the forward's list of covered tiles (KAMD_BWD_COV_LIST=2: one workgroup per tile, for A/B runs)
   static const bool cov_list = kamd_env_int("KAMD_BWD_COV_LIST", 1) == 1;
   if (!use_side || kamd::prof_all()) {
+    // (the hot faces' partial sums -- tile_lists.h, WORK_BIGHASH_WORD -- are scratch inside the forward's work buffer: written by the
+    // first launch, folded into g_img and cleared by the second; only when the second one is the list form)
+    const bool list_form = cov_list && tile_cov != nullptr;
+    unsigned int* bigwork = list_form && kamd_env_int("KAMD_BWD_BIG_SIDE", 1) == 1 ? work + tl::WORK_BIGHASH_WORD : nullptr;
     KAMD_CHECK(soft_mask_backward_list_launch<T>(st, B, H, W, F, K, grad_soft, soft_mask, list, work, img, multiplier, sigmainv,
-                                                 (float)multiplier, g_img));
-    if (cov_list && tile_cov != nullptr)
+                                                 (float)multiplier, g_img, bigwork));
+    if (list_form)
       return kamd::raster_backward_draw_list<T>(st, B, H, W, F, D, grad_feat, face_idx, weights, img, feat, eps, g_img, g_feat,
                                                 work + tl::WORK_COV_WORD, work + tl::work_covlist_offset_words(B, H, W),
                                                 tl::cov_shard_cap((size_t)B, (size_t)tl::pass_geom(H, W, tl::R_TILE).ntiles),
-                                                work + tl::WORK_MAGIC_WORD);
+                                                work + tl::WORK_MAGIC_WORD, bigwork);
     return kamd::raster_backward_draw<T>(st, B, H, W, F, D, grad_feat, face_idx, weights, img, feat, eps, g_img, g_feat, tile_cov,
                                          row_centre);
   }
@@ -722,7 +727,7 @@ size_t kamd_dibr_rasterization_workspace(int B, int H, int W, int F, int K, int 
   int kamd_dibr_rasterization_backward_##SFX(                                                                         \
       void* stream, int B, int H, int W, int F, int D, int K, const T* grad_feat, const T* grad_soft,                 \
       const int64_t* face_idx, const T* weights, const T* soft_mask, const int32_t* hit_pair, const T* hit_prob,      \
-      const int32_t* hit_rec, const int32_t* item_count, const uint32_t* work, const T* img, const T* feat,          \
+      const int32_t* hit_rec, const int32_t* item_count, uint32_t* work, const T* img, const T* feat,                \
       double multiplier, float eps, float sigmainv, T* g_img, T* g_feat) {                                            \
     HitList2<T> l{(int2*)hit_pair, (T*)hit_prob, (uint2*)hit_rec, (int*)item_count, (unsigned int*)work + FLAT_COUNT_WORD, flat_shard_cap_of(B, H, W, K)};                               \
     return dibr_backward_fused<T>((hipStream_t)stream, B, H, W, F, D, K, grad_feat, grad_soft, face_idx, weights,     \

@@ -255,10 +255,31 @@ __global__ __launch_bounds__(256) void raster_backward_list_kernel(
     const T* __restrict__ weights, const T* __restrict__ img, const T* __restrict__ feat, float eps,
     T* __restrict__ g_img, T* __restrict__ g_feat, const unsigned int* __restrict__ cov_counts,
     const unsigned int* __restrict__ cov_list, unsigned int cov_cap, int grouped, const unsigned int* __restrict__ magic_word,
-    unsigned int magic) {
+    unsigned int magic, unsigned int* __restrict__ bigwork) {
   __shared__ unsigned int s_end[tl::COV_SHARDS];  // inclusive prefix of the shards' entry counts
   const int tiles_x = (W + 15) / 16, ntiles = tiles_x * ((H + 15) / 16);
   const int lane = threadIdx.x & 63;
+  // The soft mask's backward launch, which ran before this one, left the hot faces' terms in per-XCD copies of their records
+  // (tile_lists.h, WORK_BIGHASH_WORD): fold them into the gradient -- six consecutive lanes = one face's record = one request --
+  // and clear them (a second backward through a retained graph starts from zero again).  fp32 only; nothing to do without big faces.
+  if constexpr (sizeof(T) == 4) {
+    if (bigwork != nullptr && tl::big_hash_usable(bigwork[0])) {
+      T* const side = reinterpret_cast<T*>(bigwork + (tl::WORK_BIGSIDE_WORD - tl::WORK_BIGHASH_WORD));
+      for (unsigned int i = blockIdx.x * 256u + threadIdx.x; i < (unsigned int)tl::BIG_HASH_SLOTS * 6u; i += gridDim.x * 256u) {
+        const unsigned int slot = i / 6u, c = i - slot * 6u;
+        const unsigned int tag = bigwork[tl::BIG_HASH_TAGS_OFF + slot];
+        if (tag == 0u) continue;
+        T v = 0;
+#pragma unroll
+        for (int x = 0; x < tl::BIG_SIDE_COPIES; ++x) {
+          T* p = side + ((size_t)x * tl::BIG_HASH_SLOTS + slot) * 8 + c;
+          v += *p;
+          *p = 0;
+        }
+        if (v != (T)0) kamd_atomic_add(g_img + (size_t)(tag - 1u) * 6 + c, v);
+      }
+    }
+  }
   // The list is trusted only with the forward's signature in the header (tl::WORK_MAGIC_WORD: a work buffer of another
   // operator / build / shape would otherwise be read as tile indices); without it every tile is visited -- each wavefront
   // finds out from face_idx whether it has anything to do, as the one-workgroup-per-tile launch does.  (Uniform: a scalar load.)
@@ -377,7 +398,7 @@ template <typename T>
 int rasterize_backward_list_launch(hipStream_t st, int B, int H, int W, int F, int D, const T* grad, const int64_t* face_idx,
                                    const T* weights, const T* img, const T* feat, float eps, T* g_img, T* g_feat,
                                    const unsigned int* cov_counts, const unsigned int* cov_list, unsigned int cov_cap,
-                                   const unsigned int* magic_word) {
+                                   const unsigned int* magic_word, unsigned int* bigwork) {
   const long long n_groups = (long long)B * ((W + 15) / 16) * ((H + 15) / 16);
   const unsigned int magic = tl::work_magic(B, H, W);
   if (n_groups <= 0 || F <= 0) return 0;
@@ -387,10 +408,10 @@ int rasterize_backward_list_launch(hipStream_t st, int B, int H, int W, int F, i
 #define KAMD_RBL(DT)                                                                                                       \
   if (g_feat != nullptr)                                                                                                   \
     KAMD_LAUNCH_TIMED(kamd::K_RASTER_BACKWARD, (raster_backward_list_kernel<T, DT, true>), grid, dim3(256), 0, st, B, H, W, F, D, grad, face_idx,  \
-                      weights, img, feat, eps, g_img, g_feat, cov_counts, cov_list, cov_cap, grouped, magic_word, magic);  \
+                      weights, img, feat, eps, g_img, g_feat, cov_counts, cov_list, cov_cap, grouped, magic_word, magic, bigwork);  \
   else                                                                                                                     \
     KAMD_LAUNCH_TIMED(kamd::K_RASTER_BACKWARD, (raster_backward_list_kernel<T, DT, false>), grid, dim3(256), 0, st, B, H, W, F, D, grad, face_idx, \
-                      weights, img, feat, eps, g_img, g_feat, cov_counts, cov_list, cov_cap, grouped, magic_word, magic)
+                      weights, img, feat, eps, g_img, g_feat, cov_counts, cov_list, cov_cap, grouped, magic_word, magic, bigwork)
   switch (D) {
     case 1: KAMD_RBL(1); break;
     case 2: KAMD_RBL(2); break;
@@ -408,16 +429,16 @@ namespace kamd {
 template <typename T>
 int raster_backward_draw_list(hipStream_t st, int B, int H, int W, int F, int D, const T* grad, const int64_t* face_idx, const T* weights,
                               const T* img, const T* feat, float eps, T* g_img, T* g_feat, const unsigned int* cov_counts,
-                              const unsigned int* cov_list, unsigned int cov_cap, const unsigned int* magic_word) {
+                              const unsigned int* cov_list, unsigned int cov_cap, const unsigned int* magic_word, unsigned int* bigwork) {
   return rasterize_backward_list_launch<T>(st, B, H, W, F, D, grad, face_idx, weights, img, feat, eps, g_img, g_feat, cov_counts, cov_list, cov_cap,
-                                           magic_word);
+                                           magic_word, bigwork);
 }
 template int raster_backward_draw_list<float>(hipStream_t, int, int, int, int, int, const float*, const int64_t*, const float*, const float*,
                                               const float*, float, float*, float*, const unsigned int*, const unsigned int*, unsigned int,
-                                              const unsigned int*);
+                                              const unsigned int*, unsigned int*);
 template int raster_backward_draw_list<double>(hipStream_t, int, int, int, int, int, const double*, const int64_t*, const double*, const double*,
                                                const double*, float, double*, double*, const unsigned int*, const unsigned int*, unsigned int,
-                                               const unsigned int*);
+                                               const unsigned int*, unsigned int*);
 template <typename T>
 int raster2_draw(hipStream_t st, int B, int H, int W, int D, int F_dense, float multiplier, float eps, const T* rec,
                  const tl::Lists& LR, const T* feat, T* interp, int64_t* sel_idx, T* weights, const tl::ClassifyOut& co,

@@ -141,6 +141,7 @@ struct Lists {
   int C, maxc;
   unsigned int* big_count;    // [B]               zeroed; faces of mesh b in the big list
   unsigned int* big_list;     // [total_faces]     mesh b's segment starts at its first packed face
+  unsigned int* big_hash;     // soft pass of the fused operator (nullptr: none): work + WORK_BIGHASH_WORD, where big faces are entered
   // raster pass only (0: none): big_rows_off 32-bit words behind big_count, zeroed: per view and tile row ceil(tiles_x / 64) 64-bit
   // words, bit = some big face's tile rectangle holds the tile.  A view with ONE big face (a floor under the object) otherwise
   // costs every tile of the view its background fast path: the big list is a candidate of all of them.
@@ -235,7 +236,45 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
 constexpr int WORK_FLAT_WORD = 8 * COUNTER_STRIDE;                    // the flat hit list's shard counters (soft2.inc) follow the worklist's
 constexpr int COV_SHARDS = 32;                                        // shards of the list of tiles that hold a covered pixel
 constexpr int WORK_COV_WORD = WORK_FLAT_WORD + 64 * COUNTER_STRIDE;   // ... whose counters follow the flat list's
-constexpr int WORK_HEADER = WORK_COV_WORD + COV_SHARDS * COUNTER_STRIDE;  // words; all zeroed per call
+// ... then the hot faces of the soft mask's backward pass.  A face of the soft pass' big list (an enlarged box of more than 8 x 8 soft
+// tiles: the knot scene's ~170 image-sized faces per view) collects a gradient term from every soft pixel it reaches -- thousands of
+// atomic requests on ONE 24-byte record, and requests on one line are performed one at a time, ~40 ns each (the knot: soft backward
+// 3.0x the sphere's time for 2.0x the hits).  The binning launch enters such faces into a hash table (key = packed face index,
+// open addressing, at most BIG_HASH_MAX keys: beyond that the table is not used), the fused backward adds their terms to the
+// copy of the workgroup's XCD (BIG_SIDE_COPIES records per face, a line apart from each other) and the rasterizer's backward
+// launch, which runs next, folds the copies into the gradient and clears them.
+constexpr int BIG_HASH_SLOTS = 4096;
+constexpr int BIG_HASH_MAX = 2048;
+constexpr int BIG_SIDE_COPIES = 8;
+constexpr int BIG_HASH_BITS_OFF = 32;                                           // behind the count: one bit per slot, set when the slot is taken
+constexpr int BIG_HASH_TAGS_OFF = BIG_HASH_BITS_OFF + BIG_HASH_SLOTS / 32;      // then the slots' tags (key + 1; 0: free)
+constexpr int WORK_BIGHASH_WORD = WORK_COV_WORD + COV_SHARDS * COUNTER_STRIDE;  // [0] keys entered, bits, tags
+constexpr int WORK_BIGSIDE_WORD = WORK_BIGHASH_WORD + BIG_HASH_TAGS_OFF + BIG_HASH_SLOTS;  // BIG_SIDE_COPIES x BIG_HASH_SLOTS x 8 floats (6 used)
+constexpr int WORK_HEADER = WORK_BIGSIDE_WORD + BIG_SIDE_COPIES * BIG_HASH_SLOTS * 8;  // words; all zeroed per call
+__device__ __forceinline__ unsigned int big_hash_of(unsigned int key) { return (key * 2654435761u) >> 20; }  // 12 bits
+static_assert(BIG_HASH_SLOTS == 4096, "big_hash_of yields 12 bits");
+// bh = work + WORK_BIGHASH_WORD
+__device__ __forceinline__ void big_hash_insert(unsigned int* bh, unsigned int key) {
+  if (atomicAdd(bh, 1u) >= (unsigned int)BIG_HASH_MAX) return;  // (readers find the count above the limit and leave the table alone)
+  unsigned int h = big_hash_of(key);
+  for (int probe = 0; probe < BIG_HASH_SLOTS; ++probe) {
+    const unsigned int old = atomicCAS(bh + BIG_HASH_TAGS_OFF + h, 0u, key + 1u);
+    if (old == 0u) atomicOr(bh + BIG_HASH_BITS_OFF + (h >> 5), 1u << (h & 31u));
+    if (old == 0u || old == key + 1u) return;
+    h = (h + 1u) & (unsigned int)(BIG_HASH_SLOTS - 1);
+  }
+}
+__device__ __forceinline__ bool big_hash_usable(unsigned int n) { return n > 0u && n <= (unsigned int)BIG_HASH_MAX; }
+__device__ __forceinline__ int big_hash_find(const unsigned int* bh, unsigned int key) {  // -> slot, or -1
+  unsigned int h = big_hash_of(key);
+  for (int probe = 0; probe < BIG_HASH_SLOTS; ++probe) {
+    const unsigned int t = bh[BIG_HASH_TAGS_OFF + h];
+    if (t == key + 1u) return (int)h;
+    if (t == 0u) return -1;
+    h = (h + 1u) & (unsigned int)(BIG_HASH_SLOTS - 1);
+  }
+  return -1;
+}
 // A free word of the header's first line: the fused forward (its last launch) leaves a signature of the layout here, and the
 // fused backward's covered-tile walk trusts the list only when it finds it -- a work buffer that did not come from
 // kamd_dibr_rasterization_forward_* of THIS build and shape (another operator's, a tool's, stale memory) makes it visit every
@@ -291,6 +330,7 @@ inline Lists lists_of(void* ws, const PassLayout& p, int B, bool soft) {
   l.maxc = p.maxc;
   l.big_count = (unsigned int*)(c + p.big_count);
   l.big_list = (unsigned int*)(c + p.big_list);
+  l.big_hash = nullptr;
   l.big_rows_off = (!soft && p.big_rows != 0) ? (unsigned int)((p.big_rows - p.big_count) / 4) : 0u;
   l.sub_touched = soft ? (unsigned int*)(c + p.sub_touched) : nullptr;
   l.tiles_x = p.g.tiles_x;
@@ -632,6 +672,7 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
       if (lane == leader) start = atomicAdd(L.big_count + bL, (unsigned int)__popcll(bigm));
       start = (unsigned int)__builtin_amdgcn_readlane((int)start, leader);
       if (mine && big) L.big_list[first_b + start + __popcll(bigm & ((1ull << lane) - 1ull))] = (unsigned int)f;
+      if (SOFT && L.big_hash != nullptr && mine && big) big_hash_insert(L.big_hash, (unsigned int)f);
       if (!SOFT && L.big_rows_off != 0u) {
         // the tiles a big face's rectangle holds, a 64-bit word per 64 tiles of a row: one face at a time, a lane per row
         const int wpr = big_row_words(L.tiles_x), tiles_y = L.ntiles / L.tiles_x;

@@ -763,3 +763,41 @@ def test_box_edges_within_two_thousandths_of_a_pixel_centre(dtype, H, W, big_x):
     assert rel_close(soft, ref['soft_mask'])
     s2, prob, idx, typ = _c_forward(fimg.cuda(), face_idx, 7000, 0.002, 8, 1000.)
     assert torch.equal(idx.cpu(), ref['close_face_idx']) and torch.equal(typ.cpu(), ref['close_face_dist_type'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n_big', [40, 2500])
+def test_fused_backward_with_image_sized_faces_equals_the_composition(n_big):
+    """Faces whose enlarged box spans more than 8 x 8 soft tiles collect their soft-mask gradient in per-XCD partial sums that the
+    rasterizer's backward launch folds in (csrc/tile_lists.h, WORK_BIGHASH_WORD): with 40 such faces the table is in use, with
+    2 500 it is over its limit and left alone.  Either way the fused operator's vertex gradient equals the composition's
+    (rasterize + dibr_soft_mask: the stand-alone soft-mask backward never uses the table), and a second backward through the
+    retained graph gives the same again (the partial sums are left cleared)."""
+    import kaolin_amd as kal
+    g = torch.Generator().manual_seed(n_big)
+    H = W = 288
+    n_small = 300
+    F = n_big + n_small
+    size = torch.cat([torch.full((n_big,), 2.2), torch.full((n_small,), 0.06)])[torch.randperm(F, generator=g)]
+    centre = (torch.rand(1, F, 1, 2, generator=g) - 0.5) * 1.6
+    img = centre + (torch.rand(1, F, 3, 2, generator=g) - 0.5) * size.view(1, F, 1, 1)
+    z = -(torch.rand(1, F, 3, generator=g) * 2 + 0.5)
+    feat = torch.rand(1, F, 3, 2, generator=g)
+    nz = torch.rand(1, F, generator=g) - 0.3          # 30 % back faces
+    g1, g2 = torch.rand(1, H, W, 2, generator=g).cuda(), torch.rand(1, H, W, generator=g).cuda()
+    a = img.cuda().requires_grad_()
+    out, soft, face_idx = kal.render.mesh.dibr_rasterization(H, W, z.cuda(), a, feat.cuda(), nz.cuda(), knum=5)
+    loss = (out * g1).sum() + (soft * g2).sum()
+    grad_fused, = torch.autograd.grad(loss, a, retain_graph=True)
+    grad_again, = torch.autograd.grad(loss, a)
+    b = img.cuda().requires_grad_()
+    out2, idx2 = kal.render.mesh.rasterize(H, W, z.cuda(), b, feat.cuda(), valid_faces=nz.cuda() >= 0)
+    soft2 = kal.render.mesh.dibr_soft_mask(b, idx2, knum=5)
+    assert torch.equal(idx2, face_idx) and torch.equal(out2, out) and torch.equal(soft2, soft)
+    grad_comp, = torch.autograd.grad((out2 * g1).sum() + (soft2 * g2).sum(), b)
+    scale = float(grad_comp.abs().max())
+    assert scale > 0
+    for name, got in (('fused', grad_fused), ('second backward', grad_again)):
+        d = (got - grad_comp).abs()
+        bad = d > 1e-4 * grad_comp.abs() + 2e-5 * scale     # (sums of thousands of float atomics in two different orders)
+        assert not bool(bad.any()), f'{name}: {int(bad.sum())} of {bad.numel()} elements off, worst {float(d.max()):.3g} at scale {scale:.3g}'
