@@ -140,8 +140,7 @@ struct Lists {
   unsigned int cap_chunks;
   int C, maxc;
   unsigned int* big_count;    // [B]               zeroed; elements of mesh b's big list
-  unsigned int* big_list;     // raster pass: [total_faces] face ids, mesh b's segment starts at its first packed face; soft pass: 3 words per
-                              // element {64-face block, mask.lo, mask.hi}, mesh b's segment at 3 x its first packed face
+  unsigned int* big_list;     // [3 * total_faces]  3 words per element {64-face block, mask.lo, mask.hi}, mesh b's segment at 3 x its first packed face
   unsigned int* big_hash;     // soft pass of the fused operator (nullptr: none): work + WORK_BIGHASH_WORD, where big faces are entered
   // raster pass only (0: none): big_rows_off 32-bit words behind big_count, zeroed: per view and tile row ceil(tiles_x / 64) 64-bit
   // words, bit = some big face's tile rectangle holds the tile.  A view with ONE big face (a floor under the object) otherwise
@@ -214,7 +213,7 @@ inline Layout make_layout(int B, int H, int W, long long total_faces, int esz, b
     L.r.cap_chunks = pool_chunks(total_faces, (long long)ntr);
     L.r.inl = off; off += a256(ntr * L.r.C * 16);
     L.r.pool = off; off += a256((size_t)L.r.cap_chunks * OVC * 16);
-    L.r.big_list = off; off += a256((size_t)total_faces * 4);
+    L.r.big_list = off; off += a256((size_t)total_faces * 3 * 4);  // entries {block, mask.lo, mask.hi}: at most one per face (wave_bin)
     L.r.rec = off; off += a256((size_t)total_faces * REC_R * esz);
   }
   if (with_s) {
@@ -669,11 +668,13 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
     // big faces: appended to the mesh's big list
     const unsigned long long bigm = __ballot(mine && big);
     if (bigm != 0ull) {
-      if constexpr (SOFT) {
-        // The soft pass' big list holds ENTRIES {block, face mask} like the tiles' own: the big faces of this wavefront, merged per 64-face
-        // block (at most two blocks: its faces are consecutive).  Every work item of the mesh orders the big list among its tile's
-        // entries (soft2.inc): the knot's ~170 image-sized faces per view are consecutive in its face list -- a handful of entries
-        // instead of 170, and far fewer tiles over the ordered-slot limit.  (Rounds 2-6: one list element per face.)
+      {
+        // The big list holds ENTRIES {block, face mask} like the tiles' own: the big faces of this wavefront, merged per 64-face block
+        // (at most two blocks: its faces are consecutive).  Every soft work item of the mesh orders the big list among its tile's
+        // entries (soft2.inc), every rasterizer tile a big face's rectangle holds expands it behind its own (raster2.inc): the knot's
+        // ~170 image-sized faces per view are consecutive in its face list -- a handful of entries instead of 170, few soft tiles
+        // left over the ordered-slot limit, rasterizer tiles back under the 64 entries one wavefront holds.  (Rounds 2-6: one list
+        // element per face.)
         for (unsigned long long todo = bigm; todo != 0ull;) {
           const int l0 = __ffsll((long long)todo) - 1;
           const unsigned int blk = (unsigned int)__builtin_amdgcn_readlane((int)block, l0);
@@ -689,12 +690,7 @@ __device__ __forceinline__ void wave_bin(bool active, bool big, int b, long long
             e[2] = mhi;
           }
         }
-        if (L.big_hash != nullptr && mine && big) big_hash_insert(L.big_hash, (unsigned int)f);
-      } else {
-        unsigned int start = 0;
-        if (lane == leader) start = atomicAdd(L.big_count + bL, (unsigned int)__popcll(bigm));
-        start = (unsigned int)__builtin_amdgcn_readlane((int)start, leader);
-        if (mine && big) L.big_list[first_b + start + __popcll(bigm & ((1ull << lane) - 1ull))] = (unsigned int)f;
+        if (SOFT && L.big_hash != nullptr && mine && big) big_hash_insert(L.big_hash, (unsigned int)f);
       }
       if (!SOFT && L.big_rows_off != 0u) {
         // the tiles a big face's rectangle holds, a 64-bit word per 64 tiles of a row: one face at a time, a lane per row
