@@ -12,6 +12,10 @@
 // the reference's answer unless the winner sits in a dead tile -- which takes a non-finite coordinate at a target index 512 k.
 // The fix-up below costs nothing without such targets (callers gate it on a flag found once per call) and is exact with them:
 // the wavefront takes its affected queries in turn, lane = target, and redoes the search over the live tiles only.
+// Cost with them: a redo is O(M / 64) steps of one wavefront per affected query, one query after the other -- a cloud or
+// mesh with non-finite coordinates at MANY indices 512 k (every tile dead for most queries) degrades towards O(N * M / 64) serial
+// work, a cliff that depends on the data; such inputs are outside what the reference itself handles meaningfully (its answer for
+// them is "the best of whatever tiles happen to be alive"), and the tests pin the answers, not the speed.
 #pragma once
 #include <hip/hip_runtime.h>
 
