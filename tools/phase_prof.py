@@ -8,10 +8,12 @@ from kaolin_amd import _lib
 from kaolin_amd.utils import testing as T
 lib = _lib.load()
 V, H, W = 8, 1024, 1024
-scene = os.environ.get('KAMD_PROF_SCENE', 'sphere')   # sphere | knot | bowl (the knot scene's ~170 image-sized faces alone)
+scene = os.environ.get('KAMD_PROF_SCENE', 'sphere')   # sphere | knot | knot_shuffled | bowl (the knot scene's ~170 image-sized faces alone)
 if scene == 'bowl':
     kv, kf = T.knot_mesh()
     fz, fimg, feats, nz = T.mesh_scene(kv, kf[2 * 440 * 48 + 20 * 12 * 12 + 20 * 14 * 14:], V, 'cuda', torch.float, 0, 2.5)
+elif scene == 'knot_shuffled':
+    fz, fimg, feats, nz = T.mesh_scene(*T.scene_mesh('knot_shuffled'), V, 'cuda', torch.float, 0, 2.5)
 else:
     fz, fimg, feats, nz = (T.knot_scene(num_views=V, device='cuda') if scene == 'knot' else T.sphere_scene(level=50, num_views=V, device='cuda'))
 feat = torch.cat(feats, -1).contiguous()
