@@ -384,8 +384,12 @@ def main():
     def timed(fn, steps, warmup):
         for _ in range(warmup):
             fn()
-        gc.collect()
-        gc.disable()     # (no collector pause inside the timed region: the step allocates a few hundred Python objects)
+        # No collector pause inside the timed region (the step allocates a few hundred Python objects) -- and NO gc.collect() in front
+        # of it: a full collection here hands the caching allocator every buffer the last steps' garbage still held, the first timed
+        # step then takes the host 0.83 instead of 0.34 ms to enqueue and the following ones run on different blocks, 3 % slower
+        # (K = 20 after W = 5: 0.454 ms per step with the collection, 0.418 without; profiles/r06zs_timed_region.txt).  The warm-up
+        # steps have just put the allocator into its steady state: the timed steps should start from it.
+        gc.disable()
         D.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
