@@ -524,8 +524,8 @@ def main():
     lib.kamd_profile_select(kernel_ids.get(dom, -1) if dom else -1)
     lib.kamd_profile_enable(1 if dom else 0)
     posted0 = reducer.posted
-    dt = timed(dibr_step, args.steps, 2)      # (two untimed steps in this mode: its event pool is created on first use)
-    reducer_posted_per_step = (reducer.posted - posted0) / (args.steps + 2)
+    dt = timed(dibr_step, args.steps, max(2, args.warmup))   # (untimed steps in THIS mode: its event pool is created on first use)
+    reducer_posted_per_step = (reducer.posted - posted0) / (args.steps + max(2, args.warmup))
     dibr_enqueue_ms = timed.enqueue_ms
     dibr_enqueue_idle_ms = host_enqueue_idle_ms(dibr_step)
     lib.kamd_profile_enable(0)
